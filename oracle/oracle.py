@@ -1,0 +1,247 @@
+"""ctypes front-end of ``smoqy_oracle.c`` (CPU restatement of the reference hot path).
+
+TEST INFRASTRUCTURE ONLY — see ``oracle/__init__.py``.  All arrays use the reference layout:
+state vectors / fields are ``(Ltau, N)`` Fortran-ordered numpy arrays (tau contiguous), the
+neighbour table is ``(2, Nh)`` Fortran-ordered int64, 1-based and colour sorted.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsmoqy_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement with gcc (a few seconds)."""
+    src = os.path.join(_HERE, "smoqy_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B", "libsmoqy_oracle.so"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_fdm_create.restype = C.c_void_p
+        _lib.orc_kpm_create.restype = C.c_void_p
+        _lib.orc_fft_create.restype = C.c_void_p
+        _lib.orc_cg_solve.restype = C.c_int
+        _lib.orc_kpm_active.restype = C.c_int
+        _lib.orc_kpm_order.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def fvec(a, dtype=np.complex128):
+    """Return a Fortran-ordered, owned copy of ``a`` with the given dtype."""
+    return np.array(a, dtype=dtype, order="F", copy=True)
+
+
+class OracleFDM:
+    """Restatement of Sym/AsymFermionDetMatrix (src/FermionDetMatrix.jl:44-55, 137-148)."""
+
+    def __init__(self, neighbor_table, expV, cosh, sinh, is_sym=True):
+        self.nt = np.asfortranarray(neighbor_table, dtype=np.int64)
+        self.expV = np.asfortranarray(expV, dtype=np.float64)
+        self.cosh = np.asfortranarray(cosh, dtype=np.float64)
+        self.sinh = np.asfortranarray(sinh, dtype=np.float64)
+        self.Lt, self.N = self.expV.shape
+        self.Nh = self.nt.shape[1]
+        self.is_sym = bool(is_sym)
+        assert self.cosh.shape == (self.Lt, self.Nh) and self.sinh.shape == (self.Lt, self.Nh)
+        self._h = C.c_void_p(lib().orc_fdm_create(self.Lt, self.N, self.Nh, int(self.is_sym), _p(self.nt), _p(self.expV), _p(self.cosh), _p(self.sinh)))
+
+    def __del__(self):
+        try:
+            lib().orc_fdm_destroy(self._h)
+        except Exception:
+            pass
+
+    def _apply(self, fn, v):
+        v = fvec(v).reshape(self.Lt, self.N, order="F")
+        out = np.zeros_like(v, order="F")
+        fn(self._h, _p(out), _p(v))
+        return out
+
+    def mul_M(self, v):
+        return self._apply(lib().orc_mul_M, v)
+
+    def mul_Mt(self, v):
+        return self._apply(lib().orc_mul_Mt, v)
+
+    def mul_MtM(self, v):
+        return self._apply(lib().orc_mul_MtM, v)
+
+    def mul_MMt(self, v):
+        return self._apply(lib().orc_mul_MMt, v)
+
+    def checkerboard(self, v, transposed=False, inverse=False, interval=None):
+        v = fvec(v).reshape(self.Lt, self.N, order="F")
+        h0, h1 = (0, self.Nh) if interval is None else interval
+        fn = lib().orc_checkerboard_ldiv if inverse else lib().orc_checkerboard_lmul
+        fn(_p(v), self.Lt, self.N, _p(self.nt), _p(self.cosh), _p(self.sinh), int(transposed), int(h0), int(h1))
+        return v
+
+    def cg_solve(self, b, x0=None, precond=None, tol=1e-10, maxiter=10000):
+        """cg_solve! (src/IterativeSolvers/ConjugateGradient.jl:93-249).  ``x0=None`` is the
+        ``x === b`` case (zero initial guess).  Returns (x, iters, eps)."""
+        b = fvec(b).reshape(self.Lt, self.N, order="F")
+        x = np.zeros_like(b, order="F") if x0 is None else fvec(x0).reshape(self.Lt, self.N, order="F")
+        eps = C.c_double(0.0)
+        ph = precond._h if precond is not None else None
+        it = lib().orc_cg_solve(self._h, ph, _p(x), _p(b), int(x0 is None), C.c_double(tol), int(maxiter), C.byref(eps))
+        return x, int(it), float(eps.value)
+
+
+def update_fields(V, t, perm, dtau, is_sym=True):
+    """update!(fdm, fpi) (src/FermionDetMatrix.jl:208-236).  V is (N, Ltau), t is (Nh, Ltau),
+    perm is the 1-based checkerboard permutation.  Returns (expV, cosh, sinh)."""
+    V = np.asfortranarray(V, dtype=np.float64)
+    t = np.asfortranarray(t, dtype=np.float64)
+    perm = np.ascontiguousarray(perm, dtype=np.int64)
+    N, Lt = V.shape
+    Nh = t.shape[0]
+    expV = np.zeros((Lt, N), order="F")
+    ch = np.zeros((Lt, Nh), order="F")
+    sh = np.zeros((Lt, Nh), order="F")
+    lib().orc_update_fields(_p(expV), _p(ch), _p(sh), Lt, N, Nh, _p(V), _p(t), _p(perm), C.c_double(dtau), int(is_sym))
+    return expV, ch, sh
+
+
+LAMBDA_OPS = {"mul": 0, "ldiv": 1, "mulT": 2, "ldivT": 3}
+
+
+def lambda_apply(Lam, v, op):
+    """mul_Λ!, ldiv_Λ!, mul_Λᵀ!, ldiv_Λᵀ! (src/holstein_shift_matrix.jl:47-153)."""
+    Lam = np.asfortranarray(Lam, dtype=np.float64)
+    Lt, N = Lam.shape
+    v = fvec(v).reshape(Lt, N, order="F")
+    out = np.zeros_like(v, order="F")
+    lib().orc_lambda_apply(_p(out), _p(v), _p(Lam), Lt, N, LAMBDA_OPS[op])
+    return out
+
+
+def update_lambda(Lt, N, x, dtau, coupling_to_phonon, coupling_to_site, alpha, alpha3, ph_sym):
+    """update_Λ! (src/holstein_shift_matrix.jl:2-44); x is (Nph, Ltau); ids are 1-based."""
+    x = np.asfortranarray(x, dtype=np.float64)
+    Lam = np.zeros((Lt, N), order="F")
+    c2p = np.ascontiguousarray(coupling_to_phonon, dtype=np.int64)
+    c2s = np.ascontiguousarray(coupling_to_site, dtype=np.int64)
+    al = np.ascontiguousarray(alpha, dtype=np.float64)
+    a3 = np.ascontiguousarray(alpha3, dtype=np.float64)
+    ps = np.ascontiguousarray(ph_sym, dtype=np.int32)
+    lib().orc_update_lambda(_p(Lam), Lt, N, _p(x), x.shape[0], C.c_double(dtau), len(c2p), _p(c2p), _p(c2s), _p(al), _p(a3), _p(ps))
+    return Lam
+
+
+class OracleFT:
+    """FourierTransformer (src/FourierTransformer.jl)."""
+
+    def __init__(self, Lt, N):
+        self.Lt, self.N = Lt, N
+        self._h = C.c_void_p(lib().orc_fft_create(Lt))
+
+    def __del__(self):
+        try:
+            lib().orc_fft_destroy(self._h)
+        except Exception:
+            pass
+
+    def forward(self, v):
+        v = fvec(v).reshape(self.Lt, self.N, order="F")
+        lib().orc_ft_forward(self._h, _p(v), self.Lt, self.N)
+        return v
+
+    def inverse(self, v):
+        v = fvec(v).reshape(self.Lt, self.N, order="F")
+        lib().orc_ft_inverse(self._h, _p(v), self.Lt, self.N)
+        return v
+
+
+class OracleKPM:
+    """Sym/AsymKPMPreconditioner (src/KPMPreconditioner.jl:61-99, 132-170, 198-284)."""
+
+    def __init__(self, fdm: OracleFDM, rbuf=0.10, n=20, a1=1.0, a2=1.0):
+        self.fdm = fdm
+        self.n = n
+        self._h = C.c_void_p(lib().orc_kpm_create(fdm.Lt, fdm.N, fdm.Nh, int(fdm.is_sym), _p(fdm.nt), C.c_double(rbuf), int(n), C.c_double(a1), C.c_double(a2)))
+
+    def __del__(self):
+        try:
+            lib().orc_kpm_destroy(self._h)
+        except Exception:
+            pass
+
+    def update(self, randvec):
+        """update_preconditioner! (:554-597); ``randvec`` = the N normal deviates drawn at :634."""
+        rv = np.ascontiguousarray(randvec, dtype=np.float64)
+        assert rv.shape == (self.fdm.N,)
+        lib().orc_kpm_update(self._h, _p(self.fdm.expV), _p(self.fdm.cosh), _p(self.fdm.sinh), _p(rv))
+
+    def apply(self, v):
+        """ldiv!(u', P, u), complex method (:355-414 / :488-550)."""
+        f = self.fdm
+        v = fvec(v).reshape(f.Lt, f.N, order="F")
+        out = np.zeros_like(v, order="F")
+        lib().orc_kpm_apply(self._h, _p(out), _p(v))
+        return out
+
+    @property
+    def active(self):
+        return bool(lib().orc_kpm_active(self._h))
+
+    @property
+    def bounds(self):
+        b = np.zeros(2)
+        lib().orc_kpm_bounds(self._h, _p(b))
+        return float(b[0]), float(b[1])
+
+    @property
+    def order(self):
+        o = np.zeros(self.fdm.Lt, dtype=np.int32)
+        n = lib().orc_kpm_order(self._h, _p(o))
+        return o[:n].copy()
+
+    def coefs(self, slot):
+        n = int(self.order[slot])
+        c = np.zeros(n, dtype=np.complex128)
+        lib().orc_kpm_coefs(self._h, int(slot), _p(c))
+        return c
+
+    def lanczos(self):
+        a = np.zeros(self.n)
+        b = np.zeros(self.n - 1)
+        lib().orc_kpm_lanczos(self._h, _p(a), _p(b))
+        return a, b
+
+    def bbar(self):
+        f = self.fdm
+        d, c, s = np.zeros(f.N), np.zeros(f.Nh), np.zeros(f.Nh)
+        lib().orc_kpm_bbar(self._h, _p(d), _p(c), _p(s))
+        return d, c, s
+
+    def bbar_mul(self, v):
+        v = np.array(v, dtype=np.complex128)
+        lib().orc_kpm_bbar_mul(self._h, _p(v))
+        return v
+
+
+def tridiag_extremes(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    lo, hi = C.c_double(0), C.c_double(0)
+    lib().orc_tridiag_extremes(_p(a), _p(b), len(a), C.byref(lo), C.byref(hi))
+    return lo.value, hi.value

@@ -1,0 +1,12 @@
+"""Import alias for the product package, whose directory name (``smoqyelphqmc.jl_amd``)
+contains a dot and so cannot be imported by name.  ``import smoqyelphqmc_amd`` loads that
+directory as a regular package (sub-modules resolve inside it)."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "smoqyelphqmc.jl_amd")
+_spec = importlib.util.spec_from_file_location(__name__, os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)
