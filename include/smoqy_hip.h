@@ -1,0 +1,164 @@
+/*
+ * smoqy_hip.h — C ABI of the MI355X-native (gfx950, HIP) CG / stochastic-trace hot path of
+ * SmoQyElPhQMC.jl.
+ *
+ * The reference has no FFI: its "operator API" is Julia multiple dispatch on
+ * FermionDetMatrix / KPMPreconditioner / PFFCalculator.  Each entry point below cites the
+ * reference method (file:line under /root/reference) it replaces; INTEGRATION.md shows the
+ * `ccall` shim a maintainer would add on the Julia side.
+ *
+ * Conventions at this boundary:
+ *   - every function returns 0 on success, non-zero on error; smoqy_last_error() gives text.
+ *     CG non-convergence is NOT an error (iters == maxiter is returned, as in the reference).
+ *   - host arrays are column-major: state vectors are Ltau x N complex128 (interleaved re,im;
+ *     tau contiguous), `count` vectors are stacked back to back (an Ltau x N x count array);
+ *     fields are Ltau x N / Ltau x Nh float64.  Indices are Int64 and 1-based.
+ *   - the library never keeps a host pointer after a call returns.
+ *   - one in-flight call per handle; a handle owns one HIP stream.
+ *   - only real matrix-element type T = Float64 is implemented (is_complex_T must be 0).
+ *
+ * A handle carries `nwalkers` independent field sets (one FermionDetMatrix + Λ + KPM
+ * preconditioner each) times `nrhs` right-hand sides per walker; system s belongs to walker
+ * s / nrhs.  nwalkers = nrhs = 1 is exactly one reference FermionDetMatrix.
+ *
+ * Device-resident batch vectors ("vec ids") hold one state vector per system in the device's
+ * own slice-major layout; the *_v entry points work on them without touching the host.
+ */
+#ifndef SMOQY_HIP_H
+#define SMOQY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smoqy_ctx smoqy_ctx;
+
+/* op codes for smoqy_lambda_apply*: mul_Λ!, ldiv_Λ!, mul_Λᵀ!, ldiv_Λᵀ!
+ * (src/holstein_shift_matrix.jl:47, 74, 102, 129) */
+enum { SMOQY_LAMBDA_MUL = 0, SMOQY_LAMBDA_LDIV = 1, SMOQY_LAMBDA_MULT = 2, SMOQY_LAMBDA_LDIVT = 3 };
+
+/* matvec selectors: mul_M!, mul_Mt!, mul_MtM! (= mul!), mul_MMt!
+ * (src/FermionDetMatrix.jl:385/430, 484/528, 329, 357) */
+enum { SMOQY_OP_M = 0, SMOQY_OP_MT = 1, SMOQY_OP_MTM = 2, SMOQY_OP_MMT = 3 };
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+
+/* Sym/AsymFermionDetMatrix constructor (src/FermionDetMatrix.jl:66-111, 159-204) minus the
+ * checkerboard decomposition, which is an INPUT: neighbor_table is 2 x Nh (1-based, colour
+ * sorted), color_ranges is 2 x ncolors (1-based inclusive first/last bond of each colour).
+ * Bonds of one colour must touch disjoint sites (checked).  device_id < 0 = current device. */
+int smoqy_create(smoqy_ctx **out, int Ltau, int N, int Nh, int ncolors, const int64_t *neighbor_table,
+                 const int64_t *color_ranges, int is_sym, int is_complex_T, int nwalkers, int nrhs, int device_id);
+int smoqy_destroy(smoqy_ctx *ctx);
+/* text of the last error on this handle (or of the last failed smoqy_create when ctx == NULL) */
+const char *smoqy_last_error(const smoqy_ctx *ctx);
+/* adopt a caller-owned hipStream_t (pass NULL to return to the handle's own stream) */
+int smoqy_set_stream(smoqy_ctx *ctx, void *hip_stream);
+int smoqy_sync(smoqy_ctx *ctx);
+/* size(fdm) (src/FermionDetMatrix.jl:243): dims = {Ltau, N, Nh, ncolors, nwalkers, nrhs} */
+int smoqy_dims(const smoqy_ctx *ctx, int dims[6]);
+
+/* tau-chunk of the slice kernels (time slices per workgroup); Tc <= 0 restores the heuristic */
+int smoqy_set_tau_chunk(smoqy_ctx *ctx, int Tc);
+int smoqy_get_tau_chunk(const smoqy_ctx *ctx, int *Tc);
+
+/* ---- fields --------------------------------------------------------------------------- */
+
+/* overwrite expnΔτV, coshΔτt, sinhΔτt of one walker (fields of src/FermionDetMatrix.jl:46-48) */
+int smoqy_update_fields(smoqy_ctx *ctx, int walker, const double *expV, const double *cosh_dtt, const double *sinh_dtt);
+/* update!(fdm, fpi) on the device (src/FermionDetMatrix.jl:208-236): V is N x Ltau, t is
+ * Nh x Ltau (FermionPathIntegral layout), perm the 1-based checkerboard permutation */
+int smoqy_update_from_path_integral(smoqy_ctx *ctx, int walker, const double *V, const double *t, const int64_t *perm, double dtau);
+/* read the fields back (field access .expnΔτV etc., used by KPMPreconditioner.jl:208-209) */
+int smoqy_get_fields(smoqy_ctx *ctx, int walker, double *expV, double *cosh_dtt, double *sinh_dtt);
+
+/* ---- device-resident batch vectors ---------------------------------------------------- */
+
+int smoqy_vec_alloc(smoqy_ctx *ctx, int *id);
+int smoqy_vec_free(smoqy_ctx *ctx, int id);
+/* host (Ltau x N x count, reference layout) <-> systems [sys0, sys0+count) of vector `id` */
+int smoqy_vec_upload(smoqy_ctx *ctx, int id, const void *host, int sys0, int count);
+int smoqy_vec_download(smoqy_ctx *ctx, int id, void *host, int sys0, int count);
+int smoqy_vec_copy(smoqy_ctx *ctx, int dst, int src);
+/* out[s] = dot(a_s, b_s) (conjugate-linear in a, like LinearAlgebra.dot); out is nsys complex128 */
+int smoqy_vec_dot(smoqy_ctx *ctx, int a, int b, void *out);
+
+/* ---- FermionDetMatrix applies --------------------------------------------------------- */
+
+/* out = op(in) for every system; out == in allowed (lmul_M!/lmul_Mt!, :372, :470) */
+int smoqy_matvec_v(smoqy_ctx *ctx, int op, int out, int in);
+/* host form: `count` vectors starting at system sys0 (fields of walker sys/nrhs); out == in allowed */
+int smoqy_matvec(smoqy_ctx *ctx, int op, void *out, const void *in, int sys0, int count);
+
+/* ---- Holstein shift matrix Λ ---------------------------------------------------------- */
+
+/* set Λ (Ltau x N) of one walker from the host (what update_Λ! produced, :2-44) */
+int smoqy_lambda_set(smoqy_ctx *ctx, int walker, const double *Lambda);
+/* update_Λ! on the device (src/holstein_shift_matrix.jl:2-44): x is Nph x Ltau; ncoup
+ * couplings with 1-based phonon / site ids; ph_sym[c] != 0 marks particle-hole symmetric form */
+int smoqy_lambda_update(smoqy_ctx *ctx, int walker, const double *x, int Nph, double dtau, int ncoup,
+                        const int64_t *coupling_to_phonon, const int64_t *coupling_to_site,
+                        const double *alpha, const double *alpha3, const int32_t *ph_sym);
+int smoqy_lambda_get(smoqy_ctx *ctx, int walker, double *Lambda);
+/* mul_Λ!/ldiv_Λ!/mul_Λᵀ!/ldiv_Λᵀ! with the walker's stored Λ; out == in allowed */
+int smoqy_lambda_apply_v(smoqy_ctx *ctx, int op, int out, int in);
+/* host form with Λ passed by the caller; uses walker sys0/nrhs's slot as scratch */
+int smoqy_lambda_apply(smoqy_ctx *ctx, int op, void *out, const void *in, const double *Lambda, int sys0, int count);
+
+/* ---- FourierTransformer (src/FourierTransformer.jl:39-64) ----------------------------- */
+
+int smoqy_fft_forward_v(smoqy_ctx *ctx, int id); /* lmul!(U, v): tau -> omega, unitary, antiperiodic */
+int smoqy_fft_inverse_v(smoqy_ctx *ctx, int id); /* ldiv!(U, v) */
+int smoqy_fft_forward(smoqy_ctx *ctx, void *inout, int sys0, int count);
+int smoqy_fft_inverse(smoqy_ctx *ctx, void *inout, int sys0, int count);
+
+/* ---- KPMPreconditioner ---------------------------------------------------------------- */
+
+/* KPMPreconditioner keyword arguments (src/KPMPreconditioner.jl:198-206); call before the first
+ * update (defaults rbuf = 0.10, n = 20, a1 = 1.0, a2 = 1.0; a1 is doubled for Sym, :263) */
+int smoqy_precond_config(smoqy_ctx *ctx, double rbuf, int n_lanczos, double a1, double a2);
+/* update_preconditioner! (src/KPMPreconditioner.jl:554-597) for one walker.  randvec holds the
+ * N normal deviates the caller's rng produces at :634 (the rng stays on the host). */
+int smoqy_precond_update(smoqy_ctx *ctx, int walker, const double *randvec);
+/* state readback: active flag, bounds[2], order[] (cld(Ltau,2) entries for Sym, Ltau for Asym;
+ * returns the count in *norder), Lanczos alpha[n] / beta[n-1].  Any pointer may be NULL. */
+int smoqy_precond_get(smoqy_ctx *ctx, int walker, int *active, double *bounds, int *order, int *norder, double *lanczos_alpha, double *lanczos_beta);
+/* coefficients of one frequency slot as complex128[order[slot]] */
+int smoqy_precond_get_coefs(smoqy_ctx *ctx, int walker, int slot, void *coefs);
+/* host-supplied state instead of smoqy_precond_update: bounds, order and the
+ * concatenated complex128 coefficients of all slots; B̄ is still taken from the current fields */
+int smoqy_precond_set(smoqy_ctx *ctx, int walker, int active, const double *bounds, const int *order, const void *coefs);
+/* ldiv!(u', P, u) complex method (Sym :355-414, Asym :488-550); identity while inactive */
+int smoqy_precond_apply_v(smoqy_ctx *ctx, int out, int in);
+int smoqy_precond_apply(smoqy_ctx *ctx, void *out, const void *in, int sys0, int count);
+
+/* ---- conjugate gradient (ldiv!(v', fdm, v), src/FermionDetMatrix.jl:248-288) ----------- */
+
+/* cg_solve! (src/IterativeSolvers/ConjugateGradient.jl:93-167 without, :169-249 with
+ * preconditioner) of MᵀM x = b for every system.  x == b (same id) is the `x === b` case: zero
+ * initial guess, b overwritten by the solution; otherwise x is the warm start.  iters / eps are
+ * nsys entries.  use_precond != 0 applies each walker's KPM preconditioner (call
+ * smoqy_precond_update first, as ldiv! does at FermionDetMatrix.jl:259). */
+int smoqy_cg_solve_v(smoqy_ctx *ctx, int x, int b, double tol, int maxiter, int use_precond, int *iters, double *eps);
+/* host form; x_is_b != 0 ignores the contents of x on entry */
+int smoqy_cg_solve(smoqy_ctx *ctx, void *x, const void *b, int x_is_b, int sys0, int count, double tol, int maxiter, int use_precond, int *iters, double *eps);
+/* host <-> device convergence polling period of the on-device CG loop (iterations per poll) */
+int smoqy_cg_config(smoqy_ctx *ctx, int check_every);
+
+/* ---- measurement aids (bench.py) -------------------------------------------------------- */
+
+/* HIP events on the handle's stream */
+int smoqy_timer_start(smoqy_ctx *ctx);
+int smoqy_timer_stop(smoqy_ctx *ctx, double *ms);
+/* `reps` back-to-back launches of one matvec kernel between two HIP events; *ms = total */
+int smoqy_bench_matvec(smoqy_ctx *ctx, int op, int out, int in, int reps, double *ms);
+/* algorithmic bytes of one launch of `op` over all systems ((2S+F) per M / Mᵀ,
+ * 2(2S+F) per MᵀM / MMᵀ, F counted once per walker) */
+int smoqy_algorithmic_bytes(const smoqy_ctx *ctx, int op, double *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMOQY_HIP_H */

@@ -1,0 +1,212 @@
+"""ctypes binding of ``libsmoqy_hip.so`` (C ABI in ``include/smoqy_hip.h``).
+
+There is no CPU fallback: if the HIP library is missing or no MI355X is visible every entry
+point raises ``SmoqyError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libsmoqy_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "smoqy_hip.h")
+
+OP_M, OP_MT, OP_MTM, OP_MMT = 0, 1, 2, 3
+LAMBDA_MUL, LAMBDA_LDIV, LAMBDA_MULT, LAMBDA_LDIVT = 0, 1, 2, 3
+
+
+class SmoqyError(RuntimeError):
+    """Raised for any non-zero status of the C ABI (the Julia shim throws the same way, so the
+    reference's try/catch around force/action evaluations keeps rejecting the update,
+    src/EFAPFFHMCUpdater.jl:168-187)."""
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [HEADER]
+    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        r = subprocess.run(["make", "-C", CSRC, "-j4"] + (["-B"] if force else []), capture_output=True, text=True)
+        if r.returncode != 0:
+            raise SmoqyError("hipcc build of libsmoqy_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+_p = C.c_void_p
+_i = C.c_int
+_d = C.c_double
+_pi = C.POINTER(C.c_int)
+_pd = C.POINTER(C.c_double)
+
+# name -> argtypes (every function returns int except smoqy_last_error)
+SIGNATURES = {
+    "smoqy_create": [C.POINTER(_p), _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i],
+    "smoqy_destroy": [_p],
+    "smoqy_set_stream": [_p, _p],
+    "smoqy_sync": [_p],
+    "smoqy_dims": [_p, _pi],
+    "smoqy_set_tau_chunk": [_p, _i],
+    "smoqy_get_tau_chunk": [_p, _pi],
+    "smoqy_update_fields": [_p, _i, _p, _p, _p],
+    "smoqy_update_from_path_integral": [_p, _i, _p, _p, _p, _d],
+    "smoqy_get_fields": [_p, _i, _p, _p, _p],
+    "smoqy_vec_alloc": [_p, _pi],
+    "smoqy_vec_free": [_p, _i],
+    "smoqy_vec_upload": [_p, _i, _p, _i, _i],
+    "smoqy_vec_download": [_p, _i, _p, _i, _i],
+    "smoqy_vec_copy": [_p, _i, _i],
+    "smoqy_vec_dot": [_p, _i, _i, _p],
+    "smoqy_matvec_v": [_p, _i, _i, _i],
+    "smoqy_matvec": [_p, _i, _p, _p, _i, _i],
+    "smoqy_lambda_set": [_p, _i, _p],
+    "smoqy_lambda_update": [_p, _i, _p, _i, _d, _i, _p, _p, _p, _p, _p],
+    "smoqy_lambda_get": [_p, _i, _p],
+    "smoqy_lambda_apply_v": [_p, _i, _i, _i],
+    "smoqy_lambda_apply": [_p, _i, _p, _p, _p, _i, _i],
+    "smoqy_fft_forward_v": [_p, _i],
+    "smoqy_fft_inverse_v": [_p, _i],
+    "smoqy_fft_forward": [_p, _p, _i, _i],
+    "smoqy_fft_inverse": [_p, _p, _i, _i],
+    "smoqy_precond_config": [_p, _d, _i, _d, _d],
+    "smoqy_precond_update": [_p, _i, _p],
+    "smoqy_precond_get": [_p, _i, _pi, _pd, _pi, _pi, _pd, _pd],
+    "smoqy_precond_get_coefs": [_p, _i, _i, _p],
+    "smoqy_precond_set": [_p, _i, _i, _p, _p, _p],
+    "smoqy_precond_apply_v": [_p, _i, _i],
+    "smoqy_precond_apply": [_p, _p, _p, _i, _i],
+    "smoqy_cg_solve_v": [_p, _i, _i, _d, _i, _i, _p, _p],
+    "smoqy_cg_solve": [_p, _p, _p, _i, _i, _i, _d, _i, _i, _p, _p],
+    "smoqy_cg_config": [_p, _i],
+    "smoqy_timer_start": [_p],
+    "smoqy_timer_stop": [_p, _pd],
+    "smoqy_bench_matvec": [_p, _i, _i, _i, _i, _pd],
+    "smoqy_algorithmic_bytes": [_p, _i, _pd],
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library and attach prototypes.  Raises ``SmoqyError`` when it is missing —
+    callers must not fall back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SmoqyError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.smoqy_last_error.argtypes = [_p]
+    lib.smoqy_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def as_state(a, Lt, N, count=1):
+    """Check / convert ``a`` to the boundary layout: complex128, Fortran order, tau contiguous,
+    ``count`` systems stacked along the last axis.  Returns an array that aliases ``a`` when
+    ``a`` already has that layout (so in-place semantics work)."""
+    a = np.asarray(a)
+    want = Lt * N * count
+    if a.size != want:
+        raise ValueError(f"state vector has {a.size} elements, expected {want} (Ltau={Lt}, N={N}, count={count})")
+    if a.dtype == np.complex128 and (a.flags.f_contiguous or a.ndim == 1):
+        return a
+    return np.asfortranarray(a, dtype=np.complex128)
+
+
+def writable_state(a, Lt, N, count=1):
+    b = as_state(a, Lt, N, count)
+    if b is not a and not np.shares_memory(a, b):
+        raise ValueError("output vector must be a complex128 Fortran-contiguous (tau-fastest) array")
+    if not b.flags.writeable:
+        raise ValueError("output vector is read-only")
+    return b
+
+
+class Handle:
+    """Owns one ``smoqy_ctx`` (one FermionDetMatrix worth of device state per walker)."""
+
+    def __init__(self, Lt, N, neighbor_table, color_ranges, is_sym=True, nwalkers=1, nrhs=1, device=-1):
+        self.lib = load()
+        nt = np.asfortranarray(neighbor_table, dtype=np.int64)
+        cr = np.asfortranarray(color_ranges, dtype=np.int64)
+        self.Lt, self.N, self.Nh, self.ncol = int(Lt), int(N), int(nt.shape[1]) if nt.ndim == 2 else 0, int(cr.shape[1]) if cr.ndim == 2 else 0
+        self.is_sym, self.nw, self.nrhs = bool(is_sym), int(nwalkers), int(nrhs)
+        self.nsys = self.nw * self.nrhs
+        h = _p()
+        rc = self.lib.smoqy_create(C.byref(h), self.Lt, self.N, self.Nh, self.ncol, ptr(nt), ptr(cr), int(self.is_sym), 0, self.nw, self.nrhs, int(device))
+        if rc != 0:
+            raise SmoqyError(f"smoqy_create failed ({rc}): " + (self.lib.smoqy_last_error(None) or b"").decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.smoqy_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, name)(self._h, *args)
+        if rc != 0:
+            raise SmoqyError(f"{name} failed ({rc}): " + (self.lib.smoqy_last_error(self._h) or b"").decode())
+
+    # ---- small conveniences -------------------------------------------------------------------
+    def vec_alloc(self) -> int:
+        i = C.c_int(-1)
+        self.call("smoqy_vec_alloc", C.byref(i))
+        return i.value
+
+    def vec_upload(self, vid, host, sys0=0, count=None):
+        count = self.nsys - sys0 if count is None else count
+        a = as_state(host, self.Lt, self.N, count)
+        self.call("smoqy_vec_upload", vid, ptr(a), sys0, count)
+
+    def vec_download(self, vid, sys0=0, count=None):
+        count = self.nsys - sys0 if count is None else count
+        shape = (self.Lt, self.N) if count == 1 else (self.Lt, self.N, count)
+        out = np.zeros(shape, dtype=np.complex128, order="F")
+        self.call("smoqy_vec_download", vid, ptr(out), sys0, count)
+        return out
+
+    def vec_dot(self, a, b):
+        out = np.zeros(self.nsys, dtype=np.complex128)
+        self.call("smoqy_vec_dot", a, b, ptr(out))
+        return out
+
+    def algorithmic_bytes(self, op):
+        v = C.c_double(0)
+        self.call("smoqy_algorithmic_bytes", op, C.byref(v))
+        return v.value
+
+    def bench_matvec(self, op, out, inp, reps):
+        ms = C.c_double(0)
+        self.call("smoqy_bench_matvec", op, out, inp, reps, C.byref(ms))
+        return ms.value
+
+    def timer_start(self):
+        self.call("smoqy_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_double(0)
+        self.call("smoqy_timer_stop", C.byref(ms))
+        return ms.value

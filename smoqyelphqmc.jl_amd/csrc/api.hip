@@ -1,0 +1,1128 @@
+// C ABI of libsmoqy_hip.so (declared in include/smoqy_hip.h): handle management, boundary
+// layout conversion, rocFFT plans, the KPM preconditioner's host-side bookkeeping and the
+// on-device conjugate-gradient driver.  gfx950 / ROCm only; there is no CPU path.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "smoqy_internal.h"
+
+using namespace smoqy;
+
+namespace {
+std::string g_create_error;
+std::once_flag g_rocfft_once;
+}  // namespace
+
+struct WalkerPrecond {
+    int active = 0;
+    double emin = 0.0, emax = 0.0;
+    std::vector<int> order;                  // nslot
+    std::vector<std::vector<double2>> coefs; // nslot x order
+    std::vector<double> lan_a, lan_b;
+};
+
+struct smoqy_ctx {
+    Geometry g{};
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+    int Tc = 1, nchunk = 1;
+    bool user_Tc = false;
+    // geometry
+    int2 *d_bonds = nullptr;
+    int *d_col_off = nullptr;
+    // fields [nw][Lt][*]
+    double *d_expV = nullptr, *d_ch = nullptr, *d_sh = nullptr, *d_lam = nullptr;
+    // user vectors
+    std::vector<double2 *> vecs;
+    // scratch
+    double2 *d_stage = nullptr;     // nsys vectors in host layout
+    double *d_stage_real = nullptr; // max(N,Nh,Nph?) * Lt doubles (+ growth on demand)
+    size_t stage_real_cap = 0;
+    int *d_stage_int = nullptr;
+    size_t stage_int_cap = 0;
+    double2 *scr[3] = {nullptr, nullptr, nullptr};
+    // cg
+    double2 *cg_r = nullptr, *cg_p = nullptr, *cg_z = nullptr, *cg_v = nullptr;
+    double2 *part_pz = nullptr, *part_rz = nullptr, *part_c = nullptr, *d_dot_out = nullptr;
+    double *part_rr = nullptr, *part_bb = nullptr;
+    CgState *d_st = nullptr, *h_st = nullptr;
+    int check_every = 4;
+    // fft
+    rocfft_plan plan_f = nullptr, plan_b = nullptr;
+    rocfft_execution_info fft_info = nullptr;
+    void *fft_work = nullptr;
+    double2 *d_tw = nullptr;
+    // kpm
+    double rbuf = 0.10, a1 = 1.0, a2 = 1.0;
+    int nlanczos = 20;
+    int nslot = 0, maxorder = 64;
+    std::vector<WalkerPrecond> pre;
+    double *d_dbar = nullptr, *d_cbar = nullptr, *d_sbar = nullptr, *d_bounds = nullptr, *d_rand = nullptr, *d_lan = nullptr;
+    int *d_order = nullptr, *d_active = nullptr;
+    double2 *d_coefs = nullptr;
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    size_t vec_elems() const { return (size_t)g.nsys * g.Lt * g.N; }
+};
+
+#define FAIL(ctx, code, ...)                                  \
+    do {                                                      \
+        char _b[512];                                         \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                \
+        (ctx)->err = _b;                                      \
+        return (code);                                        \
+    } while (0)
+
+#define HIPCHK(ctx, expr)                                                                                   \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) FAIL(ctx, 2, "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
+    } while (0)
+
+#define FFTCHK(ctx, expr)                                                                 \
+    do {                                                                                  \
+        rocfft_status _s = (expr);                                                        \
+        if (_s != rocfft_status_success) FAIL(ctx, 3, "rocFFT error %d at %s:%d (%s)", (int)_s, __FILE__, __LINE__, #expr); \
+    } while (0)
+
+#define CHECK_CTX(ctx) \
+    if (!(ctx)) return 1
+
+static int check_vec(smoqy_ctx *c, int id)
+{
+    if (id < 0 || id >= (int)c->vecs.size() || !c->vecs[id]) FAIL(c, 1, "invalid vector id %d", id);
+    return 0;
+}
+
+static int check_launch(smoqy_ctx *c, const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(c, 2, "kernel launch failed in %s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+static void choose_chunking(smoqy_ctx *c)
+{
+    const Geometry &g = c->g;
+    if (!c->user_Tc) {
+        // largest chunk that still gives >= 2 workgroups per CU and <= 64 KiB of LDS for the
+        // fused MᵀM kernel; at small batch this degenerates to Tc = 1 (latency regime)
+        int best = 1;
+        const int cand[] = {2, 3, 4, 6, 8};
+        for (int t : cand) {
+            const long wgs = (long)((g.Lt + t - 1) / t) * g.nsys;
+            if (wgs >= 512 && fdm_lds_bytes(SMOQY_OP_MTM, g.N, t) <= 64 * 1024) best = t;
+        }
+        c->Tc = best;
+    }
+    c->nchunk = (g.Lt + c->Tc - 1) / c->Tc;
+}
+
+static FdmArgs fdm_args(smoqy_ctx *c, const double2 *in, double2 *out, double2 *partial, const CgState *cg, int sys0, int count)
+{
+    FdmArgs a{};
+    const Geometry &g = c->g;
+    a.Lt = g.Lt; a.N = g.N; a.Nh = g.Nh; a.ncol = g.ncol; a.nsys = g.nsys; a.nrhs = g.nrhs;
+    a.Tc = c->Tc; a.nchunk = c->nchunk;
+    a.bonds = c->d_bonds; a.col_off = c->d_col_off;
+    a.expV = c->d_expV; a.ch = c->d_ch; a.sh = c->d_sh;
+    a.in = in; a.out = out; a.partial = partial; a.cg = cg;
+    a.sys_first = sys0; a.sys_count = count;
+    return a;
+}
+
+static KpmArgs kpm_args(smoqy_ctx *c, double2 *v, const CgState *cg)
+{
+    KpmArgs k{};
+    const Geometry &g = c->g;
+    k.Lt = g.Lt; k.N = g.N; k.Nh = g.Nh; k.ncol = g.ncol; k.nsys = g.nsys; k.nrhs = g.nrhs; k.is_sym = g.is_sym;
+    k.bonds = c->d_bonds; k.col_off = c->d_col_off;
+    k.dbar = c->d_dbar; k.cbar = c->d_cbar; k.sbar = c->d_sbar;
+    k.order = c->d_order; k.coefs = c->d_coefs; k.bounds = c->d_bounds; k.active = c->d_active;
+    k.nslot = c->nslot; k.maxorder = c->maxorder;
+    k.v = v; k.cg = cg;
+    return k;
+}
+
+static int ensure_stage_real(smoqy_ctx *c, size_t n)
+{
+    if (n <= c->stage_real_cap) return 0;
+    if (c->d_stage_real) (void)hipFree(c->d_stage_real);
+    c->d_stage_real = nullptr;
+    HIPCHK(c, hipMalloc(&c->d_stage_real, n * sizeof(double)));
+    c->stage_real_cap = n;
+    return 0;
+}
+
+static int ensure_stage_int(smoqy_ctx *c, size_t n)
+{
+    if (n <= c->stage_int_cap) return 0;
+    if (c->d_stage_int) (void)hipFree(c->d_stage_int);
+    c->d_stage_int = nullptr;
+    HIPCHK(c, hipMalloc(&c->d_stage_int, n * sizeof(int)));
+    c->stage_int_cap = n;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *smoqy_last_error(const smoqy_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int smoqy_destroy(smoqy_ctx *c)
+{
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->plan_f) rocfft_plan_destroy(c->plan_f);
+    if (c->plan_b) rocfft_plan_destroy(c->plan_b);
+    if (c->fft_info) rocfft_execution_info_destroy(c->fft_info);
+    void *ptrs[] = {c->d_bonds, c->d_col_off, c->d_expV, c->d_ch, c->d_sh, c->d_lam, c->d_stage, c->d_stage_real, c->d_stage_int, c->scr[0], c->scr[1], c->scr[2], c->cg_r, c->cg_p,
+                    c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->fft_work, c->d_tw, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
+                    c->d_rand, c->d_lan, c->d_order, c->d_active, c->d_coefs};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (double2 *v : c->vecs)
+        if (v) (void)hipFree(v);
+    if (c->h_st) (void)hipHostFree(c->h_st);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return 0;
+}
+
+static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
+{
+    const Geometry &g = c->g;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) FAIL(c, 4, "this library is built for gfx950 (MI355X) only; device %d is %s", c->device, prop.gcnArchName);
+    HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIPCHK(c, hipEventCreate(&c->ev0));
+    HIPCHK(c, hipEventCreate(&c->ev1));
+
+    // neighbour table -> 0-based int2, colour offsets; validate the decomposition
+    std::vector<int2> bonds((size_t)std::max(g.Nh, 1));
+    for (int h = 0; h < g.Nh; ++h) {
+        const int64_t i = nt[2 * h], j = nt[2 * h + 1];
+        if (i < 1 || i > g.N || j < 1 || j > g.N || i == j) FAIL(c, 1, "neighbor_table column %d = (%lld, %lld) out of range 1..%d", h + 1, (long long)i, (long long)j, g.N);
+        bonds[h] = make_int2((int)i - 1, (int)j - 1);
+    }
+    std::vector<int> off((size_t)g.ncol + 1, 0);
+    int expect = 1;
+    for (int col = 0; col < g.ncol; ++col) {
+        const int64_t a = cr[2 * col], b = cr[2 * col + 1];
+        if (a != expect || b < a || b > g.Nh) FAIL(c, 1, "color_ranges[%d] = %lld:%lld is not a contiguous partition of 1..%d", col + 1, (long long)a, (long long)b, g.Nh);
+        off[col] = (int)a - 1;
+        off[col + 1] = (int)b;
+        expect = (int)b + 1;
+        std::vector<char> seen((size_t)g.N, 0);
+        for (int h = (int)a - 1; h < (int)b; ++h) {
+            if (seen[bonds[h].x] || seen[bonds[h].y]) FAIL(c, 1, "colour %d is not a matching: bond %d shares a site with another bond of the same colour", col + 1, h + 1);
+            seen[bonds[h].x] = seen[bonds[h].y] = 1;
+        }
+    }
+    if (expect != g.Nh + 1) FAIL(c, 1, "color_ranges cover %d of %d bonds", expect - 1, g.Nh);
+    HIPCHK(c, hipMalloc(&c->d_bonds, bonds.size() * sizeof(int2)));
+    HIPCHK(c, hipMemcpy(c->d_bonds, bonds.data(), bonds.size() * sizeof(int2), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_col_off, off.size() * sizeof(int)));
+    HIPCHK(c, hipMemcpy(c->d_col_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+
+    const size_t V = (size_t)g.Lt * g.N, VH = (size_t)g.Lt * std::max(g.Nh, 1);
+    HIPCHK(c, hipMalloc(&c->d_expV, g.nw * V * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_ch, g.nw * VH * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_sh, g.nw * VH * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_lam, g.nw * V * sizeof(double)));
+    HIPCHK(c, hipMemset(c->d_expV, 0, g.nw * V * sizeof(double)));
+    HIPCHK(c, hipMemset(c->d_ch, 0, g.nw * VH * sizeof(double)));
+    HIPCHK(c, hipMemset(c->d_sh, 0, g.nw * VH * sizeof(double)));
+    HIPCHK(c, hipMemset(c->d_lam, 0, g.nw * V * sizeof(double)));
+
+    const size_t ve = c->vec_elems();
+    HIPCHK(c, hipMalloc(&c->d_stage, ve * sizeof(double2)));
+    for (auto &s : c->scr) { HIPCHK(c, hipMalloc(&s, ve * sizeof(double2))); HIPCHK(c, hipMemset(s, 0, ve * sizeof(double2))); }
+    double2 **cgv[] = {&c->cg_r, &c->cg_p, &c->cg_z, &c->cg_v};
+    for (auto p : cgv) { HIPCHK(c, hipMalloc(p, ve * sizeof(double2))); HIPCHK(c, hipMemset(*p, 0, ve * sizeof(double2))); }
+    const size_t np = (size_t)g.nsys * g.Lt;  // nchunk <= Lt
+    HIPCHK(c, hipMalloc(&c->part_pz, np * sizeof(double2)));
+    HIPCHK(c, hipMalloc(&c->part_rz, np * sizeof(double2)));
+    HIPCHK(c, hipMalloc(&c->part_c, np * sizeof(double2)));
+    HIPCHK(c, hipMalloc(&c->part_rr, np * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->part_bb, np * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_dot_out, (size_t)g.nsys * sizeof(double2)));
+    HIPCHK(c, hipMalloc(&c->d_st, (size_t)g.nsys * sizeof(CgState)));
+    HIPCHK(c, hipMemset(c->d_st, 0, (size_t)g.nsys * sizeof(CgState)));
+    HIPCHK(c, hipHostMalloc(&c->h_st, (size_t)g.nsys * sizeof(CgState)));
+    choose_chunking(c);
+    if (fdm_lds_bytes(SMOQY_OP_MTM, g.N, 1) > 160 * 1024 - 256)
+        FAIL(c, 5, "N = %d does not fit the LDS-resident slice kernels (max %d sites)", g.N, (int)((160 * 1024 - 256) / (4 * sizeof(double2))));
+
+    // FourierTransformer: strided batched rocFFT along tau (stride nsys*N, distance 1)
+    std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+    HIPCHK(c, hipMalloc(&c->d_tw, (size_t)g.Lt * sizeof(double2)));
+    launch_make_twiddle(c->stream, c->d_tw, g.Lt);
+    {
+        rocfft_plan_description desc = nullptr;
+        FFTCHK(c, rocfft_plan_description_create(&desc));
+        size_t stride[1] = {(size_t)g.nsys * g.N};
+        FFTCHK(c, rocfft_plan_description_set_data_layout(desc, rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, nullptr, nullptr, 1, stride, 1, 1, stride, 1));
+        size_t len[1] = {(size_t)g.Lt};
+        FFTCHK(c, rocfft_plan_create(&c->plan_f, rocfft_placement_inplace, rocfft_transform_type_complex_forward, rocfft_precision_double, 1, len, (size_t)g.nsys * g.N, desc));
+        FFTCHK(c, rocfft_plan_create(&c->plan_b, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, rocfft_precision_double, 1, len, (size_t)g.nsys * g.N, desc));
+        rocfft_plan_description_destroy(desc);
+        size_t wf = 0, wb = 0;
+        FFTCHK(c, rocfft_plan_get_work_buffer_size(c->plan_f, &wf));
+        FFTCHK(c, rocfft_plan_get_work_buffer_size(c->plan_b, &wb));
+        FFTCHK(c, rocfft_execution_info_create(&c->fft_info));
+        const size_t wsz = std::max(wf, wb);
+        if (wsz) {
+            HIPCHK(c, hipMalloc(&c->fft_work, wsz));
+            FFTCHK(c, rocfft_execution_info_set_work_buffer(c->fft_info, c->fft_work, wsz));
+        }
+        FFTCHK(c, rocfft_execution_info_set_stream(c->fft_info, c->stream));
+    }
+
+    // KPM preconditioner state
+    c->nslot = g.is_sym ? (g.Lt + 1) / 2 : g.Lt;  // KPMPreconditioner.jl:254-257, 268-271
+    c->pre.resize((size_t)g.nw);
+    for (auto &p : c->pre) { p.order.assign((size_t)c->nslot, 0); p.coefs.resize((size_t)c->nslot); }
+    HIPCHK(c, hipMalloc(&c->d_dbar, (size_t)g.nw * g.N * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_cbar, (size_t)g.nw * std::max(g.Nh, 1) * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_sbar, (size_t)g.nw * std::max(g.Nh, 1) * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_bounds, (size_t)g.nw * 2 * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_rand, (size_t)g.N * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_lan, 2 * 1024 * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_order, (size_t)g.nw * c->nslot * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->d_active, (size_t)g.nw * sizeof(int)));
+    HIPCHK(c, hipMemset(c->d_active, 0, (size_t)g.nw * sizeof(int)));
+    HIPCHK(c, hipMemset(c->d_order, 0, (size_t)g.nw * c->nslot * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->d_coefs, (size_t)g.nw * c->nslot * c->maxorder * sizeof(double2)));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_launch(c, "create");
+}
+
+int smoqy_create(smoqy_ctx **out, int Ltau, int N, int Nh, int ncolors, const int64_t *neighbor_table, const int64_t *color_ranges, int is_sym, int is_complex_T, int nwalkers, int nrhs, int device_id)
+{
+    if (!out) return 1;
+    *out = nullptr;
+    if (Ltau < 1 || N < 1 || Nh < 0 || ncolors < 0 || nwalkers < 1 || nrhs < 1 || (Nh > 0 && (!neighbor_table || !color_ranges))) {
+        g_create_error = "smoqy_create: invalid dimensions or null tables";
+        return 1;
+    }
+    if (is_complex_T) {
+        g_create_error = "smoqy_create: complex matrix-element type T is not implemented (real hoppings only)";
+        return 6;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        g_create_error = "smoqy_create: no HIP device visible — this library has no CPU path";
+        return 4;
+    }
+    smoqy_ctx *c = new smoqy_ctx();
+    c->g = Geometry{Ltau, N, Nh, ncolors, nwalkers, nrhs, nwalkers * nrhs, is_sym ? 1 : 0};
+    if (device_id < 0) { if (hipGetDevice(&c->device) != hipSuccess) c->device = 0; }
+    else c->device = device_id;
+    int rc = create_impl(c, neighbor_table, color_ranges);
+    if (rc) {
+        g_create_error = c->err;
+        smoqy_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+int smoqy_set_stream(smoqy_ctx *c, void *s)
+{
+    CHECK_CTX(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    FFTCHK(c, rocfft_execution_info_set_stream(c->fft_info, c->stream));
+    return 0;
+}
+
+int smoqy_sync(smoqy_ctx *c)
+{
+    CHECK_CTX(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smoqy_dims(const smoqy_ctx *c, int d[6])
+{
+    CHECK_CTX(c);
+    d[0] = c->g.Lt; d[1] = c->g.N; d[2] = c->g.Nh; d[3] = c->g.ncol; d[4] = c->g.nw; d[5] = c->g.nrhs;
+    return 0;
+}
+
+int smoqy_set_tau_chunk(smoqy_ctx *c, int Tc)
+{
+    CHECK_CTX(c);
+    if (Tc <= 0) { c->user_Tc = false; choose_chunking(c); return 0; }
+    if (fdm_lds_bytes(SMOQY_OP_MTM, c->g.N, Tc) > 160 * 1024 - 256) FAIL(c, 1, "tau chunk %d needs more than 160 KiB of LDS at N = %d", Tc, c->g.N);
+    c->user_Tc = true;
+    c->Tc = std::min(Tc, c->g.Lt);
+    choose_chunking(c);
+    return 0;
+}
+
+int smoqy_get_tau_chunk(const smoqy_ctx *c, int *Tc)
+{
+    CHECK_CTX(c);
+    *Tc = c->Tc;
+    return 0;
+}
+
+// ---- fields -----------------------------------------------------------------------------------
+
+static int upload_real_field(smoqy_ctx *c, const double *host, double *dev, int n)
+{
+    const size_t cnt = (size_t)c->g.Lt * n;
+    if (cnt == 0) return 0;
+    if (int rc = ensure_stage_real(c, cnt)) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_stage_real, host, cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_transpose_real_in(c->stream, c->d_stage_real, dev, c->g.Lt, n);
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer is reused by the next field
+    return 0;
+}
+
+static int download_real_field(smoqy_ctx *c, const double *dev, double *host, int n)
+{
+    const size_t cnt = (size_t)c->g.Lt * n;
+    if (cnt == 0) return 0;
+    if (int rc = ensure_stage_real(c, cnt)) return rc;
+    launch_transpose_real_out(c->stream, dev, c->d_stage_real, c->g.Lt, n);
+    HIPCHK(c, hipMemcpyAsync(host, c->d_stage_real, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+#define CHECK_WALKER(c, w) \
+    if ((w) < 0 || (w) >= (c)->g.nw) FAIL(c, 1, "walker %d out of range 0..%d", (w), (c)->g.nw - 1)
+
+int smoqy_update_fields(smoqy_ctx *c, int w, const double *expV, const double *ch, const double *sh)
+{
+    CHECK_CTX(c);
+    CHECK_WALKER(c, w);
+    const Geometry &g = c->g;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = upload_real_field(c, expV, c->d_expV + (size_t)w * g.Lt * g.N, g.N)) return rc;
+    if (int rc = upload_real_field(c, ch, c->d_ch + (size_t)w * g.Lt * g.Nh, g.Nh)) return rc;
+    if (int rc = upload_real_field(c, sh, c->d_sh + (size_t)w * g.Lt * g.Nh, g.Nh)) return rc;
+    return check_launch(c, "update_fields");
+}
+
+int smoqy_update_from_path_integral(smoqy_ctx *c, int w, const double *V, const double *t, const int64_t *perm, double dtau)
+{
+    CHECK_CTX(c);
+    CHECK_WALKER(c, w);
+    const Geometry &g = c->g;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nV = (size_t)g.Lt * g.N, nT = (size_t)g.Lt * g.Nh;
+    if (int rc = ensure_stage_real(c, nV + nT)) return rc;
+    if (int rc = ensure_stage_int(c, (size_t)std::max(g.Nh, 1))) return rc;
+    std::vector<int> p0((size_t)g.Nh);
+    for (int h = 0; h < g.Nh; ++h) {
+        if (perm[h] < 1 || perm[h] > g.Nh) FAIL(c, 1, "perm[%d] = %lld out of range", h + 1, (long long)perm[h]);
+        p0[h] = (int)perm[h] - 1;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_stage_real, V, nV * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (nT) HIPCHK(c, hipMemcpyAsync(c->d_stage_real + nV, t, nT * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (g.Nh) HIPCHK(c, hipMemcpyAsync(c->d_stage_int, p0.data(), p0.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    launch_fields_from_path_integral(c->stream, c->d_stage_real, c->d_stage_real + nV, c->d_stage_int, c->d_expV + (size_t)w * nV, c->d_ch + (size_t)w * nT, c->d_sh + (size_t)w * nT, g.Lt, g.N, g.Nh, dtau,
+                                     g.is_sym ? dtau / 2 : dtau);  // FermionDetMatrix.jl:220
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_launch(c, "update_from_path_integral");
+}
+
+int smoqy_get_fields(smoqy_ctx *c, int w, double *expV, double *ch, double *sh)
+{
+    CHECK_CTX(c);
+    CHECK_WALKER(c, w);
+    const Geometry &g = c->g;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (expV) if (int rc = download_real_field(c, c->d_expV + (size_t)w * g.Lt * g.N, expV, g.N)) return rc;
+    if (ch) if (int rc = download_real_field(c, c->d_ch + (size_t)w * g.Lt * g.Nh, ch, g.Nh)) return rc;
+    if (sh) if (int rc = download_real_field(c, c->d_sh + (size_t)w * g.Lt * g.Nh, sh, g.Nh)) return rc;
+    return check_launch(c, "get_fields");
+}
+
+// ---- vectors ------------------------------------------------------------------------------------
+
+int smoqy_vec_alloc(smoqy_ctx *c, int *id)
+{
+    CHECK_CTX(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    double2 *p = nullptr;
+    HIPCHK(c, hipMalloc(&p, c->vec_elems() * sizeof(double2)));
+    HIPCHK(c, hipMemsetAsync(p, 0, c->vec_elems() * sizeof(double2), c->stream));
+    for (size_t k = 0; k < c->vecs.size(); ++k)
+        if (!c->vecs[k]) { c->vecs[k] = p; *id = (int)k; return 0; }
+    c->vecs.push_back(p);
+    *id = (int)c->vecs.size() - 1;
+    return 0;
+}
+
+int smoqy_vec_free(smoqy_ctx *c, int id)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, id)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(c->vecs[id]));
+    c->vecs[id] = nullptr;
+    return 0;
+}
+
+#define CHECK_RANGE(c, sys0, count) \
+    if ((sys0) < 0 || (count) < 1 || (sys0) + (count) > (c)->g.nsys) FAIL(c, 1, "system range [%d, %d) outside 0..%d", (sys0), (sys0) + (count), (c)->g.nsys)
+
+static int upload_into(smoqy_ctx *c, double2 *dev, const void *host, int sys0, int count)
+{
+    const Geometry &g = c->g;
+    const size_t bytes = (size_t)count * g.Lt * g.N * sizeof(double2);
+    HIPCHK(c, hipMemcpyAsync(c->d_stage, host, bytes, hipMemcpyHostToDevice, c->stream));
+    launch_transpose_in(c->stream, c->d_stage, dev, g.Lt, g.N, g.nsys, sys0, count);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_launch(c, "upload");
+}
+
+static int download_from(smoqy_ctx *c, const double2 *dev, void *host, int sys0, int count)
+{
+    const Geometry &g = c->g;
+    const size_t bytes = (size_t)count * g.Lt * g.N * sizeof(double2);
+    launch_transpose_out(c->stream, dev, c->d_stage, g.Lt, g.N, g.nsys, sys0, count);
+    HIPCHK(c, hipMemcpyAsync(host, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_launch(c, "download");
+}
+
+int smoqy_vec_upload(smoqy_ctx *c, int id, const void *host, int sys0, int count)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, id)) return rc;
+    CHECK_RANGE(c, sys0, count);
+    HIPCHK(c, hipSetDevice(c->device));
+    return upload_into(c, c->vecs[id], host, sys0, count);
+}
+
+int smoqy_vec_download(smoqy_ctx *c, int id, void *host, int sys0, int count)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, id)) return rc;
+    CHECK_RANGE(c, sys0, count);
+    HIPCHK(c, hipSetDevice(c->device));
+    return download_from(c, c->vecs[id], host, sys0, count);
+}
+
+int smoqy_vec_copy(smoqy_ctx *c, int dst, int src)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, dst)) return rc;
+    if (int rc = check_vec(c, src)) return rc;
+    if (dst != src) HIPCHK(c, hipMemcpyAsync(c->vecs[dst], c->vecs[src], c->vec_elems() * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int smoqy_vec_dot(smoqy_ctx *c, int a, int b, void *out)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, a)) return rc;
+    if (int rc = check_vec(c, b)) return rc;
+    const Geometry &g = c->g;
+    launch_dot(c->stream, c->vecs[a], c->vecs[b], c->part_c, c->d_dot_out, g.Lt, g.N, g.nsys, c->Tc, c->nchunk);
+    HIPCHK(c, hipMemcpyAsync(out, c->d_dot_out, (size_t)g.nsys * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_launch(c, "vec_dot");
+}
+
+// ---- matvec -------------------------------------------------------------------------------------
+
+static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, double2 *partial, const CgState *cg, int sys0, int count)
+{
+    if (op < SMOQY_OP_M || op > SMOQY_OP_MMT) FAIL(c, 1, "unknown matvec op %d", op);
+    FdmArgs a = fdm_args(c, in, out, partial, cg, sys0, count);
+    launch_fdm(c->stream, op, c->g.is_sym != 0, a, fdm_lds_bytes(op, c->g.N, c->Tc));
+    return check_launch(c, "matvec");
+}
+
+int smoqy_matvec_v(smoqy_ctx *c, int op, int out, int in)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, out)) return rc;
+    if (int rc = check_vec(c, in)) return rc;
+    if (out == in) {  // lmul_M!/lmul_Mt! (:372, :470): result lands in a scratch buffer that then becomes the vector
+        if (int rc = matvec_dev(c, op, c->scr[0], c->vecs[in], nullptr, nullptr, 0, c->g.nsys)) return rc;
+        std::swap(c->scr[0], c->vecs[out]);
+        return 0;
+    }
+    return matvec_dev(c, op, c->vecs[out], c->vecs[in], nullptr, nullptr, 0, c->g.nsys);
+}
+
+int smoqy_matvec(smoqy_ctx *c, int op, void *out, const void *in, int sys0, int count)
+{
+    CHECK_CTX(c);
+    CHECK_RANGE(c, sys0, count);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = upload_into(c, c->scr[1], in, sys0, count)) return rc;
+    if (int rc = matvec_dev(c, op, c->scr[2], c->scr[1], nullptr, nullptr, sys0, count)) return rc;
+    return download_from(c, c->scr[2], out, sys0, count);
+}
+
+// ---- Λ ------------------------------------------------------------------------------------------
+
+int smoqy_lambda_set(smoqy_ctx *c, int w, const double *Lambda)
+{
+    CHECK_CTX(c);
+    CHECK_WALKER(c, w);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = upload_real_field(c, Lambda, c->d_lam + (size_t)w * c->g.Lt * c->g.N, c->g.N)) return rc;
+    return check_launch(c, "lambda_set");
+}
+
+int smoqy_lambda_get(smoqy_ctx *c, int w, double *Lambda)
+{
+    CHECK_CTX(c);
+    CHECK_WALKER(c, w);
+    HIPCHK(c, hipSetDevice(c->device));
+    return download_real_field(c, c->d_lam + (size_t)w * c->g.Lt * c->g.N, Lambda, c->g.N);
+}
+
+int smoqy_lambda_update(smoqy_ctx *c, int w, const double *x, int Nph, double dtau, int ncoup, const int64_t *c2p, const int64_t *c2s, const double *alpha, const double *alpha3, const int32_t *ph_sym)
+{
+    CHECK_CTX(c);
+    CHECK_WALKER(c, w);
+    const Geometry &g = c->g;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (Nph < 0 || ncoup < 0) FAIL(c, 1, "negative Nph/ncoup");
+    const size_t nx = (size_t)Nph * g.Lt;
+    if (int rc = ensure_stage_real(c, nx + 2 * (size_t)ncoup + 1)) return rc;
+    if (int rc = ensure_stage_int(c, 3 * (size_t)ncoup + 1)) return rc;
+    std::vector<int> ib(3 * (size_t)ncoup);
+    for (int k = 0; k < ncoup; ++k) {
+        if (c2p[k] < 1 || c2p[k] > Nph || c2s[k] < 1 || c2s[k] > g.N) FAIL(c, 1, "coupling %d maps to phonon %lld / site %lld out of range", k + 1, (long long)c2p[k], (long long)c2s[k]);
+        ib[k] = (int)c2p[k] - 1;
+        ib[ncoup + k] = (int)c2s[k] - 1;
+        ib[2 * ncoup + k] = ph_sym[k] ? 1 : 0;
+    }
+    if (nx) HIPCHK(c, hipMemcpyAsync(c->d_stage_real, x, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (ncoup) {
+        HIPCHK(c, hipMemcpyAsync(c->d_stage_real + nx, alpha, (size_t)ncoup * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_stage_real + nx + ncoup, alpha3, (size_t)ncoup * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_stage_int, ib.data(), ib.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    }
+    launch_lambda_update(c->stream, c->d_lam + (size_t)w * g.Lt * g.N, g.Lt, g.N, c->d_stage_real, Nph, dtau, ncoup, c->d_stage_int, c->d_stage_int + ncoup, c->d_stage_real + nx, c->d_stage_real + nx + ncoup,
+                         c->d_stage_int + 2 * ncoup);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_launch(c, "lambda_update");
+}
+
+int smoqy_lambda_apply_v(smoqy_ctx *c, int op, int out, int in)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, out)) return rc;
+    if (int rc = check_vec(c, in)) return rc;
+    if (op < 0 || op > 3) FAIL(c, 1, "unknown lambda op %d", op);
+    const Geometry &g = c->g;
+    if (out == in) {
+        launch_lambda_apply(c->stream, op, c->scr[0], c->vecs[in], c->d_lam, g.Lt, g.N, g.nsys, g.nrhs, -1);
+        std::swap(c->scr[0], c->vecs[out]);
+    } else {
+        launch_lambda_apply(c->stream, op, c->vecs[out], c->vecs[in], c->d_lam, g.Lt, g.N, g.nsys, g.nrhs, -1);
+    }
+    return check_launch(c, "lambda_apply");
+}
+
+int smoqy_lambda_apply(smoqy_ctx *c, int op, void *out, const void *in, const double *Lambda, int sys0, int count)
+{
+    CHECK_CTX(c);
+    CHECK_RANGE(c, sys0, count);
+    if (op < 0 || op > 3) FAIL(c, 1, "unknown lambda op %d", op);
+    const Geometry &g = c->g;
+    const int w = sys0 / g.nrhs;
+    if (Lambda) if (int rc = smoqy_lambda_set(c, w, Lambda)) return rc;
+    if (int rc = upload_into(c, c->scr[1], in, sys0, count)) return rc;
+    launch_lambda_apply(c->stream, op, c->scr[2], c->scr[1], c->d_lam, g.Lt, g.N, g.nsys, g.nrhs, Lambda ? w : -1);
+    if (int rc = check_launch(c, "lambda_apply")) return rc;
+    return download_from(c, c->scr[2], out, sys0, count);
+}
+
+// ---- FourierTransformer ---------------------------------------------------------------------------
+
+static int fft_dev(smoqy_ctx *c, double2 *v, bool inverse)
+{
+    const Geometry &g = c->g;
+    void *buf[1] = {v};
+    if (!inverse) {
+        launch_fft_twiddle(c->stream, v, c->d_tw, g.Lt, g.N, g.nsys, 0);  // FourierTransformer.jl:46
+        FFTCHK(c, rocfft_execute(c->plan_f, buf, nullptr, c->fft_info)); // :47
+    } else {
+        FFTCHK(c, rocfft_execute(c->plan_b, buf, nullptr, c->fft_info)); // :60 (rocFFT's inverse carries no 1/n)
+        launch_fft_twiddle(c->stream, v, c->d_tw, g.Lt, g.N, g.nsys, 1);  // :61 with the 1/Lτ folded in
+    }
+    return check_launch(c, "fft");
+}
+
+int smoqy_fft_forward_v(smoqy_ctx *c, int id)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, id)) return rc;
+    return fft_dev(c, c->vecs[id], false);
+}
+
+int smoqy_fft_inverse_v(smoqy_ctx *c, int id)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, id)) return rc;
+    return fft_dev(c, c->vecs[id], true);
+}
+
+static int fft_host(smoqy_ctx *c, void *inout, int sys0, int count, bool inverse)
+{
+    CHECK_RANGE(c, sys0, count);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = upload_into(c, c->scr[1], inout, sys0, count)) return rc;
+    if (int rc = fft_dev(c, c->scr[1], inverse)) return rc;
+    return download_from(c, c->scr[1], inout, sys0, count);
+}
+
+int smoqy_fft_forward(smoqy_ctx *c, void *inout, int sys0, int count) { CHECK_CTX(c); return fft_host(c, inout, sys0, count, false); }
+int smoqy_fft_inverse(smoqy_ctx *c, void *inout, int sys0, int count) { CHECK_CTX(c); return fft_host(c, inout, sys0, count, true); }
+
+// ---- KPM preconditioner ---------------------------------------------------------------------------
+
+int smoqy_precond_config(smoqy_ctx *c, double rbuf, int n_lanczos, double a1, double a2)
+{
+    CHECK_CTX(c);
+    if (n_lanczos < 2 || n_lanczos > 1024 || !(rbuf > 0) || !(a1 > 0) || !(a2 >= 0)) FAIL(c, 1, "invalid preconditioner configuration");
+    c->rbuf = rbuf; c->nlanczos = n_lanczos; c->a1 = a1; c->a2 = a2;
+    return 0;
+}
+
+// extreme eigenvalues of the Lanczos tridiagonal matrix (eigmin/eigmax at KPMPreconditioner.jl:636)
+static int sturm(const double *a, const double *b, int n, double x)
+{
+    int cnt = 0;
+    double q = a[0] - x;
+    if (q < 0) ++cnt;
+    for (int i = 1; i < n; ++i) {
+        const double den = (std::fabs(q) < 1e-300) ? (q < 0 ? -1e-300 : 1e-300) : q;
+        q = a[i] - x - b[i - 1] * b[i - 1] / den;
+        if (q < 0) ++cnt;
+    }
+    return cnt;
+}
+
+static void tridiag_extremes(const double *a, const double *b, int n, double &emin, double &emax)
+{
+    double lo = a[0], hi = a[0];
+    for (int i = 0; i < n; ++i) {
+        const double r = (i > 0 ? std::fabs(b[i - 1]) : 0.0) + (i < n - 1 ? std::fabs(b[i]) : 0.0);
+        lo = std::min(lo, a[i] - r);
+        hi = std::max(hi, a[i] + r);
+    }
+    double l = lo, h = hi;
+    for (int it = 0; it < 200; ++it) { const double m = 0.5 * (l + h); if (sturm(a, b, n, m) >= 1) h = m; else l = m; }
+    emin = 0.5 * (l + h);
+    l = lo; h = hi;
+    for (int it = 0; it < 200; ++it) { const double m = 0.5 * (l + h); if (sturm(a, b, n, m) >= n) h = m; else l = m; }
+    emax = 0.5 * (l + h);
+}
+
+// kpm_coefs! (SmoQyKPMCore, restated): n Chebyshev coefficients of f on [emin, emax] from
+// Chebyshev-Gauss quadrature with 2n nodes (buffer of 2n at KPMPreconditioner.jl:749); no damping kernel.
+}  // extern "C" (templates need C++ linkage)
+template <typename F>
+static void kpm_coefs(std::vector<double> &out, int n, F f, double emin, double emax)
+{
+    const int M = 2 * n;
+    const double avg = 0.5 * (emax + emin), mag = 0.5 * (emax - emin);
+    std::vector<double> g((size_t)M), ctab((size_t)4 * M);
+    for (int m = 0; m < 4 * M; ++m) ctab[m] = std::cos(M_PI * m / (2.0 * M));  // cos(pi k (j+1/2)/M) = ctab[k(2j+1) mod 4M]
+    for (int j = 0; j < M; ++j) g[j] = f(avg + mag * ctab[2 * j + 1]);
+    out.assign((size_t)n, 0.0);
+    for (int k = 0; k < n; ++k) {
+        double acc = 0;
+        for (int j = 0; j < M; ++j) acc += g[j] * ctab[(size_t)((long long)k * (2 * j + 1) % (4 * M))];
+        out[k] = (k == 0 ? 1.0 : 2.0) * acc / M;
+    }
+}
+
+extern "C" {
+
+static int upload_precond(smoqy_ctx *c, int w)
+{
+    const WalkerPrecond &p = c->pre[w];
+    int need = 1;
+    for (int o : p.order) need = std::max(need, o);
+    if (need > c->maxorder) {  // grow the padded coefficient table and re-upload every walker
+        int cap = c->maxorder;
+        while (cap < need) cap *= 2;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(c->d_coefs));
+        c->d_coefs = nullptr;
+        HIPCHK(c, hipMalloc(&c->d_coefs, (size_t)c->g.nw * c->nslot * cap * sizeof(double2)));
+        c->maxorder = cap;
+        for (int ww = 0; ww < c->g.nw; ++ww)
+            if (ww != w && !c->pre[ww].order.empty()) if (int rc = upload_precond(c, ww)) return rc;
+    }
+    std::vector<double2> tab((size_t)c->nslot * c->maxorder, make_double2(0.0, 0.0));
+    for (int s = 0; s < c->nslot; ++s)
+        for (size_t k = 0; k < p.coefs[s].size(); ++k) tab[(size_t)s * c->maxorder + k] = p.coefs[s][k];
+    const double bnd[2] = {p.emin, p.emax};
+    HIPCHK(c, hipMemcpyAsync(c->d_coefs + (size_t)w * c->nslot * c->maxorder, tab.data(), tab.size() * sizeof(double2), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_order + (size_t)w * c->nslot, p.order.data(), (size_t)c->nslot * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_bounds + 2 * (size_t)w, bnd, sizeof(bnd), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_active + w, &p.active, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // host buffers above are temporaries
+    return 0;
+}
+
+// update_kpm_expansion_order! (:696-731) + update_kpm_expansion_coefs! (:734-795)
+static void update_expansions(smoqy_ctx *c, WalkerPrecond &p)
+{
+    const int Lt = c->g.Lt, Lo2 = (Lt + 1) / 2;
+    const double a1 = c->g.is_sym ? 2.0 * c->a1 : c->a1;  // :263
+    for (int l = 0; l < c->nslot; ++l) {
+        double phi = 2.0 * M_PI / Lt * (l + 0.5);  // :220
+        if (phi > M_PI) phi = 2.0 * M_PI - phi;    // :710
+        int n = (int)std::floor((p.emax - p.emin) * (a1 / phi + c->a2));  // :711
+        n = std::max(n, 1);
+        p.order[l] = n;
+        p.coefs[l].assign((size_t)n, make_double2(0.0, 0.0));
+    }
+    std::vector<double> re, im;
+    for (int l = 0; l < Lo2; ++l) {
+        const int n = p.order[l];
+        const double phi = 2.0 * M_PI / Lt * (l + 0.5);
+        const double cp = std::cos(phi), sp = std::sin(phi);
+        if (c->g.is_sym) {
+            kpm_coefs(re, n, [cp](double b) { return 1.0 / (b * b - 2.0 * b * cp + 1.0); }, p.emin, p.emax);  // f_B̄_sym :800
+            for (int k = 0; k < n; ++k) p.coefs[l][k] = make_double2(re[k], 0.0);
+        } else {
+            // f_B̄_asym = 1/(1 - e^{-iφ} b) :804 -> (1 - b cosφ - i b sinφ) / ((1 - b cosφ)² + (b sinφ)²)
+            kpm_coefs(re, n, [cp, sp](double b) { const double x = 1.0 - b * cp, y = b * sp; return x / (x * x + y * y); }, p.emin, p.emax);
+            kpm_coefs(im, n, [cp, sp](double b) { const double x = 1.0 - b * cp, y = b * sp; return -y / (x * x + y * y); }, p.emin, p.emax);
+            for (int k = 0; k < n; ++k) {
+                p.coefs[l][k] = make_double2(re[k], im[k]);
+                p.coefs[Lt - l - 1][k] = make_double2(re[k], -im[k]);  // :791
+            }
+        }
+    }
+}
+
+int smoqy_precond_update(smoqy_ctx *c, int w, const double *randvec)
+{
+    CHECK_CTX(c);
+    CHECK_WALKER(c, w);
+    const Geometry &g = c->g;
+    HIPCHK(c, hipSetDevice(c->device));
+    WalkerPrecond &p = c->pre[w];
+    const int n = c->nlanczos;
+    // update_B̄! :604-621
+    launch_tau_means(c->stream, c->d_expV + (size_t)w * g.Lt * g.N, c->d_ch + (size_t)w * g.Lt * g.Nh, c->d_sh + (size_t)w * g.Lt * g.Nh, c->d_dbar + (size_t)w * g.N, c->d_cbar + (size_t)w * g.Nh,
+                     c->d_sbar + (size_t)w * g.Nh, g.Lt, g.N, g.Nh, w);
+    // calculate_bounds! :625-658 (start vector drawn by the caller's rng at :634 / :652)
+    HIPCHK(c, hipMemcpyAsync(c->d_rand, randvec, (size_t)g.N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    KpmArgs k = kpm_args(c, nullptr, nullptr);
+    launch_lanczos(c->stream, k, w, c->d_rand, n, c->d_lan, c->d_lan + 1024, !g.is_sym);
+    p.lan_a.assign((size_t)n, 0.0);
+    p.lan_b.assign((size_t)n - 1, 0.0);
+    HIPCHK(c, hipMemcpyAsync(p.lan_a.data(), c->d_lan, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p.lan_b.data(), c->d_lan + 1024, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int rc = check_launch(c, "precond_update")) return rc;
+    double emin, emax;
+    tridiag_extremes(p.lan_a.data(), p.lan_b.data(), n, emin, emax);
+    if (!g.is_sym) { emin = std::sqrt(emin); emax = std::sqrt(emax); }  // :655
+    emin *= (1.0 - c->rbuf);  // :569-570
+    emax *= (1.0 + c->rbuf);
+    const int was_active = p.active;
+    bool changed = false;
+    if (0.0 < emin && emin < 1.0 && 1.0 < emax && emax < 2.0) {  // :573
+        p.active = 1;
+        if (std::fabs((emin - p.emin) / p.emin) > c->rbuf / 2 || std::fabs((emax - p.emax) / p.emax) > c->rbuf / 2) {  // :582
+            p.emin = emin;
+            p.emax = emax;
+            update_expansions(c, p);
+            changed = true;
+        }
+    } else {
+        p.active = 0;  // :593
+    }
+    if (changed) return upload_precond(c, w);
+    if (p.active != was_active) {
+        HIPCHK(c, hipMemcpyAsync(c->d_active + w, &p.active, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int smoqy_precond_get(smoqy_ctx *c, int w, int *active, double *bounds, int *order, int *norder, double *la, double *lb)
+{
+    CHECK_CTX(c);
+    CHECK_WALKER(c, w);
+    const WalkerPrecond &p = c->pre[w];
+    if (active) *active = p.active;
+    if (bounds) { bounds[0] = p.emin; bounds[1] = p.emax; }
+    if (order) std::copy(p.order.begin(), p.order.end(), order);
+    if (norder) *norder = c->nslot;
+    if (la) std::copy(p.lan_a.begin(), p.lan_a.end(), la);
+    if (lb) std::copy(p.lan_b.begin(), p.lan_b.end(), lb);
+    return 0;
+}
+
+int smoqy_precond_get_coefs(smoqy_ctx *c, int w, int slot, void *coefs)
+{
+    CHECK_CTX(c);
+    CHECK_WALKER(c, w);
+    if (slot < 0 || slot >= c->nslot) FAIL(c, 1, "slot %d out of range", slot);
+    const auto &v = c->pre[w].coefs[slot];
+    std::memcpy(coefs, v.data(), v.size() * sizeof(double2));
+    return 0;
+}
+
+int smoqy_precond_set(smoqy_ctx *c, int w, int active, const double *bounds, const int *order, const void *coefs)
+{
+    CHECK_CTX(c);
+    CHECK_WALKER(c, w);
+    const Geometry &g = c->g;
+    HIPCHK(c, hipSetDevice(c->device));
+    WalkerPrecond &p = c->pre[w];
+    p.active = active ? 1 : 0;
+    p.emin = bounds[0];
+    p.emax = bounds[1];
+    const double2 *src = (const double2 *)coefs;
+    for (int s = 0; s < c->nslot; ++s) {
+        if (order[s] < 1) FAIL(c, 1, "order[%d] = %d < 1", s, order[s]);
+        p.order[s] = order[s];
+        p.coefs[s].assign(src, src + order[s]);
+        src += order[s];
+    }
+    launch_tau_means(c->stream, c->d_expV + (size_t)w * g.Lt * g.N, c->d_ch + (size_t)w * g.Lt * g.Nh, c->d_sh + (size_t)w * g.Lt * g.Nh, c->d_dbar + (size_t)w * g.N, c->d_cbar + (size_t)w * g.Nh,
+                     c->d_sbar + (size_t)w * g.Nh, g.Lt, g.N, g.Nh, w);
+    return upload_precond(c, w);
+}
+
+// z-space part of ldiv!(u', P, u): FFT, per-frequency Chebyshev, inverse FFT on the raw buffer v
+static int precond_core(smoqy_ctx *c, double2 *v, const CgState *cg)
+{
+    void *buf[1] = {v};
+    FFTCHK(c, rocfft_execute(c->plan_f, buf, nullptr, c->fft_info));  // KPMPreconditioner.jl:375 (twiddle applied by the producer)
+    KpmArgs k = kpm_args(c, v, cg);
+    launch_cheb(c->stream, k);                                         // :381-400 (no transposes needed in this layout)
+    FFTCHK(c, rocfft_execute(c->plan_b, buf, nullptr, c->fft_info));  // :406
+    return check_launch(c, "precond_core");
+}
+
+static int precond_apply_dev(smoqy_ctx *c, double2 *out, const double2 *in)
+{
+    const Geometry &g = c->g;
+    // inactive walkers: copy (:410).  Active ones are overwritten below.
+    if (out != in) HIPCHK(c, hipMemcpyAsync(out, in, c->vec_elems() * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    bool any = false;
+    for (auto &p : c->pre) any = any || p.active;
+    if (!any) return 0;
+    HIPCHK(c, hipMemcpyAsync(c->cg_v, in, c->vec_elems() * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    launch_fft_twiddle(c->stream, c->cg_v, c->d_tw, g.Lt, g.N, g.nsys, 0);
+    if (int rc = precond_core(c, c->cg_v, nullptr)) return rc;
+    launch_fft_twiddle(c->stream, c->cg_v, c->d_tw, g.Lt, g.N, g.nsys, 1);
+    // merge: active walkers take the preconditioned vector
+    bool all = true;
+    for (auto &p : c->pre) all = all && p.active;
+    if (all) {
+        HIPCHK(c, hipMemcpyAsync(out, c->cg_v, c->vec_elems() * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        for (int w = 0; w < g.nw; ++w) {
+            if (!c->pre[w].active) continue;
+            // systems of walker w are contiguous within every slice: copy slice by slice
+            HIPCHK(c, hipMemcpy2DAsync(out + (size_t)w * g.nrhs * g.N, (size_t)g.nsys * g.N * sizeof(double2), c->cg_v + (size_t)w * g.nrhs * g.N, (size_t)g.nsys * g.N * sizeof(double2),
+                                       (size_t)g.nrhs * g.N * sizeof(double2), (size_t)g.Lt, hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    return check_launch(c, "precond_apply");
+}
+
+int smoqy_precond_apply_v(smoqy_ctx *c, int out, int in)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, out)) return rc;
+    if (int rc = check_vec(c, in)) return rc;
+    return precond_apply_dev(c, c->vecs[out], c->vecs[in]);
+}
+
+int smoqy_precond_apply(smoqy_ctx *c, void *out, const void *in, int sys0, int count)
+{
+    CHECK_CTX(c);
+    CHECK_RANGE(c, sys0, count);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = upload_into(c, c->scr[1], in, sys0, count)) return rc;
+    if (int rc = precond_apply_dev(c, c->scr[2], c->scr[1])) return rc;
+    return download_from(c, c->scr[2], out, sys0, count);
+}
+
+// ---- conjugate gradient ---------------------------------------------------------------------------
+
+int smoqy_cg_config(smoqy_ctx *c, int check_every)
+{
+    CHECK_CTX(c);
+    if (check_every < 1) FAIL(c, 1, "check_every must be >= 1");
+    c->check_every = check_every;
+    return 0;
+}
+
+static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, double tol, int maxiter, int use_precond, int *iters, double *eps)
+{
+    const Geometry &g = c->g;
+    if (maxiter < 0) FAIL(c, 1, "maxiter < 0");
+    // per-system flags
+    for (int s = 0; s < g.nsys; ++s) {
+        std::memset(&c->h_st[s], 0, sizeof(CgState));
+        c->h_st[s].precond_on = (use_precond && c->pre[s / g.nrhs].active) ? 1 : 0;
+    }
+    bool any_pre = false;
+    for (int s = 0; s < g.nsys; ++s) any_pre = any_pre || c->h_st[s].precond_on;
+    HIPCHK(c, hipMemcpyAsync(c->d_st, c->h_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyHostToDevice, c->stream));
+
+    CgArgs a{};
+    a.Lt = g.Lt; a.N = g.N; a.nsys = g.nsys; a.nrhs = g.nrhs; a.Tc = c->Tc; a.nchunk = c->nchunk;
+    a.x = x; a.r = c->cg_r; a.p = c->cg_p; a.z = c->cg_z; a.v = c->cg_v; a.tw = c->d_tw; a.b = b;
+    a.part_pz = c->part_pz; a.part_rz = c->part_rz; a.part_rr = c->part_rr; a.part_bb = c->part_bb;
+    a.st = c->d_st; a.tol = tol; a.maxiter = maxiter; a.use_precond = any_pre ? 1 : 0;
+
+    if (!x_is_b) {  // r0 = b - A x0  (ConjugateGradient.jl:119-120)
+        if (int rc = matvec_dev(c, SMOQY_OP_MTM, c->cg_z, x, nullptr, nullptr, 0, g.nsys)) return rc;
+    }
+    launch_cg_init(c->stream, a, x_is_b);
+    if (any_pre) if (int rc = precond_core(c, c->cg_v, nullptr)) return rc;  // z0 = P⁻¹ r0 (:200)
+    launch_cg_start(c->stream, a);
+    if (int rc = check_launch(c, "cg setup")) return rc;
+
+    int launched = 0;
+    bool all_done = (maxiter == 0);
+    while (!all_done) {
+        const int burst = std::min(c->check_every, maxiter - launched);
+        for (int it = 0; it < burst; ++it) {
+            FdmArgs f = fdm_args(c, c->cg_p, c->cg_z, c->part_pz, c->d_st, 0, g.nsys);
+            launch_fdm(c->stream, SMOQY_OP_MTM, g.is_sym != 0, f, fdm_lds_bytes(SMOQY_OP_MTM, g.N, c->Tc));  // z = A p, partial p·Ap
+            launch_cg_update_xr(c->stream, a);
+            if (any_pre) if (int rc = precond_core(c, c->cg_v, c->d_st)) return rc;
+            launch_cg_check(c->stream, a);
+            launch_cg_update_p(c->stream, a);
+        }
+        launched += burst;
+        HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (int rc = check_launch(c, "cg loop")) return rc;
+        all_done = true;
+        for (int s = 0; s < g.nsys; ++s) all_done = all_done && (c->h_st[s].done != 0);
+        if (launched >= maxiter) break;
+    }
+    if (maxiter == 0) {
+        HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    for (int s = 0; s < g.nsys; ++s) {
+        const CgState &st = c->h_st[s];
+        if (!std::isfinite(st.eps)) FAIL(c, 7, "non-finite residual in CG for system %d (iters %d)", s, st.iters);
+        if (iters) iters[s] = st.done == 1 ? st.iters : maxiter;  // (maxiter, ϵ) on non-convergence (:166 / :248)
+        if (eps) eps[s] = st.eps;
+    }
+    return 0;
+}
+
+int smoqy_cg_solve_v(smoqy_ctx *c, int x, int b, double tol, int maxiter, int use_precond, int *iters, double *eps)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, x)) return rc;
+    if (int rc = check_vec(c, b)) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (x == b) {
+        // `x === b` (:112-116): r0 = b, x = 0.  b's buffer becomes x; a scratch copy serves as b.
+        HIPCHK(c, hipMemcpyAsync(c->scr[0], c->vecs[b], c->vec_elems() * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+        return cg_dev(c, c->vecs[x], c->scr[0], true, tol, maxiter, use_precond, iters, eps);
+    }
+    return cg_dev(c, c->vecs[x], c->vecs[b], false, tol, maxiter, use_precond, iters, eps);
+}
+
+int smoqy_cg_solve(smoqy_ctx *c, void *x, const void *b, int x_is_b, int sys0, int count, double tol, int maxiter, int use_precond, int *iters, double *eps)
+{
+    CHECK_CTX(c);
+    CHECK_RANGE(c, sys0, count);
+    HIPCHK(c, hipSetDevice(c->device));
+    const Geometry &g = c->g;
+    if (count != g.nsys) {
+        // systems outside the range get b = 0, which the start kernel retires immediately
+        HIPCHK(c, hipMemsetAsync(c->scr[1], 0, c->vec_elems() * sizeof(double2), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->scr[2], 0, c->vec_elems() * sizeof(double2), c->stream));
+    }
+    if (int rc = upload_into(c, c->scr[1], b, sys0, count)) return rc;
+    if (!x_is_b) if (int rc = upload_into(c, c->scr[2], x, sys0, count)) return rc;
+    std::vector<int> it((size_t)g.nsys);
+    std::vector<double> ep((size_t)g.nsys);
+    if (int rc = cg_dev(c, c->scr[2], c->scr[1], x_is_b != 0, tol, maxiter, use_precond, it.data(), ep.data())) return rc;
+    for (int k = 0; k < count; ++k) {
+        if (iters) iters[k] = it[sys0 + k];
+        if (eps) eps[k] = ep[sys0 + k];
+    }
+    return download_from(c, c->scr[2], x, sys0, count);
+}
+
+// ---- measurement aids -------------------------------------------------------------------------------
+
+int smoqy_timer_start(smoqy_ctx *c)
+{
+    CHECK_CTX(c);
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    return 0;
+}
+
+int smoqy_timer_stop(smoqy_ctx *c, double *ms)
+{
+    CHECK_CTX(c);
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float f = 0;
+    HIPCHK(c, hipEventElapsedTime(&f, c->ev0, c->ev1));
+    *ms = f;
+    return 0;
+}
+
+int smoqy_bench_matvec(smoqy_ctx *c, int op, int out, int in, int reps, double *ms)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, out)) return rc;
+    if (int rc = check_vec(c, in)) return rc;
+    if (out == in) FAIL(c, 1, "bench_matvec needs distinct vectors");
+    FdmArgs a = fdm_args(c, c->vecs[in], c->vecs[out], nullptr, nullptr, 0, c->g.nsys);
+    const size_t lds = fdm_lds_bytes(op, c->g.N, c->Tc);
+    launch_fdm(c->stream, op, c->g.is_sym != 0, a, lds);  // warm-up
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < reps; ++r) launch_fdm(c->stream, op, c->g.is_sym != 0, a, lds);
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float f = 0;
+    HIPCHK(c, hipEventElapsedTime(&f, c->ev0, c->ev1));
+    *ms = f;
+    return check_launch(c, "bench_matvec");
+}
+
+int smoqy_algorithmic_bytes(const smoqy_ctx *c, int op, double *bytes)
+{
+    CHECK_CTX(c);
+    const Geometry &g = c->g;
+    const double V = (double)g.Lt * g.N;
+    const double S = 16.0 * V, F = 8.0 * V + 16.0 * g.Lt * g.Nh;
+    const double one = g.nsys * 2.0 * S + g.nw * F;
+    *bytes = (op == SMOQY_OP_MTM || op == SMOQY_OP_MMT) ? 2.0 * one : one;
+    return 0;
+}
+
+}  // extern "C"

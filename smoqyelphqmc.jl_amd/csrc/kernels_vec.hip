@@ -1,0 +1,493 @@
+// Layout conversion at the C-ABI boundary, field refresh, Λ applies, dot products, FFT
+// twiddles and the BLAS-1 side of the on-device conjugate gradient (gfx950).
+//
+// Reference semantics cited per kernel.  All reductions are deterministic: fixed-order
+// per-workgroup partials (wavefront __shfl_down trees + one LDS hop) that every consumer
+// workgroup re-reduces in the same order, so no atomics and no run-to-run jitter.
+#include "smoqy_internal.h"
+
+namespace smoqy {
+
+__device__ __forceinline__ double wsum(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// workgroup sum of a (re, im) pair, broadcast to every thread
+__device__ __forceinline__ double2 block_sum_bcast(double2 v, double *red /* >= 18 doubles */)
+{
+    v.x = wsum(v.x);
+    v.y = wsum(v.y);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) { red[2 * wave] = v.x; red[2 * wave + 1] = v.y; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double2 t = make_double2(0.0, 0.0);
+        for (int w = 0; w < nwave; ++w) { t.x += red[2 * w]; t.y += red[2 * w + 1]; }
+        red[16] = t.x;
+        red[17] = t.y;
+    }
+    __syncthreads();
+    return make_double2(red[16], red[17]);
+}
+
+// every thread gets sum_{c<n} part[c] (complex) in a fixed order
+__device__ __forceinline__ double2 reduce_partials(const double2 *part, int n, double *red)
+{
+    double2 t = make_double2(0.0, 0.0);
+    for (int c = threadIdx.x; c < n; c += blockDim.x) { t.x += part[c].x; t.y += part[c].y; }
+    return block_sum_bcast(t, red);
+}
+
+__device__ __forceinline__ double reduce_partials(const double *part, int n, double *red)
+{
+    double2 t = make_double2(0.0, 0.0);
+    for (int c = threadIdx.x; c < n; c += blockDim.x) t.x += part[c];
+    return block_sum_bcast(t, red).x;
+}
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 cdiv(double2 a, double2 b)
+{
+    const double d = b.x * b.x + b.y * b.y;
+    return make_double2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout conversion: reference (tau fastest, Ltau x N per system) <-> device [l][s][i]
+// 32 x 32 tiles through LDS so both sides are coalesced
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool TO_DEVICE>
+__global__ void transpose_kernel(const T *__restrict__ src, T *__restrict__ dst, int Lt, int N, int dev_slice_stride /* nsys*N or n */, int dev_off /* sys*N */, size_t host_sys_stride /* Lt*N */)
+{
+    __shared__ T tile[32][33];
+    const int sysl = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int l0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+    const T *hsrc = TO_DEVICE ? src + (size_t)sysl * host_sys_stride : nullptr;
+    T *hdst = TO_DEVICE ? nullptr : dst + (size_t)sysl * host_sys_stride;
+    const size_t doff = (size_t)dev_off + (size_t)sysl * N;
+    if (TO_DEVICE) {
+        for (int r = ty; r < 32; r += 8) {  // r: site within tile, tx: slice within tile
+            const int i = i0 + r, l = l0 + tx;
+            if (i < N && l < Lt) tile[r][tx] = hsrc[(size_t)i * Lt + l];
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {  // r: slice within tile, tx: site within tile
+            const int l = l0 + r, i = i0 + tx;
+            if (i < N && l < Lt) dst[(size_t)l * dev_slice_stride + doff + i] = tile[tx][r];
+        }
+    } else {
+        for (int r = ty; r < 32; r += 8) {
+            const int l = l0 + r, i = i0 + tx;
+            if (i < N && l < Lt) tile[tx][r] = src[(size_t)l * dev_slice_stride + doff + i];
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int i = i0 + r, l = l0 + tx;
+            if (i < N && l < Lt) hdst[(size_t)i * Lt + l] = tile[r][tx];
+        }
+    }
+}
+
+void launch_transpose_in(hipStream_t st, const double2 *h, double2 *d, int Lt, int N, int nsys, int sys0, int count)
+{
+    dim3 g((Lt + 31) / 32, (N + 31) / 32, count);
+    hipLaunchKernelGGL((transpose_kernel<double2, true>), g, dim3(256), 0, st, h, d, Lt, N, nsys * N, sys0 * N, (size_t)Lt * N);
+}
+void launch_transpose_out(hipStream_t st, const double2 *d, double2 *h, int Lt, int N, int nsys, int sys0, int count)
+{
+    dim3 g((Lt + 31) / 32, (N + 31) / 32, count);
+    hipLaunchKernelGGL((transpose_kernel<double2, false>), g, dim3(256), 0, st, d, h, Lt, N, nsys * N, sys0 * N, (size_t)Lt * N);
+}
+void launch_transpose_real_in(hipStream_t st, const double *src, double *dst, int Lt, int n)
+{
+    dim3 g((Lt + 31) / 32, (n + 31) / 32, 1);
+    hipLaunchKernelGGL((transpose_kernel<double, true>), g, dim3(256), 0, st, src, dst, Lt, n, n, 0, (size_t)0);
+}
+void launch_transpose_real_out(hipStream_t st, const double *src, double *dst, int Lt, int n)
+{
+    dim3 g((Lt + 31) / 32, (n + 31) / 32, 1);
+    hipLaunchKernelGGL((transpose_kernel<double, false>), g, dim3(256), 0, st, src, dst, Lt, n, n, 0, (size_t)0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// update!(fdm, fpi) — src/FermionDetMatrix.jl:208-236.  V is N x Ltau, t is Nh x Ltau (both
+// site/bond fastest == already slice-major); outputs slice-major.
+// ---------------------------------------------------------------------------------------------
+__global__ void fields_kernel(const double *__restrict__ V, const double *__restrict__ t, const int *__restrict__ perm0, double *__restrict__ expV, double *__restrict__ ch,
+                              double *__restrict__ sh, int Lt, int N, int Nh, double dtau, double dtau_k)
+{
+    const size_t tot = (size_t)Lt * (N + Nh);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
+        if (idx < (size_t)Lt * N) {
+            expV[idx] = exp(-dtau * V[idx]);  // :217
+        } else {
+            const size_t j = idx - (size_t)Lt * N;
+            const int l = (int)(j / Nh), h = (int)(j - (size_t)l * Nh);
+            const double tt = t[(size_t)l * Nh + perm0[h]];  // :224-228
+            const double a = dtau_k * fabs(tt);
+            ch[j] = cosh(a);                                                    // :230
+            sh[j] = (tt > 0 ? 1.0 : (tt < 0 ? -1.0 : 0.0)) * sinh(a);           // :231
+        }
+    }
+}
+
+void launch_fields_from_path_integral(hipStream_t st, const double *V, const double *t, const int *perm0, double *expV, double *ch, double *sh, int Lt, int N, int Nh, double dtau, double dtau_k)
+{
+    const size_t tot = (size_t)Lt * (N + Nh);
+    int blocks = (int)((tot + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fields_kernel, dim3(blocks), dim3(256), 0, st, V, t, perm0, expV, ch, sh, Lt, N, Nh, dtau, dtau_k);
+}
+
+// ---------------------------------------------------------------------------------------------
+// update_Λ! — src/holstein_shift_matrix.jl:2-44  (x is Nph x Ltau, phonon fastest)
+// ---------------------------------------------------------------------------------------------
+__global__ void lambda_init_kernel(double *Lam, int Lt, int N)
+{
+    const size_t tot = (size_t)Lt * N;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) Lam[idx] = (idx < (size_t)N) ? 1.0 : -1.0;  // :11-12
+}
+
+__global__ void lambda_couple_kernel(double *Lam, int Lt, int N, const double *__restrict__ x, int Nph, double dtau, int ncoup, const int *c2p, const int *c2s, const double *alpha, const double *alpha3,
+                                     const int *phsym)
+{
+    // one thread per (slice, coupling).  Several couplings may hit the same site: they multiply,
+    // and multiplication order does not matter for the few couplings per site that occur, but
+    // to stay race free the launch walks couplings sequentially (grid covers slices only).
+    for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < Lt; l += gridDim.x * blockDim.x) {
+        for (int c = 0; c < ncoup; ++c) {
+            if (!phsym[c]) continue;
+            const double xp = x[(size_t)l * Nph + c2p[c]];
+            Lam[(size_t)l * N + c2s[c]] *= exp(dtau * (alpha[c] * xp + alpha3[c] * xp * xp * xp) / 2);  // :37
+        }
+    }
+}
+
+void launch_lambda_update(hipStream_t st, double *Lam, int Lt, int N, const double *x, int Nph, double dtau, int ncoup, const int *c2p, const int *c2s, const double *alpha, const double *alpha3, const int *phsym)
+{
+    hipLaunchKernelGGL(lambda_init_kernel, dim3(256), dim3(256), 0, st, Lam, Lt, N);
+    if (ncoup > 0) hipLaunchKernelGGL(lambda_couple_kernel, dim3((Lt + 63) / 64), dim3(64), 0, st, Lam, Lt, N, x, Nph, dtau, ncoup, c2p, c2s, alpha, alpha3, phsym);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Λ applies — src/holstein_shift_matrix.jl:47-71, 74-98, 102-126, 129-153.
+// In slice-major layout all four are one-slice shifts with a diagonal scale; out-of-place here,
+// the host wrapper handles out == in by ping-ponging buffers.
+// ---------------------------------------------------------------------------------------------
+__global__ void lambda_apply_kernel(int op, double2 *__restrict__ out, const double2 *__restrict__ in, const double *__restrict__ Lam, int Lt, int N, int nsys, int nrhs, int wfixed)
+{
+    const size_t per_slice = (size_t)nsys * N, tot = per_slice * Lt;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(idx / per_slice);
+        const size_t rem = idx - (size_t)l * per_slice;
+        const int s = (int)(rem / N), i = (int)(rem - (size_t)s * N);
+        const int w = wfixed >= 0 ? wfixed : s / nrhs;
+        const double *L = Lam + (size_t)w * Lt * N;
+        double2 o;
+        if (op == SMOQY_LAMBDA_MUL) {  // (Λv)[l] = Λ[l+1] v[l+1], wrap to slice 0
+            const int lp = (l + 1 == Lt) ? 0 : l + 1;
+            const double f = L[(size_t)lp * N + i];
+            const double2 v = in[(size_t)lp * per_slice + rem];
+            o = make_double2(f * v.x, f * v.y);
+        } else if (op == SMOQY_LAMBDA_LDIV) {  // (Λ⁻¹v)[l] = v[l-1] / Λ[l]
+            const int lm = (l == 0) ? Lt - 1 : l - 1;
+            const double f = L[(size_t)l * N + i];
+            const double2 v = in[(size_t)lm * per_slice + rem];
+            o = make_double2(v.x / f, v.y / f);
+        } else if (op == SMOQY_LAMBDA_MULT) {  // (Λᵀv)[l] = Λ[l] v[l-1]
+            const int lm = (l == 0) ? Lt - 1 : l - 1;
+            const double f = L[(size_t)l * N + i];
+            const double2 v = in[(size_t)lm * per_slice + rem];
+            o = make_double2(f * v.x, f * v.y);
+        } else {  // (Λ⁻ᵀv)[l] = v[l+1] / Λ[l+1]
+            const int lp = (l + 1 == Lt) ? 0 : l + 1;
+            const double f = L[(size_t)lp * N + i];
+            const double2 v = in[(size_t)lp * per_slice + rem];
+            o = make_double2(v.x / f, v.y / f);
+        }
+        out[idx] = o;
+    }
+}
+
+void launch_lambda_apply(hipStream_t st, int op, double2 *out, const double2 *in, const double *Lam, int Lt, int N, int nsys, int nrhs, int wfixed)
+{
+    const size_t tot = (size_t)Lt * nsys * N;
+    int blocks = (int)((tot + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(lambda_apply_kernel, dim3(blocks), dim3(256), 0, st, op, out, in, Lam, Lt, N, nsys, nrhs, wfixed);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dot(a, b) per system (LinearAlgebra.dot: conjugate-linear in a)
+// ---------------------------------------------------------------------------------------------
+__global__ void dot_partial_kernel(const double2 *__restrict__ a, const double2 *__restrict__ b, double2 *__restrict__ partial, int Lt, int N, int nsys, int Tc, int nchunk)
+{
+    __shared__ double red[18];
+    const int chunk = blockIdx.x % nchunk, sys = blockIdx.x / nchunk;
+    const int l0 = chunk * Tc, nk = min(Tc, Lt - l0);
+    const size_t sstride = (size_t)nsys * N;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {
+        const int k = idx / N, i = idx - k * N;
+        const size_t off = (size_t)(l0 + k) * sstride + (size_t)sys * N + i;
+        const double2 x = a[off], y = b[off];
+        acc.x += x.x * y.x + x.y * y.y;
+        acc.y += x.x * y.y - x.y * y.x;
+    }
+    const double2 t = block_sum_bcast(acc, red);
+    if (threadIdx.x == 0) partial[(size_t)sys * nchunk + chunk] = t;
+}
+
+__global__ void dot_final_kernel(const double2 *__restrict__ partial, double2 *__restrict__ out, int nchunk)
+{
+    __shared__ double red[18];
+    const double2 t = reduce_partials(partial + (size_t)blockIdx.x * nchunk, nchunk, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+
+void launch_dot(hipStream_t st, const double2 *a, const double2 *b, double2 *partial, double2 *out, int Lt, int N, int nsys, int Tc, int nchunk)
+{
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(nchunk * nsys), dim3(kThreads), 0, st, a, b, partial, Lt, N, nsys, Tc, nchunk);
+    hipLaunchKernelGGL(dot_final_kernel, dim3(nsys), dim3(64), 0, st, partial, out, nchunk);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FourierTransformer twiddle — src/FourierTransformer.jl:15, 46, 61:  θ_l = exp(-iπ l/Lτ).
+// forward:  v[l] *= θ_l/√Lτ  (before the FFT);  inverse:  v[l] *= conj(θ_l)/√Lτ  (after the
+// unnormalised inverse FFT, i.e. (1/Lτ)·√Lτ/θ_l).
+// ---------------------------------------------------------------------------------------------
+__global__ void make_twiddle_kernel(double2 *tw, int Lt)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= Lt) return;
+    double s, c;
+    sincospi(-(double)l / (double)Lt, &s, &c);
+    const double f = 1.0 / sqrt((double)Lt);
+    tw[l] = make_double2(c * f, s * f);
+}
+
+void launch_make_twiddle(hipStream_t st, double2 *tw, int Lt) { hipLaunchKernelGGL(make_twiddle_kernel, dim3((Lt + 63) / 64), dim3(64), 0, st, tw, Lt); }
+
+__device__ __forceinline__ double2 twiddle(const double2 *__restrict__ tw, int l, bool conj_)
+{
+    const double2 t = tw[l];
+    return conj_ ? make_double2(t.x, -t.y) : t;
+}
+
+__global__ void twiddle_kernel(double2 *v, const double2 *__restrict__ tw, int Lt, int N, int nsys, int inverse)
+{
+    const size_t per_slice = (size_t)nsys * N, tot = per_slice * Lt;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(idx / per_slice);
+        v[idx] = cmul(v[idx], twiddle(tw, l, inverse != 0));
+    }
+}
+
+void launch_fft_twiddle(hipStream_t st, double2 *v, const double2 *tw, int Lt, int N, int nsys, int inverse)
+{
+    const size_t tot = (size_t)Lt * nsys * N;
+    int blocks = (int)((tot + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(twiddle_kernel, dim3(blocks), dim3(256), 0, st, v, tw, Lt, N, nsys, inverse);
+}
+
+// ---------------------------------------------------------------------------------------------
+// update_B̄! — src/KPMPreconditioner.jl:604-621: means over tau of the three field arrays
+// ---------------------------------------------------------------------------------------------
+__global__ void tau_means_kernel(const double *__restrict__ expV, const double *__restrict__ ch, const double *__restrict__ sh, double *dbar, double *cbar, double *sbar, int Lt, int N, int Nh)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < N) {
+        double a = 0;
+        for (int l = 0; l < Lt; ++l) a += expV[(size_t)l * N + j];
+        dbar[j] = a / Lt;
+    } else if (j < N + Nh) {
+        const int h = j - N;
+        double a = 0, b = 0;
+        for (int l = 0; l < Lt; ++l) { a += ch[(size_t)l * Nh + h]; b += sh[(size_t)l * Nh + h]; }
+        cbar[h] = a / Lt;
+        sbar[h] = b / Lt;
+    }
+}
+
+void launch_tau_means(hipStream_t st, const double *expV, const double *ch, const double *sh, double *dbar, double *cbar, double *sbar, int Lt, int N, int Nh, int w)
+{
+    (void)w;
+    hipLaunchKernelGGL(tau_means_kernel, dim3((N + Nh + 255) / 256), dim3(256), 0, st, expV, ch, sh, dbar, cbar, sbar, Lt, N, Nh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// conjugate gradient, BLAS-1 side — src/IterativeSolvers/ConjugateGradient.jl:93-249.
+// One workgroup per (tau-chunk, system); per-system scalars never leave the device.
+// ---------------------------------------------------------------------------------------------
+#define CG_PROLOGUE                                                        \
+    __shared__ double red[18];                                             \
+    const int chunk = blockIdx.x % a.nchunk, sys = blockIdx.x / a.nchunk; \
+    const int l0 = chunk * a.Tc, nk = min(a.Tc, a.Lt - l0);               \
+    const size_t sstride = (size_t)a.nsys * a.N;                           \
+    const size_t base = (size_t)sys * a.N;                                 \
+    const size_t pidx = (size_t)sys * a.nchunk + chunk;                    \
+    (void)red; (void)l0; (void)nk; (void)sstride; (void)base; (void)pidx;
+
+// :108-121 — r0 = b (x = 0) or r0 = b - z where z = A x0 was computed by the MᵀM kernel;
+// partial |b|², |r|²; and the FFT input v = θ r / √Lτ when preconditioning.
+template <bool X_IS_B>
+__global__ void __launch_bounds__(kThreads) cg_init_kernel(CgArgs a)
+{
+    CG_PROLOGUE
+    const bool pre = a.use_precond && a.st[sys].precond_on;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int idx = threadIdx.x; idx < nk * a.N; idx += blockDim.x) {
+        const int k = idx / a.N, i = idx - k * a.N, l = l0 + k;
+        const size_t off = (size_t)l * sstride + base + i;
+        const double2 bv = a.b[off];
+        double2 rv;
+        if (X_IS_B) {
+            rv = bv;
+            a.x[off] = make_double2(0.0, 0.0);
+        } else {
+            const double2 zv = a.z[off];
+            rv = make_double2(bv.x - zv.x, bv.y - zv.y);
+        }
+        a.r[off] = rv;
+        acc.x += bv.x * bv.x + bv.y * bv.y;
+        acc.y += rv.x * rv.x + rv.y * rv.y;
+        if (a.use_precond) a.v[off] = pre ? cmul(rv, twiddle(a.tw, l, false)) : make_double2(0.0, 0.0);
+    }
+    const double2 t = block_sum_bcast(acc, red);
+    if (threadIdx.x == 0) { a.part_bb[pidx] = t.x; a.part_rr[pidx] = t.y; }
+}
+
+// :123-134 / :199-212 — z0 = P⁻¹ r0 (or r0), p0 = z0, partial r·z, eps0, early exit
+__global__ void __launch_bounds__(kThreads) cg_start_kernel(CgArgs a)
+{
+    CG_PROLOGUE
+    const double bb = reduce_partials(a.part_bb + (size_t)sys * a.nchunk, a.nchunk, red);
+    const double rr = reduce_partials(a.part_rr + (size_t)sys * a.nchunk, a.nchunk, red);
+    const double eps = (bb > 0.0) ? sqrt(rr) / sqrt(bb) : 0.0;
+    const bool conv = !(bb > 0.0) || eps < a.tol;
+    const bool pre = a.use_precond && a.st[sys].precond_on;
+    double2 acc = make_double2(0.0, 0.0);
+    if (!conv) {
+        for (int idx = threadIdx.x; idx < nk * a.N; idx += blockDim.x) {
+            const int k = idx / a.N, i = idx - k * a.N, l = l0 + k;
+            const size_t off = (size_t)l * sstride + base + i;
+            const double2 rv = a.r[off];
+            const double2 zv = pre ? cmul(a.v[off], twiddle(a.tw, l, true)) : rv;
+            a.z[off] = zv;
+            a.p[off] = zv;
+            acc.x += rv.x * zv.x + rv.y * zv.y;
+            acc.y += rv.x * zv.y - rv.y * zv.x;
+        }
+    }
+    const double2 t = block_sum_bcast(acc, red);
+    if (threadIdx.x == 0) {
+        a.part_rz[pidx] = t;
+        if (chunk == 0) {
+            CgState &s = a.st[sys];
+            s.normb2 = bb;
+            s.eps = eps;
+            s.iters = 0;
+            s.done = conv ? 1 : 0;
+        }
+    }
+}
+
+// :219-226 / :219-226 — α = (r·z)/(p·Ap);  x += α p;  r -= α Ap;  partial |r|²;  v = θ r/√Lτ
+__global__ void __launch_bounds__(kThreads) cg_update_xr_kernel(CgArgs a)
+{
+    CG_PROLOGUE
+    if (a.st[sys].done) return;
+    const double2 rz = reduce_partials(a.part_rz + (size_t)sys * a.nchunk, a.nchunk, red);
+    const double2 pz = reduce_partials(a.part_pz + (size_t)sys * a.nchunk, a.nchunk, red);
+    const double2 alpha = cdiv(rz, pz);
+    const bool pre = a.use_precond && a.st[sys].precond_on;
+    double acc = 0.0;
+    for (int idx = threadIdx.x; idx < nk * a.N; idx += blockDim.x) {
+        const int k = idx / a.N, i = idx - k * a.N, l = l0 + k;
+        const size_t off = (size_t)l * sstride + base + i;
+        const double2 pv = a.p[off], zv = a.z[off];
+        double2 xv = a.x[off], rv = a.r[off];
+        const double2 ap = cmul(alpha, pv), az = cmul(alpha, zv);
+        xv.x += ap.x; xv.y += ap.y;
+        rv.x -= az.x; rv.y -= az.y;
+        a.x[off] = xv;
+        a.r[off] = rv;
+        acc += rv.x * rv.x + rv.y * rv.y;
+        if (a.use_precond) a.v[off] = pre ? cmul(rv, twiddle(a.tw, l, false)) : make_double2(0.0, 0.0);
+    }
+    const double2 t = block_sum_bcast(make_double2(acc, 0.0), red);
+    if (threadIdx.x == 0) {
+        a.part_rr[pidx] = t.x;
+        if (chunk == 0) { a.st[sys].rho_re = rz.x; a.st[sys].rho_im = rz.y; }
+    }
+}
+
+// :229-237 — eps = |r|/|b|, stop test (on the unpreconditioned residual), z = P⁻¹ r, partial r·z
+__global__ void __launch_bounds__(kThreads) cg_check_kernel(CgArgs a)
+{
+    CG_PROLOGUE
+    // snapshot before anybody can have rewritten it: the writer (chunk 0, thread 0) only
+    // writes after the block-wide reductions below, which every thread of chunk 0 has passed
+    const int done_before = a.st[sys].done;
+    if (done_before) return;
+    const double rr = reduce_partials(a.part_rr + (size_t)sys * a.nchunk, a.nchunk, red);
+    const double eps = sqrt(rr) / sqrt(a.st[sys].normb2);
+    const bool conv = eps < a.tol;
+    const bool pre = a.use_precond && a.st[sys].precond_on;
+    double2 acc = make_double2(0.0, 0.0);
+    if (!conv) {
+        for (int idx = threadIdx.x; idx < nk * a.N; idx += blockDim.x) {
+            const int k = idx / a.N, i = idx - k * a.N, l = l0 + k;
+            const size_t off = (size_t)l * sstride + base + i;
+            const double2 rv = a.r[off];
+            const double2 zv = pre ? cmul(a.v[off], twiddle(a.tw, l, true)) : rv;
+            a.z[off] = zv;
+            acc.x += rv.x * zv.x + rv.y * zv.y;
+            acc.y += rv.x * zv.y - rv.y * zv.x;
+        }
+    }
+    const double2 t = block_sum_bcast(acc, red);
+    if (threadIdx.x == 0) {
+        a.part_rz[pidx] = t;
+        if (chunk == 0) {
+            CgState &s = a.st[sys];
+            s.eps = eps;
+            s.iters += 1;
+            if (conv) s.done = 1;
+            else if (s.iters >= a.maxiter) s.done = 2;
+        }
+    }
+}
+
+// :239-245 — β = (r·z)_new/(r·z)_old;  p = z + β p
+__global__ void __launch_bounds__(kThreads) cg_update_p_kernel(CgArgs a)
+{
+    CG_PROLOGUE
+    if (a.st[sys].done) return;
+    const double2 rz = reduce_partials(a.part_rz + (size_t)sys * a.nchunk, a.nchunk, red);
+    const double2 beta = cdiv(rz, make_double2(a.st[sys].rho_re, a.st[sys].rho_im));
+    for (int idx = threadIdx.x; idx < nk * a.N; idx += blockDim.x) {
+        const int k = idx / a.N, i = idx - k * a.N;
+        const size_t off = (size_t)(l0 + k) * sstride + base + i;
+        const double2 zv = a.z[off], bp = cmul(beta, a.p[off]);
+        a.p[off] = make_double2(zv.x + bp.x, zv.y + bp.y);
+    }
+}
+
+void launch_cg_init(hipStream_t s, const CgArgs &a, bool x_is_b)
+{
+    if (x_is_b) hipLaunchKernelGGL((cg_init_kernel<true>), dim3(a.nchunk * a.nsys), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((cg_init_kernel<false>), dim3(a.nchunk * a.nsys), dim3(kThreads), 0, s, a);
+}
+void launch_cg_start(hipStream_t s, const CgArgs &a) { hipLaunchKernelGGL(cg_start_kernel, dim3(a.nchunk * a.nsys), dim3(kThreads), 0, s, a); }
+void launch_cg_update_xr(hipStream_t s, const CgArgs &a) { hipLaunchKernelGGL(cg_update_xr_kernel, dim3(a.nchunk * a.nsys), dim3(kThreads), 0, s, a); }
+void launch_cg_check(hipStream_t s, const CgArgs &a) { hipLaunchKernelGGL(cg_check_kernel, dim3(a.nchunk * a.nsys), dim3(kThreads), 0, s, a); }
+void launch_cg_update_p(hipStream_t s, const CgArgs &a) { hipLaunchKernelGGL(cg_update_p_kernel, dim3(a.nchunk * a.nsys), dim3(kThreads), 0, s, a); }
+void launch_cg_begin_iter(hipStream_t, const CgArgs &) {}
+
+}  // namespace smoqy

@@ -1,0 +1,105 @@
+// Internal declarations shared by the translation units of libsmoqy_hip.so (gfx950 only).
+//
+// Device data layout ("slice-major", chosen for MI355X — see DESIGN.md §3):
+//   state vector batch   v[l][s][i]   complex128, l = imaginary-time slice, s = system, i = site
+//   per-walker fields    expV[w][l][i], cosh/sinh[w][l][h], Lambda[w][l][i]   float64
+// i.e. one time slice of one system is a contiguous N-vector (perfectly coalesced for the
+// checkerboard kernels and for the per-frequency Chebyshev recurrence), and the tau-FFT is a
+// strided batched transform with stride nsys*N and distance 1.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/smoqy_hip.h"
+
+namespace smoqy {
+
+constexpr int kThreads = 256;       // workgroup size of the slice kernels (4 wavefronts)
+constexpr int kMaxPartials = 1024;  // upper bound on tau-chunks per system
+
+struct Geometry {
+    int Lt, N, Nh, ncol, nw, nrhs, nsys;
+    int is_sym;
+};
+
+// per-system CG state living on the device
+struct CgState {
+    double normb2;      // |b|^2
+    double rho_re, rho_im;  // r.z of the current iteration
+    double eps;         // last relative residual
+    int iters;          // completed iterations
+    int done;           // 0 running, 1 converged, 2 maxiter reached
+    int precond_on;     // this system's walker has an active preconditioner
+    int pad;
+};
+
+struct FdmArgs {
+    int Lt, N, Nh, ncol, nsys, nrhs, Tc, nchunk;
+    const int2 *bonds;      // [Nh] 0-based site pairs, colour sorted
+    const int *col_off;     // [ncol+1] bond offsets of the colours
+    const double *expV, *ch, *sh;
+    const double2 *in;
+    double2 *out;
+    double2 *partial;       // [nsys][nchunk] dot(in, out) partials, or nullptr
+    const CgState *cg;      // optional: skip systems with done != 0
+    int sys_first, sys_count;  // systems [sys_first, sys_first + sys_count) are processed
+};
+
+struct KpmArgs {
+    int Lt, N, Nh, ncol, nsys, nrhs, is_sym;
+    const int2 *bonds;
+    const int *col_off;
+    const double *dbar, *cbar, *sbar;   // [w][N], [w][Nh], [w][Nh] tau-means
+    const int *order;                   // [w][nslot]
+    const double2 *coefs;               // [w][nslot][maxorder]
+    const double *bounds;               // [w][2]
+    const int *active;                  // [w]
+    int nslot, maxorder;
+    double2 *v;                         // in place, slice(=frequency)-major
+    const CgState *cg;
+};
+
+// ---- launchers (defined in the .hip files) -----------------------------------------------
+void launch_fdm(hipStream_t st, int op, bool sym, const FdmArgs &a, size_t lds_bytes);
+size_t fdm_lds_bytes(int op, int N, int Tc);
+
+void launch_transpose_in(hipStream_t st, const double2 *host_layout, double2 *dev_layout, int Lt, int N, int nsys, int sys0, int count);
+void launch_transpose_out(hipStream_t st, const double2 *dev_layout, double2 *host_layout, int Lt, int N, int nsys, int sys0, int count);
+void launch_transpose_real_in(hipStream_t st, const double *src, double *dst, int Lt, int n);   // (Lt x n col-major) -> [l][n]
+void launch_transpose_real_out(hipStream_t st, const double *src, double *dst, int Lt, int n);  // [l][n] -> (Lt x n col-major)
+void launch_fields_from_path_integral(hipStream_t st, const double *V, const double *t, const int *perm0, double *expV, double *ch, double *sh, int Lt, int N, int Nh, double dtau, double dtau_k);
+void launch_lambda_update(hipStream_t st, double *Lam, int Lt, int N, const double *x, int Nph, double dtau, int ncoup, const int *c2p, const int *c2s, const double *alpha, const double *alpha3, const int *phsym);
+void launch_lambda_apply(hipStream_t st, int op, double2 *out, const double2 *in, const double *Lam, int Lt, int N, int nsys, int nrhs, int wslot_override);
+void launch_dot(hipStream_t st, const double2 *a, const double2 *b, double2 *partial, double2 *out, int Lt, int N, int nsys, int Tc, int nchunk);
+void launch_fft_twiddle(hipStream_t st, double2 *v, const double2 *tw, int Lt, int N, int nsys, int inverse);
+void launch_make_twiddle(hipStream_t st, double2 *tw, int Lt);
+void launch_tau_means(hipStream_t st, const double *expV, const double *ch, const double *sh, double *dbar, double *cbar, double *sbar, int Lt, int N, int Nh, int w);
+void launch_lanczos(hipStream_t st, const KpmArgs &k, int w, const double *randvec, int nsteps, double *alpha, double *beta, bool use_BtB);
+void launch_cheb(hipStream_t st, const KpmArgs &k);
+
+// CG kernels
+struct CgArgs {
+    int Lt, N, nsys, nrhs, Tc, nchunk;
+    double2 *x, *r, *p, *z, *v;
+    const double2 *tw;            // [Lt] theta_l / sqrt(Lt)
+    const double2 *b;
+    double2 *part_pz, *part_rz;   // [nsys][nchunk]
+    double *part_rr, *part_bb;    // [nsys][nchunk]
+    CgState *st;
+    double tol;
+    int maxiter;
+    int use_precond;
+};
+void launch_cg_init(hipStream_t s, const CgArgs &a, bool x_is_b);       // r, x, |b|^2, |r|^2 partials, v = theta r
+void launch_cg_start(hipStream_t s, const CgArgs &a);                   // z, p, rho, eps, done (after optional precond)
+void launch_cg_update_xr(hipStream_t s, const CgArgs &a);               // K2
+void launch_cg_check(hipStream_t s, const CgArgs &a);                   // K3
+void launch_cg_update_p(hipStream_t s, const CgArgs &a);                // K4
+void launch_cg_begin_iter(hipStream_t s, const CgArgs &a);              // bookkeeping: rho <- new, iters++
+
+}  // namespace smoqy
