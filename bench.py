@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py — QMC sweeps/sec + FermionDetMatrix matvec GB/s vs the HBM roofline, fp64.
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU; every rank owns ``--walkers-per-gpu`` independent Monte Carlo walkers of
+the synthetic Holstein-honeycomb workload (default L = 16, Ltau = 128 — the configuration
+BASELINE.json's target is quoted on).  Walkers never exchange state (the reference's
+one-MPI-rank-per-walker model), so there is no data-path collective: RCCL is only used for the
+barrier and the max-over-ranks of the wall time.  A "step" is one synthetic sweep of every
+walker: reflection + swap + HMC(Nt = 24) = 27 CG solves of MᵀM x = b with the KPM
+preconditioner (smoqyelphqmc.jl_amd/walkers.py).  Inputs (phonon fields, lattice tables) are
+generated before the timed region; random vectors are drawn on the host inside it, as the
+reference does.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      dominant kernel = the fused MᵀM apply (fdm_kernel<…, MTM>): algorithmic bytes per
+                launch (2·(2S+F) per system, F once per walker) divided by the
+                average launch duration measured with HIP events on the kernel's own stream.
+  cpu_baseline  the CPU oracle (a single-threaded restatement of the reference algorithm, NOT the
+                Julia reference, which cannot run here) timed on a bounded sample of the same
+                workload on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="holstein_honeycomb_L16_Ltau128")
+    ap.add_argument("--walkers-per-gpu", type=int, default=8)
+    ap.add_argument("--tau-chunk", type=int, default=0)
+    ap.add_argument("--check-every", type=int, default=0)
+    ap.add_argument("--matvec-reps", type=int, default=400)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-scan", action="store_true", help="also report matvec GB/s vs batch size")
+    return ap.parse_args()
+
+
+def cpu_baseline(workload, tol, Nt):
+    """Time the CPU oracle (single thread) on a bounded sample of the workload: one
+    preconditioned action solve (tol) and one force solve (sqrt(tol)) of walker 0, each
+    including the preconditioner update, extrapolated to the 27 solves of a sweep."""
+    import numpy as np
+
+    import smoqyelphqmc_amd as sq
+    from oracle import oracle as orc
+
+    lat = sq.lattice
+    m = lat.CONFIGS[workload](walker=0)
+    nt, perm, colors = lat.checkerboard_decomposition(m.fpi.neighbor_table)
+    expV, ch, sh = orc.update_fields(m.fpi.V, m.fpi.t, perm, m.fpi.dtau, True)
+    o = orc.OracleFDM(nt, expV, ch, sh, True)
+    P = orc.OracleKPM(o)
+    g = np.random.default_rng(1)
+    Lt, N = expV.shape
+    b = np.asfortranarray(g.standard_normal((Lt, N)) + 1j * g.standard_normal((Lt, N)))
+    t0 = time.perf_counter()
+    P.update(g.standard_normal(N))
+    _, it_a, _ = o.cg_solve(b, precond=P, tol=tol, maxiter=10000)
+    t_action = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    P.update(g.standard_normal(N))
+    _, it_f, _ = o.cg_solve(b, precond=P, tol=float(np.sqrt(tol)), maxiter=10000)
+    t_force = time.perf_counter() - t0
+    # matvec alone, for the GB/s comparison
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        o.mul_MtM(b)
+    t_mv = (time.perf_counter() - t0) / reps
+    t_sweep = 3 * t_action + Nt * t_force
+    V = Lt * N
+    alg = 2 * (2 * 16 * V + 8 * V + 16 * Lt * nt.shape[1])
+    return {
+        "value": 1.0 / t_sweep,
+        "unit": "sweeps/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"walker 0 of {workload}: 1 action solve (tol {tol:g}, {it_a} iters, {t_action:.2f} s) + 1 force solve (tol {np.sqrt(tol):g}, {it_f} iters, {t_force:.2f} s) "
+        f"with the KPM preconditioner, single thread, extrapolated to 3 action + {Nt} force solves per sweep",
+        "matvec_MtM_ms": t_mv * 1e3,
+        "matvec_MtM_GBs": alg / t_mv / 1e9,
+        "host_cores_available": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+
+    import smoqyelphqmc_amd as sq
+    from smoqyelphqmc_amd import _lib as L
+    from smoqyelphqmc_amd.walkers import WalkerBatch
+
+    wpg = args.walkers_per_gpu
+    batch = WalkerBatch(args.workload, nwalkers=wpg, walker0=rank * wpg, device=local_rank, check_every=args.check_every or None, tau_chunk=args.tau_chunk or None)
+
+    def fence():
+        batch.h.call("smoqy_sync")
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        batch.sweep()
+    batch.stats.solves = batch.stats.iters_sum = 0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.sweep()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    sweeps = world * wpg * args.steps
+    value = sweeps / elapsed
+
+    if rank == 0:
+        # --- roofline of the dominant kernel: fused MᵀM apply ------------------------------------
+        h = batch.h
+        a, b = h.vec_alloc(), h.vec_alloc()
+        g = np.random.default_rng(3)
+        h.vec_upload(a, np.asfortranarray(g.standard_normal((batch.Lt, batch.N, wpg)) + 1j * g.standard_normal((batch.Lt, batch.N, wpg))))
+        h.bench_matvec(L.OP_MTM, b, a, 50)
+        ms = h.bench_matvec(L.OP_MTM, b, a, args.matvec_reps)
+        per_launch_s = ms * 1e-3 / args.matvec_reps
+        alg = h.algorithmic_bytes(L.OP_MTM)
+        achieved = alg / per_launch_s / 1e9
+        tc = L.C.c_int(0)
+        h.call("smoqy_get_tau_chunk", L.C.byref(tc))
+        roofline = {
+            "bound": "hbm",
+            "kernel": "fdm_kernel<Sym, MtM> (fused MᵀM apply)",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": alg,
+            "avg_launch_us": per_launch_s * 1e6,
+            "systems_per_launch": wpg,
+            "tau_chunk": tc.value,
+            "note": "working set is L2/Infinity-Cache resident at this size; fraction is algorithmic bytes over wall time, see DESIGN.md",
+        }
+        extra = {}
+        if args.batch_scan:
+            scan = []
+            for nb in (1, 2, 4, 8, 16, 32, 64):
+                hb = L.Handle(batch.Lt, batch.N, batch.nt, batch.colors, True, nb, 1, local_rank)
+                for w in range(nb):
+                    m = batch.models[w % wpg]
+                    hb.call("smoqy_update_from_path_integral", w, L.ptr(m.fpi.V), L.ptr(m.fpi.t), L.ptr(batch.perm), L.C.c_double(m.fpi.dtau))
+                va, vb = hb.vec_alloc(), hb.vec_alloc()
+                hb.vec_upload(va, np.asfortranarray(g.standard_normal((batch.Lt, batch.N, nb)) + 1j * g.standard_normal((batch.Lt, batch.N, nb))))
+                best = None
+                for tcand in (1, 2, 3, 4):
+                    hb.call("smoqy_set_tau_chunk", tcand)
+                    hb.bench_matvec(L.OP_MTM, vb, va, 20)
+                    t_ms = hb.bench_matvec(L.OP_MTM, vb, va, 200) / 200
+                    gbs = hb.algorithmic_bytes(L.OP_MTM) / (t_ms * 1e-3) / 1e9
+                    if best is None or gbs > best["GBs"]:
+                        best = {"batch": nb, "tau_chunk": tcand, "us": t_ms * 1e3, "GBs": gbs, "frac": gbs / HBM_PEAK_GBS}
+                scan.append(best)
+                hb.close()
+            extra["matvec_batch_scan"] = scan
+        cpu = None if args.no_cpu_baseline else cpu_baseline(args.workload, batch.tol, batch.Nt)
+        out = {
+            "metric": "QMC sweeps/sec (27 preconditioned CG solves per sweep) + FermionDetMatrix matvec GB/s vs HBM roofline, fp64",
+            "value": value,
+            "unit": "sweeps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": args.workload,
+                "walkers_per_gpu": wpg,
+                "walkers_total": world * wpg,
+                "solves_per_sweep": batch.solves_per_sweep,
+                "cg_tol": batch.tol,
+                "avg_cg_iters": batch.stats.iters_sum / max(batch.stats.solves, 1),
+                "preconditioner": "KPM (Sym)",
+                "parallelism": f"walker-parallel, {world} rank(s) x {wpg} walkers, no collective",
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        out.update(extra)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

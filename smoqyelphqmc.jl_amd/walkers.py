@@ -1,0 +1,149 @@
+"""Lock-step batch of independent Monte Carlo walkers on one GPU, and the synthetic "sweep"
+that ``bench.py`` times.
+
+The reference runs one walker per MPI rank with no state exchange
+(tutorials/holstein_honeycomb_mpi.jl:60-72); here every rank (= GPU) owns ``nwalkers`` walkers
+whose pseudofermion-action solves advance in lock step through one ``smoqy_ctx`` so that all
+kernels are launched once for the whole batch (SURVEY.md §7 hard part 1).
+
+A sweep follows tutorials/holstein_honeycomb.jl:611-684: reflection update + swap update +
+one HMC update with ``Nt`` force evaluations, i.e. ``1 + 1 + (Nt + 1)`` CG solves
+(27 at ``Nt = 24``).  Everything the hot path owns runs on the device exactly as in the
+reference call stack:
+
+  sample_pseudofermion_fields!   Φ = Λᵀ Mᵀ R                        src/PFFCalculator.jl:56-76
+  calculate_fermionic_action!    Ψ = Λ⁻¹ (MᵀM)⁻¹ Λ⁻ᵀ Φ, S = Φ·Ψ     src/PFFCalculator.jl:79-116
+  force operator applies         ΛΨ, M ΛΨ, Mᵀ M ΛΨ                   src/PFFCalculator.jl:146-153
+  update!(fdm, fpi)              exp/cosh/sinh refresh               src/FermionDetMatrix.jl:208-236
+  update_preconditioner!         B̄ means, Lanczos, KPM coefficients  src/KPMPreconditioner.jl:554-597
+
+What is NOT part of the hot path (SmoQyDQMC's EFA leapfrog, the bosonic action, the force
+contractions ∂M/∂x — SURVEY.md §8(f)) is replaced by a synthetic drift of the phonon field
+``x ← x + δ·π`` with a fixed random "momentum" π, so successive solves see slowly moving
+fields like an HMC trajectory does.  Random numbers are drawn on the host (the reference's rng
+stays on the host).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+from . import lattice as lat
+
+
+@dataclass
+class SweepStats:
+    solves: int = 0
+    iters_sum: int = 0
+    action: float = 0.0
+
+
+class WalkerBatch:
+    def __init__(self, workload: str, nwalkers: int = 1, walker0: int = 0, is_sym: bool = True, device: int = -1, tol: float = 1e-10, maxiter: int = 10_000, Nt: int = 24,
+                 drift: float = 0.02, check_every: int | None = None, tau_chunk: int | None = None, smooth: bool = False):
+        self.models = [lat.CONFIGS[workload](walker=walker0 + w, smooth=smooth) for w in range(nwalkers)]
+        m0 = self.models[0]
+        self.workload = workload
+        self.nt, self.perm, self.colors = lat.checkerboard_decomposition(m0.fpi.neighbor_table)
+        self.Lt, self.N, self.nw = m0.fpi.Ltau, m0.fpi.N, nwalkers
+        self.dtau = m0.fpi.dtau
+        self.tol, self.tol_force, self.maxiter, self.Nt, self.drift = tol, float(np.sqrt(tol)), maxiter, Nt, drift  # tutorials/holstein_honeycomb.jl:591
+        self.h = L.Handle(self.Lt, self.N, self.nt, self.colors, is_sym, nwalkers, 1, device)
+        if check_every:
+            self.h.call("smoqy_cg_config", int(check_every))
+        if tau_chunk:
+            self.h.call("smoqy_set_tau_chunk", int(tau_chunk))
+        self.rng = [np.random.Generator(np.random.PCG64(lat.SEED0 + 7919 * (walker0 + w) + 1)) for w in range(nwalkers)]
+        # device-resident PFFCalculator state (src/PFFCalculator.jl:9-16): Φ, u, u′, u″
+        self.phi, self.u, self.u1, self.u2 = (self.h.vec_alloc() for _ in range(4))
+        self.stats = SweepStats()
+        self.refresh_fields()
+
+    # ---- field plumbing -------------------------------------------------------------------------
+    def refresh_fields(self):
+        """update!(fdm, fpi) and update_Λ! for every walker from its current phonon field."""
+        for w, m in enumerate(self.models):
+            m.refresh_from_x()
+            self.h.call("smoqy_update_from_path_integral", w, L.ptr(m.fpi.V), L.ptr(m.fpi.t), L.ptr(self.perm), C.c_double(m.fpi.dtau))
+            hol = m.elph.holstein
+            if hol is not None:
+                self.h.call("smoqy_lambda_update", w, L.ptr(m.elph.x), m.elph.x.shape[0], C.c_double(m.elph.dtau), len(hol.alpha), L.ptr(np.ascontiguousarray(hol.coupling_to_phonon, dtype=np.int64)),
+                            L.ptr(np.ascontiguousarray(hol.coupling_to_site, dtype=np.int64)), L.ptr(np.ascontiguousarray(hol.alpha, dtype=np.float64)), L.ptr(np.ascontiguousarray(hol.alpha3, dtype=np.float64)),
+                            L.ptr(np.ascontiguousarray(hol.ph_sym_form, dtype=np.int32)))
+            else:
+                self.h.call("smoqy_lambda_update", w, None, 0, C.c_double(m.elph.dtau), 0, None, None, None, None, None)
+
+    def update_preconditioner(self):
+        for w in range(self.nw):
+            rv = self.rng[w].standard_normal(self.N)  # randn!(rng, v) at KPMPreconditioner.jl:634
+            self.h.call("smoqy_precond_update", w, L.ptr(rv))
+
+    # ---- PFFCalculator on the device ---------------------------------------------------------------
+    def sample_pseudofermion_fields(self):
+        """Φ = Λᵀ Mᵀ R with R ~ CN(0,1) drawn on the host; returns |R|² per walker."""
+        R = np.empty((self.Lt, self.N, self.nw), dtype=np.complex128, order="F")
+        for w in range(self.nw):
+            # randn!(rng, Φ) for ComplexF64 draws real and imaginary parts with variance 1/2
+            z = self.rng[w].standard_normal((2, self.N, self.Lt)) * np.sqrt(0.5)
+            R[:, :, w] = (z[0] + 1j * z[1]).T
+        self.h.vec_upload(self.phi, R)
+        sf = self.h.vec_dot(self.phi, self.phi).real
+        self.h.call("smoqy_matvec_v", L.OP_MT, self.phi, self.phi)          # lmul_Mt!  (:71)
+        self.h.call("smoqy_lambda_apply_v", L.LAMBDA_MULT, self.phi, self.phi)  # mul_Λᵀ!  (:73)
+        return sf
+
+    def calculate_fermionic_action(self, tol, use_precond=True):
+        """Returns (S_f, iters, eps) per walker; Ψ is left in ``self.u``."""
+        if use_precond:
+            self.update_preconditioner()                                     # ldiv! -> update_preconditioner! (FermionDetMatrix.jl:259)
+        self.h.call("smoqy_lambda_apply_v", L.LAMBDA_LDIVT, self.u, self.phi)  # Ψ = Λ⁻ᵀ Φ   (:97)
+        iters = np.zeros(self.nw, dtype=np.int32)
+        eps = np.zeros(self.nw)
+        self.h.call("smoqy_cg_solve_v", self.u, self.u, C.c_double(tol), int(self.maxiter), int(bool(use_precond)), L.ptr(iters), L.ptr(eps))  # (:99)
+        self.h.call("smoqy_lambda_apply_v", L.LAMBDA_LDIV, self.u, self.u)   # Ψ = Λ⁻¹ Ψ   (:107)
+        sf = self.h.vec_dot(self.phi, self.u)                                 # S = Φ·Ψ     (:109)
+        self.stats.solves += self.nw
+        self.stats.iters_sum += int(iters.sum())
+        return sf.real, iters, eps
+
+    def force_operator_applies(self):
+        """The operator applies of calculate_derivative_fermionic_action! that belong to the hot
+        path (src/PFFCalculator.jl:146, 148, 153); the ∂M/∂x contractions are out of scope."""
+        self.h.call("smoqy_lambda_apply_v", L.LAMBDA_MUL, self.u1, self.u)   # ΛΨ
+        self.h.call("smoqy_matvec_v", L.OP_M, self.u2, self.u1)              # AΨ = M ΛΨ
+        self.h.call("smoqy_matvec_v", L.OP_MT, self.u1, self.u2)             # Mᵀ AΨ
+
+    def drift_fields(self, pis, step):
+        for m, pi in zip(self.models, pis):
+            m.elph.x += step * pi
+        self.refresh_fields()
+
+    # ---- one synthetic sweep -------------------------------------------------------------------------
+    def sweep(self):
+        last = None
+        # reflection-like and swap-like global moves: sample Φ, move the fields, one action solve
+        # (src/reflection_update.jl:69-114, src/swap_update.jl)
+        for _ in range(2):
+            self.sample_pseudofermion_fields()
+            pis = [g.standard_normal(m.elph.x.shape) for g, m in zip(self.rng, self.models)]
+            self.drift_fields(pis, self.drift)
+            last = self.calculate_fermionic_action(self.tol)
+            self.drift_fields(pis, -self.drift)  # "rejected": restore x, update! (src/reflection_update.jl)
+        # HMC trajectory (src/EFAPFFHMCUpdater.jl:102-276)
+        self.sample_pseudofermion_fields()
+        pis = [g.standard_normal(m.elph.x.shape) for g, m in zip(self.rng, self.models)]
+        for _ in range(self.Nt):
+            self.calculate_fermionic_action(self.tol_force)
+            self.force_operator_applies()
+            self.drift_fields(pis, self.drift / self.Nt)
+        last = self.calculate_fermionic_action(self.tol)
+        self.drift_fields(pis, -self.drift)      # reject: restore x
+        self.stats.action = float(np.sum(last[0]))
+        return last
+
+    @property
+    def solves_per_sweep(self):
+        return 2 + self.Nt + 1
