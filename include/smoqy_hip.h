@@ -89,6 +89,8 @@ int smoqy_vec_dot(smoqy_ctx *ctx, int a, int b, void *out);
 
 /* out = op(in) for every system; out == in allowed (lmul_M!/lmul_Mt!, :372, :470) */
 int smoqy_matvec_v(smoqy_ctx *ctx, int op, int out, int in);
+/* testing aid: route the applies through the generic kernels (any colouring / Asym path) */
+int smoqy_matvec_force_generic(smoqy_ctx *ctx, int on);
 /* host form: `count` vectors starting at system sys0 (fields of walker sys/nrhs); out == in allowed */
 int smoqy_matvec(smoqy_ctx *ctx, int op, void *out, const void *in, int sys0, int count);
 
@@ -122,6 +124,11 @@ int smoqy_precond_config(smoqy_ctx *ctx, double rbuf, int n_lanczos, double a1, 
 /* update_preconditioner! (src/KPMPreconditioner.jl:554-597) for one walker.  randvec holds the
  * N normal deviates the caller's rng produces at :634 (the rng stays on the host). */
 int smoqy_precond_update(smoqy_ctx *ctx, int walker, const double *randvec);
+/* the same for every walker of the handle in one pass; randvecs is N x nwalkers */
+int smoqy_precond_update_all(smoqy_ctx *ctx, const double *randvecs);
+/* testing aid: route the KPM kernels through the generic (any colouring) fallback instead of the
+ * register-resident fast path */
+int smoqy_precond_force_generic(smoqy_ctx *ctx, int on);
 /* state readback: active flag, bounds[2], order[] (cld(Ltau,2) entries for Sym, Ltau for Asym;
  * returns the count in *norder), Lanczos alpha[n] / beta[n-1].  Any pointer may be NULL. */
 int smoqy_precond_get(smoqy_ctx *ctx, int walker, int *active, double *bounds, int *order, int *norder, double *lanczos_alpha, double *lanczos_beta);

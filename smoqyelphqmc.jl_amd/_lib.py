@@ -62,6 +62,7 @@ SIGNATURES = {
     "smoqy_vec_copy": [_p, _i, _i],
     "smoqy_vec_dot": [_p, _i, _i, _p],
     "smoqy_matvec_v": [_p, _i, _i, _i],
+    "smoqy_matvec_force_generic": [_p, _i],
     "smoqy_matvec": [_p, _i, _p, _p, _i, _i],
     "smoqy_lambda_set": [_p, _i, _p],
     "smoqy_lambda_update": [_p, _i, _p, _i, _d, _i, _p, _p, _p, _p, _p],
@@ -74,6 +75,8 @@ SIGNATURES = {
     "smoqy_fft_inverse": [_p, _p, _i, _i],
     "smoqy_precond_config": [_p, _d, _i, _d, _d],
     "smoqy_precond_update": [_p, _i, _p],
+    "smoqy_precond_update_all": [_p, _p],
+    "smoqy_precond_force_generic": [_p, _i],
     "smoqy_precond_get": [_p, _i, _pi, _pd, _pi, _pi, _pd, _pd],
     "smoqy_precond_get_coefs": [_p, _i, _i, _p],
     "smoqy_precond_set": [_p, _i, _i, _p, _p, _p],

@@ -64,6 +64,13 @@ struct smoqy_ctx {
     double *d_dbar = nullptr, *d_cbar = nullptr, *d_sbar = nullptr, *d_bounds = nullptr, *d_rand = nullptr, *d_lan = nullptr;
     int *d_order = nullptr, *d_active = nullptr;
     double2 *d_coefs = nullptr;
+    KpmGeom kg{};
+    FdmFast ff{};
+    double2 *d_csf = nullptr;
+    int2 *d_pbonds = nullptr;
+    int *d_poff = nullptr, *d_psrc = nullptr;
+    double2 *d_pcs = nullptr;
+    double *h_lan = nullptr;  // pinned [nw][2][1024]
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -115,6 +122,7 @@ static void choose_chunking(smoqy_ctx *c)
         int best = 1;
         const int cand[] = {2, 3, 4, 6, 8};
         for (int t : cand) {
+            if (c->ff.enabled && t > 2) break;  // the register-resident kernels hold <= 3 slices
             const long wgs = (long)((g.Lt + t - 1) / t) * g.nsys;
             if (wgs >= 512 && fdm_lds_bytes(SMOQY_OP_MTM, g.N, t) <= 64 * 1024) best = t;
         }
@@ -184,12 +192,13 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->fft_info) rocfft_execution_info_destroy(c->fft_info);
     void *ptrs[] = {c->d_bonds, c->d_col_off, c->d_expV, c->d_ch, c->d_sh, c->d_lam, c->d_stage, c->d_stage_real, c->d_stage_int, c->scr[0], c->scr[1], c->scr[2], c->cg_r, c->cg_p,
                     c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->fft_work, c->d_tw, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
-                    c->d_rand, c->d_lan, c->d_order, c->d_active, c->d_coefs};
+                    c->d_rand, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (double2 *v : c->vecs)
         if (v) (void)hipFree(v);
     if (c->h_st) (void)hipHostFree(c->h_st);
+    if (c->h_lan) (void)hipHostFree(c->h_lan);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -298,8 +307,46 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     HIPCHK(c, hipMalloc(&c->d_cbar, (size_t)g.nw * std::max(g.Nh, 1) * sizeof(double)));
     HIPCHK(c, hipMalloc(&c->d_sbar, (size_t)g.nw * std::max(g.Nh, 1) * sizeof(double)));
     HIPCHK(c, hipMalloc(&c->d_bounds, (size_t)g.nw * 2 * sizeof(double)));
-    HIPCHK(c, hipMalloc(&c->d_rand, (size_t)g.N * sizeof(double)));
-    HIPCHK(c, hipMalloc(&c->d_lan, 2 * 1024 * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_rand, (size_t)g.nw * g.N * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_lan, (size_t)g.nw * 2 * 1024 * sizeof(double)));
+    HIPCHK(c, hipHostMalloc(&c->h_lan, (size_t)g.nw * 2 * 1024 * sizeof(double)));
+    {
+        // padded per-colour bond lists for the register-resident KPM kernels (kernels_kpm.hip)
+        std::vector<int2> pb;
+        std::vector<int> psrc, poff((size_t)g.ncol + 1, 0);
+        int maxp = 0;
+        for (int col = 0; col < g.ncol; ++col) {
+            std::vector<char> seen((size_t)g.N, 0);
+            poff[col] = (int)pb.size();
+            for (int h = off[col]; h < off[col + 1]; ++h) {
+                pb.push_back(bonds[h]);
+                psrc.push_back(h);
+                seen[bonds[h].x] = seen[bonds[h].y] = 1;
+            }
+            for (int i = 0; i < g.N; ++i)
+                if (!seen[i]) { pb.push_back(make_int2(i, i)); psrc.push_back(-1); }
+            poff[col + 1] = (int)pb.size();
+            maxp = std::max(maxp, poff[col + 1] - poff[col]);
+        }
+        c->kg.ptotal = (int)pb.size();
+        c->kg.threads = std::max(64, ((maxp + 63) / 64) * 64);
+        c->kg.fast = (g.ncol >= 1 && g.ncol <= kMaxColours && maxp <= 1024) ? 1 : 0;
+        HIPCHK(c, hipMalloc(&c->d_pbonds, std::max<size_t>(pb.size(), 1) * sizeof(int2)));
+        HIPCHK(c, hipMalloc(&c->d_psrc, std::max<size_t>(pb.size(), 1) * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->d_poff, poff.size() * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->d_pcs, (size_t)g.nw * std::max<size_t>(pb.size(), 1) * sizeof(double2)));
+        if (!pb.empty()) {
+            HIPCHK(c, hipMemcpy(c->d_pbonds, pb.data(), pb.size() * sizeof(int2), hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(c->d_psrc, psrc.data(), psrc.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+        HIPCHK(c, hipMemcpy(c->d_poff, poff.data(), poff.size() * sizeof(int), hipMemcpyHostToDevice));
+        c->kg.pbonds = c->d_pbonds; c->kg.poff = c->d_poff; c->kg.psrc = c->d_psrc; c->kg.pcs = c->d_pcs;
+        HIPCHK(c, hipMalloc(&c->d_csf, (size_t)g.nw * g.Lt * std::max<size_t>(pb.size(), 1) * sizeof(double2)));
+        HIPCHK(c, hipMemset(c->d_csf, 0, (size_t)g.nw * g.Lt * std::max<size_t>(pb.size(), 1) * sizeof(double2)));
+        c->ff.pbonds = c->d_pbonds; c->ff.poff = c->d_poff; c->ff.csf = c->d_csf; c->ff.ptotal = c->kg.ptotal; c->ff.threads = c->kg.threads;
+        c->ff.enabled = (g.is_sym && g.ncol >= 1 && g.ncol <= kFdmColours && maxp <= 1024) ? 1 : 0;
+        choose_chunking(c);
+    }
     HIPCHK(c, hipMalloc(&c->d_order, (size_t)g.nw * c->nslot * sizeof(int)));
     HIPCHK(c, hipMalloc(&c->d_active, (size_t)g.nw * sizeof(int)));
     HIPCHK(c, hipMemset(c->d_active, 0, (size_t)g.nw * sizeof(int)));
@@ -417,6 +464,7 @@ int smoqy_update_fields(smoqy_ctx *c, int w, const double *expV, const double *c
     if (int rc = upload_real_field(c, expV, c->d_expV + (size_t)w * g.Lt * g.N, g.N)) return rc;
     if (int rc = upload_real_field(c, ch, c->d_ch + (size_t)w * g.Lt * g.Nh, g.Nh)) return rc;
     if (int rc = upload_real_field(c, sh, c->d_sh + (size_t)w * g.Lt * g.Nh, g.Nh)) return rc;
+    launch_pack_csf(c->stream, c->d_ch + (size_t)w * g.Lt * g.Nh, c->d_sh + (size_t)w * g.Lt * g.Nh, c->d_psrc, c->d_csf + (size_t)w * g.Lt * c->kg.ptotal, g.Lt, g.Nh, c->kg.ptotal);
     return check_launch(c, "update_fields");
 }
 
@@ -439,6 +487,7 @@ int smoqy_update_from_path_integral(smoqy_ctx *c, int w, const double *V, const 
     if (g.Nh) HIPCHK(c, hipMemcpyAsync(c->d_stage_int, p0.data(), p0.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     launch_fields_from_path_integral(c->stream, c->d_stage_real, c->d_stage_real + nV, c->d_stage_int, c->d_expV + (size_t)w * nV, c->d_ch + (size_t)w * nT, c->d_sh + (size_t)w * nT, g.Lt, g.N, g.Nh, dtau,
                                      g.is_sym ? dtau / 2 : dtau);  // FermionDetMatrix.jl:220
+    launch_pack_csf(c->stream, c->d_ch + (size_t)w * nT, c->d_sh + (size_t)w * nT, c->d_psrc, c->d_csf + (size_t)w * g.Lt * c->kg.ptotal, g.Lt, g.Nh, c->kg.ptotal);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_launch(c, "update_from_path_integral");
 }
@@ -549,7 +598,8 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
 {
     if (op < SMOQY_OP_M || op > SMOQY_OP_MMT) FAIL(c, 1, "unknown matvec op %d", op);
     FdmArgs a = fdm_args(c, in, out, partial, cg, sys0, count);
-    launch_fdm(c->stream, op, c->g.is_sym != 0, a, fdm_lds_bytes(op, c->g.N, c->Tc));
+    if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_fast(c->stream, op, a, c->ff);
+    else launch_fdm(c->stream, op, c->g.is_sym != 0, a, fdm_lds_bytes(op, c->g.N, c->Tc));
     return check_launch(c, "matvec");
 }
 
@@ -604,13 +654,19 @@ int smoqy_lambda_update(smoqy_ctx *c, int w, const double *x, int Nph, double dt
     if (Nph < 0 || ncoup < 0) FAIL(c, 1, "negative Nph/ncoup");
     const size_t nx = (size_t)Nph * g.Lt;
     if (int rc = ensure_stage_real(c, nx + 2 * (size_t)ncoup + 1)) return rc;
-    if (int rc = ensure_stage_int(c, 3 * (size_t)ncoup + 1)) return rc;
-    std::vector<int> ib(3 * (size_t)ncoup);
+    if (int rc = ensure_stage_int(c, 4 * (size_t)ncoup + g.N + 1)) return rc;
+    // [c2p | c2s | ph_sym | site_next(ncoup) | site_first(N)]; per-site coupling lists keep the reference's coupling order
+    std::vector<int> ib(4 * (size_t)ncoup + g.N, -1);
+    std::vector<int> last((size_t)g.N, -1);
     for (int k = 0; k < ncoup; ++k) {
         if (c2p[k] < 1 || c2p[k] > Nph || c2s[k] < 1 || c2s[k] > g.N) FAIL(c, 1, "coupling %d maps to phonon %lld / site %lld out of range", k + 1, (long long)c2p[k], (long long)c2s[k]);
         ib[k] = (int)c2p[k] - 1;
         ib[ncoup + k] = (int)c2s[k] - 1;
         ib[2 * ncoup + k] = ph_sym[k] ? 1 : 0;
+        const int site = (int)c2s[k] - 1;
+        if (last[site] < 0) ib[4 * (size_t)ncoup + site] = k;
+        else ib[3 * (size_t)ncoup + last[site]] = k;
+        last[site] = k;
     }
     if (nx) HIPCHK(c, hipMemcpyAsync(c->d_stage_real, x, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (ncoup) {
@@ -619,7 +675,7 @@ int smoqy_lambda_update(smoqy_ctx *c, int w, const double *x, int Nph, double dt
         HIPCHK(c, hipMemcpyAsync(c->d_stage_int, ib.data(), ib.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     }
     launch_lambda_update(c->stream, c->d_lam + (size_t)w * g.Lt * g.N, g.Lt, g.N, c->d_stage_real, Nph, dtau, ncoup, c->d_stage_int, c->d_stage_int + ncoup, c->d_stage_real + nx, c->d_stage_real + nx + ncoup,
-                         c->d_stage_int + 2 * ncoup);
+                         c->d_stage_int + 2 * ncoup, c->d_stage_int + 4 * (size_t)ncoup, c->d_stage_int + 3 * (size_t)ncoup);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_launch(c, "lambda_update");
 }
@@ -818,51 +874,87 @@ static void update_expansions(smoqy_ctx *c, WalkerPrecond &p)
     }
 }
 
+// update_preconditioner! (:554-597) for walkers [w0, w0 + nw): one means launch, one Lanczos
+// launch (a workgroup per walker), one readback; the scalar bookkeeping stays on the host.
+static int precond_update_range(smoqy_ctx *c, int w0, int nw, const double *randvecs)
+{
+    const Geometry &g = c->g;
+    const int n = c->nlanczos;
+    // update_B̄! :604-621
+    launch_tau_means(c->stream, c->kg, c->d_expV, c->d_ch, c->d_sh, c->d_dbar, c->d_cbar, c->d_sbar, g.Lt, g.N, g.Nh, w0, nw);
+    // calculate_bounds! :625-658 (start vectors drawn by the caller's rng at :634 / :652)
+    HIPCHK(c, hipMemcpyAsync(c->d_rand, randvecs, (size_t)nw * g.N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    KpmArgs k = kpm_args(c, nullptr, nullptr);
+    launch_lanczos(c->stream, k, c->kg, w0, nw, c->d_rand, n, c->d_lan, c->d_lan + (size_t)g.nw * 1024, !g.is_sym);
+    HIPCHK(c, hipMemcpyAsync(c->h_lan, c->d_lan, (size_t)g.nw * 2 * 1024 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int rc = check_launch(c, "precond_update")) return rc;
+    for (int j = 0; j < nw; ++j) {
+        const int w = w0 + j;
+        WalkerPrecond &p = c->pre[w];
+        p.lan_a.assign(c->h_lan + (size_t)j * 1024, c->h_lan + (size_t)j * 1024 + n);
+        p.lan_b.assign(c->h_lan + (size_t)(g.nw + j) * 1024, c->h_lan + (size_t)(g.nw + j) * 1024 + n - 1);
+        double emin, emax;
+        tridiag_extremes(p.lan_a.data(), p.lan_b.data(), n, emin, emax);
+        if (!g.is_sym) { emin = std::sqrt(emin); emax = std::sqrt(emax); }  // :655
+        emin *= (1.0 - c->rbuf);  // :569-570
+        emax *= (1.0 + c->rbuf);
+        const int was_active = p.active;
+        bool changed = false;
+        if (0.0 < emin && emin < 1.0 && 1.0 < emax && emax < 2.0) {  // :573
+            p.active = 1;
+            if (std::fabs((emin - p.emin) / p.emin) > c->rbuf / 2 || std::fabs((emax - p.emax) / p.emax) > c->rbuf / 2) {  // :582
+                p.emin = emin;
+                p.emax = emax;
+                update_expansions(c, p);
+                changed = true;
+            }
+        } else {
+            p.active = 0;  // :593
+        }
+        if (changed) {
+            if (int rc = upload_precond(c, w)) return rc;
+        } else if (p.active != was_active) {
+            HIPCHK(c, hipMemcpyAsync(c->d_active + w, &p.active, sizeof(int), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    return 0;
+}
+
+int smoqy_matvec_force_generic(smoqy_ctx *c, int on)
+{
+    CHECK_CTX(c);
+    const Geometry &g = c->g;
+    c->ff.enabled = (!on && g.is_sym && g.ncol >= 1 && g.ncol <= kFdmColours && c->ff.threads <= 1024) ? 1 : 0;
+    choose_chunking(c);
+    return 0;
+}
+
+int smoqy_precond_force_generic(smoqy_ctx *c, int on)
+{
+    CHECK_CTX(c);
+    const Geometry &g = c->g;
+    int maxp = 0;
+    (void)g;
+    maxp = c->kg.threads;
+    c->kg.fast = (!on && g.ncol >= 1 && g.ncol <= kMaxColours && maxp <= 1024) ? 1 : 0;
+    return 0;
+}
+
 int smoqy_precond_update(smoqy_ctx *c, int w, const double *randvec)
 {
     CHECK_CTX(c);
     CHECK_WALKER(c, w);
-    const Geometry &g = c->g;
     HIPCHK(c, hipSetDevice(c->device));
-    WalkerPrecond &p = c->pre[w];
-    const int n = c->nlanczos;
-    // update_B̄! :604-621
-    launch_tau_means(c->stream, c->d_expV + (size_t)w * g.Lt * g.N, c->d_ch + (size_t)w * g.Lt * g.Nh, c->d_sh + (size_t)w * g.Lt * g.Nh, c->d_dbar + (size_t)w * g.N, c->d_cbar + (size_t)w * g.Nh,
-                     c->d_sbar + (size_t)w * g.Nh, g.Lt, g.N, g.Nh, w);
-    // calculate_bounds! :625-658 (start vector drawn by the caller's rng at :634 / :652)
-    HIPCHK(c, hipMemcpyAsync(c->d_rand, randvec, (size_t)g.N * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    KpmArgs k = kpm_args(c, nullptr, nullptr);
-    launch_lanczos(c->stream, k, w, c->d_rand, n, c->d_lan, c->d_lan + 1024, !g.is_sym);
-    p.lan_a.assign((size_t)n, 0.0);
-    p.lan_b.assign((size_t)n - 1, 0.0);
-    HIPCHK(c, hipMemcpyAsync(p.lan_a.data(), c->d_lan, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(p.lan_b.data(), c->d_lan + 1024, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (int rc = check_launch(c, "precond_update")) return rc;
-    double emin, emax;
-    tridiag_extremes(p.lan_a.data(), p.lan_b.data(), n, emin, emax);
-    if (!g.is_sym) { emin = std::sqrt(emin); emax = std::sqrt(emax); }  // :655
-    emin *= (1.0 - c->rbuf);  // :569-570
-    emax *= (1.0 + c->rbuf);
-    const int was_active = p.active;
-    bool changed = false;
-    if (0.0 < emin && emin < 1.0 && 1.0 < emax && emax < 2.0) {  // :573
-        p.active = 1;
-        if (std::fabs((emin - p.emin) / p.emin) > c->rbuf / 2 || std::fabs((emax - p.emax) / p.emax) > c->rbuf / 2) {  // :582
-            p.emin = emin;
-            p.emax = emax;
-            update_expansions(c, p);
-            changed = true;
-        }
-    } else {
-        p.active = 0;  // :593
-    }
-    if (changed) return upload_precond(c, w);
-    if (p.active != was_active) {
-        HIPCHK(c, hipMemcpyAsync(c->d_active + w, &p.active, sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    return 0;
+    return precond_update_range(c, w, 1, randvec);
+}
+
+int smoqy_precond_update_all(smoqy_ctx *c, const double *randvecs)
+{
+    CHECK_CTX(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    return precond_update_range(c, 0, c->g.nw, randvecs);
 }
 
 int smoqy_precond_get(smoqy_ctx *c, int w, int *active, double *bounds, int *order, int *norder, double *la, double *lb)
@@ -906,8 +998,7 @@ int smoqy_precond_set(smoqy_ctx *c, int w, int active, const double *bounds, con
         p.coefs[s].assign(src, src + order[s]);
         src += order[s];
     }
-    launch_tau_means(c->stream, c->d_expV + (size_t)w * g.Lt * g.N, c->d_ch + (size_t)w * g.Lt * g.Nh, c->d_sh + (size_t)w * g.Lt * g.Nh, c->d_dbar + (size_t)w * g.N, c->d_cbar + (size_t)w * g.Nh,
-                     c->d_sbar + (size_t)w * g.Nh, g.Lt, g.N, g.Nh, w);
+    launch_tau_means(c->stream, c->kg, c->d_expV, c->d_ch, c->d_sh, c->d_dbar, c->d_cbar, c->d_sbar, g.Lt, g.N, g.Nh, w, 1);
     return upload_precond(c, w);
 }
 
@@ -917,7 +1008,7 @@ static int precond_core(smoqy_ctx *c, double2 *v, const CgState *cg)
     void *buf[1] = {v};
     FFTCHK(c, rocfft_execute(c->plan_f, buf, nullptr, c->fft_info));  // KPMPreconditioner.jl:375 (twiddle applied by the producer)
     KpmArgs k = kpm_args(c, v, cg);
-    launch_cheb(c->stream, k);                                         // :381-400 (no transposes needed in this layout)
+    launch_cheb(c->stream, k, c->kg);                                       // :381-400 (no transposes needed in this layout)
     FFTCHK(c, rocfft_execute(c->plan_b, buf, nullptr, c->fft_info));  // :406
     return check_launch(c, "precond_core");
 }
@@ -1010,8 +1101,7 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
     while (!all_done) {
         const int burst = std::min(c->check_every, maxiter - launched);
         for (int it = 0; it < burst; ++it) {
-            FdmArgs f = fdm_args(c, c->cg_p, c->cg_z, c->part_pz, c->d_st, 0, g.nsys);
-            launch_fdm(c->stream, SMOQY_OP_MTM, g.is_sym != 0, f, fdm_lds_bytes(SMOQY_OP_MTM, g.N, c->Tc));  // z = A p, partial p·Ap
+            if (int rc = matvec_dev(c, SMOQY_OP_MTM, c->cg_z, c->cg_p, c->part_pz, c->d_st, 0, g.nsys)) return rc;  // z = A p, partial p·Ap
             launch_cg_update_xr(c->stream, a);
             if (any_pre) if (int rc = precond_core(c, c->cg_v, c->d_st)) return rc;
             launch_cg_check(c->stream, a);
@@ -1101,11 +1191,10 @@ int smoqy_bench_matvec(smoqy_ctx *c, int op, int out, int in, int reps, double *
     if (int rc = check_vec(c, out)) return rc;
     if (int rc = check_vec(c, in)) return rc;
     if (out == in) FAIL(c, 1, "bench_matvec needs distinct vectors");
-    FdmArgs a = fdm_args(c, c->vecs[in], c->vecs[out], nullptr, nullptr, 0, c->g.nsys);
-    const size_t lds = fdm_lds_bytes(op, c->g.N, c->Tc);
-    launch_fdm(c->stream, op, c->g.is_sym != 0, a, lds);  // warm-up
+    if (int rc = matvec_dev(c, op, c->vecs[out], c->vecs[in], nullptr, nullptr, 0, c->g.nsys)) return rc;  // warm-up
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    for (int r = 0; r < reps; ++r) launch_fdm(c->stream, op, c->g.is_sym != 0, a, lds);
+    for (int r = 0; r < reps; ++r)
+        if (int rc = matvec_dev(c, op, c->vecs[out], c->vecs[in], nullptr, nullptr, 0, c->g.nsys)) return rc;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
     float f = 0;

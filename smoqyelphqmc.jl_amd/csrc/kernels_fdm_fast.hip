@@ -1,0 +1,329 @@
+// Register-resident FermionDetMatrix kernels for gfx950 (Sym, <= kFdmColours colours, tau-chunk
+// <= 2): M, Mᵀ, MᵀM, MMᵀ as ONE launch each.  Same semantics as kernels_fdm.hip (which stays as the
+// generic path for Asym / many colours / large chunks); reference: src/FermionDetMatrix.jl:385-427,
+// 484-525, 329-340, 357-368 and src/checkerboard_matrix_multiply.jl:50-69.
+//
+// What changed relative to the generic kernel and why:
+//   * every colour's bond list is padded with identity self bonds so that it covers all N sites
+//     and a lane owns exactly one (padded) bond per colour; the cosh/sinh pairs are stored
+//     interleaved per padded bond (csf[w][l][idx] = (c, s)), so a lane fetches ALL the hopping
+//     data it will ever need with one coalesced 16-byte load per (colour, slice) at kernel entry;
+//     after that the stage chain touches LDS only — no global-load latency between barriers;
+//   * exp(-ΔτV) is folded into the first colour's stage (C₁ D C₁ in registers): 2L-1 stages;
+//   * the last colour's stage leaves B v in the registers of the lane owning that bond; the
+//     "v ∓ B v" combines, the hand-over from M to Mᵀ inside the fused MᵀM, the output store and
+//     the dot(in, out) partial all happen on those registers — the intermediate M v never exists
+//     in memory and only one LDS array (the propagating slices) is needed.
+#include "smoqy_internal.h"
+
+namespace smoqy {
+
+namespace {
+
+constexpr int KMAX = 3;  // slices a workgroup propagates at once (tau-chunk + 1 halo)
+
+__device__ __forceinline__ int wrapl(int l, int Lt) { return l >= Lt ? l - Lt : (l < 0 ? l + Lt : l); }
+__device__ __forceinline__ double2 lin(double a, double2 x, double b, double2 y) { return make_double2(a * x.x + b * y.x, a * x.y + b * y.y); }
+__device__ __forceinline__ double2 scl(double a, double2 x) { return make_double2(a * x.x, a * x.y); }
+__device__ __forceinline__ double2 addsub(double2 v, double2 u, bool plus) { return plus ? make_double2(v.x + u.x, v.y + u.y) : make_double2(v.x - u.x, v.y - u.y); }
+
+struct Lane {
+    int2 b[kFdmColours];
+    bool on[kFdmColours];
+    double2 cs[kFdmColours][KMAX];  // (cosh, sinh) of the lane's bond in colour c on slice k
+    double di[KMAX], dj[KMAX];      // exp(-ΔτV) at the two sites of the lane's first-colour bond
+};
+
+// one plain colour stage on nk LDS-resident slices; SH selects the slice->register offset
+template <int C, int SH>
+__device__ __forceinline__ void stage(double2 *U, int N, int nk, const Lane &ln)
+{
+    if (ln.on[C]) {
+#pragma unroll
+        for (int k = 0; k < KMAX - SH; ++k) {
+            if (k < nk) {
+                double2 *row = U + (size_t)k * N;
+                const double2 a = row[ln.b[C].x], d = row[ln.b[C].y];
+                const double c = ln.cs[C][k + SH].x, s = ln.cs[C][k + SH].y;
+                row[ln.b[C].x] = lin(c, a, s, d);
+                row[ln.b[C].y] = lin(c, d, s, a);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// first colour with the diagonal folded in: C₁ D C₁.  LAST: keep the result in registers.
+template <int SH, bool LAST>
+__device__ __forceinline__ void middle(double2 *U, int N, int nk, const Lane &ln, double2 (&ri)[KMAX], double2 (&rj)[KMAX])
+{
+    if (ln.on[0]) {
+#pragma unroll
+        for (int k = 0; k < KMAX - SH; ++k) {
+            if (k < nk) {
+                double2 *row = U + (size_t)k * N;
+                const double2 a = row[ln.b[0].x], d = row[ln.b[0].y];
+                const double c = ln.cs[0][k + SH].x, s = ln.cs[0][k + SH].y;
+                const double2 x = scl(ln.di[k + SH], lin(c, a, s, d)), y = scl(ln.dj[k + SH], lin(c, d, s, a));
+                if (LAST) {
+                    ri[k] = lin(c, x, s, y);
+                    rj[k] = lin(c, y, s, x);
+                } else {
+                    row[ln.b[0].x] = lin(c, x, s, y);
+                    row[ln.b[0].y] = lin(c, y, s, x);
+                }
+            }
+        }
+    }
+    if (!LAST) __syncthreads();
+}
+
+// last colour: results stay in registers (no LDS write, no barrier)
+template <int C, int SH>
+__device__ __forceinline__ void last_stage(const double2 *U, int N, int nk, const Lane &ln, double2 (&ri)[KMAX], double2 (&rj)[KMAX])
+{
+    if (ln.on[C]) {
+#pragma unroll
+        for (int k = 0; k < KMAX - SH; ++k) {
+            if (k < nk) {
+                const double2 *row = U + (size_t)k * N;
+                const double2 a = row[ln.b[C].x], d = row[ln.b[C].y];
+                const double c = ln.cs[C][k + SH].x, s = ln.cs[C][k + SH].y;
+                ri[k] = lin(c, a, s, d);
+                rj[k] = lin(c, d, s, a);
+            }
+        }
+    }
+}
+
+// U[k] <- B_l U[k] for the Hermitian Sym propagator B = C_L…C_2 (C_1 D C_1) C_2…C_L; the final
+// colour's output is returned in (ri, rj) at the sites of the lane's bond in that colour.
+template <int NCOL, int SH>
+__device__ __forceinline__ void propagate_sym(double2 *U, int N, int nk, const Lane &ln, double2 (&ri)[KMAX], double2 (&rj)[KMAX])
+{
+    if (NCOL == 1) {
+        middle<SH, true>(U, N, nk, ln, ri, rj);
+        return;
+    }
+    if (NCOL >= 4) stage<3 < NCOL ? 3 : 0, SH>(U, N, nk, ln);
+    if (NCOL >= 3) stage<2 < NCOL ? 2 : 0, SH>(U, N, nk, ln);
+    if (NCOL >= 2) stage<1 < NCOL ? 1 : 0, SH>(U, N, nk, ln);
+    middle<SH, false>(U, N, nk, ln, ri, rj);
+    if (NCOL >= 3) stage<1 < NCOL ? 1 : 0, SH>(U, N, nk, ln);
+    if (NCOL >= 4) stage<2 < NCOL ? 2 : 0, SH>(U, N, nk, ln);
+    last_stage<NCOL - 1, SH>(U, N, nk, ln, ri, rj);
+}
+
+template <int NCOL, int OP>
+__global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
+{
+    extern __shared__ double2 U[];
+    __shared__ double red[34];
+    // XCD-aware order: consecutive tau-chunks of one system share halo slices and field lines, so
+    // they are dealt to the same XCD (blocks b and b+8 share an XCD's L2)
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    if ((nblk & 7) == 0) bid = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int chunk = bid % a.nchunk, sys = a.sys_first + bid / a.nchunk;
+    if (a.cg && a.cg[sys].done) return;
+    const int w = sys / a.nrhs;
+    const int Lt = a.Lt, N = a.N;
+    const int l0 = chunk * a.Tc;
+    const int nk = min(a.Tc, Lt - l0);
+    const size_t sstride = (size_t)a.nsys * N;
+    const double2 *in = a.in + (size_t)sys * N;
+    double2 *out = a.out + (size_t)sys * N;
+    const double *expV = a.expV + (size_t)w * Lt * N;
+    const double2 *csf = ff.csf + (size_t)w * Lt * ff.ptotal;
+    constexpr bool FUSED = (OP == SMOQY_OP_MTM || OP == SMOQY_OP_MMT);
+    const int K1 = FUSED ? nk + 1 : nk;                        // slices of the first propagate
+    const int fbase = (OP == SMOQY_OP_MT) ? l0 + 1 : l0;       // field slice of register index 0
+    const int ubase = (OP == SMOQY_OP_M || OP == SMOQY_OP_MTM) ? l0 - 1 : (OP == SMOQY_OP_MT ? l0 + 1 : l0);  // source slice of U[0]
+
+    // ---- everything this workgroup needs from memory is requested here, up front ----
+    Lane ln;
+#pragma unroll
+    for (int c = 0; c < kFdmColours; ++c) {
+        ln.on[c] = false;
+        ln.b[c] = make_int2(0, 0);
+        if (c < NCOL) {
+            const int idx = ff.poff[c] + (int)threadIdx.x;
+            if (idx < ff.poff[c + 1]) {
+                ln.on[c] = true;
+                ln.b[c] = ff.pbonds[idx];
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < K1) ln.cs[c][k] = csf[(size_t)wrapl(fbase + k, Lt) * ff.ptotal + idx];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        ln.di[k] = ln.dj[k] = 1.0;
+        if (k < K1 && ln.on[0]) {
+            const double *e = expV + (size_t)wrapl(fbase + k, Lt) * N;
+            ln.di[k] = e[ln.b[0].x];
+            ln.dj[k] = e[ln.b[0].y];
+        }
+    }
+    const int2 bL = ln.b[NCOL - 1];
+    const bool onL = ln.on[NCOL - 1];
+    // the "v" of v ∓ B v at the lane's own (last-colour) site pair
+    double2 vi[KMAX], vj[KMAX];
+    const int vbase = (OP == SMOQY_OP_MMT) ? l0 - 1 : l0;  // slice of vi[0]
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        vi[k] = vj[k] = make_double2(0.0, 0.0);
+        if (k < K1 && onL) {
+            const double2 *row = in + (size_t)wrapl(vbase + k, Lt) * sstride;
+            vi[k] = row[bL.x];
+            vj[k] = row[bL.y];
+        }
+    }
+    for (int idx = threadIdx.x; idx < K1 * N; idx += blockDim.x) {
+        const int k = idx / N, i = idx - k * N;
+        U[idx] = in[(size_t)wrapl(ubase + k, Lt) * sstride + i];
+    }
+    __syncthreads();
+
+    double2 ri[KMAX], rj[KMAX];
+    double2 acc = make_double2(0.0, 0.0);
+    propagate_sym<NCOL, 0>(U, N, K1, ln, ri, rj);
+    if (!FUSED) {
+        // M:  out[l] = v[l] ∓ B_l v[l-1]  (+ on the first slice);  Mᵀ: out[l] = v[l] ∓ B_{l+1} v[l+1]  (+ on the last)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < nk && onL) {
+                const int l = l0 + k;
+                const bool plus = (OP == SMOQY_OP_M) ? (l == 0) : (l == Lt - 1);
+                const double2 oi = addsub(vi[k], ri[k], plus), oj = addsub(vj[k], rj[k], plus);
+                double2 *row = out + (size_t)l * sstride;
+                row[bL.x] = oi;
+                acc.x += vi[k].x * oi.x + vi[k].y * oi.y;
+                acc.y += vi[k].x * oi.y - vi[k].y * oi.x;
+                if (bL.y != bL.x) {
+                    row[bL.y] = oj;
+                    acc.x += vj[k].x * oj.x + vj[k].y * oj.y;
+                    acc.y += vj[k].x * oj.y - vj[k].y * oj.x;
+                }
+            }
+        }
+    } else {
+        // y = first operator applied on nk+1 slices, kept in registers at the lane's own site pair
+        double2 yi[KMAX], yj[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            yi[k] = yj[k] = make_double2(0.0, 0.0);
+            if (k < K1) {
+                const int l = wrapl(vbase + k, Lt);  // slice of y[k]
+                const bool plus = (OP == SMOQY_OP_MTM) ? (l == 0) : (l == Lt - 1);
+                yi[k] = addsub(vi[k], ri[k], plus);
+                yj[k] = addsub(vj[k], rj[k], plus);
+            }
+        }
+        // hand over to the second operator: MᵀM propagates y[1..nk] with fields of slices l0+1..,
+        // MMᵀ propagates y[0..nk-1] with fields of slices l0..
+        __syncthreads();  // every lane is done reading U in the last stage
+        if (onL) {
+#pragma unroll
+            for (int k = 0; k < KMAX - 1; ++k) {
+                if (k < nk) {
+                    double2 *row = U + (size_t)k * N;
+                    row[bL.x] = (OP == SMOQY_OP_MTM) ? yi[k + 1] : yi[k];
+                    row[bL.y] = (OP == SMOQY_OP_MTM) ? yj[k + 1] : yj[k];
+                }
+            }
+        }
+        __syncthreads();
+        if (OP == SMOQY_OP_MTM) propagate_sym<NCOL, 1>(U, N, nk, ln, ri, rj);
+        else propagate_sym<NCOL, 0>(U, N, nk, ln, ri, rj);
+        // the dot(in, out) partial needs `in` on the output slices at the own site pair: for MᵀM
+        // that is vi/vj (slices l0+k); for MMᵀ vi[k+1]
+#pragma unroll
+        for (int k = 0; k < KMAX - 1; ++k) {
+            if (k < nk && onL) {
+                const int l = l0 + k;
+                const bool plus = (OP == SMOQY_OP_MTM) ? (l == Lt - 1) : (l == 0);
+                const double2 bi = (OP == SMOQY_OP_MTM) ? yi[k] : yi[k + 1], bj = (OP == SMOQY_OP_MTM) ? yj[k] : yj[k + 1];
+                const double2 oi = addsub(bi, ri[k], plus), oj = addsub(bj, rj[k], plus);
+                const double2 pi = (OP == SMOQY_OP_MTM) ? vi[k] : vi[k + 1], pj = (OP == SMOQY_OP_MTM) ? vj[k] : vj[k + 1];
+                double2 *row = out + (size_t)l * sstride;
+                row[bL.x] = oi;
+                acc.x += pi.x * oi.x + pi.y * oi.y;
+                acc.y += pi.x * oi.y - pi.y * oi.x;
+                if (bL.y != bL.x) {
+                    row[bL.y] = oj;
+                    acc.x += pj.x * oj.x + pj.y * oj.y;
+                    acc.y += pj.x * oj.y - pj.y * oj.x;
+                }
+            }
+        }
+    }
+    if (a.partial) {
+        // wavefront shuffles, then one LDS hop across the workgroup's wavefronts
+        for (int off = 32; off > 0; off >>= 1) {
+            acc.x += __shfl_down(acc.x, off, 64);
+            acc.y += __shfl_down(acc.y, off, 64);
+        }
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = (blockDim.x + 63) >> 6;
+        if (lane == 0) { red[2 * wave] = acc.x; red[2 * wave + 1] = acc.y; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double2 t = make_double2(0.0, 0.0);
+            for (int q = 0; q < nwave; ++q) { t.x += red[2 * q]; t.y += red[2 * q + 1]; }
+            a.partial[(size_t)sys * a.nchunk + chunk] = t;
+        }
+    }
+}
+
+template <int NCOL>
+void launch_ncol(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff)
+{
+    const dim3 grid((unsigned)(a.nchunk * a.sys_count)), block((unsigned)ff.threads);
+    const size_t lds = sizeof(double2) * (size_t)a.N * (size_t)(a.Tc + 1);
+    switch (op) {
+        case SMOQY_OP_M: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_M>), grid, block, lds, st, a, ff); break;
+        case SMOQY_OP_MT: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MT>), grid, block, lds, st, a, ff); break;
+        case SMOQY_OP_MTM: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MTM>), grid, block, lds, st, a, ff); break;
+        default: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MMT>), grid, block, lds, st, a, ff); break;
+    }
+}
+
+}  // namespace
+
+bool fdm_fast_supported(const FdmArgs &a, const FdmFast &ff, bool sym)
+{
+    return sym && ff.enabled && a.ncol >= 1 && a.ncol <= kFdmColours && a.Tc + 1 <= KMAX && sizeof(double2) * (size_t)a.N * (size_t)(a.Tc + 1) <= 60 * 1024;
+}
+
+void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff)
+{
+    switch (a.ncol) {
+        case 1: launch_ncol<1>(st, op, a, ff); break;
+        case 2: launch_ncol<2>(st, op, a, ff); break;
+        case 3: launch_ncol<3>(st, op, a, ff); break;
+        default: launch_ncol<4>(st, op, a, ff); break;
+    }
+}
+
+// pack cosh/sinh into the padded interleaved table csf[l][idx] = (c, s) (self bonds: (1, 0))
+__global__ void pack_csf_kernel(const double *__restrict__ ch, const double *__restrict__ sh, const int *__restrict__ psrc, double2 *__restrict__ csf, int Lt, int Nh, int ptotal)
+{
+    const size_t tot = (size_t)Lt * ptotal;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(idx / ptotal), j = (int)(idx - (size_t)l * ptotal);
+        const int h = psrc[j];
+        csf[idx] = h >= 0 ? make_double2(ch[(size_t)l * Nh + h], sh[(size_t)l * Nh + h]) : make_double2(1.0, 0.0);
+    }
+}
+
+void launch_pack_csf(hipStream_t st, const double *ch, const double *sh, const int *psrc, double2 *csf, int Lt, int Nh, int ptotal)
+{
+    const size_t tot = (size_t)Lt * ptotal;
+    if (tot == 0) return;
+    int blocks = (int)((tot + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pack_csf_kernel, dim3(blocks), dim3(256), 0, st, ch, sh, psrc, csf, Lt, Nh, ptotal);
+}
+
+}  // namespace smoqy

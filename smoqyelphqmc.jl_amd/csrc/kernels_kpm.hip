@@ -2,15 +2,26 @@
 // tau-averaged propagator B̄ and the Lanczos eigen-bound estimate.
 //
 // Reference semantics: ldiv!(u', P, u) src/KPMPreconditioner.jl:355-414 (Sym), :488-550 (Asym);
-// calculate_bounds! :625-658; B̄ = Γ̄ D̄ Γ̄ᴴ (Sym) / D̄ Γ̄ (Asym) as in JDQMCFramework's
-// Sym/AsymChkbrdPropagator; kpm_lmul!/lanczos! restated from SmoQyKPMCore (three-term Chebyshev
-// recurrence on B̄ rescaled to [-1,1]; plain Lanczos) — third-party source absent, see DESIGN.md.
+// calculate_bounds! :625-658; update_B̄! :604-621; B̄ = Γ̄ D̄ Γ̄ᴴ (Sym) / D̄ Γ̄ (Asym) as in
+// JDQMCFramework's Sym/AsymChkbrdPropagator; kpm_lmul!/lanczos! restated from SmoQyKPMCore
+// (three-term Chebyshev recurrence on B̄ rescaled to [-1,1]; plain Lanczos) — third-party source
+// absent, see DESIGN.md.
 //
-// Mapping: after the tau-FFT the device layout v[ω][s][i] already has one frequency of one
+// Mapping.  After the tau-FFT the device layout v[ω][s][i] already has one frequency of one
 // system as a contiguous N-vector, so there is no transpose (the reference needs two,
-// :378/:403).  One workgroup owns one (ω, system): the vector sits in LDS, each colour of B̄ is
-// one barrier-separated stage with lane == bond, and the recurrence state (T_{k-1}, T_k, the
-// running sum) stays in LDS next to it.  Workgroups are issued heaviest expansion order first.
+// :378/:403).  One workgroup owns one (ω, system); the chain of up to ~a1/φ dependent B̄ applies
+// is pure latency, so the kernel is organised around the number of barrier-separated stages:
+//   * every colour's bond list is padded with identity "self bonds" so that it covers all N
+//     sites; a lane owns one (padded) bond per colour and keeps its site pair and the (c̄, s̄)
+//     pair of every colour in registers for the whole chain — no memory traffic besides LDS;
+//   * Sym: the diagonal D̄ is folded into the first colour's stage (C₁ D̄ C₁ in registers), and
+//     the recurrence runs in the basis α̃ = C_L α, where B̃ = C_L B̄ C_L⁻¹ = C_L² C_{L-1}…C₁D̄C₁…C_{L-1}
+//     merges the two applications of the last colour: 2L-2 stages per step instead of 2L+1;
+//   * the three-term recurrence and the running sum live in the registers of the lane that owns
+//     the last colour's bond and are fused into that colour's stage.
+// Workgroups are issued heaviest expansion order first.  A generic LDS-table kernel remains as
+// the fallback for decompositions with more than kMaxColours colours or more padded bonds per
+// colour than 1024.
 #include "smoqy_internal.h"
 
 namespace smoqy {
@@ -21,7 +32,7 @@ __device__ __forceinline__ double wsum_k(double v)
     return v;
 }
 
-__device__ __forceinline__ double block_sum_real(double v, double *red /* >= 9 doubles */)
+__device__ __forceinline__ double block_sum_real(double v, double *red /* >= 17 doubles */)
 {
     v = wsum_k(v);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = (blockDim.x + 63) >> 6;
@@ -31,12 +42,314 @@ __device__ __forceinline__ double block_sum_real(double v, double *red /* >= 9 d
     if (threadIdx.x == 0) {
         double t = 0;
         for (int w = 0; w < nwave; ++w) t += red[w];
-        red[8] = t;
+        red[16] = t;
     }
     __syncthreads();
-    return red[8];
+    return red[16];
 }
 
+__device__ __forceinline__ double2 cmulk(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 axpy2(double a, double2 x, double2 y) { return make_double2(a * x.x + y.x, a * x.y + y.y); }
+__device__ __forceinline__ double2 lin2(double a, double2 x, double b, double2 y) { return make_double2(a * x.x + b * y.x, a * x.y + b * y.y); }
+
+// ---------------------------------------------------------------------------------------------
+// update_B̄! (:604-621) for every walker in one launch, plus the padded (c̄, s̄) table
+// ---------------------------------------------------------------------------------------------
+__global__ void tau_means_kernel(const double *__restrict__ expV, const double *__restrict__ ch, const double *__restrict__ sh, double *dbar, double *cbar, double *sbar, double2 *pcs,
+                                 const int *__restrict__ psrc, int ptotal, int Lt, int N, int Nh)
+{
+    // 64 outputs x 4 tau-groups per workgroup: lanes run over sites/bonds (coalesced), each
+    // thread sums every 4th slice with 8 loads in flight, then one LDS hop across the groups
+    __shared__ double2 part[4][64];
+    const int w = blockIdx.y;
+    const int j = blockIdx.x * 64 + threadIdx.x, ty = threadIdx.y;
+    expV += (size_t)w * Lt * N; ch += (size_t)w * Lt * Nh; sh += (size_t)w * Lt * Nh;
+    double a = 0, b = 0;
+    int h = -1;
+    if (j < N) {
+#pragma unroll 8
+        for (int l = ty; l < Lt; l += 4) a += expV[(size_t)l * N + j];
+    } else if (j < N + ptotal) {
+        h = psrc[j - N];
+        if (h >= 0) {
+#pragma unroll 8
+            for (int l = ty; l < Lt; l += 4) { a += ch[(size_t)l * Nh + h]; b += sh[(size_t)l * Nh + h]; }
+        }
+    }
+    part[ty][threadIdx.x] = make_double2(a, b);
+    __syncthreads();
+    if (ty != 0) return;
+    a = (part[0][threadIdx.x].x + part[1][threadIdx.x].x) + (part[2][threadIdx.x].x + part[3][threadIdx.x].x);
+    b = (part[0][threadIdx.x].y + part[1][threadIdx.x].y) + (part[2][threadIdx.x].y + part[3][threadIdx.x].y);
+    if (j < N) {
+        dbar[(size_t)w * N + j] = a / Lt;
+    } else if (j < N + ptotal) {
+        if (h >= 0) {
+            a /= Lt; b /= Lt;
+            cbar[(size_t)w * Nh + h] = a;
+            sbar[(size_t)w * Nh + h] = b;
+        } else {
+            a = 1.0; b = 0.0;  // identity self bond
+        }
+        pcs[(size_t)w * ptotal + (j - N)] = make_double2(a, b);
+    }
+}
+
+void launch_tau_means(hipStream_t st, const KpmGeom &kg, const double *expV, const double *ch, const double *sh, double *dbar, double *cbar, double *sbar, int Lt, int N, int Nh, int w0, int nw)
+{
+    dim3 grid((N + kg.ptotal + 63) / 64, nw);
+    hipLaunchKernelGGL(tau_means_kernel, grid, dim3(64, 4), 0, st, expV + (size_t)w0 * Lt * N, ch + (size_t)w0 * Lt * Nh, sh + (size_t)w0 * Lt * Nh, dbar + (size_t)w0 * N, cbar + (size_t)w0 * Nh,
+                       sbar + (size_t)w0 * Nh, kg.pcs + (size_t)w0 * kg.ptotal, kg.psrc, kg.ptotal, Lt, N, Nh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// register-resident bond program of one lane
+// ---------------------------------------------------------------------------------------------
+struct LaneBonds {
+    int2 b[kMaxColours];
+    double2 cs[kMaxColours];
+    bool on[kMaxColours];
+};
+
+__device__ __forceinline__ void load_lane_bonds(LaneBonds &lb, const KpmGeom &kg, int w, int ncol)
+{
+#pragma unroll
+    for (int c = 0; c < kMaxColours; ++c) {
+        lb.on[c] = false;
+        lb.b[c] = make_int2(0, 0);
+        lb.cs[c] = make_double2(1.0, 0.0);
+        if (c < ncol) {
+            const int idx = kg.poff[c] + (int)threadIdx.x;
+            if (idx < kg.poff[c + 1]) {
+                lb.on[c] = true;
+                lb.b[c] = kg.pbonds[idx];
+                lb.cs[c] = kg.pcs[(size_t)w * kg.ptotal + idx];
+            }
+        }
+    }
+}
+
+// plain colour stage on the LDS vector W
+#define PLAIN_STAGE(c_)                                                         \
+    {                                                                           \
+        if (lb.on[c_]) {                                                        \
+            const double2 a_ = W[lb.b[c_].x], d_ = W[lb.b[c_].y];               \
+            W[lb.b[c_].x] = lin2(lb.cs[c_].x, a_, lb.cs[c_].y, d_);             \
+            W[lb.b[c_].y] = lin2(lb.cs[c_].x, d_, lb.cs[c_].y, a_);             \
+        }                                                                       \
+        __syncthreads();                                                        \
+    }
+
+// W <- B W where B = Sym B̄ (MODE 0), Asym B̄ = D̄Γ̄ (MODE 1) or Asym B̄ᵀB̄ = Γ̄ᵀD̄²Γ̄ (MODE 2); plain form
+// used by Lanczos (no basis change)
+template <int MODE>
+__device__ __forceinline__ void bbar_apply_regs(double2 *W, const LaneBonds &lb, int ncol, int N, const double *__restrict__ dbar)
+{
+    if (MODE == 0) {
+#pragma unroll
+        for (int c = kMaxColours - 1; c >= 1; --c)
+            if (c < ncol) PLAIN_STAGE(c)
+        // C₁ D̄ C₁ fused (colour 0 is padded to cover every site)
+        if (lb.on[0]) {
+            const double2 a = W[lb.b[0].x], d = W[lb.b[0].y];
+            const double di = dbar[lb.b[0].x], dj = dbar[lb.b[0].y];
+            double2 x = lin2(lb.cs[0].x, a, lb.cs[0].y, d), y = lin2(lb.cs[0].x, d, lb.cs[0].y, a);
+            x = make_double2(di * x.x, di * x.y);
+            y = make_double2(dj * y.x, dj * y.y);
+            W[lb.b[0].x] = lin2(lb.cs[0].x, x, lb.cs[0].y, y);
+            W[lb.b[0].y] = lin2(lb.cs[0].x, y, lb.cs[0].y, x);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 1; c < kMaxColours; ++c)
+            if (c < ncol) PLAIN_STAGE(c)
+    } else {
+#pragma unroll
+        for (int c = 0; c < kMaxColours; ++c)
+            if (c < ncol) PLAIN_STAGE(c)
+        for (int i = threadIdx.x; i < N; i += blockDim.x) {
+            const double d = (MODE == 2) ? dbar[i] * dbar[i] : dbar[i];
+            W[i] = make_double2(d * W[i].x, d * W[i].y);
+        }
+        __syncthreads();
+        if (MODE == 2) {
+#pragma unroll
+            for (int c = kMaxColours - 1; c >= 0; --c)
+                if (c < ncol) PLAIN_STAGE(c)
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fast Chebyshev kernel
+// ---------------------------------------------------------------------------------------------
+// One polynomial: on entry the lane holds the input at its last-colour site pair in (vi, vj);
+// on exit (vi, vj) hold Σ_k coefs[k] T_k(B') v at the same sites.  W is the N-vector in LDS.
+template <bool SYM>
+__device__ __forceinline__ void kpm_poly_regs(double2 *W, const LaneBonds &lb, int ncol, const double2 *__restrict__ coefs, int n, double avg, double imag_, double di, double dj, double dLi, double dLj,
+                                              double2 &vi, double2 &vj)
+{
+    const int L = ncol;
+    const int cl = L - 1;          // last colour (owner of the recurrence state)
+    // last-colour data (runtime colour index -> select through an unrolled scan)
+    int2 bL = make_int2(0, 0);
+    double2 csL = make_double2(1.0, 0.0);
+    bool onL = false;
+#pragma unroll
+    for (int c = 0; c < kMaxColours; ++c)
+        if (c == cl) { bL = lb.b[c]; csL = lb.cs[c]; onL = lb.on[c]; }
+    // Sym with L >= 2 runs in the basis α̃ = C_L α
+    const bool xf = SYM && L >= 2;
+    double2 a1i = vi, a1j = vj;
+    if (xf) {
+        a1i = lin2(csL.x, vi, csL.y, vj);
+        a1j = lin2(csL.x, vj, csL.y, vi);
+    }
+    if (onL) { W[bL.x] = a1i; W[bL.y] = a1j; }
+    __syncthreads();
+    const double q_c = csL.x * csL.x + csL.y * csL.y, q_s = 2.0 * csL.x * csL.y;  // C_L²
+    double2 a2i = make_double2(0, 0), a2j = a2i, acci = a2i, accj = a2i;
+    for (int k = 1; k < n; ++k) {
+        const double2 ck = coefs[k];  // issued early; consumed after the stages
+        double2 xi, xj;
+        if (SYM) {
+#pragma unroll
+            for (int c = kMaxColours - 2; c >= 1; --c)
+                if (c < L - 1) PLAIN_STAGE(c)
+            if (L >= 2) {
+                if (lb.on[0]) {
+                    const double2 a = W[lb.b[0].x], d = W[lb.b[0].y];
+                    double2 x = lin2(lb.cs[0].x, a, lb.cs[0].y, d), y = lin2(lb.cs[0].x, d, lb.cs[0].y, a);
+                    x = make_double2(di * x.x, di * x.y);
+                    y = make_double2(dj * y.x, dj * y.y);
+                    W[lb.b[0].x] = lin2(lb.cs[0].x, x, lb.cs[0].y, y);
+                    W[lb.b[0].y] = lin2(lb.cs[0].x, y, lb.cs[0].y, x);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int c = 1; c < kMaxColours - 1; ++c)
+                    if (c < L - 1) PLAIN_STAGE(c)
+                const double2 a = W[bL.x], d = W[bL.y];
+                xi = lin2(q_c, a, q_s, d);
+                xj = lin2(q_c, d, q_s, a);
+            } else {  // single colour: B̄ = C₁ D̄ C₁, state owned by colour 0 itself
+                const double2 a = W[bL.x], d = W[bL.y];
+                double2 x = lin2(csL.x, a, csL.y, d), y = lin2(csL.x, d, csL.y, a);
+                x = make_double2(di * x.x, di * x.y);
+                y = make_double2(dj * y.x, dj * y.y);
+                xi = lin2(csL.x, x, csL.y, y);
+                xj = lin2(csL.x, y, csL.y, x);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < kMaxColours - 1; ++c)
+                if (c < L - 1) PLAIN_STAGE(c)
+            const double2 a = W[bL.x], d = W[bL.y];
+            xi = lin2(csL.x, a, csL.y, d);
+            xj = lin2(csL.x, d, csL.y, a);
+            xi = make_double2(dLi * xi.x, dLi * xi.y);
+            xj = make_double2(dLj * xj.x, dLj * xj.y);
+        }
+        // three-term recurrence on the lane's own site pair (kpm_lmul!)
+        double2 a3i, a3j;
+        if (k == 1) {
+            a3i = make_double2((xi.x - avg * a1i.x) * imag_, (xi.y - avg * a1i.y) * imag_);
+            a3j = make_double2((xj.x - avg * a1j.x) * imag_, (xj.y - avg * a1j.y) * imag_);
+            const double2 c0 = coefs[0];
+            const double2 t0i = cmulk(c0, a1i), t0j = cmulk(c0, a1j), t1i = cmulk(ck, a3i), t1j = cmulk(ck, a3j);
+            acci = make_double2(t0i.x + t1i.x, t0i.y + t1i.y);
+            accj = make_double2(t0j.x + t1j.x, t0j.y + t1j.y);
+            a2i = a3i; a2j = a3j;
+        } else {
+            a3i = make_double2(2.0 * (xi.x - avg * a2i.x) * imag_ - a1i.x, 2.0 * (xi.y - avg * a2i.y) * imag_ - a1i.y);
+            a3j = make_double2(2.0 * (xj.x - avg * a2j.x) * imag_ - a1j.x, 2.0 * (xj.y - avg * a2j.y) * imag_ - a1j.y);
+            const double2 ti = cmulk(ck, a3i), tj = cmulk(ck, a3j);
+            acci = make_double2(acci.x + ti.x, acci.y + ti.y);
+            accj = make_double2(accj.x + tj.x, accj.y + tj.y);
+            a1i = a2i; a1j = a2j;
+            a2i = a3i; a2j = a3j;
+        }
+        if (k + 1 < n) {
+            if (onL) { W[bL.x] = a3i; W[bL.y] = a3j; }
+            __syncthreads();
+        }
+    }
+    if (xf) {  // back to the original basis: C_L⁻¹
+        const double idet = 1.0 / (csL.x * csL.x - csL.y * csL.y);
+        vi = make_double2((csL.x * acci.x - csL.y * accj.x) * idet, (csL.x * acci.y - csL.y * accj.y) * idet);
+        vj = make_double2((csL.x * accj.x - csL.y * acci.x) * idet, (csL.x * accj.y - csL.y * acci.y) * idet);
+    } else {
+        vi = acci;
+        vj = accj;
+    }
+}
+
+template <bool SYM>
+__global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
+{
+    extern __shared__ double2 lds[];
+    double2 *W = lds;
+    const int N = k.N, Lt = k.Lt;
+    // rank-major block order: the heaviest chains of all systems are dispatched first and land
+    // on different CUs / XCDs (a system-major order parks them on the same CU)
+    const int sys = blockIdx.x % k.nsys, rank = blockIdx.x / k.nsys;
+    const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);  // heaviest orders first
+    const int w = sys / k.nrhs;
+    if (!k.active[w]) return;
+    if (k.cg && k.cg[sys].done) return;
+    double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
+    const int Lo2 = (Lt + 1) / 2;
+    const int slot = SYM ? (om >= Lo2 ? Lt - om - 1 : om) : om;  // :387
+    const int n = k.order[(size_t)w * k.nslot + slot];
+    const double2 *coefs = k.coefs + ((size_t)w * k.nslot + slot) * k.maxorder;
+    if (n <= 1) {
+        // single-term expansion: scalar multiply (:398 / :534)
+        const double2 c0 = coefs[0];
+        const double f = SYM ? c0.x : (c0.x * c0.x + c0.y * c0.y);
+        for (int i = threadIdx.x; i < N; i += blockDim.x) v[i] = make_double2(f * v[i].x, f * v[i].y);
+        return;
+    }
+    const double emin = k.bounds[2 * w], emax = k.bounds[2 * w + 1];
+    const double avg = 0.5 * (emax + emin), imag_ = 1.0 / (0.5 * (emax - emin));
+    LaneBonds lb;
+    load_lane_bonds(lb, kg, w, k.ncol);
+    const double *dbar = k.dbar + (size_t)w * N;
+    const int cl = k.ncol - 1;
+    int2 bL = make_int2(0, 0);
+    bool onL = false;
+#pragma unroll
+    for (int c = 0; c < kMaxColours; ++c)
+        if (c == cl) { bL = lb.b[c]; onL = lb.on[c]; }
+    const double di = lb.on[0] ? dbar[lb.b[0].x] : 1.0, dj = lb.on[0] ? dbar[lb.b[0].y] : 1.0;
+    const double dLi = onL ? dbar[bL.x] : 1.0, dLj = onL ? dbar[bL.y] : 1.0;
+    double2 vi = make_double2(0, 0), vj = vi;
+    if (onL) { vi = v[bL.x]; vj = v[bL.y]; }
+    // expansion coefficients go to LDS once: no global load (and no vmcnt wait) inside the chain
+    double2 *CF = W + N, *CF2 = CF + k.maxorder;
+    const int omc = Lt - om - 1;  // :523-530
+    const int n2 = SYM ? 0 : k.order[(size_t)w * k.nslot + omc];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) CF[i] = coefs[i];
+    if (!SYM) {
+        const double2 *coefs_c = k.coefs + ((size_t)w * k.nslot + omc) * k.maxorder;
+        for (int i = threadIdx.x; i < n2; i += blockDim.x) CF2[i] = coefs_c[i];
+    }
+    __syncthreads();
+    if (SYM) {
+        kpm_poly_regs<true>(W, lb, k.ncol, CF, n, avg, imag_, di, dj, dLi, dLj, vi, vj);  // :394
+    } else {
+        kpm_poly_regs<false>(W, lb, k.ncol, CF2, n2, avg, imag_, di, dj, dLi, dLj, vi, vj);
+        __syncthreads();
+        kpm_poly_regs<false>(W, lb, k.ncol, CF, n, avg, imag_, di, dj, dLi, dLj, vi, vj);
+    }
+    if (onL) {
+        v[bL.x] = vi;
+        if (bL.y != bL.x) v[bL.y] = vj;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic fallback (any number of colours / sites): bond tables read from memory each stage
+// ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void bbar_colour(double2 *W, const int2 *__restrict__ bonds, const double *__restrict__ cbar, const double *__restrict__ sbar, int cb, int ce)
 {
     for (int h = cb + (int)threadIdx.x; h < ce; h += (int)blockDim.x) {
@@ -49,7 +362,6 @@ __device__ __forceinline__ void bbar_colour(double2 *W, const int2 *__restrict__
     __syncthreads();
 }
 
-// MODE 0: Sym B̄ = Γ̄ D̄ Γ̄ᴴ;  1: Asym B̄ = D̄ Γ̄;  2: B̄ᵀB̄ for Asym = Γ̄ᴴ D̄² Γ̄ (KPMPreconditioner.jl:661-679)
 template <int MODE>
 __device__ __forceinline__ void bbar_apply(double2 *W, int N, int ncol, const int2 *bonds, const int *col_off, const double *dbar, const double *cbar, const double *sbar)
 {
@@ -68,20 +380,15 @@ __device__ __forceinline__ void bbar_apply(double2 *W, int N, int ncol, const in
         for (int c = ncol - 1; c >= 0; --c) bbar_colour(W, bonds, cbar, sbar, col_off[c], col_off[c + 1]);
 }
 
-__device__ __forceinline__ double2 cmulk(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-
-// v <- Σ_k coefs[k] T_k(B') v with B' = (B̄ - avg)/mag  (kpm_lmul!, restated); v lives in ACC on exit
 template <int MODE>
-__device__ __forceinline__ void kpm_poly(double2 *W, double2 *A1, double2 *A2, double2 *ACC, const double2 *__restrict__ coefs, int n, bool conj_coefs, double avg, double mag, const KpmArgs &k,
-                                         const double *dbar, const double *cbar, const double *sbar)
+__device__ __forceinline__ void kpm_poly(double2 *W, double2 *A1, double2 *A2, double2 *ACC, const double2 *__restrict__ coefs, int n, double avg, double mag, const KpmArgs &k, const double *dbar,
+                                         const double *cbar, const double *sbar)
 {
     const int N = k.N;
-    // on entry the input vector is in ACC
     for (int i = threadIdx.x; i < N; i += blockDim.x) { A1[i] = ACC[i]; W[i] = ACC[i]; }
     __syncthreads();
     bbar_apply<MODE>(W, N, k.ncol, k.bonds, k.col_off, dbar, cbar, sbar);
-    double2 c0 = coefs[0], c1 = n > 1 ? coefs[1] : make_double2(0.0, 0.0);
-    if (conj_coefs) { c0.y = -c0.y; c1.y = -c1.y; }
+    const double2 c0 = coefs[0], c1 = n > 1 ? coefs[1] : make_double2(0.0, 0.0);
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
         const double2 a1 = A1[i];
         const double2 a2 = make_double2((W[i].x - avg * a1.x) / mag, (W[i].y - avg * a1.y) / mag);
@@ -93,8 +400,7 @@ __device__ __forceinline__ void kpm_poly(double2 *W, double2 *A1, double2 *A2, d
     __syncthreads();
     for (int kk = 2; kk < n; ++kk) {
         bbar_apply<MODE>(W, N, k.ncol, k.bonds, k.col_off, dbar, cbar, sbar);
-        double2 ck = coefs[kk];
-        if (conj_coefs) ck.y = -ck.y;
+        const double2 ck = coefs[kk];
         for (int i = threadIdx.x; i < N; i += blockDim.x) {
             const double2 a1 = A1[i], a2 = A2[i];
             const double2 a3 = make_double2(2.0 * (W[i].x - avg * a2.x) / mag - a1.x, 2.0 * (W[i].y - avg * a2.y) / mag - a1.y);
@@ -108,13 +414,13 @@ __device__ __forceinline__ void kpm_poly(double2 *W, double2 *A1, double2 *A2, d
     }
 }
 
-__global__ void __launch_bounds__(kThreads) cheb_kernel(KpmArgs k)
+__global__ void __launch_bounds__(kThreads) cheb_generic_kernel(KpmArgs k)
 {
     extern __shared__ double2 lds[];
     const int N = k.N, Lt = k.Lt;
     double2 *W = lds, *A1 = W + N, *A2 = A1 + N, *ACC = A2 + N;
     const int rank = blockIdx.x % Lt, sys = blockIdx.x / Lt;
-    const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);  // heaviest orders first
+    const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);
     const int w = sys / k.nrhs;
     if (!k.active[w]) return;
     if (k.cg && k.cg[sys].done) return;
@@ -124,57 +430,70 @@ __global__ void __launch_bounds__(kThreads) cheb_kernel(KpmArgs k)
     double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
     const int Lo2 = (Lt + 1) / 2;
     if (k.is_sym) {
-        const int slot = om >= Lo2 ? Lt - om - 1 : om;  // :387
+        const int slot = om >= Lo2 ? Lt - om - 1 : om;
         const int n = k.order[(size_t)w * k.nslot + slot];
         const double2 *coefs = k.coefs + ((size_t)w * k.nslot + slot) * k.maxorder;
         if (n > 1) {
             for (int i = threadIdx.x; i < N; i += blockDim.x) ACC[i] = v[i];
             __syncthreads();
-            kpm_poly<0>(W, A1, A2, ACC, coefs, n, false, avg, mag, k, dbar, cbar, sbar);  // :394
+            kpm_poly<0>(W, A1, A2, ACC, coefs, n, avg, mag, k, dbar, cbar, sbar);
             for (int i = threadIdx.x; i < N; i += blockDim.x) v[i] = ACC[i];
         } else {
             const double c = coefs[0].x;
-            for (int i = threadIdx.x; i < N; i += blockDim.x) v[i] = make_double2(c * v[i].x, c * v[i].y);  // :398
+            for (int i = threadIdx.x; i < N; i += blockDim.x) v[i] = make_double2(c * v[i].x, c * v[i].y);
         }
     } else {
         const int n = k.order[(size_t)w * k.nslot + om];
         const double2 *coefs = k.coefs + ((size_t)w * k.nslot + om) * k.maxorder;
-        if (n > 1) {  // :520-530
+        if (n > 1) {
             const int omc = Lt - om - 1;
             const double2 *coefs_c = k.coefs + ((size_t)w * k.nslot + omc) * k.maxorder;
             for (int i = threadIdx.x; i < N; i += blockDim.x) ACC[i] = v[i];
             __syncthreads();
-            kpm_poly<1>(W, A1, A2, ACC, coefs_c, k.order[(size_t)w * k.nslot + omc], false, avg, mag, k, dbar, cbar, sbar);
-            kpm_poly<1>(W, A1, A2, ACC, coefs, n, false, avg, mag, k, dbar, cbar, sbar);
+            kpm_poly<1>(W, A1, A2, ACC, coefs_c, k.order[(size_t)w * k.nslot + omc], avg, mag, k, dbar, cbar, sbar);
+            kpm_poly<1>(W, A1, A2, ACC, coefs, n, avg, mag, k, dbar, cbar, sbar);
             for (int i = threadIdx.x; i < N; i += blockDim.x) v[i] = ACC[i];
         } else {
-            const double c = coefs[0].x * coefs[0].x + coefs[0].y * coefs[0].y;  // :534
+            const double c = coefs[0].x * coefs[0].x + coefs[0].y * coefs[0].y;
             for (int i = threadIdx.x; i < N; i += blockDim.x) v[i] = make_double2(c * v[i].x, c * v[i].y);
         }
     }
 }
 
-void launch_cheb(hipStream_t st, const KpmArgs &k)
+void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
 {
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute((const void *)cheb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute((const void *)cheb_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         configured = true;
     }
-    const size_t lds = sizeof(double2) * 4 * (size_t)k.N;
-    hipLaunchKernelGGL(cheb_kernel, dim3((unsigned)(k.Lt * k.nsys)), dim3(kThreads), lds, st, k);
+    if (kg.fast) {
+        const size_t lds = sizeof(double2) * ((size_t)k.N + 2 * (size_t)k.maxorder);
+        if (k.is_sym) hipLaunchKernelGGL((cheb_fast_kernel<true>), dim3((unsigned)(k.Lt * k.nsys)), dim3(kg.threads), lds, st, k, kg);
+        else hipLaunchKernelGGL((cheb_fast_kernel<false>), dim3((unsigned)(k.Lt * k.nsys)), dim3(kg.threads), lds, st, k, kg);
+    } else {
+        const size_t lds = sizeof(double2) * 4 * (size_t)k.N;
+        hipLaunchKernelGGL(cheb_generic_kernel, dim3((unsigned)(k.Lt * k.nsys)), dim3(kThreads), lds, st, k);
+    }
 }
 
+// ---------------------------------------------------------------------------------------------
 // lanczos! (SmoQyKPMCore, restated): n-step Lanczos on B̄ (Sym) or B̄ᵀB̄ (Asym) from the host
-// supplied start vector; one workgroup, everything in LDS.
-template <int MODE>
-__global__ void __launch_bounds__(kThreads) lanczos_kernel(KpmArgs k, int w, const double *__restrict__ randvec, int nsteps, double *alpha, double *beta)
+// supplied start vectors; one workgroup per walker, everything in LDS / registers.
+// ---------------------------------------------------------------------------------------------
+template <int MODE, bool FAST>
+__global__ void __launch_bounds__(1024) lanczos_kernel(KpmArgs k, KpmGeom kg, int w0, const double *__restrict__ randvec, int nsteps, double *alpha, double *beta)
 {
     extern __shared__ double2 lds[];
-    __shared__ double red[9];
-    const int N = k.N;
+    __shared__ double red[17];
+    const int N = k.N, w = w0 + blockIdx.x;
     double2 *W = lds, *VK = W + N, *VKM = VK + N;
     const double *dbar = k.dbar + (size_t)w * N, *cbar = k.cbar + (size_t)w * k.Nh, *sbar = k.sbar + (size_t)w * k.Nh;
+    randvec += (size_t)blockIdx.x * N;
+    alpha += (size_t)blockIdx.x * 1024;
+    beta += (size_t)blockIdx.x * 1024;
+    LaneBonds lb;
+    if (FAST) load_lane_bonds(lb, kg, w, k.ncol);
     double acc = 0;
     for (int i = threadIdx.x; i < N; i += blockDim.x) acc += randvec[i] * randvec[i];
     const double nrm = sqrt(block_sum_real(acc, red));
@@ -184,7 +503,8 @@ __global__ void __launch_bounds__(kThreads) lanczos_kernel(KpmArgs k, int w, con
     for (int s = 0; s < nsteps; ++s) {
         for (int i = threadIdx.x; i < N; i += blockDim.x) W[i] = VK[i];
         __syncthreads();
-        bbar_apply<MODE>(W, N, k.ncol, k.bonds, k.col_off, dbar, cbar, sbar);
+        if (FAST) bbar_apply_regs<MODE>(W, lb, k.ncol, N, dbar);
+        else bbar_apply<MODE>(W, N, k.ncol, k.bonds, k.col_off, dbar, cbar, sbar);
         acc = 0;
         for (int i = threadIdx.x; i < N; i += blockDim.x) acc += VK[i].x * W[i].x;
         const double al = block_sum_real(acc, red);
@@ -208,17 +528,23 @@ __global__ void __launch_bounds__(kThreads) lanczos_kernel(KpmArgs k, int w, con
     }
 }
 
-void launch_lanczos(hipStream_t st, const KpmArgs &k, int w, const double *randvec, int nsteps, double *alpha, double *beta, bool use_BtB)
+void launch_lanczos(hipStream_t st, const KpmArgs &k, const KpmGeom &kg, int w0, int nw, const double *randvec, int nsteps, double *alpha, double *beta, bool use_BtB)
 {
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute((const void *)lanczos_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        (void)hipFuncSetAttribute((const void *)lanczos_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute((const void *)lanczos_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute((const void *)lanczos_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         configured = true;
     }
     const size_t lds = sizeof(double2) * 3 * (size_t)k.N;
-    if (use_BtB) hipLaunchKernelGGL((lanczos_kernel<2>), dim3(1), dim3(kThreads), lds, st, k, w, randvec, nsteps, alpha, beta);
-    else hipLaunchKernelGGL((lanczos_kernel<0>), dim3(1), dim3(kThreads), lds, st, k, w, randvec, nsteps, alpha, beta);
+    const int threads = kg.fast ? kg.threads : kThreads;
+    if (kg.fast) {
+        if (use_BtB) hipLaunchKernelGGL((lanczos_kernel<2, true>), dim3(nw), dim3(threads), lds, st, k, kg, w0, randvec, nsteps, alpha, beta);
+        else hipLaunchKernelGGL((lanczos_kernel<0, true>), dim3(nw), dim3(threads), lds, st, k, kg, w0, randvec, nsteps, alpha, beta);
+    } else {
+        if (use_BtB) hipLaunchKernelGGL((lanczos_kernel<2, false>), dim3(nw), dim3(threads), lds, st, k, kg, w0, randvec, nsteps, alpha, beta);
+        else hipLaunchKernelGGL((lanczos_kernel<0, false>), dim3(nw), dim3(threads), lds, st, k, kg, w0, randvec, nsteps, alpha, beta);
+    }
 }
 
 }  // namespace smoqy

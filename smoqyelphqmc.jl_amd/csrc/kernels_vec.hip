@@ -153,24 +153,31 @@ __global__ void lambda_init_kernel(double *Lam, int Lt, int N)
 }
 
 __global__ void lambda_couple_kernel(double *Lam, int Lt, int N, const double *__restrict__ x, int Nph, double dtau, int ncoup, const int *c2p, const int *c2s, const double *alpha, const double *alpha3,
-                                     const int *phsym)
+                                     const int *phsym, const int *site_first, const int *site_next)
 {
-    // one thread per (slice, coupling).  Several couplings may hit the same site: they multiply,
-    // and multiplication order does not matter for the few couplings per site that occur, but
-    // to stay race free the launch walks couplings sequentially (grid covers slices only).
-    for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < Lt; l += gridDim.x * blockDim.x) {
-        for (int c = 0; c < ncoup; ++c) {
+    // one thread per (slice, site); the couplings of a site are walked through a linked list
+    // (site_first / site_next) in coupling order, exactly the order of the reference loop (:17-40)
+    const size_t tot = (size_t)Lt * N;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(idx / N), i = (int)(idx - (size_t)l * N);
+        double v = Lam[idx];
+        for (int c = site_first[i]; c >= 0; c = site_next[c]) {
             if (!phsym[c]) continue;
             const double xp = x[(size_t)l * Nph + c2p[c]];
-            Lam[(size_t)l * N + c2s[c]] *= exp(dtau * (alpha[c] * xp + alpha3[c] * xp * xp * xp) / 2);  // :37
+            v *= exp(dtau * (alpha[c] * xp + alpha3[c] * xp * xp * xp) / 2);  // :37
         }
+        Lam[idx] = v;
     }
 }
 
-void launch_lambda_update(hipStream_t st, double *Lam, int Lt, int N, const double *x, int Nph, double dtau, int ncoup, const int *c2p, const int *c2s, const double *alpha, const double *alpha3, const int *phsym)
+void launch_lambda_update(hipStream_t st, double *Lam, int Lt, int N, const double *x, int Nph, double dtau, int ncoup, const int *c2p, const int *c2s, const double *alpha, const double *alpha3, const int *phsym,
+                          const int *site_first, const int *site_next)
 {
-    hipLaunchKernelGGL(lambda_init_kernel, dim3(256), dim3(256), 0, st, Lam, Lt, N);
-    if (ncoup > 0) hipLaunchKernelGGL(lambda_couple_kernel, dim3((Lt + 63) / 64), dim3(64), 0, st, Lam, Lt, N, x, Nph, dtau, ncoup, c2p, c2s, alpha, alpha3, phsym);
+    const size_t tot = (size_t)Lt * N;
+    int blocks = (int)((tot + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(lambda_init_kernel, dim3(blocks), dim3(256), 0, st, Lam, Lt, N);
+    if (ncoup > 0) hipLaunchKernelGGL(lambda_couple_kernel, dim3(blocks), dim3(256), 0, st, Lam, Lt, N, x, Nph, dtau, ncoup, c2p, c2s, alpha, alpha3, phsym, site_first, site_next);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -293,31 +300,6 @@ void launch_fft_twiddle(hipStream_t st, double2 *v, const double2 *tw, int Lt, i
     int blocks = (int)((tot + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(twiddle_kernel, dim3(blocks), dim3(256), 0, st, v, tw, Lt, N, nsys, inverse);
-}
-
-// ---------------------------------------------------------------------------------------------
-// update_B̄! — src/KPMPreconditioner.jl:604-621: means over tau of the three field arrays
-// ---------------------------------------------------------------------------------------------
-__global__ void tau_means_kernel(const double *__restrict__ expV, const double *__restrict__ ch, const double *__restrict__ sh, double *dbar, double *cbar, double *sbar, int Lt, int N, int Nh)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < N) {
-        double a = 0;
-        for (int l = 0; l < Lt; ++l) a += expV[(size_t)l * N + j];
-        dbar[j] = a / Lt;
-    } else if (j < N + Nh) {
-        const int h = j - N;
-        double a = 0, b = 0;
-        for (int l = 0; l < Lt; ++l) { a += ch[(size_t)l * Nh + h]; b += sh[(size_t)l * Nh + h]; }
-        cbar[h] = a / Lt;
-        sbar[h] = b / Lt;
-    }
-}
-
-void launch_tau_means(hipStream_t st, const double *expV, const double *ch, const double *sh, double *dbar, double *cbar, double *sbar, int Lt, int N, int Nh, int w)
-{
-    (void)w;
-    hipLaunchKernelGGL(tau_means_kernel, dim3((N + Nh + 255) / 256), dim3(256), 0, st, expV, ch, sh, dbar, cbar, sbar, Lt, N, Nh);
 }
 
 // ---------------------------------------------------------------------------------------------

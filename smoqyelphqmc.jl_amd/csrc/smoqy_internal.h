@@ -21,6 +21,8 @@ namespace smoqy {
 
 constexpr int kThreads = 256;       // workgroup size of the slice kernels (4 wavefronts)
 constexpr int kMaxPartials = 1024;  // upper bound on tau-chunks per system
+constexpr int kMaxColours = 6;      // colours held in registers by the fast KPM kernels
+constexpr int kFdmColours = 4;      // colours held in registers by the fast FermionDetMatrix kernels
 
 struct Geometry {
     int Lt, N, Nh, ncol, nw, nrhs, nsys;
@@ -64,23 +66,49 @@ struct KpmArgs {
     const CgState *cg;
 };
 
+// geometry of the KPM fast path: per-colour bond lists padded with identity self bonds (i, i) so
+// that every colour covers all N sites; lane t of a workgroup owns padded bond poff[c] + t
+struct KpmGeom {
+    const int2 *pbonds;  // [ptotal]
+    const int *poff;     // [ncol + 1] (device)
+    const int *psrc;     // [ptotal] source bond index, -1 for a self bond
+    double2 *pcs;        // [nw][ptotal] tau-averaged (cosh, sinh) per padded bond
+    int ptotal;
+    int threads;         // workgroup size = padded bonds per colour rounded up to a wavefront
+    int fast;            // 0: use the generic kernels
+};
+
+// geometry + packed hopping table of the register-resident FermionDetMatrix kernels
+struct FdmFast {
+    const int2 *pbonds;  // padded bond lists (shared with KpmGeom)
+    const int *poff;     // [ncol + 1] (device)
+    const double2 *csf;  // [nw][Lt][ptotal] (cosh, sinh) per padded bond, (1, 0) on self bonds
+    int ptotal;
+    int threads;
+    int enabled;
+};
+
 // ---- launchers (defined in the .hip files) -----------------------------------------------
 void launch_fdm(hipStream_t st, int op, bool sym, const FdmArgs &a, size_t lds_bytes);
 size_t fdm_lds_bytes(int op, int N, int Tc);
+bool fdm_fast_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
+void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff);
+void launch_pack_csf(hipStream_t st, const double *ch, const double *sh, const int *psrc, double2 *csf, int Lt, int Nh, int ptotal);
 
 void launch_transpose_in(hipStream_t st, const double2 *host_layout, double2 *dev_layout, int Lt, int N, int nsys, int sys0, int count);
 void launch_transpose_out(hipStream_t st, const double2 *dev_layout, double2 *host_layout, int Lt, int N, int nsys, int sys0, int count);
 void launch_transpose_real_in(hipStream_t st, const double *src, double *dst, int Lt, int n);   // (Lt x n col-major) -> [l][n]
 void launch_transpose_real_out(hipStream_t st, const double *src, double *dst, int Lt, int n);  // [l][n] -> (Lt x n col-major)
 void launch_fields_from_path_integral(hipStream_t st, const double *V, const double *t, const int *perm0, double *expV, double *ch, double *sh, int Lt, int N, int Nh, double dtau, double dtau_k);
-void launch_lambda_update(hipStream_t st, double *Lam, int Lt, int N, const double *x, int Nph, double dtau, int ncoup, const int *c2p, const int *c2s, const double *alpha, const double *alpha3, const int *phsym);
+void launch_lambda_update(hipStream_t st, double *Lam, int Lt, int N, const double *x, int Nph, double dtau, int ncoup, const int *c2p, const int *c2s, const double *alpha, const double *alpha3, const int *phsym, const int *site_first, const int *site_next);
 void launch_lambda_apply(hipStream_t st, int op, double2 *out, const double2 *in, const double *Lam, int Lt, int N, int nsys, int nrhs, int wslot_override);
 void launch_dot(hipStream_t st, const double2 *a, const double2 *b, double2 *partial, double2 *out, int Lt, int N, int nsys, int Tc, int nchunk);
 void launch_fft_twiddle(hipStream_t st, double2 *v, const double2 *tw, int Lt, int N, int nsys, int inverse);
 void launch_make_twiddle(hipStream_t st, double2 *tw, int Lt);
-void launch_tau_means(hipStream_t st, const double *expV, const double *ch, const double *sh, double *dbar, double *cbar, double *sbar, int Lt, int N, int Nh, int w);
-void launch_lanczos(hipStream_t st, const KpmArgs &k, int w, const double *randvec, int nsteps, double *alpha, double *beta, bool use_BtB);
-void launch_cheb(hipStream_t st, const KpmArgs &k);
+void launch_tau_means(hipStream_t st, const KpmGeom &kg, const double *expV, const double *ch, const double *sh, double *dbar, double *cbar, double *sbar, int Lt, int N, int Nh, int w0, int nw);
+// alpha/beta: [nw][1024] each; randvec: [nw][N]
+void launch_lanczos(hipStream_t st, const KpmArgs &k, const KpmGeom &kg, int w0, int nw, const double *randvec, int nsteps, double *alpha, double *beta, bool use_BtB);
+void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg);
 
 // CG kernels
 struct CgArgs {

@@ -77,9 +77,9 @@ class WalkerBatch:
                 self.h.call("smoqy_lambda_update", w, None, 0, C.c_double(m.elph.dtau), 0, None, None, None, None, None)
 
     def update_preconditioner(self):
-        for w in range(self.nw):
-            rv = self.rng[w].standard_normal(self.N)  # randn!(rng, v) at KPMPreconditioner.jl:634
-            self.h.call("smoqy_precond_update", w, L.ptr(rv))
+        # randn!(rng, v) at KPMPreconditioner.jl:634, one start vector per walker
+        rv = np.ascontiguousarray(np.stack([g.standard_normal(self.N) for g in self.rng]))
+        self.h.call("smoqy_precond_update_all", L.ptr(rv))
 
     # ---- PFFCalculator on the device ---------------------------------------------------------------
     def sample_pseudofermion_fields(self):
@@ -118,7 +118,7 @@ class WalkerBatch:
 
     def drift_fields(self, pis, step):
         for m, pi in zip(self.models, pis):
-            m.elph.x += step * pi
+            np.add(m.elph.x, step * pi, out=m.elph.x)
         self.refresh_fields()
 
     # ---- one synthetic sweep -------------------------------------------------------------------------
@@ -128,13 +128,13 @@ class WalkerBatch:
         # (src/reflection_update.jl:69-114, src/swap_update.jl)
         for _ in range(2):
             self.sample_pseudofermion_fields()
-            pis = [g.standard_normal(m.elph.x.shape) for g, m in zip(self.rng, self.models)]
+            pis = [g.standard_normal(m.elph.x.shape[::-1]).T for g, m in zip(self.rng, self.models)]  # same (Fortran) order as x
             self.drift_fields(pis, self.drift)
             last = self.calculate_fermionic_action(self.tol)
             self.drift_fields(pis, -self.drift)  # "rejected": restore x, update! (src/reflection_update.jl)
         # HMC trajectory (src/EFAPFFHMCUpdater.jl:102-276)
         self.sample_pseudofermion_fields()
-        pis = [g.standard_normal(m.elph.x.shape) for g, m in zip(self.rng, self.models)]
+        pis = [g.standard_normal(m.elph.x.shape[::-1]).T for g, m in zip(self.rng, self.models)]  # same (Fortran) order as x
         for _ in range(self.Nt):
             self.calculate_fermionic_action(self.tol_force)
             self.force_operator_applies()

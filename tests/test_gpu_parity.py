@@ -78,8 +78,10 @@ def test_upload_download_roundtrip():
 @pytest.mark.parametrize("kind", ["honeycomb", "square", "chain"])
 @pytest.mark.parametrize("is_sym", [True, False])
 @pytest.mark.parametrize("Tc", [1, 2, 3, 4])
-def test_matvec_all_ops(kind, is_sym, Tc):
+@pytest.mark.parametrize("generic", [False, True])
+def test_matvec_all_ops(kind, is_sym, Tc, generic):
     p = Problem(kind, is_sym)
+    p.h.call("smoqy_matvec_force_generic", int(generic))
     p.h.call("smoqy_set_tau_chunk", Tc)
     v = p.rand(1, 3)
     o = p.oracles[0]
@@ -214,8 +216,10 @@ def _precond_state(p, w=0):
 
 @pytest.mark.parametrize("kind", ["honeycomb_L4", "square_L6", "chain_L24"])  # N > 20 Lanczos steps
 @pytest.mark.parametrize("is_sym", [True, False])
-def test_kpm_preconditioner_state_and_apply(kind, is_sym):
+@pytest.mark.parametrize("generic", [False, True])
+def test_kpm_preconditioner_state_and_apply(kind, is_sym, generic):
     p = Problem(kind, is_sym, nwalkers=1, nrhs=2)
+    p.h.call("smoqy_precond_force_generic", int(generic))
     rv = np.random.default_rng(8).standard_normal(p.N)
     P = orc.OracleKPM(p.oracles[0])
     P.update(rv)
