@@ -71,6 +71,10 @@ int smoqy_update_fields(smoqy_ctx *ctx, int walker, const double *expV, const do
 /* update!(fdm, fpi) on the device (src/FermionDetMatrix.jl:208-236): V is N x Ltau, t is
  * Nh x Ltau (FermionPathIntegral layout), perm the 1-based checkerboard permutation */
 int smoqy_update_from_path_integral(smoqy_ctx *ctx, int walker, const double *V, const double *t, const int64_t *perm, double dtau);
+/* the same for every walker of the handle in one pass: V_all is N x Ltau x nwalkers, t_all is
+ * Nh x Ltau x nwalkers.  V_all == NULL or t_all == NULL leaves that part of the fields unchanged
+ * (a walker whose hoppings do not depend on the phonon field need not resend them). */
+int smoqy_update_from_path_integral_all(smoqy_ctx *ctx, const double *V_all, const double *t_all, const int64_t *perm, double dtau);
 /* read the fields back (field access .expnΔτV etc., used by KPMPreconditioner.jl:208-209) */
 int smoqy_get_fields(smoqy_ctx *ctx, int walker, double *expV, double *cosh_dtt, double *sinh_dtt);
 
@@ -103,6 +107,9 @@ int smoqy_lambda_set(smoqy_ctx *ctx, int walker, const double *Lambda);
 int smoqy_lambda_update(smoqy_ctx *ctx, int walker, const double *x, int Nph, double dtau, int ncoup,
                         const int64_t *coupling_to_phonon, const int64_t *coupling_to_site,
                         const double *alpha, const double *alpha3, const int32_t *ph_sym);
+/* every walker in one pass (same coupling tables for all); x_all is Nph x Ltau x nwalkers */
+int smoqy_lambda_update_all(smoqy_ctx *ctx, const double *x_all, int Nph, double dtau, int ncoup, const int64_t *coupling_to_phonon,
+                            const int64_t *coupling_to_site, const double *alpha, const double *alpha3, const int32_t *ph_sym);
 int smoqy_lambda_get(smoqy_ctx *ctx, int walker, double *Lambda);
 /* mul_Λ!/ldiv_Λ!/mul_Λᵀ!/ldiv_Λᵀ! with the walker's stored Λ; out == in allowed */
 int smoqy_lambda_apply_v(smoqy_ctx *ctx, int op, int out, int in);

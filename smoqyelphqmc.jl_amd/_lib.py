@@ -54,6 +54,7 @@ SIGNATURES = {
     "smoqy_get_tau_chunk": [_p, _pi],
     "smoqy_update_fields": [_p, _i, _p, _p, _p],
     "smoqy_update_from_path_integral": [_p, _i, _p, _p, _p, _d],
+    "smoqy_update_from_path_integral_all": [_p, _p, _p, _p, _d],
     "smoqy_get_fields": [_p, _i, _p, _p, _p],
     "smoqy_vec_alloc": [_p, _pi],
     "smoqy_vec_free": [_p, _i],
@@ -66,6 +67,7 @@ SIGNATURES = {
     "smoqy_matvec": [_p, _i, _p, _p, _i, _i],
     "smoqy_lambda_set": [_p, _i, _p],
     "smoqy_lambda_update": [_p, _i, _p, _i, _d, _i, _p, _p, _p, _p, _p],
+    "smoqy_lambda_update_all": [_p, _p, _i, _d, _i, _p, _p, _p, _p, _p],
     "smoqy_lambda_get": [_p, _i, _p],
     "smoqy_lambda_apply_v": [_p, _i, _i, _i],
     "smoqy_lambda_apply": [_p, _i, _p, _p, _p, _i, _i],

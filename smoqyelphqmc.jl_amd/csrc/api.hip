@@ -468,28 +468,48 @@ int smoqy_update_fields(smoqy_ctx *c, int w, const double *expV, const double *c
     return check_launch(c, "update_fields");
 }
 
+// update!(fdm, fpi) for walkers [w0, w0 + nw): arrays of the walkers are stacked back to back.
+// V == NULL or t == NULL leaves that part of the fields as it is.
+static int update_pi_range(smoqy_ctx *c, int w0, int nw, const double *V, const double *t, const int64_t *perm, double dtau)
+{
+    const Geometry &g = c->g;
+    const size_t nV = (size_t)g.Lt * g.N, nT = (size_t)g.Lt * g.Nh;
+    if (int rc = ensure_stage_real(c, (size_t)nw * (nV + nT) + 1)) return rc;
+    if (int rc = ensure_stage_int(c, (size_t)std::max(g.Nh, 1))) return rc;
+    double *dV = c->d_stage_real, *dT = c->d_stage_real + (size_t)nw * nV;
+    if (V) HIPCHK(c, hipMemcpyAsync(dV, V, (size_t)nw * nV * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (t && nT) {
+        if (!perm) FAIL(c, 1, "perm must be given with t");
+        std::vector<int> p0((size_t)g.Nh);
+        for (int h = 0; h < g.Nh; ++h) {
+            if (perm[h] < 1 || perm[h] > g.Nh) FAIL(c, 1, "perm[%d] = %lld out of range", h + 1, (long long)perm[h]);
+            p0[h] = (int)perm[h] - 1;
+        }
+        HIPCHK(c, hipMemcpyAsync(dT, t, (size_t)nw * nT * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_stage_int, p0.data(), p0.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // p0 is a temporary
+    }
+    const bool do_t = t && nT;
+    launch_fields_from_path_integral(c->stream, V ? dV : nullptr, do_t ? dT : nullptr, c->d_stage_int, c->d_expV + (size_t)w0 * nV, c->d_ch + (size_t)w0 * nT, c->d_sh + (size_t)w0 * nT, nw * g.Lt, g.N, g.Nh,
+                                     dtau, g.is_sym ? dtau / 2 : dtau);  // FermionDetMatrix.jl:220
+    if (do_t) launch_pack_csf(c->stream, c->d_ch + (size_t)w0 * nT, c->d_sh + (size_t)w0 * nT, c->d_psrc, c->d_csf + (size_t)w0 * g.Lt * c->kg.ptotal, nw * g.Lt, g.Nh, c->kg.ptotal);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_launch(c, "update_from_path_integral");
+}
+
 int smoqy_update_from_path_integral(smoqy_ctx *c, int w, const double *V, const double *t, const int64_t *perm, double dtau)
 {
     CHECK_CTX(c);
     CHECK_WALKER(c, w);
-    const Geometry &g = c->g;
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t nV = (size_t)g.Lt * g.N, nT = (size_t)g.Lt * g.Nh;
-    if (int rc = ensure_stage_real(c, nV + nT)) return rc;
-    if (int rc = ensure_stage_int(c, (size_t)std::max(g.Nh, 1))) return rc;
-    std::vector<int> p0((size_t)g.Nh);
-    for (int h = 0; h < g.Nh; ++h) {
-        if (perm[h] < 1 || perm[h] > g.Nh) FAIL(c, 1, "perm[%d] = %lld out of range", h + 1, (long long)perm[h]);
-        p0[h] = (int)perm[h] - 1;
-    }
-    HIPCHK(c, hipMemcpyAsync(c->d_stage_real, V, nV * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (nT) HIPCHK(c, hipMemcpyAsync(c->d_stage_real + nV, t, nT * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (g.Nh) HIPCHK(c, hipMemcpyAsync(c->d_stage_int, p0.data(), p0.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    launch_fields_from_path_integral(c->stream, c->d_stage_real, c->d_stage_real + nV, c->d_stage_int, c->d_expV + (size_t)w * nV, c->d_ch + (size_t)w * nT, c->d_sh + (size_t)w * nT, g.Lt, g.N, g.Nh, dtau,
-                                     g.is_sym ? dtau / 2 : dtau);  // FermionDetMatrix.jl:220
-    launch_pack_csf(c->stream, c->d_ch + (size_t)w * nT, c->d_sh + (size_t)w * nT, c->d_psrc, c->d_csf + (size_t)w * g.Lt * c->kg.ptotal, g.Lt, g.Nh, c->kg.ptotal);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return check_launch(c, "update_from_path_integral");
+    return update_pi_range(c, w, 1, V, t, perm, dtau);
+}
+
+int smoqy_update_from_path_integral_all(smoqy_ctx *c, const double *V_all, const double *t_all, const int64_t *perm, double dtau)
+{
+    CHECK_CTX(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    return update_pi_range(c, 0, c->g.nw, V_all, t_all, perm, dtau);
 }
 
 int smoqy_get_fields(smoqy_ctx *c, int w, double *expV, double *ch, double *sh)
@@ -645,14 +665,11 @@ int smoqy_lambda_get(smoqy_ctx *c, int w, double *Lambda)
     return download_real_field(c, c->d_lam + (size_t)w * c->g.Lt * c->g.N, Lambda, c->g.N);
 }
 
-int smoqy_lambda_update(smoqy_ctx *c, int w, const double *x, int Nph, double dtau, int ncoup, const int64_t *c2p, const int64_t *c2s, const double *alpha, const double *alpha3, const int32_t *ph_sym)
+static int lambda_update_range(smoqy_ctx *c, int w0, int nw, const double *x, int Nph, double dtau, int ncoup, const int64_t *c2p, const int64_t *c2s, const double *alpha, const double *alpha3, const int32_t *ph_sym)
 {
-    CHECK_CTX(c);
-    CHECK_WALKER(c, w);
     const Geometry &g = c->g;
-    HIPCHK(c, hipSetDevice(c->device));
     if (Nph < 0 || ncoup < 0) FAIL(c, 1, "negative Nph/ncoup");
-    const size_t nx = (size_t)Nph * g.Lt;
+    const size_t nx = (size_t)nw * Nph * g.Lt;
     if (int rc = ensure_stage_real(c, nx + 2 * (size_t)ncoup + 1)) return rc;
     if (int rc = ensure_stage_int(c, 4 * (size_t)ncoup + g.N + 1)) return rc;
     // [c2p | c2s | ph_sym | site_next(ncoup) | site_first(N)]; per-site coupling lists keep the reference's coupling order
@@ -672,12 +689,27 @@ int smoqy_lambda_update(smoqy_ctx *c, int w, const double *x, int Nph, double dt
     if (ncoup) {
         HIPCHK(c, hipMemcpyAsync(c->d_stage_real + nx, alpha, (size_t)ncoup * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_stage_real + nx + ncoup, alpha3, (size_t)ncoup * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_stage_int, ib.data(), ib.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     }
-    launch_lambda_update(c->stream, c->d_lam + (size_t)w * g.Lt * g.N, g.Lt, g.N, c->d_stage_real, Nph, dtau, ncoup, c->d_stage_int, c->d_stage_int + ncoup, c->d_stage_real + nx, c->d_stage_real + nx + ncoup,
-                         c->d_stage_int + 2 * ncoup, c->d_stage_int + 4 * (size_t)ncoup, c->d_stage_int + 3 * (size_t)ncoup);
+    HIPCHK(c, hipMemcpyAsync(c->d_stage_int, ib.data(), ib.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    launch_lambda_update(c->stream, c->d_lam + (size_t)w0 * g.Lt * g.N, nw * g.Lt, g.N, c->d_stage_real, Nph, dtau, ncoup, c->d_stage_int, c->d_stage_int + ncoup, c->d_stage_real + nx, c->d_stage_real + nx + ncoup,
+                         c->d_stage_int + 2 * ncoup, c->d_stage_int + 4 * (size_t)ncoup, c->d_stage_int + 3 * (size_t)ncoup, g.Lt);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_launch(c, "lambda_update");
+}
+
+int smoqy_lambda_update(smoqy_ctx *c, int w, const double *x, int Nph, double dtau, int ncoup, const int64_t *c2p, const int64_t *c2s, const double *alpha, const double *alpha3, const int32_t *ph_sym)
+{
+    CHECK_CTX(c);
+    CHECK_WALKER(c, w);
+    HIPCHK(c, hipSetDevice(c->device));
+    return lambda_update_range(c, w, 1, x, Nph, dtau, ncoup, c2p, c2s, alpha, alpha3, ph_sym);
+}
+
+int smoqy_lambda_update_all(smoqy_ctx *c, const double *x_all, int Nph, double dtau, int ncoup, const int64_t *c2p, const int64_t *c2s, const double *alpha, const double *alpha3, const int32_t *ph_sym)
+{
+    CHECK_CTX(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    return lambda_update_range(c, 0, c->g.nw, x_all, Nph, dtau, ncoup, c2p, c2s, alpha, alpha3, ph_sym);
 }
 
 int smoqy_lambda_apply_v(smoqy_ctx *c, int op, int out, int in)

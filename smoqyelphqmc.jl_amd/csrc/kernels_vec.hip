@@ -120,12 +120,14 @@ void launch_transpose_real_out(hipStream_t st, const double *src, double *dst, i
 __global__ void fields_kernel(const double *__restrict__ V, const double *__restrict__ t, const int *__restrict__ perm0, double *__restrict__ expV, double *__restrict__ ch,
                               double *__restrict__ sh, int Lt, int N, int Nh, double dtau, double dtau_k)
 {
-    const size_t tot = (size_t)Lt * (N + Nh);
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
-        if (idx < (size_t)Lt * N) {
+    // Lt may be nwalkers * Ltau: the walkers' arrays are contiguous on both sides.  V == nullptr or
+    // t == nullptr skips that part (fields unchanged).
+    const size_t nV = V ? (size_t)Lt * N : 0, nT = t ? (size_t)Lt * Nh : 0;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nV + nT; idx += (size_t)gridDim.x * blockDim.x) {
+        if (idx < nV) {
             expV[idx] = exp(-dtau * V[idx]);  // :217
         } else {
-            const size_t j = idx - (size_t)Lt * N;
+            const size_t j = idx - nV;
             const int l = (int)(j / Nh), h = (int)(j - (size_t)l * Nh);
             const double tt = t[(size_t)l * Nh + perm0[h]];  // :224-228
             const double a = dtau_k * fabs(tt);
@@ -137,7 +139,8 @@ __global__ void fields_kernel(const double *__restrict__ V, const double *__rest
 
 void launch_fields_from_path_integral(hipStream_t st, const double *V, const double *t, const int *perm0, double *expV, double *ch, double *sh, int Lt, int N, int Nh, double dtau, double dtau_k)
 {
-    const size_t tot = (size_t)Lt * (N + Nh);
+    const size_t tot = (V ? (size_t)Lt * N : 0) + (t ? (size_t)Lt * Nh : 0);
+    if (tot == 0) return;
     int blocks = (int)((tot + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(fields_kernel, dim3(blocks), dim3(256), 0, st, V, t, perm0, expV, ch, sh, Lt, N, Nh, dtau, dtau_k);
@@ -146,10 +149,11 @@ void launch_fields_from_path_integral(hipStream_t st, const double *V, const dou
 // ---------------------------------------------------------------------------------------------
 // update_Λ! — src/holstein_shift_matrix.jl:2-44  (x is Nph x Ltau, phonon fastest)
 // ---------------------------------------------------------------------------------------------
-__global__ void lambda_init_kernel(double *Lam, int Lt, int N)
+__global__ void lambda_init_kernel(double *Lam, int Lt, int N, int Lt1)
 {
-    const size_t tot = (size_t)Lt * N;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) Lam[idx] = (idx < (size_t)N) ? 1.0 : -1.0;  // :11-12
+    // Lt = nwalkers * Lt1 slices in a row; the first slice of every walker is +1 (:11-12)
+    const size_t tot = (size_t)Lt * N, per = (size_t)Lt1 * N;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) Lam[idx] = (idx % per < (size_t)N) ? 1.0 : -1.0;
 }
 
 __global__ void lambda_couple_kernel(double *Lam, int Lt, int N, const double *__restrict__ x, int Nph, double dtau, int ncoup, const int *c2p, const int *c2s, const double *alpha, const double *alpha3,
@@ -171,12 +175,12 @@ __global__ void lambda_couple_kernel(double *Lam, int Lt, int N, const double *_
 }
 
 void launch_lambda_update(hipStream_t st, double *Lam, int Lt, int N, const double *x, int Nph, double dtau, int ncoup, const int *c2p, const int *c2s, const double *alpha, const double *alpha3, const int *phsym,
-                          const int *site_first, const int *site_next)
+                          const int *site_first, const int *site_next, int Lt1)
 {
     const size_t tot = (size_t)Lt * N;
     int blocks = (int)((tot + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(lambda_init_kernel, dim3(blocks), dim3(256), 0, st, Lam, Lt, N);
+    hipLaunchKernelGGL(lambda_init_kernel, dim3(blocks), dim3(256), 0, st, Lam, Lt, N, Lt1);
     if (ncoup > 0) hipLaunchKernelGGL(lambda_couple_kernel, dim3(blocks), dim3(256), 0, st, Lam, Lt, N, x, Nph, dtau, ncoup, c2p, c2s, alpha, alpha3, phsym, site_first, site_next);
 }
 

@@ -100,7 +100,7 @@ void launch_transpose_out(hipStream_t st, const double2 *dev_layout, double2 *ho
 void launch_transpose_real_in(hipStream_t st, const double *src, double *dst, int Lt, int n);   // (Lt x n col-major) -> [l][n]
 void launch_transpose_real_out(hipStream_t st, const double *src, double *dst, int Lt, int n);  // [l][n] -> (Lt x n col-major)
 void launch_fields_from_path_integral(hipStream_t st, const double *V, const double *t, const int *perm0, double *expV, double *ch, double *sh, int Lt, int N, int Nh, double dtau, double dtau_k);
-void launch_lambda_update(hipStream_t st, double *Lam, int Lt, int N, const double *x, int Nph, double dtau, int ncoup, const int *c2p, const int *c2s, const double *alpha, const double *alpha3, const int *phsym, const int *site_first, const int *site_next);
+void launch_lambda_update(hipStream_t st, double *Lam, int Lt, int N, const double *x, int Nph, double dtau, int ncoup, const int *c2p, const int *c2s, const double *alpha, const double *alpha3, const int *phsym, const int *site_first, const int *site_next, int Lt1);
 void launch_lambda_apply(hipStream_t st, int op, double2 *out, const double2 *in, const double *Lam, int Lt, int N, int nsys, int nrhs, int wslot_override);
 void launch_dot(hipStream_t st, const double2 *a, const double2 *b, double2 *partial, double2 *out, int Lt, int N, int nsys, int Tc, int nchunk);
 void launch_fft_twiddle(hipStream_t st, double2 *v, const double2 *tw, int Lt, int N, int nsys, int inverse);

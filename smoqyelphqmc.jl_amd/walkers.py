@@ -20,12 +20,13 @@ reference call stack:
 What is NOT part of the hot path (SmoQyDQMC's EFA leapfrog, the bosonic action, the force
 contractions ∂M/∂x — SURVEY.md §8(f)) is replaced by a synthetic drift of the phonon field
 ``x ← x + δ·π`` with a fixed random "momentum" π, so successive solves see slowly moving
-fields like an HMC trajectory does.  Random numbers are drawn on the host (the reference's rng
-stays on the host).
+fields like an HMC trajectory does.  Random numbers are drawn on the host, one generator per
+walker (the reference's rng stays on the host).
 """
 from __future__ import annotations
 
 import ctypes as C
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 
 import numpy as np
@@ -43,52 +44,75 @@ class SweepStats:
 
 class WalkerBatch:
     def __init__(self, workload: str, nwalkers: int = 1, walker0: int = 0, is_sym: bool = True, device: int = -1, tol: float = 1e-10, maxiter: int = 10_000, Nt: int = 24,
-                 drift: float = 0.02, check_every: int | None = None, tau_chunk: int | None = None, smooth: bool = False):
+                 drift: float = 0.02, check_every: int | None = None, tau_chunk: int | None = None, smooth: bool = False, host_threads: int = 8):
         self.models = [lat.CONFIGS[workload](walker=walker0 + w, smooth=smooth) for w in range(nwalkers)]
         m0 = self.models[0]
         self.workload = workload
         self.nt, self.perm, self.colors = lat.checkerboard_decomposition(m0.fpi.neighbor_table)
         self.Lt, self.N, self.nw = m0.fpi.Ltau, m0.fpi.N, nwalkers
+        self.Nh, self.Nph = m0.fpi.t.shape[0], m0.elph.x.shape[0]
         self.dtau = m0.fpi.dtau
         self.tol, self.tol_force, self.maxiter, self.Nt, self.drift = tol, float(np.sqrt(tol)), maxiter, Nt, drift  # tutorials/holstein_honeycomb.jl:591
+        # stacked host storage: walker w's (Nph x Ltau) / (N x Ltau) / (Nh x Ltau) column-major arrays
+        # are the transposed views xs[w].T etc., so the whole batch crosses the C ABI in one call
+        self.xs = np.empty((nwalkers, self.Lt, self.Nph))
+        self.Vs = np.empty((nwalkers, self.Lt, self.N))
+        self.ts = np.empty((nwalkers, self.Lt, self.Nh))
+        for w, m in enumerate(self.models):
+            self.xs[w] = m.elph.x.T
+            self.Vs[w] = m.fpi.V.T
+            self.ts[w] = m.fpi.t.T
+            m.elph.x, m.fpi.V, m.fpi.t = self.xs[w].T, self.Vs[w].T, self.ts[w].T
+        self.hoppings_move = m0.kind != "holstein"  # Holstein: t is constant, only V follows the phonons
         self.h = L.Handle(self.Lt, self.N, self.nt, self.colors, is_sym, nwalkers, 1, device)
         if check_every:
             self.h.call("smoqy_cg_config", int(check_every))
         if tau_chunk:
             self.h.call("smoqy_set_tau_chunk", int(tau_chunk))
         self.rng = [np.random.Generator(np.random.PCG64(lat.SEED0 + 7919 * (walker0 + w) + 1)) for w in range(nwalkers)]
+        self.pool = ThreadPoolExecutor(max_workers=max(1, min(host_threads, nwalkers)))
         # device-resident PFFCalculator state (src/PFFCalculator.jl:9-16): Φ, u, u′, u″
         self.phi, self.u, self.u1, self.u2 = (self.h.vec_alloc() for _ in range(4))
+        self._R = np.empty((self.Lt, self.N, nwalkers), dtype=np.complex128, order="F")
         self.stats = SweepStats()
-        self.refresh_fields()
+        self.refresh_fields(first=True)
 
     # ---- field plumbing -------------------------------------------------------------------------
-    def refresh_fields(self):
+    def refresh_fields(self, first: bool = False):
         """update!(fdm, fpi) and update_Λ! for every walker from its current phonon field."""
-        for w, m in enumerate(self.models):
+        for m in self.models:
             m.refresh_from_x()
-            self.h.call("smoqy_update_from_path_integral", w, L.ptr(m.fpi.V), L.ptr(m.fpi.t), L.ptr(self.perm), C.c_double(m.fpi.dtau))
-            hol = m.elph.holstein
-            if hol is not None:
-                self.h.call("smoqy_lambda_update", w, L.ptr(m.elph.x), m.elph.x.shape[0], C.c_double(m.elph.dtau), len(hol.alpha), L.ptr(np.ascontiguousarray(hol.coupling_to_phonon, dtype=np.int64)),
-                            L.ptr(np.ascontiguousarray(hol.coupling_to_site, dtype=np.int64)), L.ptr(np.ascontiguousarray(hol.alpha, dtype=np.float64)), L.ptr(np.ascontiguousarray(hol.alpha3, dtype=np.float64)),
-                            L.ptr(np.ascontiguousarray(hol.ph_sym_form, dtype=np.int32)))
-            else:
-                self.h.call("smoqy_lambda_update", w, None, 0, C.c_double(m.elph.dtau), 0, None, None, None, None, None)
+        t_all = L.ptr(self.ts) if (first or self.hoppings_move) else None
+        self.h.call("smoqy_update_from_path_integral_all", L.ptr(self.Vs), t_all, L.ptr(self.perm), C.c_double(self.dtau))
+        hol = self.models[0].elph.holstein
+        if hol is not None:
+            self.h.call("smoqy_lambda_update_all", L.ptr(self.xs), self.Nph, C.c_double(self.dtau), len(hol.alpha), L.ptr(np.ascontiguousarray(hol.coupling_to_phonon, dtype=np.int64)),
+                        L.ptr(np.ascontiguousarray(hol.coupling_to_site, dtype=np.int64)), L.ptr(np.ascontiguousarray(hol.alpha, dtype=np.float64)), L.ptr(np.ascontiguousarray(hol.alpha3, dtype=np.float64)),
+                        L.ptr(np.ascontiguousarray(hol.ph_sym_form, dtype=np.int32)))
+        elif first:
+            self.h.call("smoqy_lambda_update_all", None, 0, C.c_double(self.dtau), 0, None, None, None, None, None)
 
     def update_preconditioner(self):
         # randn!(rng, v) at KPMPreconditioner.jl:634, one start vector per walker
         rv = np.ascontiguousarray(np.stack([g.standard_normal(self.N) for g in self.rng]))
         self.h.call("smoqy_precond_update_all", L.ptr(rv))
 
+    def _randn_all(self, shape):
+        """One standard-normal array per walker from that walker's generator (host threads)."""
+        return list(self.pool.map(lambda g: g.standard_normal(shape), self.rng))
+
     # ---- PFFCalculator on the device ---------------------------------------------------------------
     def sample_pseudofermion_fields(self):
         """Φ = Λᵀ Mᵀ R with R ~ CN(0,1) drawn on the host; returns |R|² per walker."""
-        R = np.empty((self.Lt, self.N, self.nw), dtype=np.complex128, order="F")
-        for w in range(self.nw):
-            # randn!(rng, Φ) for ComplexF64 draws real and imaginary parts with variance 1/2
-            z = self.rng[w].standard_normal((2, self.N, self.Lt)) * np.sqrt(0.5)
-            R[:, :, w] = (z[0] + 1j * z[1]).T
+        R = self._R
+
+        def fill(w):
+            # randn!(rng, Φ) for ComplexF64: (re, im) pairs in memory order, each of variance 1/2
+            flat = R[:, :, w].reshape(-1, order="F").view(np.float64)
+            self.rng[w].standard_normal(out=flat)
+            flat *= np.sqrt(0.5)
+
+        list(self.pool.map(fill, range(self.nw)))
         self.h.vec_upload(self.phi, R)
         sf = self.h.vec_dot(self.phi, self.phi).real
         self.h.call("smoqy_matvec_v", L.OP_MT, self.phi, self.phi)          # lmul_Mt!  (:71)
@@ -117,9 +141,11 @@ class WalkerBatch:
         self.h.call("smoqy_matvec_v", L.OP_MT, self.u1, self.u2)             # Mᵀ AΨ
 
     def drift_fields(self, pis, step):
-        for m, pi in zip(self.models, pis):
-            np.add(m.elph.x, step * pi, out=m.elph.x)
+        self.xs += step * pis
         self.refresh_fields()
+
+    def _momentum(self):
+        return np.stack(self._randn_all((self.Lt, self.Nph)))
 
     # ---- one synthetic sweep -------------------------------------------------------------------------
     def sweep(self):
@@ -128,13 +154,13 @@ class WalkerBatch:
         # (src/reflection_update.jl:69-114, src/swap_update.jl)
         for _ in range(2):
             self.sample_pseudofermion_fields()
-            pis = [g.standard_normal(m.elph.x.shape[::-1]).T for g, m in zip(self.rng, self.models)]  # same (Fortran) order as x
+            pis = self._momentum()
             self.drift_fields(pis, self.drift)
             last = self.calculate_fermionic_action(self.tol)
             self.drift_fields(pis, -self.drift)  # "rejected": restore x, update! (src/reflection_update.jl)
         # HMC trajectory (src/EFAPFFHMCUpdater.jl:102-276)
         self.sample_pseudofermion_fields()
-        pis = [g.standard_normal(m.elph.x.shape[::-1]).T for g, m in zip(self.rng, self.models)]  # same (Fortran) order as x
+        pis = self._momentum()
         for _ in range(self.Nt):
             self.calculate_fermionic_action(self.tol_force)
             self.force_operator_applies()
