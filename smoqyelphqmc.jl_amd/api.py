@@ -1,0 +1,473 @@
+"""Host-side mirror of the reference's operator API for the CG / stochastic-trace hot path.
+
+Same names, argument meaning and error behaviour as the Julia functions (minus the ``!``), so
+the parity tests read like the reference's own call sites.  Every function that computes goes
+through the C ABI of ``libsmoqy_hip.so``; there is no CPU implementation behind these names.
+
+Vectors are numpy ``complex128`` arrays in the reference layout (``Ltau x N`` column-major, i.e.
+``order="F"``; a flat vector of length ``Ltau*N`` is accepted too, like ``reshaped`` at
+src/SmoQyElPhQMC.jl:18-20).  Output arguments are written in place.
+
+reference type / function                      here
+---------------------------------------------  ----------------------------------------------
+SymFermionDetMatrix / AsymFermionDetMatrix     same (src/FermionDetMatrix.jl:44-204)
+update!(fdm, fpi)                              update(fdm, fpi)                 (:208-236)
+mul_M!, mul_Mt!, mul_MtM!, mul_MMt!, mul!      mul_M, mul_Mt, mul_MtM, mul_MMt, mul
+lmul_M!, lmul_Mt!, lmul_MtM!, lmul_MMt!, lmul! lmul_M, lmul_Mt, lmul_MtM, lmul_MMt, lmul
+ldiv!(v', fdm, v; preconditioner, ...)         ldiv(vp, fdm, v, preconditioner=I, ...) (:248-288)
+ConjugateGradientSolver, cg_solve!             same, cg_solve (IterativeSolvers/ConjugateGradient.jl)
+KPMPreconditioner, update_preconditioner!      same, update_preconditioner (KPMPreconditioner.jl)
+ldiv!(u', P, u)                                ldiv(up, P, u)
+FourierTransformer, mul!/lmul!/ldiv!           same, mul / lmul / ldiv (FourierTransformer.jl)
+update_Λ!, mul_Λ!, ldiv_Λ!, mul_Λᵀ!, ldiv_Λᵀ!   update_Λ, mul_Λ, ldiv_Λ, mul_Λᵀ, ldiv_Λᵀ (+ ASCII aliases)
+PFFCalculator, sample_pseudofermion_fields!,   same (src/PFFCalculator.jl)
+calculate_fermionic_action!
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from . import _lib as L
+from .lattice import ElectronPhononParameters, FermionPathIntegral, checkerboard_decomposition
+
+
+class _Identity:
+    """``LinearAlgebra.I`` — the default ``preconditioner = I``."""
+
+    def __repr__(self):
+        return "I"
+
+
+I = _Identity()
+
+
+class ConjugateGradientSolver:
+    """src/IterativeSolvers/ConjugateGradient.jl:16-60.  The work vectors r, p, z live on the
+    device inside the handle; this object carries ``maxiter``, ``tol`` and ``N``."""
+
+    def __init__(self, z, maxiter=None, tol=1e-2):
+        n = int(np.size(z))
+        self.N = n
+        self.maxiter = n if maxiter is None else int(maxiter)  # the reference default is the (buggy) length(z), :50
+        self.tol = float(tol)
+
+
+class FermionDetMatrix:
+    """Abstract base (src/FermionDetMatrix.jl:19).  One instance owns one ``smoqy_ctx`` with a
+    single walker; ``nrhs`` > 1 lets batched callers (GreensEstimator-style multi-RHS solves)
+    share the fields."""
+
+    is_sym = True
+
+    def __init__(self, fermion_path_integral: FermionPathIntegral, maxiter=None, tol=1e-6, nrhs=1, device=-1):
+        fpi = fermion_path_integral
+        self.Lt, self.N = int(fpi.Ltau), int(fpi.N)
+        self.Nh = int(np.shape(fpi.t)[0])
+        maxiter = self.N * self.Lt if maxiter is None else int(maxiter)
+        # checkerboard decomposition (Checkerboard.jl stand-in), :96 / :189
+        self.checkerboard_neighbor_table, self.checkerboard_perm, colors = checkerboard_decomposition(fpi.neighbor_table)
+        self._colors = colors
+        self.checkerboard_colors = [range(int(colors[0, c]), int(colors[1, c]) + 1) for c in range(colors.shape[1])]
+        self.cgs = ConjugateGradientSolver(np.empty(self.Lt * self.N), maxiter=maxiter, tol=tol)
+        self.handle = L.Handle(self.Lt, self.N, self.checkerboard_neighbor_table, colors, self.is_sym, 1, nrhs, device)
+        self.nrhs = nrhs
+        update(self, fpi)
+
+    # field access used by KPMPreconditioner (:208-209) and the force code
+    def _fields(self):
+        e = np.zeros((self.Lt, self.N), order="F")
+        c = np.zeros((self.Lt, self.Nh), order="F")
+        s = np.zeros((self.Lt, self.Nh), order="F")
+        self.handle.call("smoqy_get_fields", 0, L.ptr(e), L.ptr(c), L.ptr(s))
+        return e, c, s
+
+    @property
+    def expnΔτV(self):
+        return self._fields()[0]
+
+    @property
+    def coshΔτt(self):
+        return self._fields()[1]
+
+    @property
+    def sinhΔτt(self):
+        return self._fields()[2]
+
+
+class SymFermionDetMatrix(FermionDetMatrix):
+    """B_l = [e^{-ΔτK_l/2}]ᵀ e^{-ΔτV_l} e^{-ΔτK_l/2} (src/FermionDetMatrix.jl:22-111)."""
+
+    is_sym = True
+
+
+class AsymFermionDetMatrix(FermionDetMatrix):
+    """B_l = e^{-ΔτV_l} e^{-ΔτK_l} (src/FermionDetMatrix.jl:115-204)."""
+
+    is_sym = False
+
+
+def update(fermion_det_matrix: FermionDetMatrix, fermion_path_integral: FermionPathIntegral):
+    """update!(fdm, fpi), src/FermionDetMatrix.jl:208-236, computed on the device."""
+    fpi = fermion_path_integral
+    V = np.asfortranarray(fpi.V, dtype=np.float64)
+    t = np.asfortranarray(fpi.t, dtype=np.float64)
+    if V.shape != (fermion_det_matrix.N, fermion_det_matrix.Lt) or t.shape != (fermion_det_matrix.Nh, fermion_det_matrix.Lt):
+        raise ValueError("FermionPathIntegral arrays do not match the FermionDetMatrix")
+    fermion_det_matrix.handle.call("smoqy_update_from_path_integral", 0, L.ptr(V), L.ptr(t), L.ptr(fermion_det_matrix.checkerboard_perm), C.c_double(fpi.dtau))
+
+
+def size(fermion_det_matrix: FermionDetMatrix, dim=None):
+    n = fermion_det_matrix.Lt * fermion_det_matrix.N
+    return n if dim is not None else (n, n)
+
+
+def eltype(fermion_det_matrix: FermionDetMatrix):
+    return np.float64
+
+
+# ---- matrix-vector products --------------------------------------------------------------------
+
+def _matvec(op, vp, fdm, v):
+    h = fdm.handle
+    vin = L.as_state(v, h.Lt, h.N)
+    vout = L.writable_state(vp, h.Lt, h.N)
+    h.call("smoqy_matvec", op, L.ptr(vout), L.ptr(vin), 0, 1)
+
+
+def mul_M(vp, fdm, v):
+    """mul_M!: v′ = M v (Sym :385-427, Asym :430-466)."""
+    _matvec(L.OP_M, vp, fdm, v)
+
+
+def mul_Mt(vp, fdm, v):
+    """mul_Mt!: v′ = Mᵀ v (Sym :484-525, Asym :528-563)."""
+    _matvec(L.OP_MT, vp, fdm, v)
+
+
+def mul_MtM(vp, fdm, v):
+    """mul_MtM!: v′ = Mᵀ M v (:329-340)."""
+    _matvec(L.OP_MTM, vp, fdm, v)
+
+
+def mul_MMt(vp, fdm, v):
+    """mul_MMt!: v′ = M Mᵀ v (:357-368)."""
+    _matvec(L.OP_MMT, vp, fdm, v)
+
+
+def lmul_M(fdm, v):
+    mul_M(v, fdm, v)
+
+
+def lmul_Mt(fdm, v):
+    mul_Mt(v, fdm, v)
+
+
+def lmul_MtM(fdm, v):
+    mul_MtM(v, fdm, v)
+
+
+def lmul_MMt(fdm, v):
+    mul_MMt(v, fdm, v)
+
+
+# ---- FourierTransformer ------------------------------------------------------------------------------
+
+class FourierTransformer:
+    """src/FourierTransformer.jl:2-21.  ``θ`` as in the reference; the plans are rocFFT plans
+    owned by a handle (an existing FermionDetMatrix's, or a private bond-less one)."""
+
+    def __init__(self, T=np.float64, Lτ=None, N=None, handle=None):
+        if isinstance(T, np.ndarray):  # FourierTransformer(v::Matrix)
+            Lτ, N = T.shape
+        self.Lτ, self.N = int(Lτ), int(N)
+        self.θ = np.exp(-1j * np.pi * np.arange(self.Lτ) / self.Lτ)
+        if handle is None:
+            handle = L.Handle(self.Lτ, self.N, np.zeros((2, 0), dtype=np.int64), np.zeros((2, 0), dtype=np.int64), True, 1, 1, -1)
+        self.handle = handle
+
+
+# ---- KPM preconditioner ----------------------------------------------------------------------------
+
+class KPMPreconditioner:
+    """KPMPreconditioner(fdm; rng, rbuf, n, a1, a2), src/KPMPreconditioner.jl:198-284.  The state
+    (B̄, bounds, order, coefs, Lanczos vectors) lives in the FermionDetMatrix's handle."""
+
+    def __init__(self, fermion_det_matrix: FermionDetMatrix, rng=None, rbuf=0.10, n=20, a1=1.0, a2=1.0):
+        self.fdm = fermion_det_matrix
+        self.handle = fermion_det_matrix.handle
+        self.rbuf, self.n = rbuf, n
+        self.a1 = 2 * a1 if fermion_det_matrix.is_sym else a1  # :263
+        self.a2 = a2
+        self.handle.call("smoqy_precond_config", C.c_double(rbuf), int(n), C.c_double(a1), C.c_double(a2))
+        self.U = FourierTransformer(np.float64, self.fdm.Lt, self.fdm.N, handle=self.handle)
+        self.ϕs = 2 * np.pi / self.fdm.Lt * (np.arange(self.fdm.Lt) + 0.5)  # :220
+        update_preconditioner(self, fermion_det_matrix, rng if rng is not None else np.random.default_rng())  # :281
+
+    def _state(self):
+        act, norder = C.c_int(0), C.c_int(0)
+        bounds = np.zeros(2)
+        order = np.zeros(self.fdm.Lt, dtype=np.int32)
+        la, lb = np.zeros(self.n), np.zeros(max(self.n - 1, 1))
+        self.handle.call("smoqy_precond_get", 0, C.byref(act), bounds.ctypes.data_as(C.POINTER(C.c_double)), order.ctypes.data_as(C.POINTER(C.c_int)), C.byref(norder),
+                         la.ctypes.data_as(C.POINTER(C.c_double)), lb.ctypes.data_as(C.POINTER(C.c_double)))
+        return bool(act.value), (float(bounds[0]), float(bounds[1])), order[: norder.value].copy(), la, lb[: self.n - 1]
+
+    @property
+    def active(self):
+        return self._state()[0]
+
+    @property
+    def bounds(self):
+        return self._state()[1]
+
+    @property
+    def order(self):
+        return self._state()[2]
+
+    @property
+    def coefs(self):
+        out = []
+        for slot, n in enumerate(self.order):
+            c = np.zeros(int(n), dtype=np.complex128)
+            self.handle.call("smoqy_precond_get_coefs", 0, slot, L.ptr(c))
+            out.append(c.real.copy() if self.fdm.is_sym else c)
+        return out
+
+
+SymKPMPreconditioner = AsymKPMPreconditioner = KPMPreconditioner
+
+
+def update_preconditioner(P, fermion_det_matrix=None, rng=None, *ignore):
+    """update_preconditioner!(Pkpm, fdm, rng), src/KPMPreconditioner.jl:554-597; a no-op for any
+    other ``P`` (:600) — this is how ``preconditioner = I`` works."""
+    if not isinstance(P, KPMPreconditioner):
+        return None
+    rng = rng if rng is not None else np.random.default_rng()
+    rv = np.ascontiguousarray(rng.standard_normal(P.fdm.N))  # randn!(rng, v), :634
+    P.handle.call("smoqy_precond_update", 0, L.ptr(rv))
+    return None
+
+
+# ---- conjugate gradient -------------------------------------------------------------------------------
+
+def cg_solve(x, A, b, cg_solver: ConjugateGradientSolver | None = None, P=I, maxiter=None, tol=None):
+    """cg_solve!(x, A, b, cgs, P; maxiter, tol), src/IterativeSolvers/ConjugateGradient.jl:93-249.
+    ``A`` must be a FermionDetMatrix (``mul!(z, A, p)`` ≡ MᵀM, src/FermionDetMatrix.jl:304); the
+    loop runs on the device.  ``x is b`` selects the zero initial guess (:112-116).  Returns
+    ``(iters, ϵ)``; non-convergence returns ``(maxiter, ϵ)`` without raising."""
+    if not isinstance(A, FermionDetMatrix):
+        raise TypeError("the device CG solves MᵀM x = b for a FermionDetMatrix A; no generic (CPU) operator path exists")
+    cgs = cg_solver or A.cgs
+    maxiter = cgs.maxiter if maxiter is None else int(maxiter)
+    tol = cgs.tol if tol is None else float(tol)
+    if isinstance(P, KPMPreconditioner) and P.handle is not A.handle:
+        raise ValueError("the KPMPreconditioner belongs to a different FermionDetMatrix")
+    h = A.handle
+    xb = L.writable_state(x, h.Lt, h.N)
+    same = x is b or (isinstance(b, np.ndarray) and isinstance(x, np.ndarray) and np.shares_memory(x, b))
+    bb = xb if same else L.as_state(b, h.Lt, h.N)
+    iters = np.zeros(1, dtype=np.int32)
+    eps = np.zeros(1)
+    h.call("smoqy_cg_solve", L.ptr(xb), L.ptr(bb), int(same), 0, 1, C.c_double(tol), maxiter, int(isinstance(P, KPMPreconditioner)), L.ptr(iters), L.ptr(eps))
+    return int(iters[0]), float(eps[0])
+
+
+# ---- generic mul!/lmul!/ldiv! dispatch -------------------------------------------------------------------
+
+def mul(out, op, v):
+    """mul!(v′, fdm, v) ≡ MᵀM (src/FermionDetMatrix.jl:304-313); mul!(u, U, v) ≡ U v, τ → ω
+    (src/FourierTransformer.jl:26-36)."""
+    if isinstance(op, FermionDetMatrix):
+        return mul_MtM(out, op, v)
+    if isinstance(op, FourierTransformer):
+        o = L.writable_state(out, op.Lτ, op.N)
+        o[...] = np.asarray(v).reshape(o.shape, order="F")
+        return lmul(op, o)
+    raise TypeError(f"mul: unsupported operator {type(op).__name__}")
+
+
+def lmul(op, v):
+    """lmul!(fdm, v) ≡ v = MᵀM v (:292-300); lmul!(U, v) (src/FourierTransformer.jl:39-50)."""
+    if isinstance(op, FermionDetMatrix):
+        return mul_MtM(v, op, v)
+    if isinstance(op, FourierTransformer):
+        a = L.writable_state(v, op.Lτ, op.N)
+        op.handle.call("smoqy_fft_forward", L.ptr(a), 0, 1)
+        return None
+    raise TypeError(f"lmul: unsupported operator {type(op).__name__}")
+
+
+def ldiv(*args, preconditioner=I, rng=None, maxiter=None, tol=None):
+    """The reference's ``ldiv!`` methods on the hot path:
+
+    ``ldiv(vp, fdm, v; preconditioner, rng, maxiter, tol)``  v′ = [MᵀM]⁻¹ v   (FermionDetMatrix.jl:248-267)
+    ``ldiv(fdm, v; ...)``                                    in place          (:270-288)
+    ``ldiv(up, P, u)``                                       u′ = P⁻¹ u        (KPMPreconditioner.jl:355-414, 488-550)
+    ``ldiv(U, v)`` / ``ldiv(u, U, v)``                       ω → τ             (FourierTransformer.jl:53-77)
+    """
+    if len(args) == 3 and isinstance(args[1], FermionDetMatrix):
+        vp, fdm, v = args
+        update_preconditioner(preconditioner, fdm, rng)  # :259
+        return cg_solve(vp, fdm, v, fdm.cgs, preconditioner, maxiter=maxiter, tol=tol)
+    if len(args) == 2 and isinstance(args[0], FermionDetMatrix):
+        fdm, v = args
+        return ldiv(v, fdm, v, preconditioner=preconditioner, rng=rng, maxiter=maxiter, tol=tol)
+    if len(args) == 3 and isinstance(args[1], KPMPreconditioner):
+        up, P, u = args
+        h = P.handle
+        uin = L.as_state(u, h.Lt, h.N)
+        uout = L.writable_state(up, h.Lt, h.N)
+        h.call("smoqy_precond_apply", L.ptr(uout), L.ptr(uin), 0, 1)
+        return None
+    if len(args) == 3 and isinstance(args[1], _Identity):
+        up, _, u = args
+        L.writable_state(up, np.size(u), 1)[...] = np.asarray(u).reshape(np.shape(up), order="F")
+        return None
+    if len(args) == 2 and isinstance(args[0], FourierTransformer):
+        U, v = args
+        a = L.writable_state(v, U.Lτ, U.N)
+        U.handle.call("smoqy_fft_inverse", L.ptr(a), 0, 1)
+        return None
+    if len(args) == 3 and isinstance(args[1], FourierTransformer):
+        u, U, v = args
+        o = L.writable_state(u, U.Lτ, U.N)
+        o[...] = np.asarray(v).reshape(o.shape, order="F")
+        return ldiv(U, o)
+    raise TypeError("ldiv: unsupported argument combination")
+
+
+# ---- Holstein shift matrix Λ ------------------------------------------------------------------------------
+
+def update_Λ(Λ, electron_phonon_parameters: ElectronPhononParameters, handle: L.Handle | None = None):
+    """update_Λ!(Λ, elph), src/holstein_shift_matrix.jl:2-44, computed on the device and written
+    into ``Λ`` (``Ltau x N``)."""
+    elph = electron_phonon_parameters
+    Lt, N = Λ.shape
+    if handle is None:
+        handle = L.Handle(Lt, N, np.zeros((2, 0), dtype=np.int64), np.zeros((2, 0), dtype=np.int64), True, 1, 1, -1)
+    _lambda_update_device(handle, elph)
+    out = Λ if (Λ.flags.f_contiguous and Λ.dtype == np.float64) else np.zeros((Lt, N), order="F")
+    handle.call("smoqy_lambda_get", 0, L.ptr(out))
+    if out is not Λ:
+        Λ[...] = out
+
+
+def _lambda_update_device(handle, elph):
+    hol = elph.holstein
+    x = np.asfortranarray(elph.x, dtype=np.float64)
+    if hol is None:
+        handle.call("smoqy_lambda_update", 0, L.ptr(x), x.shape[0], C.c_double(elph.dtau), 0, None, None, None, None, None)
+        return
+    handle.call("smoqy_lambda_update", 0, L.ptr(x), x.shape[0], C.c_double(elph.dtau), len(hol.alpha), L.ptr(np.ascontiguousarray(hol.coupling_to_phonon, dtype=np.int64)),
+                L.ptr(np.ascontiguousarray(hol.coupling_to_site, dtype=np.int64)), L.ptr(np.ascontiguousarray(hol.alpha, dtype=np.float64)), L.ptr(np.ascontiguousarray(hol.alpha3, dtype=np.float64)),
+                L.ptr(np.ascontiguousarray(hol.ph_sym_form, dtype=np.int32)))
+
+
+_scratch_handles: dict = {}
+
+
+def _lambda_apply(op, up, Λ, u, handle=None):
+    Lt, N = Λ.shape
+    if handle is None:
+        key = (Lt, N)
+        if key not in _scratch_handles:
+            _scratch_handles[key] = L.Handle(Lt, N, np.zeros((2, 0), dtype=np.int64), np.zeros((2, 0), dtype=np.int64), True, 1, 1, -1)
+        handle = _scratch_handles[key]
+    lam = np.asfortranarray(Λ, dtype=np.float64)
+    uin = L.as_state(u, Lt, N)
+    uout = L.writable_state(up, Lt, N)
+    handle.call("smoqy_lambda_apply", op, L.ptr(uout), L.ptr(uin), L.ptr(lam), 0, 1)
+
+
+def mul_Λ(up, Λ, u, handle=None):
+    """mul_Λ!: |u′⟩ = Λ|u⟩ (src/holstein_shift_matrix.jl:47-71); ``up is u`` allowed."""
+    _lambda_apply(L.LAMBDA_MUL, up, Λ, u, handle)
+
+
+def ldiv_Λ(up, Λ, u, handle=None):
+    """ldiv_Λ!: |u′⟩ = Λ⁻¹|u⟩ (:74-98)."""
+    _lambda_apply(L.LAMBDA_LDIV, up, Λ, u, handle)
+
+
+def mul_Λᵀ(up, Λ, u, handle=None):
+    """mul_Λᵀ!: |u′⟩ = Λᵀ|u⟩ (:102-126)."""
+    _lambda_apply(L.LAMBDA_MULT, up, Λ, u, handle)
+
+
+def ldiv_Λᵀ(up, Λ, u, handle=None):
+    """ldiv_Λᵀ!: |u′⟩ = Λ⁻ᵀ|u⟩ (:129-153)."""
+    _lambda_apply(L.LAMBDA_LDIVT, up, Λ, u, handle)
+
+
+update_Lambda, mul_Lambda, ldiv_Lambda, mul_LambdaT, ldiv_LambdaT = update_Λ, mul_Λ, ldiv_Λ, mul_Λᵀ, ldiv_Λᵀ
+
+
+# ---- PFFCalculator ---------------------------------------------------------------------------------------
+
+class PFFCalculator:
+    """src/PFFCalculator.jl:9-53.  Φ, Λ, u, u′, u″ are device-resident (vectors of the
+    FermionDetMatrix's handle); the properties download a host copy on access."""
+
+    def __init__(self, electron_phonon_parameters: ElectronPhononParameters, fermion_det_matrix: FermionDetMatrix):
+        self.fdm = fermion_det_matrix
+        self.handle = fermion_det_matrix.handle
+        if fermion_det_matrix.nrhs != 1:
+            raise ValueError("PFFCalculator expects a FermionDetMatrix with nrhs = 1")
+        self._phi, self._u, self._u1, self._u2 = (self.handle.vec_alloc() for _ in range(4))
+
+    @property
+    def Φ(self):
+        return self.handle.vec_download(self._phi)
+
+    @property
+    def u(self):
+        return self.handle.vec_download(self._u)
+
+    @property
+    def Λ(self):
+        out = np.zeros((self.fdm.Lt, self.fdm.N), order="F")
+        self.handle.call("smoqy_lambda_get", 0, L.ptr(out))
+        return out
+
+
+def _complex_randn(rng, Lt, N):
+    """randn!(rng, Φ) for a ComplexF64 matrix: (re, im) pairs in memory order, variance 1/2 each."""
+    flat = rng.standard_normal(2 * Lt * N) * np.sqrt(0.5)
+    return flat.view(np.complex128).reshape((Lt, N), order="F")
+
+
+def sample_pseudofermion_fields(pff_calculator: PFFCalculator, electron_phonon_parameters, fermion_det_matrix, rng=None, R=None):
+    """sample_pseudofermion_fields!: Φ = Λᵀ Mᵀ R, returns |R|² (src/PFFCalculator.jl:56-76).
+    ``R`` may be supplied instead of being drawn from ``rng`` (testing aid)."""
+    pff, h = pff_calculator, pff_calculator.handle
+    _lambda_update_device(h, electron_phonon_parameters)  # update_Λ!  :63
+    if R is None:
+        rng = rng if rng is not None else np.random.default_rng()
+        R = _complex_randn(rng, h.Lt, h.N)                # randn!     :67
+    h.vec_upload(pff._phi, R)
+    Sf = float(h.vec_dot(pff._phi, pff._phi)[0].real)     # |R|²       :69
+    h.call("smoqy_matvec_v", L.OP_MT, pff._phi, pff._phi)  # lmul_Mt!   :71
+    h.call("smoqy_lambda_apply_v", L.LAMBDA_MULT, pff._phi, pff._phi)  # mul_Λᵀ! :73
+    return Sf
+
+
+def calculate_fermionic_action(pff_calculator: PFFCalculator, electron_phonon_parameters, fermion_det_matrix, preconditioner=I, rng=None, tol=None, maxiter=None):
+    """calculate_fermionic_action!: S_f = Φᵀ Λ⁻¹ [MᵀM]⁻¹ Λ⁻ᵀ Φ; returns ``(Sf, iters, ϵ)``
+    (src/PFFCalculator.jl:79-116).  A complex action beyond √tol warns like the reference (:110-112)."""
+    pff, h, fdm = pff_calculator, pff_calculator.handle, fermion_det_matrix
+    tol = fdm.cgs.tol if tol is None else float(tol)
+    maxiter = fdm.cgs.maxiter if maxiter is None else int(maxiter)
+    _lambda_update_device(h, electron_phonon_parameters)                  # update_Λ!  :94
+    h.call("smoqy_lambda_apply_v", L.LAMBDA_LDIVT, pff._u, pff._phi)      # Ψ = Λ⁻ᵀ Φ  :97
+    update_preconditioner(preconditioner, fdm, rng)                       # FermionDetMatrix.jl:259
+    iters = np.zeros(1, dtype=np.int32)
+    eps = np.zeros(1)
+    h.call("smoqy_cg_solve_v", pff._u, pff._u, C.c_double(tol), maxiter, int(isinstance(preconditioner, KPMPreconditioner)), L.ptr(iters), L.ptr(eps))  # :99-105
+    h.call("smoqy_lambda_apply_v", L.LAMBDA_LDIV, pff._u, pff._u)         # Ψ = Λ⁻¹ Ψ  :107
+    Sf = complex(h.vec_dot(pff._phi, pff._u)[0])                           # Φ·Ψ        :109
+    if np.sqrt(tol) < abs(Sf.imag / Sf.real):
+        warnings.warn(f"Complex Fermionic Action Encountered. Sf={Sf} tol={tol}")
+    return Sf.real, int(iters[0]), float(eps[0])

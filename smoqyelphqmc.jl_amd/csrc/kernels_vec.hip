@@ -354,8 +354,10 @@ __global__ void __launch_bounds__(kThreads) cg_start_kernel(CgArgs a)
     CG_PROLOGUE
     const double bb = reduce_partials(a.part_bb + (size_t)sys * a.nchunk, a.nchunk, red);
     const double rr = reduce_partials(a.part_rr + (size_t)sys * a.nchunk, a.nchunk, red);
-    const double eps = (bb > 0.0) ? sqrt(rr) / sqrt(bb) : 0.0;
-    const bool conv = !(bb > 0.0) || eps < a.tol;
+    // non-finite input: report NaN and stop (the host turns it into an error); b = 0: x = 0 is exact
+    const bool bad = !(bb == bb) || !(rr == rr) || isinf(bb) || isinf(rr);
+    const double eps = bad ? nan("") : ((bb > 0.0) ? sqrt(rr) / sqrt(bb) : 0.0);
+    const bool conv = bad || !(bb > 0.0) || eps < a.tol;
     const bool pre = a.use_precond && a.st[sys].precond_on;
     double2 acc = make_double2(0.0, 0.0);
     if (!conv) {
@@ -378,7 +380,7 @@ __global__ void __launch_bounds__(kThreads) cg_start_kernel(CgArgs a)
             s.normb2 = bb;
             s.eps = eps;
             s.iters = 0;
-            s.done = conv ? 1 : 0;
+            s.done = bad ? 2 : (conv ? 1 : 0);
         }
     }
 }
