@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="holstein_honeycomb_L16_Ltau128")
-    ap.add_argument("--walkers-per-gpu", type=int, default=8)
+    ap.add_argument("--walkers-per-gpu", type=int, default=32)
+    ap.add_argument("--streams", type=int, default=2, help="concurrent lock-step batches per GPU (one HIP stream + host thread each)")
     ap.add_argument("--tau-chunk", type=int, default=0)
     ap.add_argument("--check-every", type=int, default=0)
     ap.add_argument("--matvec-reps", type=int, default=400)
@@ -67,7 +68,14 @@ def cpu_baseline(workload, tol, Nt):
     P = orc.OracleKPM(o)
     g = np.random.default_rng(1)
     Lt, N = expV.shape
-    b = np.asfortranarray(g.standard_normal((Lt, N)) + 1j * g.standard_normal((Lt, N)))
+    # the same right-hand side the sweep solves for: b = Λ⁻ᵀ Φ with Φ = Λᵀ Mᵀ R (src/PFFCalculator.jl:56-99)
+    R = np.asfortranarray((g.standard_normal((Lt, N)) + 1j * g.standard_normal((Lt, N))) * np.sqrt(0.5))
+    hol = m.elph.holstein
+    if hol is not None:
+        Lam = orc.update_lambda(Lt, N, m.elph.x, m.elph.dtau, hol.coupling_to_phonon, hol.coupling_to_site, hol.alpha, hol.alpha3, hol.ph_sym_form)
+    else:
+        Lam = orc.update_lambda(Lt, N, m.elph.x, m.elph.dtau, [], [], [], [], [])
+    b = orc.lambda_apply(Lam, orc.lambda_apply(Lam, o.mul_Mt(R), "mulT"), "ldivT")
     t0 = time.perf_counter()
     P.update(g.standard_normal(N))
     _, it_a, _ = o.cg_solve(b, precond=P, tol=tol, maxiter=10000)
@@ -119,37 +127,49 @@ def main():
     from smoqyelphqmc_amd import _lib as L
     from smoqyelphqmc_amd.walkers import WalkerBatch
 
-    wpg = args.walkers_per_gpu
-    batch = WalkerBatch(args.workload, nwalkers=wpg, walker0=rank * wpg, device=local_rank, check_every=args.check_every or None, tau_chunk=args.tau_chunk or None)
+    from concurrent.futures import ThreadPoolExecutor
+
+    from smoqyelphqmc_amd.sharding import aggregate_throughput, reduce_max_time, walker_range
+
+    wpg, S = args.walkers_per_gpu, max(1, args.streams)
+    if wpg % S:
+        raise SystemExit("--walkers-per-gpu must be a multiple of --streams")
+    mine = walker_range(rank, world, wpg)  # walkers [rank*wpg, (rank+1)*wpg): no overlap between ranks, no exchange
+    per = wpg // S
+    batches = [WalkerBatch(args.workload, nwalkers=per, walker0=mine.start + s * per, device=local_rank, check_every=args.check_every or None, tau_chunk=args.tau_chunk or None) for s in range(S)]
+    batch = batches[0]
+    pool = ThreadPoolExecutor(S) if S > 1 else None
+
+    def run(nsweeps):
+        if pool is None:
+            for _ in range(nsweeps):
+                batch.sweep()
+        else:
+            list(pool.map(lambda b: [b.sweep() for _ in range(nsweeps)], batches))
 
     def fence():
-        batch.h.call("smoqy_sync")
+        for b in batches:
+            b.h.call("smoqy_sync")
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        batch.sweep()
-    batch.stats.solves = batch.stats.iters_sum = 0
+    run(args.warmup)
+    for b in batches:
+        b.stats.solves = b.stats.iters_sum = 0
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.sweep()
+    run(args.steps)
     fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    sweeps = world * wpg * args.steps
-    value = sweeps / elapsed
+    elapsed = reduce_max_time(time.perf_counter() - t0, device="cuda")
+    value = aggregate_throughput(wpg * args.steps, world, elapsed)
 
     if rank == 0:
         # --- roofline of the dominant kernel: fused MᵀM apply ------------------------------------
         h = batch.h
         a, b = h.vec_alloc(), h.vec_alloc()
         g = np.random.default_rng(3)
-        h.vec_upload(a, np.asfortranarray(g.standard_normal((batch.Lt, batch.N, wpg)) + 1j * g.standard_normal((batch.Lt, batch.N, wpg))))
+        h.vec_upload(a, np.asfortranarray(g.standard_normal((batch.Lt, batch.N, per)) + 1j * g.standard_normal((batch.Lt, batch.N, per))))
         h.bench_matvec(L.OP_MTM, b, a, 50)
         ms = h.bench_matvec(L.OP_MTM, b, a, args.matvec_reps)
         per_launch_s = ms * 1e-3 / args.matvec_reps
@@ -157,17 +177,29 @@ def main():
         achieved = alg / per_launch_s / 1e9
         tc = L.C.c_int(0)
         h.call("smoqy_get_tau_chunk", L.C.byref(tc))
+        # HBM-side traffic of the same kernel comes from the committed PMC passes (FETCH_SIZE / WRITE_SIZE
+        # collected in separate rocprofv3 runs and corrected per MI355X_MICROARCH.md); it is only quoted
+        # when that profile was taken at this workload and batch size
+        traffic, traffic_src = None, None
+        try:
+            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_fdm_mtm.json")
+            pmc = json.load(open(pmc_path))
+            if pmc.get("workload") == args.workload and pmc.get("systems_per_launch") == per:
+                traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/r01_pmc_traffic_fdm_mtm.json"
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {
             "bound": "hbm",
-            "kernel": "fdm_kernel<Sym, MtM> (fused MᵀM apply)",
+            "kernel": "fdm_fast_kernel<3, MtM> (fused MᵀM apply)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg,
             "avg_launch_us": per_launch_s * 1e6,
-            "systems_per_launch": wpg,
+            "systems_per_launch": per,
             "tau_chunk": tc.value,
             "note": "working set is L2/Infinity-Cache resident at this size; fraction is algorithmic bytes over wall time, see DESIGN.md",
         }
@@ -177,7 +209,7 @@ def main():
             for nb in (1, 2, 4, 8, 16, 32, 64):
                 hb = L.Handle(batch.Lt, batch.N, batch.nt, batch.colors, True, nb, 1, local_rank)
                 for w in range(nb):
-                    m = batch.models[w % wpg]
+                    m = batch.models[w % per]
                     hb.call("smoqy_update_from_path_integral", w, L.ptr(m.fpi.V), L.ptr(m.fpi.t), L.ptr(batch.perm), L.C.c_double(m.fpi.dtau))
                 va, vb = hb.vec_alloc(), hb.vec_alloc()
                 hb.vec_upload(va, np.asfortranarray(g.standard_normal((batch.Lt, batch.N, nb)) + 1j * g.standard_normal((batch.Lt, batch.N, nb))))
@@ -209,12 +241,13 @@ def main():
             "config": {
                 "workload": args.workload,
                 "walkers_per_gpu": wpg,
+                "streams_per_gpu": S,
                 "walkers_total": world * wpg,
                 "solves_per_sweep": batch.solves_per_sweep,
                 "cg_tol": batch.tol,
-                "avg_cg_iters": batch.stats.iters_sum / max(batch.stats.solves, 1),
+                "avg_cg_iters": sum(b.stats.iters_sum for b in batches) / max(sum(b.stats.solves for b in batches), 1),
                 "preconditioner": "KPM (Sym)",
-                "parallelism": f"walker-parallel, {world} rank(s) x {wpg} walkers, no collective",
+                "parallelism": f"walker-parallel, {world} rank(s) x {wpg} walkers ({S} lock-step batches of {per}), no collective",
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
