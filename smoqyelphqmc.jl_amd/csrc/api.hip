@@ -52,10 +52,11 @@ struct smoqy_ctx {
     CgState *d_st = nullptr, *h_st = nullptr;
     int check_every = 4;
     // fft
-    rocfft_plan plan_f = nullptr, plan_b = nullptr;
+    rocfft_plan plan_f = nullptr, plan_b = nullptr, plan_f_oop = nullptr;
     rocfft_execution_info fft_info = nullptr;
     void *fft_work = nullptr;
-    double2 *d_tw = nullptr;
+    double2 *d_tw = nullptr;  // theta_l / sqrt(Lt)  (unitary FourierTransformer)
+    double2 *d_th = nullptr;  // theta_l
     // kpm
     double rbuf = 0.10, a1 = 1.0, a2 = 1.0;
     int nlanczos = 20;
@@ -141,6 +142,7 @@ static FdmArgs fdm_args(smoqy_ctx *c, const double2 *in, double2 *out, double2 *
     a.expV = c->d_expV; a.ch = c->d_ch; a.sh = c->d_sh;
     a.in = in; a.out = out; a.partial = partial; a.cg = cg;
     a.sys_first = sys0; a.sys_count = count;
+    a.hop_re = 1.0; a.hop_im = 0.0; a.antiperiodic = 1;  // the reference operator
     return a;
 }
 
@@ -154,6 +156,7 @@ static KpmArgs kpm_args(smoqy_ctx *c, double2 *v, const CgState *cg)
     k.order = c->d_order; k.coefs = c->d_coefs; k.bounds = c->d_bounds; k.active = c->d_active;
     k.nslot = c->nslot; k.maxorder = c->maxorder;
     k.v = v; k.cg = cg;
+    k.part_rz = nullptr; k.rz_stride = g.Lt; k.scale = 1.0 / (double)g.Lt;
     return k;
 }
 
@@ -189,9 +192,10 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->plan_f) rocfft_plan_destroy(c->plan_f);
     if (c->plan_b) rocfft_plan_destroy(c->plan_b);
+    if (c->plan_f_oop) rocfft_plan_destroy(c->plan_f_oop);
     if (c->fft_info) rocfft_execution_info_destroy(c->fft_info);
     void *ptrs[] = {c->d_bonds, c->d_col_off, c->d_expV, c->d_ch, c->d_sh, c->d_lam, c->d_stage, c->d_stage_real, c->d_stage_int, c->scr[0], c->scr[1], c->scr[2], c->cg_r, c->cg_p,
-                    c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->fft_work, c->d_tw, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
+                    c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->fft_work, c->d_tw, c->d_th, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
                     c->d_rand, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -277,7 +281,9 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     // FourierTransformer: strided batched rocFFT along tau (stride nsys*N, distance 1)
     std::call_once(g_rocfft_once, [] { rocfft_setup(); });
     HIPCHK(c, hipMalloc(&c->d_tw, (size_t)g.Lt * sizeof(double2)));
-    launch_make_twiddle(c->stream, c->d_tw, g.Lt);
+    HIPCHK(c, hipMalloc(&c->d_th, (size_t)g.Lt * sizeof(double2)));
+    launch_make_twiddle(c->stream, c->d_tw, g.Lt, 1.0 / std::sqrt((double)g.Lt));
+    launch_make_twiddle(c->stream, c->d_th, g.Lt, 1.0);
     {
         rocfft_plan_description desc = nullptr;
         FFTCHK(c, rocfft_plan_description_create(&desc));
@@ -286,12 +292,14 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
         size_t len[1] = {(size_t)g.Lt};
         FFTCHK(c, rocfft_plan_create(&c->plan_f, rocfft_placement_inplace, rocfft_transform_type_complex_forward, rocfft_precision_double, 1, len, (size_t)g.nsys * g.N, desc));
         FFTCHK(c, rocfft_plan_create(&c->plan_b, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, rocfft_precision_double, 1, len, (size_t)g.nsys * g.N, desc));
+        FFTCHK(c, rocfft_plan_create(&c->plan_f_oop, rocfft_placement_notinplace, rocfft_transform_type_complex_forward, rocfft_precision_double, 1, len, (size_t)g.nsys * g.N, desc));
         rocfft_plan_description_destroy(desc);
-        size_t wf = 0, wb = 0;
+        size_t wf = 0, wb = 0, wo = 0;
+        FFTCHK(c, rocfft_plan_get_work_buffer_size(c->plan_f_oop, &wo));
         FFTCHK(c, rocfft_plan_get_work_buffer_size(c->plan_f, &wf));
         FFTCHK(c, rocfft_plan_get_work_buffer_size(c->plan_b, &wb));
         FFTCHK(c, rocfft_execution_info_create(&c->fft_info));
-        const size_t wsz = std::max(wf, wb);
+        const size_t wsz = std::max(std::max(wf, wb), wo);
         if (wsz) {
             HIPCHK(c, hipMalloc(&c->fft_work, wsz));
             FFTCHK(c, rocfft_execution_info_set_work_buffer(c->fft_info, c->fft_work, wsz));
@@ -614,10 +622,15 @@ int smoqy_vec_dot(smoqy_ctx *c, int a, int b, void *out)
 
 // ---- matvec -------------------------------------------------------------------------------------
 
-static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, double2 *partial, const CgState *cg, int sys0, int count)
+static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, double2 *partial, const CgState *cg, int sys0, int count, bool twiddled = false)
 {
     if (op < SMOQY_OP_M || op > SMOQY_OP_MMT) FAIL(c, 1, "unknown matvec op %d", op);
     FdmArgs a = fdm_args(c, in, out, partial, cg, sys0, count);
+    if (twiddled) {  // Θ M Θᴴ: uniform hop phase exp(-iπ/Lτ), periodic in τ (kernels_vec.hip, CG section)
+        a.hop_re = std::cos(M_PI / c->g.Lt);
+        a.hop_im = -std::sin(M_PI / c->g.Lt);
+        a.antiperiodic = 0;
+    }
     if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_fast(c->stream, op, a, c->ff);
     else launch_fdm(c->stream, op, c->g.is_sym != 0, a, fdm_lds_bytes(op, c->g.N, c->Tc));
     return check_launch(c, "matvec");
@@ -1034,42 +1047,31 @@ int smoqy_precond_set(smoqy_ctx *c, int w, int active, const double *bounds, con
     return upload_precond(c, w);
 }
 
-// z-space part of ldiv!(u', P, u): FFT, per-frequency Chebyshev, inverse FFT on the raw buffer v
-static int precond_core(smoqy_ctx *c, double2 *v, const CgState *cg)
+// frequency-space part of ldiv!(u', P, u): v = FFT⁻¹ · (per-ω Chebyshev / Lτ) · FFT src, in the
+// twiddled basis (the θ phases are the caller's business).  part_rz, when given, receives the
+// Parseval partials of src·v per (system, ω).
+static int precond_core(smoqy_ctx *c, const double2 *src, double2 *v, const CgState *cg, double2 *part_rz)
 {
-    void *buf[1] = {v};
-    FFTCHK(c, rocfft_execute(c->plan_f, buf, nullptr, c->fft_info));  // KPMPreconditioner.jl:375 (twiddle applied by the producer)
+    void *in[1] = {(void *)src}, *out[1] = {v};
+    if (src == v) FFTCHK(c, rocfft_execute(c->plan_f, out, nullptr, c->fft_info));      // KPMPreconditioner.jl:375
+    else FFTCHK(c, rocfft_execute(c->plan_f_oop, in, out, c->fft_info));
     KpmArgs k = kpm_args(c, v, cg);
-    launch_cheb(c->stream, k, c->kg);                                       // :381-400 (no transposes needed in this layout)
-    FFTCHK(c, rocfft_execute(c->plan_b, buf, nullptr, c->fft_info));  // :406
+    k.part_rz = part_rz;
+    launch_cheb(c->stream, k, c->kg);                                                   // :381-400 (no transposes needed in this layout)
+    FFTCHK(c, rocfft_execute(c->plan_b, out, nullptr, c->fft_info));                    // :406
     return check_launch(c, "precond_core");
 }
 
 static int precond_apply_dev(smoqy_ctx *c, double2 *out, const double2 *in)
 {
     const Geometry &g = c->g;
-    // inactive walkers: copy (:410).  Active ones are overwritten below.
-    if (out != in) HIPCHK(c, hipMemcpyAsync(out, in, c->vec_elems() * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
-    bool any = false;
-    for (auto &p : c->pre) any = any || p.active;
-    if (!any) return 0;
+    // walkers with an inactive preconditioner come out as the identity (:410) — the Chebyshev
+    // kernel reduces to the 1/Lτ scale for them
     HIPCHK(c, hipMemcpyAsync(c->cg_v, in, c->vec_elems() * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
-    launch_fft_twiddle(c->stream, c->cg_v, c->d_tw, g.Lt, g.N, g.nsys, 0);
-    if (int rc = precond_core(c, c->cg_v, nullptr)) return rc;
-    launch_fft_twiddle(c->stream, c->cg_v, c->d_tw, g.Lt, g.N, g.nsys, 1);
-    // merge: active walkers take the preconditioned vector
-    bool all = true;
-    for (auto &p : c->pre) all = all && p.active;
-    if (all) {
-        HIPCHK(c, hipMemcpyAsync(out, c->cg_v, c->vec_elems() * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
-    } else {
-        for (int w = 0; w < g.nw; ++w) {
-            if (!c->pre[w].active) continue;
-            // systems of walker w are contiguous within every slice: copy slice by slice
-            HIPCHK(c, hipMemcpy2DAsync(out + (size_t)w * g.nrhs * g.N, (size_t)g.nsys * g.N * sizeof(double2), c->cg_v + (size_t)w * g.nrhs * g.N, (size_t)g.nsys * g.N * sizeof(double2),
-                                       (size_t)g.nrhs * g.N * sizeof(double2), (size_t)g.Lt, hipMemcpyDeviceToDevice, c->stream));
-        }
-    }
+    launch_fft_twiddle(c->stream, c->cg_v, c->d_th, g.Lt, g.N, g.nsys, 0);   // θ  (FourierTransformer.jl:46; the 1/√Lτ pair is in the kernel's scale)
+    if (int rc = precond_core(c, c->cg_v, c->cg_v, nullptr, nullptr)) return rc;
+    launch_fft_twiddle(c->stream, c->cg_v, c->d_th, g.Lt, g.N, g.nsys, 1);   // θ⁻¹ (:61)
+    HIPCHK(c, hipMemcpyAsync(out, c->cg_v, c->vec_elems() * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
     return check_launch(c, "precond_apply");
 }
 
@@ -1105,52 +1107,51 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
 {
     const Geometry &g = c->g;
     if (maxiter < 0) FAIL(c, 1, "maxiter < 0");
-    // per-system flags
+    bool any_pre = false;
     for (int s = 0; s < g.nsys; ++s) {
         std::memset(&c->h_st[s], 0, sizeof(CgState));
         c->h_st[s].precond_on = (use_precond && c->pre[s / g.nrhs].active) ? 1 : 0;
+        any_pre = any_pre || c->h_st[s].precond_on;
     }
-    bool any_pre = false;
-    for (int s = 0; s < g.nsys; ++s) any_pre = any_pre || c->h_st[s].precond_on;
     HIPCHK(c, hipMemcpyAsync(c->d_st, c->h_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyHostToDevice, c->stream));
 
     CgArgs a{};
     a.Lt = g.Lt; a.N = g.N; a.nsys = g.nsys; a.nrhs = g.nrhs; a.Tc = c->Tc; a.nchunk = c->nchunk;
-    a.x = x; a.r = c->cg_r; a.p = c->cg_p; a.z = c->cg_z; a.v = c->cg_v; a.tw = c->d_tw; a.b = b;
+    a.x = x; a.r = c->cg_r; a.p = c->cg_p; a.z = c->cg_z; a.v = c->cg_v; a.th = c->d_th; a.b = b;
     a.part_pz = c->part_pz; a.part_rz = c->part_rz; a.part_rr = c->part_rr; a.part_bb = c->part_bb;
     a.st = c->d_st; a.tol = tol; a.maxiter = maxiter; a.use_precond = any_pre ? 1 : 0;
+    a.rz_stride = g.Lt; a.nrz = any_pre ? g.Lt : c->nchunk;
 
-    if (!x_is_b) {  // r0 = b - A x0  (ConjugateGradient.jl:119-120)
-        if (int rc = matvec_dev(c, SMOQY_OP_MTM, c->cg_z, x, nullptr, nullptr, 0, g.nsys)) return rc;
+    if (!x_is_b) {  // r0 = b - A x0  (ConjugateGradient.jl:119-120), in the twiddled basis
+        launch_fft_twiddle(c->stream, x, c->d_th, g.Lt, g.N, g.nsys, 0);
+        if (int rc = matvec_dev(c, SMOQY_OP_MTM, c->cg_z, x, nullptr, nullptr, 0, g.nsys, true)) return rc;
     }
     launch_cg_init(c->stream, a, x_is_b);
-    if (any_pre) if (int rc = precond_core(c, c->cg_v, nullptr)) return rc;  // z0 = P⁻¹ r0 (:200)
+    if (any_pre) if (int rc = precond_core(c, c->cg_r, c->cg_v, nullptr, c->part_rz)) return rc;  // z0 = P⁻¹ r0 (:200)
     launch_cg_start(c->stream, a);
     if (int rc = check_launch(c, "cg setup")) return rc;
 
     int launched = 0;
-    bool all_done = (maxiter == 0);
-    while (!all_done) {
+    while (launched < maxiter) {
         const int burst = std::min(c->check_every, maxiter - launched);
         for (int it = 0; it < burst; ++it) {
-            if (int rc = matvec_dev(c, SMOQY_OP_MTM, c->cg_z, c->cg_p, c->part_pz, c->d_st, 0, g.nsys)) return rc;  // z = A p, partial p·Ap
-            launch_cg_update_xr(c->stream, a);
-            if (any_pre) if (int rc = precond_core(c, c->cg_v, c->d_st)) return rc;
-            launch_cg_check(c->stream, a);
-            launch_cg_update_p(c->stream, a);
+            if (int rc = matvec_dev(c, SMOQY_OP_MTM, c->cg_z, c->cg_p, c->part_pz, c->d_st, 0, g.nsys, true)) return rc;  // z = A p, partial p·Ap (:219)
+            launch_cg_update_xr(c->stream, a);                                                                          // :220-226
+            if (any_pre) if (int rc = precond_core(c, c->cg_r, c->cg_v, c->d_st, c->part_rz)) return rc;              // z = P⁻¹ r, partial r·z (:237-240)
+            launch_cg_update_p(c->stream, a);                                                                           // :229-245
         }
         launched += burst;
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (int rc = check_launch(c, "cg loop")) return rc;
-        all_done = true;
+        bool all_done = true;
         for (int s = 0; s < g.nsys; ++s) all_done = all_done && (c->h_st[s].done != 0);
-        if (launched >= maxiter) break;
+        if (all_done) break;
     }
-    if (maxiter == 0) {
-        HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
+    launch_cg_finish(c->stream, a);  // x = Θᴴ x̃
+    HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int rc = check_launch(c, "cg finish")) return rc;
     for (int s = 0; s < g.nsys; ++s) {
         const CgState &st = c->h_st[s];
         if (!std::isfinite(st.eps)) FAIL(c, 7, "non-finite residual in CG for system %d (iters %d)", s, st.iters);

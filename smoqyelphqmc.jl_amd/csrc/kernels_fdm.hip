@@ -16,6 +16,14 @@
 
 namespace smoqy {
 
+// v - ph·u, see hopcomb in kernels_fdm_fast.hip
+__device__ __forceinline__ double2 hopcomb_g(double2 v, double2 u, bool wrapped, bool dagger, const FdmArgs &a)
+{
+    double pr = a.hop_re, pi = dagger ? -a.hop_im : a.hop_im;
+    if (wrapped && a.antiperiodic) { pr = -pr; pi = -pi; }
+    return make_double2(v.x - (pr * u.x - pi * u.y), v.y - (pr * u.y + pi * u.x));
+}
+
 __device__ __forceinline__ int wrap(int l, int Lt) { return l >= Lt ? l - Lt : (l < 0 ? l + Lt : l); }
 
 // One checkerboard colour on nk LDS-resident slices: lane = bond.
@@ -116,7 +124,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
         for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {
             const int k = idx / N, i = idx - k * N, l = l0 + k;
             const double2 v = in[(size_t)l * sstride + i], u = U[idx];
-            const double2 o = (l == 0) ? make_double2(v.x + u.x, v.y + u.y) : make_double2(v.x - u.x, v.y - u.y);
+            const double2 o = hopcomb_g(v, u, l == 0, false, a);
             if (a.partial) { acc.x += v.x * o.x + v.y * o.y; acc.y += v.x * o.y - v.y * o.x; }
             out[(size_t)l * sstride + i] = o;
         }
@@ -131,7 +139,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
         for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {
             const int k = idx / N, i = idx - k * N, l = l0 + k;
             const double2 v = in[(size_t)l * sstride + i], u = U[idx];
-            const double2 o = (l == Lt - 1) ? make_double2(v.x + u.x, v.y + u.y) : make_double2(v.x - u.x, v.y - u.y);
+            const double2 o = hopcomb_g(v, u, l == Lt - 1, true, a);
             if (a.partial) { acc.x += v.x * o.x + v.y * o.y; acc.y += v.x * o.y - v.y * o.x; }
             out[(size_t)l * sstride + i] = o;
         }
@@ -148,7 +156,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
         for (int idx = threadIdx.x; idx < nk1 * N; idx += blockDim.x) {
             const int k = idx / N, i = idx - k * N, l = wrap(l0 + k, Lt);
             const double2 v = in[(size_t)l * sstride + i], u = U[idx];
-            Y[idx] = (l == 0) ? make_double2(v.x + u.x, v.y + u.y) : make_double2(v.x - u.x, v.y - u.y);
+            Y[idx] = hopcomb_g(v, u, l == 0, false, a);
         }
         __syncthreads();
         for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) U[idx] = Y[idx + N];
@@ -157,7 +165,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
         for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {
             const int k = idx / N, i = idx - k * N, l = l0 + k;
             const double2 y = Y[idx], u = U[idx];
-            const double2 o = (l == Lt - 1) ? make_double2(y.x + u.x, y.y + u.y) : make_double2(y.x - u.x, y.y - u.y);
+            const double2 o = hopcomb_g(y, u, l == Lt - 1, true, a);
             if (a.partial) {
                 const double2 v = in[(size_t)l * sstride + i];
                 acc.x += v.x * o.x + v.y * o.y;
@@ -178,7 +186,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
         for (int idx = threadIdx.x; idx < nk1 * N; idx += blockDim.x) {
             const int k = idx / N, i = idx - k * N, l = wrap(l0 + k - 1, Lt);
             const double2 v = in[(size_t)l * sstride + i], u = U[idx];
-            Y[idx] = (l == Lt - 1) ? make_double2(v.x + u.x, v.y + u.y) : make_double2(v.x - u.x, v.y - u.y);
+            Y[idx] = hopcomb_g(v, u, l == Lt - 1, true, a);
         }
         __syncthreads();
         for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) U[idx] = Y[idx];
@@ -187,7 +195,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
         for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {
             const int k = idx / N, i = idx - k * N, l = l0 + k;
             const double2 y = Y[idx + N], u = U[idx];
-            const double2 o = (l == 0) ? make_double2(y.x + u.x, y.y + u.y) : make_double2(y.x - u.x, y.y - u.y);
+            const double2 o = hopcomb_g(y, u, l == 0, false, a);
             if (a.partial) {
                 const double2 v = in[(size_t)l * sstride + i];
                 acc.x += v.x * o.x + v.y * o.y;

@@ -25,7 +25,15 @@ constexpr int KMAX = 3;  // slices a workgroup propagates at once (tau-chunk + 1
 __device__ __forceinline__ int wrapl(int l, int Lt) { return l >= Lt ? l - Lt : (l < 0 ? l + Lt : l); }
 __device__ __forceinline__ double2 lin(double a, double2 x, double b, double2 y) { return make_double2(a * x.x + b * y.x, a * x.y + b * y.y); }
 __device__ __forceinline__ double2 scl(double a, double2 x) { return make_double2(a * x.x, a * x.y); }
-__device__ __forceinline__ double2 addsub(double2 v, double2 u, bool plus) { return plus ? make_double2(v.x + u.x, v.y + u.y) : make_double2(v.x - u.x, v.y - u.y); }
+// v - ph·u with the hop phase ph = hop (M rows) or conj(hop) (Mᵀ rows), negated on the wrap-around row
+// when the time direction is antiperiodic.  hop = 1, antiperiodic = 1 is the reference operator
+// (v - u, v + u on the wrap row, bit for bit); the CG runs with hop = exp(-iπ/Lτ), periodic.
+__device__ __forceinline__ double2 hopcomb(double2 v, double2 u, bool wrap, bool dagger, const FdmArgs &a)
+{
+    double pr = a.hop_re, pi = dagger ? -a.hop_im : a.hop_im;
+    if (wrap && a.antiperiodic) { pr = -pr; pi = -pi; }
+    return make_double2(v.x - (pr * u.x - pi * u.y), v.y - (pr * u.y + pi * u.x));
+}
 
 struct Lane {
     int2 b[kFdmColours];
@@ -195,8 +203,8 @@ __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
         for (int k = 0; k < KMAX; ++k) {
             if (k < nk && onL) {
                 const int l = l0 + k;
-                const bool plus = (OP == SMOQY_OP_M) ? (l == 0) : (l == Lt - 1);
-                const double2 oi = addsub(vi[k], ri[k], plus), oj = addsub(vj[k], rj[k], plus);
+                const bool wrap = (OP == SMOQY_OP_M) ? (l == 0) : (l == Lt - 1);
+                const double2 oi = hopcomb(vi[k], ri[k], wrap, OP == SMOQY_OP_MT, a), oj = hopcomb(vj[k], rj[k], wrap, OP == SMOQY_OP_MT, a);
                 double2 *row = out + (size_t)l * sstride;
                 row[bL.x] = oi;
                 acc.x += vi[k].x * oi.x + vi[k].y * oi.y;
@@ -216,9 +224,9 @@ __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
             yi[k] = yj[k] = make_double2(0.0, 0.0);
             if (k < K1) {
                 const int l = wrapl(vbase + k, Lt);  // slice of y[k]
-                const bool plus = (OP == SMOQY_OP_MTM) ? (l == 0) : (l == Lt - 1);
-                yi[k] = addsub(vi[k], ri[k], plus);
-                yj[k] = addsub(vj[k], rj[k], plus);
+                const bool wrap = (OP == SMOQY_OP_MTM) ? (l == 0) : (l == Lt - 1);
+                yi[k] = hopcomb(vi[k], ri[k], wrap, OP == SMOQY_OP_MMT, a);
+                yj[k] = hopcomb(vj[k], rj[k], wrap, OP == SMOQY_OP_MMT, a);
             }
         }
         // hand over to the second operator: MᵀM propagates y[1..nk] with fields of slices l0+1..,
@@ -243,9 +251,9 @@ __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
         for (int k = 0; k < KMAX - 1; ++k) {
             if (k < nk && onL) {
                 const int l = l0 + k;
-                const bool plus = (OP == SMOQY_OP_MTM) ? (l == Lt - 1) : (l == 0);
+                const bool wrap = (OP == SMOQY_OP_MTM) ? (l == Lt - 1) : (l == 0);
                 const double2 bi = (OP == SMOQY_OP_MTM) ? yi[k] : yi[k + 1], bj = (OP == SMOQY_OP_MTM) ? yj[k] : yj[k + 1];
-                const double2 oi = addsub(bi, ri[k], plus), oj = addsub(bj, rj[k], plus);
+                const double2 oi = hopcomb(bi, ri[k], wrap, OP == SMOQY_OP_MTM, a), oj = hopcomb(bj, rj[k], wrap, OP == SMOQY_OP_MTM, a);
                 const double2 pi = (OP == SMOQY_OP_MTM) ? vi[k] : vi[k + 1], pj = (OP == SMOQY_OP_MTM) ? vj[k] : vj[k + 1];
                 double2 *row = out + (size_t)l * sstride;
                 row[bL.x] = oi;

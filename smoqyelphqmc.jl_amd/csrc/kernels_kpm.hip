@@ -284,10 +284,19 @@ __device__ __forceinline__ void kpm_poly_regs(double2 *W, const LaneBonds &lb, i
     }
 }
 
+// workgroup sum of a complex value, broadcast (red: >= 17 doubles of LDS)
+__device__ __forceinline__ double2 block_sum_cplx(double2 v, double *red)
+{
+    const double re = block_sum_real(v.x, red);
+    const double im = block_sum_real(v.y, red);
+    return make_double2(re, im);
+}
+
 template <bool SYM>
 __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
 {
     extern __shared__ double2 lds[];
+    __shared__ double red[17];
     double2 *W = lds;
     const int N = k.N, Lt = k.Lt;
     // rank-major block order: the heaviest chains of all systems are dispatched first and land
@@ -295,18 +304,31 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
     const int sys = blockIdx.x % k.nsys, rank = blockIdx.x / k.nsys;
     const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);  // heaviest orders first
     const int w = sys / k.nrhs;
-    if (!k.active[w]) return;
     if (k.cg && k.cg[sys].done) return;
     double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
+    double2 *prz = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride + om : nullptr;
     const int Lo2 = (Lt + 1) / 2;
     const int slot = SYM ? (om >= Lo2 ? Lt - om - 1 : om) : om;  // :387
-    const int n = k.order[(size_t)w * k.nslot + slot];
+    const bool act = k.active[w] != 0;                           // inactive preconditioner = identity (:410)
+    const int n = act ? k.order[(size_t)w * k.nslot + slot] : 1;
     const double2 *coefs = k.coefs + ((size_t)w * k.nslot + slot) * k.maxorder;
     if (n <= 1) {
         // single-term expansion: scalar multiply (:398 / :534)
-        const double2 c0 = coefs[0];
-        const double f = SYM ? c0.x : (c0.x * c0.x + c0.y * c0.y);
-        for (int i = threadIdx.x; i < N; i += blockDim.x) v[i] = make_double2(f * v[i].x, f * v[i].y);
+        double f = k.scale;
+        if (act) {
+            const double2 c0 = coefs[0];
+            f *= SYM ? c0.x : (c0.x * c0.x + c0.y * c0.y);
+        }
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) {
+            const double2 x = v[i];
+            v[i] = make_double2(f * x.x, f * x.y);
+            acc += f * (x.x * x.x + x.y * x.y);
+        }
+        if (prz) {
+            const double t = block_sum_real(acc, red);
+            if (threadIdx.x == 0) *prz = make_double2(t, 0.0);
+        }
         return;
     }
     const double emin = k.bounds[2 * w], emax = k.bounds[2 * w + 1];
@@ -324,6 +346,7 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
     const double dLi = onL ? dbar[bL.x] : 1.0, dLj = onL ? dbar[bL.y] : 1.0;
     double2 vi = make_double2(0, 0), vj = vi;
     if (onL) { vi = v[bL.x]; vj = v[bL.y]; }
+    const double2 vi0 = vi, vj0 = vj;
     // expansion coefficients go to LDS once: no global load (and no vmcnt wait) inside the chain
     double2 *CF = W + N, *CF2 = CF + k.maxorder;
     const int omc = Lt - om - 1;  // :523-530
@@ -341,9 +364,22 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
         __syncthreads();
         kpm_poly_regs<false>(W, lb, k.ncol, CF, n, avg, imag_, di, dj, dLi, dLj, vi, vj);
     }
+    double2 acc = make_double2(0.0, 0.0);
     if (onL) {
+        vi = make_double2(k.scale * vi.x, k.scale * vi.y);
+        vj = make_double2(k.scale * vj.x, k.scale * vj.y);
         v[bL.x] = vi;
-        if (bL.y != bL.x) v[bL.y] = vj;
+        acc.x += vi0.x * vi.x + vi0.y * vi.y;
+        acc.y += vi0.x * vi.y - vi0.y * vi.x;
+        if (bL.y != bL.x) {
+            v[bL.y] = vj;
+            acc.x += vj0.x * vj.x + vj0.y * vj.y;
+            acc.y += vj0.x * vj.y - vj0.y * vj.x;
+        }
+    }
+    if (prz) {
+        const double2 t = block_sum_cplx(acc, red);
+        if (threadIdx.x == 0) *prz = t;
     }
 }
 
@@ -417,46 +453,53 @@ __device__ __forceinline__ void kpm_poly(double2 *W, double2 *A1, double2 *A2, d
 __global__ void __launch_bounds__(kThreads) cheb_generic_kernel(KpmArgs k)
 {
     extern __shared__ double2 lds[];
+    __shared__ double red[17];
     const int N = k.N, Lt = k.Lt;
     double2 *W = lds, *A1 = W + N, *A2 = A1 + N, *ACC = A2 + N;
-    const int rank = blockIdx.x % Lt, sys = blockIdx.x / Lt;
+    const int sys = blockIdx.x % k.nsys, rank = blockIdx.x / k.nsys;
     const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);
     const int w = sys / k.nrhs;
-    if (!k.active[w]) return;
     if (k.cg && k.cg[sys].done) return;
     const double *dbar = k.dbar + (size_t)w * N, *cbar = k.cbar + (size_t)w * k.Nh, *sbar = k.sbar + (size_t)w * k.Nh;
     const double emin = k.bounds[2 * w], emax = k.bounds[2 * w + 1];
     const double avg = 0.5 * (emax + emin), mag = 0.5 * (emax - emin);
     double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
+    double2 *prz = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride + om : nullptr;
     const int Lo2 = (Lt + 1) / 2;
-    if (k.is_sym) {
-        const int slot = om >= Lo2 ? Lt - om - 1 : om;
-        const int n = k.order[(size_t)w * k.nslot + slot];
-        const double2 *coefs = k.coefs + ((size_t)w * k.nslot + slot) * k.maxorder;
-        if (n > 1) {
-            for (int i = threadIdx.x; i < N; i += blockDim.x) ACC[i] = v[i];
-            __syncthreads();
+    const bool act = k.active[w] != 0;
+    const int slot = k.is_sym ? (om >= Lo2 ? Lt - om - 1 : om) : om;
+    const int n = act ? k.order[(size_t)w * k.nslot + slot] : 1;
+    const double2 *coefs = k.coefs + ((size_t)w * k.nslot + slot) * k.maxorder;
+    double2 acc = make_double2(0.0, 0.0);
+    if (n > 1) {
+        for (int i = threadIdx.x; i < N; i += blockDim.x) ACC[i] = v[i];
+        __syncthreads();
+        if (k.is_sym) {
             kpm_poly<0>(W, A1, A2, ACC, coefs, n, avg, mag, k, dbar, cbar, sbar);
-            for (int i = threadIdx.x; i < N; i += blockDim.x) v[i] = ACC[i];
         } else {
-            const double c = coefs[0].x;
-            for (int i = threadIdx.x; i < N; i += blockDim.x) v[i] = make_double2(c * v[i].x, c * v[i].y);
-        }
-    } else {
-        const int n = k.order[(size_t)w * k.nslot + om];
-        const double2 *coefs = k.coefs + ((size_t)w * k.nslot + om) * k.maxorder;
-        if (n > 1) {
             const int omc = Lt - om - 1;
             const double2 *coefs_c = k.coefs + ((size_t)w * k.nslot + omc) * k.maxorder;
-            for (int i = threadIdx.x; i < N; i += blockDim.x) ACC[i] = v[i];
-            __syncthreads();
             kpm_poly<1>(W, A1, A2, ACC, coefs_c, k.order[(size_t)w * k.nslot + omc], avg, mag, k, dbar, cbar, sbar);
             kpm_poly<1>(W, A1, A2, ACC, coefs, n, avg, mag, k, dbar, cbar, sbar);
-            for (int i = threadIdx.x; i < N; i += blockDim.x) v[i] = ACC[i];
-        } else {
-            const double c = coefs[0].x * coefs[0].x + coefs[0].y * coefs[0].y;
-            for (int i = threadIdx.x; i < N; i += blockDim.x) v[i] = make_double2(c * v[i].x, c * v[i].y);
         }
+        for (int i = threadIdx.x; i < N; i += blockDim.x) {
+            const double2 x = v[i], o = make_double2(k.scale * ACC[i].x, k.scale * ACC[i].y);
+            v[i] = o;
+            acc.x += x.x * o.x + x.y * o.y;
+            acc.y += x.x * o.y - x.y * o.x;
+        }
+    } else {
+        double f = k.scale;
+        if (act) f *= k.is_sym ? coefs[0].x : (coefs[0].x * coefs[0].x + coefs[0].y * coefs[0].y);
+        for (int i = threadIdx.x; i < N; i += blockDim.x) {
+            const double2 x = v[i];
+            v[i] = make_double2(f * x.x, f * x.y);
+            acc.x += f * (x.x * x.x + x.y * x.y);
+        }
+    }
+    if (prz) {
+        const double2 t = block_sum_cplx(acc, red);
+        if (threadIdx.x == 0) *prz = t;
     }
 }
 

@@ -271,17 +271,17 @@ void launch_dot(hipStream_t st, const double2 *a, const double2 *b, double2 *par
 // forward:  v[l] *= θ_l/√Lτ  (before the FFT);  inverse:  v[l] *= conj(θ_l)/√Lτ  (after the
 // unnormalised inverse FFT, i.e. (1/Lτ)·√Lτ/θ_l).
 // ---------------------------------------------------------------------------------------------
-__global__ void make_twiddle_kernel(double2 *tw, int Lt)
+__global__ void make_twiddle_kernel(double2 *tw, int Lt, double f)
 {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= Lt) return;
     double s, c;
     sincospi(-(double)l / (double)Lt, &s, &c);
-    const double f = 1.0 / sqrt((double)Lt);
     tw[l] = make_double2(c * f, s * f);
 }
 
-void launch_make_twiddle(hipStream_t st, double2 *tw, int Lt) { hipLaunchKernelGGL(make_twiddle_kernel, dim3((Lt + 63) / 64), dim3(64), 0, st, tw, Lt); }
+// tw[l] = scale * exp(-iπ l / Lτ)
+void launch_make_twiddle(hipStream_t st, double2 *tw, int Lt, double scale) { hipLaunchKernelGGL(make_twiddle_kernel, dim3((Lt + 63) / 64), dim3(64), 0, st, tw, Lt, scale); }
 
 __device__ __forceinline__ double2 twiddle(const double2 *__restrict__ tw, int l, bool conj_)
 {
@@ -308,6 +308,17 @@ void launch_fft_twiddle(hipStream_t st, double2 *v, const double2 *tw, int Lt, i
 
 // ---------------------------------------------------------------------------------------------
 // conjugate gradient, BLAS-1 side — src/IterativeSolvers/ConjugateGradient.jl:93-249.
+//
+// The loop runs in the "twiddled" basis ṽ[l] = θ_l v[l], θ_l = exp(-iπ l/Lτ) (the FourierTransformer
+// phase, src/FourierTransformer.jl:15).  Θ is unitary and diagonal in τ, so every inner product and
+// the whole CG recurrence are unchanged, while
+//   * the operator Θ MᵀM Θᴴ is the same checkerboard kernel with a uniform hop phase exp(-iπ/Lτ) and
+//     a PERIODIC time direction (FdmArgs::hop, antiperiodic = 0);
+//   * the preconditioner U⁻¹ P̂ U loses both twiddle passes: P̃⁻¹ = FFT⁻¹ · P̂ · FFT, rocFFT reads r̃
+//     directly (out of place) and its output IS z̃;
+//   * r·z is formed by Parseval inside the Chebyshev kernel (it holds r̂_ω and ẑ_ω), so no pass over
+//     r and z is needed for it.
+// b is twiddled on the way in (cg_init), x on the way out (cg_finish).
 // One workgroup per (tau-chunk, system); per-system scalars never leave the device.
 // ---------------------------------------------------------------------------------------------
 #define CG_PROLOGUE                                                        \
@@ -319,18 +330,16 @@ void launch_fft_twiddle(hipStream_t st, double2 *v, const double2 *tw, int Lt, i
     const size_t pidx = (size_t)sys * a.nchunk + chunk;                    \
     (void)red; (void)l0; (void)nk; (void)sstride; (void)base; (void)pidx;
 
-// :108-121 — r0 = b (x = 0) or r0 = b - z where z = A x0 was computed by the MᵀM kernel;
-// partial |b|², |r|²; and the FFT input v = θ r / √Lτ when preconditioning.
+// :108-121 — r̃0 = Θb (x = 0) or Θb - z with z = Ã x̃0 from the MᵀM kernel; partial |b|², |r|²
 template <bool X_IS_B>
 __global__ void __launch_bounds__(kThreads) cg_init_kernel(CgArgs a)
 {
     CG_PROLOGUE
-    const bool pre = a.use_precond && a.st[sys].precond_on;
     double2 acc = make_double2(0.0, 0.0);
     for (int idx = threadIdx.x; idx < nk * a.N; idx += blockDim.x) {
         const int k = idx / a.N, i = idx - k * a.N, l = l0 + k;
         const size_t off = (size_t)l * sstride + base + i;
-        const double2 bv = a.b[off];
+        const double2 bv = cmul(a.b[off], a.th[l]);
         double2 rv;
         if (X_IS_B) {
             rv = bv;
@@ -342,13 +351,12 @@ __global__ void __launch_bounds__(kThreads) cg_init_kernel(CgArgs a)
         a.r[off] = rv;
         acc.x += bv.x * bv.x + bv.y * bv.y;
         acc.y += rv.x * rv.x + rv.y * rv.y;
-        if (a.use_precond) a.v[off] = pre ? cmul(rv, twiddle(a.tw, l, false)) : make_double2(0.0, 0.0);
     }
     const double2 t = block_sum_bcast(acc, red);
     if (threadIdx.x == 0) { a.part_bb[pidx] = t.x; a.part_rr[pidx] = t.y; }
 }
 
-// :123-134 / :199-212 — z0 = P⁻¹ r0 (or r0), p0 = z0, partial r·z, eps0, early exit
+// :123-134 / :199-212 — p0 = z0 (= P⁻¹ r0, already in v, or r0), eps0, early exit
 __global__ void __launch_bounds__(kThreads) cg_start_kernel(CgArgs a)
 {
     CG_PROLOGUE
@@ -358,23 +366,16 @@ __global__ void __launch_bounds__(kThreads) cg_start_kernel(CgArgs a)
     const bool bad = !(bb == bb) || !(rr == rr) || isinf(bb) || isinf(rr);
     const double eps = bad ? nan("") : ((bb > 0.0) ? sqrt(rr) / sqrt(bb) : 0.0);
     const bool conv = bad || !(bb > 0.0) || eps < a.tol;
-    const bool pre = a.use_precond && a.st[sys].precond_on;
-    double2 acc = make_double2(0.0, 0.0);
     if (!conv) {
+        const double2 *zz = a.use_precond ? a.v : a.r;
         for (int idx = threadIdx.x; idx < nk * a.N; idx += blockDim.x) {
-            const int k = idx / a.N, i = idx - k * a.N, l = l0 + k;
-            const size_t off = (size_t)l * sstride + base + i;
-            const double2 rv = a.r[off];
-            const double2 zv = pre ? cmul(a.v[off], twiddle(a.tw, l, true)) : rv;
-            a.z[off] = zv;
-            a.p[off] = zv;
-            acc.x += rv.x * zv.x + rv.y * zv.y;
-            acc.y += rv.x * zv.y - rv.y * zv.x;
+            const int k = idx / a.N, i = idx - k * a.N;
+            const size_t off = (size_t)(l0 + k) * sstride + base + i;
+            a.p[off] = zz[off];
         }
     }
-    const double2 t = block_sum_bcast(acc, red);
     if (threadIdx.x == 0) {
-        a.part_rz[pidx] = t;
+        if (!a.use_precond) a.part_rz[(size_t)sys * a.rz_stride + chunk] = make_double2(a.part_rr[pidx], 0.0);  // r·z = r·r
         if (chunk == 0) {
             CgState &s = a.st[sys];
             s.normb2 = bb;
@@ -385,19 +386,18 @@ __global__ void __launch_bounds__(kThreads) cg_start_kernel(CgArgs a)
     }
 }
 
-// :219-226 / :219-226 — α = (r·z)/(p·Ap);  x += α p;  r -= α Ap;  partial |r|²;  v = θ r/√Lτ
+// :219-226 — α = (r·z)/(p·Ap);  x += α p;  r -= α Ap;  partial |r|²
 __global__ void __launch_bounds__(kThreads) cg_update_xr_kernel(CgArgs a)
 {
     CG_PROLOGUE
     if (a.st[sys].done) return;
-    const double2 rz = reduce_partials(a.part_rz + (size_t)sys * a.nchunk, a.nchunk, red);
+    const double2 rz = reduce_partials(a.part_rz + (size_t)sys * a.rz_stride, a.nrz, red);
     const double2 pz = reduce_partials(a.part_pz + (size_t)sys * a.nchunk, a.nchunk, red);
     const double2 alpha = cdiv(rz, pz);
-    const bool pre = a.use_precond && a.st[sys].precond_on;
     double acc = 0.0;
     for (int idx = threadIdx.x; idx < nk * a.N; idx += blockDim.x) {
-        const int k = idx / a.N, i = idx - k * a.N, l = l0 + k;
-        const size_t off = (size_t)l * sstride + base + i;
+        const int k = idx / a.N, i = idx - k * a.N;
+        const size_t off = (size_t)(l0 + k) * sstride + base + i;
         const double2 pv = a.p[off], zv = a.z[off];
         double2 xv = a.x[off], rv = a.r[off];
         const double2 ap = cmul(alpha, pv), az = cmul(alpha, zv);
@@ -406,7 +406,6 @@ __global__ void __launch_bounds__(kThreads) cg_update_xr_kernel(CgArgs a)
         a.x[off] = xv;
         a.r[off] = rv;
         acc += rv.x * rv.x + rv.y * rv.y;
-        if (a.use_precond) a.v[off] = pre ? cmul(rv, twiddle(a.tw, l, false)) : make_double2(0.0, 0.0);
     }
     const double2 t = block_sum_bcast(make_double2(acc, 0.0), red);
     if (threadIdx.x == 0) {
@@ -415,33 +414,28 @@ __global__ void __launch_bounds__(kThreads) cg_update_xr_kernel(CgArgs a)
     }
 }
 
-// :229-237 — eps = |r|/|b|, stop test (on the unpreconditioned residual), z = P⁻¹ r, partial r·z
-__global__ void __launch_bounds__(kThreads) cg_check_kernel(CgArgs a)
+// :229-245 — eps = |r|/|b| and the stop test (on the unpreconditioned residual, before the β
+// update), then β = (r·z)_new/(r·z)_old and p = z + β p with z = P⁻¹ r (in v) or r
+__global__ void __launch_bounds__(kThreads) cg_update_p_kernel(CgArgs a)
 {
     CG_PROLOGUE
-    // snapshot before anybody can have rewritten it: the writer (chunk 0, thread 0) only
-    // writes after the block-wide reductions below, which every thread of chunk 0 has passed
-    const int done_before = a.st[sys].done;
-    if (done_before) return;
+    if (a.st[sys].done) return;
     const double rr = reduce_partials(a.part_rr + (size_t)sys * a.nchunk, a.nchunk, red);
     const double eps = sqrt(rr) / sqrt(a.st[sys].normb2);
     const bool conv = eps < a.tol;
-    const bool pre = a.use_precond && a.st[sys].precond_on;
-    double2 acc = make_double2(0.0, 0.0);
     if (!conv) {
+        const double2 rz = a.use_precond ? reduce_partials(a.part_rz + (size_t)sys * a.rz_stride, a.nrz, red) : make_double2(rr, 0.0);
+        const double2 beta = cdiv(rz, make_double2(a.st[sys].rho_re, a.st[sys].rho_im));
+        const double2 *zz = a.use_precond ? a.v : a.r;
         for (int idx = threadIdx.x; idx < nk * a.N; idx += blockDim.x) {
-            const int k = idx / a.N, i = idx - k * a.N, l = l0 + k;
-            const size_t off = (size_t)l * sstride + base + i;
-            const double2 rv = a.r[off];
-            const double2 zv = pre ? cmul(a.v[off], twiddle(a.tw, l, true)) : rv;
-            a.z[off] = zv;
-            acc.x += rv.x * zv.x + rv.y * zv.y;
-            acc.y += rv.x * zv.y - rv.y * zv.x;
+            const int k = idx / a.N, i = idx - k * a.N;
+            const size_t off = (size_t)(l0 + k) * sstride + base + i;
+            const double2 zv = zz[off], bp = cmul(beta, a.p[off]);
+            a.p[off] = make_double2(zv.x + bp.x, zv.y + bp.y);
         }
     }
-    const double2 t = block_sum_bcast(acc, red);
     if (threadIdx.x == 0) {
-        a.part_rz[pidx] = t;
+        if (!a.use_precond && !conv) a.part_rz[(size_t)sys * a.rz_stride + chunk] = make_double2(a.part_rr[pidx], 0.0);
         if (chunk == 0) {
             CgState &s = a.st[sys];
             s.eps = eps;
@@ -452,18 +446,15 @@ __global__ void __launch_bounds__(kThreads) cg_check_kernel(CgArgs a)
     }
 }
 
-// :239-245 — β = (r·z)_new/(r·z)_old;  p = z + β p
-__global__ void __launch_bounds__(kThreads) cg_update_p_kernel(CgArgs a)
+// back to the reference basis: x = Θᴴ x̃
+__global__ void __launch_bounds__(kThreads) cg_finish_kernel(CgArgs a)
 {
     CG_PROLOGUE
-    if (a.st[sys].done) return;
-    const double2 rz = reduce_partials(a.part_rz + (size_t)sys * a.nchunk, a.nchunk, red);
-    const double2 beta = cdiv(rz, make_double2(a.st[sys].rho_re, a.st[sys].rho_im));
     for (int idx = threadIdx.x; idx < nk * a.N; idx += blockDim.x) {
-        const int k = idx / a.N, i = idx - k * a.N;
-        const size_t off = (size_t)(l0 + k) * sstride + base + i;
-        const double2 zv = a.z[off], bp = cmul(beta, a.p[off]);
-        a.p[off] = make_double2(zv.x + bp.x, zv.y + bp.y);
+        const int k = idx / a.N, i = idx - k * a.N, l = l0 + k;
+        const size_t off = (size_t)l * sstride + base + i;
+        const double2 t = a.th[l];
+        a.x[off] = cmul(a.x[off], make_double2(t.x, -t.y));
     }
 }
 
@@ -474,8 +465,7 @@ void launch_cg_init(hipStream_t s, const CgArgs &a, bool x_is_b)
 }
 void launch_cg_start(hipStream_t s, const CgArgs &a) { hipLaunchKernelGGL(cg_start_kernel, dim3(a.nchunk * a.nsys), dim3(kThreads), 0, s, a); }
 void launch_cg_update_xr(hipStream_t s, const CgArgs &a) { hipLaunchKernelGGL(cg_update_xr_kernel, dim3(a.nchunk * a.nsys), dim3(kThreads), 0, s, a); }
-void launch_cg_check(hipStream_t s, const CgArgs &a) { hipLaunchKernelGGL(cg_check_kernel, dim3(a.nchunk * a.nsys), dim3(kThreads), 0, s, a); }
 void launch_cg_update_p(hipStream_t s, const CgArgs &a) { hipLaunchKernelGGL(cg_update_p_kernel, dim3(a.nchunk * a.nsys), dim3(kThreads), 0, s, a); }
-void launch_cg_begin_iter(hipStream_t, const CgArgs &) {}
+void launch_cg_finish(hipStream_t s, const CgArgs &a) { hipLaunchKernelGGL(cg_finish_kernel, dim3(a.nchunk * a.nsys), dim3(kThreads), 0, s, a); }
 
 }  // namespace smoqy

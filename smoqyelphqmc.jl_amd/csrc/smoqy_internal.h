@@ -50,6 +50,8 @@ struct FdmArgs {
     double2 *partial;       // [nsys][nchunk] dot(in, out) partials, or nullptr
     const CgState *cg;      // optional: skip systems with done != 0
     int sys_first, sys_count;  // systems [sys_first, sys_first + sys_count) are processed
+    double hop_re, hop_im;     // phase on the inter-slice hop: 1 for the reference operator, exp(-iπ/Lτ) inside the CG
+    int antiperiodic;          // 1: the wrap-around row carries the opposite sign (reference operator)
 };
 
 struct KpmArgs {
@@ -64,6 +66,9 @@ struct KpmArgs {
     int nslot, maxorder;
     double2 *v;                         // in place, slice(=frequency)-major
     const CgState *cg;
+    double2 *part_rz;                   // optional [nsys][rz_stride]: Parseval partial of r·z per (system, ω)
+    int rz_stride;
+    double scale;                       // output scale (1/Lτ: rocFFT's inverse is unnormalised)
 };
 
 // geometry of the KPM fast path: per-colour bond lists padded with identity self bonds (i, i) so
@@ -104,30 +109,31 @@ void launch_lambda_update(hipStream_t st, double *Lam, int Lt, int N, const doub
 void launch_lambda_apply(hipStream_t st, int op, double2 *out, const double2 *in, const double *Lam, int Lt, int N, int nsys, int nrhs, int wslot_override);
 void launch_dot(hipStream_t st, const double2 *a, const double2 *b, double2 *partial, double2 *out, int Lt, int N, int nsys, int Tc, int nchunk);
 void launch_fft_twiddle(hipStream_t st, double2 *v, const double2 *tw, int Lt, int N, int nsys, int inverse);
-void launch_make_twiddle(hipStream_t st, double2 *tw, int Lt);
+void launch_make_twiddle(hipStream_t st, double2 *tw, int Lt, double scale);
 void launch_tau_means(hipStream_t st, const KpmGeom &kg, const double *expV, const double *ch, const double *sh, double *dbar, double *cbar, double *sbar, int Lt, int N, int Nh, int w0, int nw);
 // alpha/beta: [nw][1024] each; randvec: [nw][N]
 void launch_lanczos(hipStream_t st, const KpmArgs &k, const KpmGeom &kg, int w0, int nw, const double *randvec, int nsteps, double *alpha, double *beta, bool use_BtB);
 void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg);
 
-// CG kernels
+// CG kernels (kernels_vec.hip): the loop runs in the twiddled basis, see there
 struct CgArgs {
     int Lt, N, nsys, nrhs, Tc, nchunk;
     double2 *x, *r, *p, *z, *v;
-    const double2 *tw;            // [Lt] theta_l / sqrt(Lt)
+    const double2 *th;            // [Lt] theta_l = exp(-i pi l / Lt)
     const double2 *b;
-    double2 *part_pz, *part_rz;   // [nsys][nchunk]
+    double2 *part_pz;             // [nsys][nchunk]
+    double2 *part_rz;             // [nsys][rz_stride]; nrz valid entries (Lt from the Chebyshev kernel, nchunk otherwise)
     double *part_rr, *part_bb;    // [nsys][nchunk]
     CgState *st;
     double tol;
     int maxiter;
     int use_precond;
+    int nrz, rz_stride;
 };
-void launch_cg_init(hipStream_t s, const CgArgs &a, bool x_is_b);       // r, x, |b|^2, |r|^2 partials, v = theta r
-void launch_cg_start(hipStream_t s, const CgArgs &a);                   // z, p, rho, eps, done (after optional precond)
-void launch_cg_update_xr(hipStream_t s, const CgArgs &a);               // K2
-void launch_cg_check(hipStream_t s, const CgArgs &a);                   // K3
-void launch_cg_update_p(hipStream_t s, const CgArgs &a);                // K4
-void launch_cg_begin_iter(hipStream_t s, const CgArgs &a);              // bookkeeping: rho <- new, iters++
+void launch_cg_init(hipStream_t s, const CgArgs &a, bool x_is_b);
+void launch_cg_start(hipStream_t s, const CgArgs &a);
+void launch_cg_update_xr(hipStream_t s, const CgArgs &a);
+void launch_cg_update_p(hipStream_t s, const CgArgs &a);
+void launch_cg_finish(hipStream_t s, const CgArgs &a);
 
 }  // namespace smoqy
