@@ -160,6 +160,9 @@ int smoqy_cg_solve_v(smoqy_ctx *ctx, int x, int b, double tol, int maxiter, int 
 int smoqy_cg_solve(smoqy_ctx *ctx, void *x, const void *b, int x_is_b, int sys0, int count, double tol, int maxiter, int use_precond, int *iters, double *eps);
 /* host <-> device convergence polling period of the on-device CG loop (iterations per poll) */
 int smoqy_cg_config(smoqy_ctx *ctx, int check_every);
+/* replay one captured CG iteration as a hipGraph instead of launching its kernels one by one (off by
+ * default: not faster on MI355X at the sizes measured) */
+int smoqy_cg_use_graph(smoqy_ctx *ctx, int on);
 
 /* ---- measurement aids (bench.py) -------------------------------------------------------- */
 

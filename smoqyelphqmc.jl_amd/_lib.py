@@ -87,6 +87,7 @@ SIGNATURES = {
     "smoqy_cg_solve_v": [_p, _i, _i, _d, _i, _i, _p, _p],
     "smoqy_cg_solve": [_p, _p, _p, _i, _i, _i, _d, _i, _i, _p, _p],
     "smoqy_cg_config": [_p, _i],
+    "smoqy_cg_use_graph": [_p, _i],
     "smoqy_timer_start": [_p],
     "smoqy_timer_stop": [_p, _pd],
     "smoqy_bench_matvec": [_p, _i, _i, _i, _i, _pd],

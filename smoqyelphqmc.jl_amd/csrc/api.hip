@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -51,6 +52,18 @@ struct smoqy_ctx {
     double *part_rr = nullptr, *part_bb = nullptr;
     CgState *d_st = nullptr, *h_st = nullptr;
     int check_every = 4;
+    // iterations the previous solve at (about) the same tolerance needed: consecutive solves of an HMC
+    // trajectory converge in nearly the same number of iterations, so the first burst runs that far
+    // before the host polls the device for the first time
+    // captured CG iteration (hipGraph), keyed by everything baked into its kernel arguments
+    struct IterGraph { const void *x = nullptr; int pre = 0, Tc = 0, ffast = 0, kfast = 0; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
+    IterGraph graphs[4];
+    int graph_next = 0;
+    // off by default: measured on MI355X the replay (≈10-16 µs per graph launch) does not beat six eager
+    // launches per iteration (76.5 vs 80 ms per single-walker sweep); reset to 0 after a failed capture
+    int use_graph = 0;
+    double hint_tol[4] = {0, 0, 0, 0};
+    int hint_iters[4] = {0, 0, 0, 0};
     // fft
     rocfft_plan plan_f = nullptr, plan_b = nullptr, plan_f_oop = nullptr;
     rocfft_execution_info fft_info = nullptr;
@@ -68,7 +81,9 @@ struct smoqy_ctx {
     KpmGeom kg{};
     FdmFast ff{};
     double2 *d_csf = nullptr;
-    int2 *d_pbonds = nullptr;
+    int *d_cs_varies = nullptr;
+    int2 *d_pbonds = nullptr, *d_psites = nullptr;
+    int *d_pos = nullptr;
     int *d_poff = nullptr, *d_psrc = nullptr;
     double2 *d_pcs = nullptr;
     double *h_lan = nullptr;  // pinned [nw][2][1024]
@@ -190,13 +205,17 @@ int smoqy_destroy(smoqy_ctx *c)
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &gph : c->graphs) {
+        if (gph.exec) (void)hipGraphExecDestroy(gph.exec);
+        if (gph.graph) (void)hipGraphDestroy(gph.graph);
+    }
     if (c->plan_f) rocfft_plan_destroy(c->plan_f);
     if (c->plan_b) rocfft_plan_destroy(c->plan_b);
     if (c->plan_f_oop) rocfft_plan_destroy(c->plan_f_oop);
     if (c->fft_info) rocfft_execution_info_destroy(c->fft_info);
     void *ptrs[] = {c->d_bonds, c->d_col_off, c->d_expV, c->d_ch, c->d_sh, c->d_lam, c->d_stage, c->d_stage_real, c->d_stage_int, c->scr[0], c->scr[1], c->scr[2], c->cg_r, c->cg_p,
                     c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->fft_work, c->d_tw, c->d_th, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
-                    c->d_rand, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf};
+                    c->d_rand, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (double2 *v : c->vecs)
@@ -217,6 +236,8 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     hipDeviceProp_t prop;
     HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) FAIL(c, 4, "this library is built for gfx950 (MI355X) only; device %d is %s", c->device, prop.gcnArchName);
+    static std::once_flag cfg_once;
+    std::call_once(cfg_once, [] { configure_fdm_kernels(); configure_kpm_kernels(); });
     HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIPCHK(c, hipEventCreate(&c->ev0));
@@ -339,18 +360,39 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
         c->kg.ptotal = (int)pb.size();
         c->kg.threads = std::max(64, ((maxp + 63) / 64) * 64);
         c->kg.fast = (g.ncol >= 1 && g.ncol <= kMaxColours && maxp <= 1024) ? 1 : 0;
+        // LDS positions: the first colour's x sites in list order, then its y sites
+        std::vector<int> pos((size_t)g.N);
+        for (int i = 0; i < g.N; ++i) pos[i] = i;
+        if (g.ncol >= 1) {
+            int q = 0;
+            for (int k = poff[0]; k < poff[1]; ++k) pos[pb[k].x] = q++;
+            for (int k = poff[0]; k < poff[1]; ++k)
+                if (pb[k].y != pb[k].x) pos[pb[k].y] = q++;
+            if (q != g.N) FAIL(c, 8, "internal: first colour's padded list does not cover all sites (%d of %d)", q, g.N);
+        }
+        std::vector<int2> pbpos(pb.size());
+        for (size_t k = 0; k < pb.size(); ++k) pbpos[k] = make_int2(pos[pb[k].x], pos[pb[k].y]);
+        HIPCHK(c, hipMalloc(&c->d_psites, std::max<size_t>(pb.size(), 1) * sizeof(int2)));
+        HIPCHK(c, hipMalloc(&c->d_pos, (size_t)g.N * sizeof(int)));
+        HIPCHK(c, hipMemcpy(c->d_pos, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (!pb.empty()) HIPCHK(c, hipMemcpy(c->d_psites, pb.data(), pb.size() * sizeof(int2), hipMemcpyHostToDevice));
         HIPCHK(c, hipMalloc(&c->d_pbonds, std::max<size_t>(pb.size(), 1) * sizeof(int2)));
         HIPCHK(c, hipMalloc(&c->d_psrc, std::max<size_t>(pb.size(), 1) * sizeof(int)));
         HIPCHK(c, hipMalloc(&c->d_poff, poff.size() * sizeof(int)));
         HIPCHK(c, hipMalloc(&c->d_pcs, (size_t)g.nw * std::max<size_t>(pb.size(), 1) * sizeof(double2)));
         if (!pb.empty()) {
-            HIPCHK(c, hipMemcpy(c->d_pbonds, pb.data(), pb.size() * sizeof(int2), hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(c->d_pbonds, pbpos.data(), pbpos.size() * sizeof(int2), hipMemcpyHostToDevice));
             HIPCHK(c, hipMemcpy(c->d_psrc, psrc.data(), psrc.size() * sizeof(int), hipMemcpyHostToDevice));
         }
         HIPCHK(c, hipMemcpy(c->d_poff, poff.data(), poff.size() * sizeof(int), hipMemcpyHostToDevice));
+        c->kg.psites = c->d_psites; c->kg.pos = c->d_pos;
         c->kg.pbonds = c->d_pbonds; c->kg.poff = c->d_poff; c->kg.psrc = c->d_psrc; c->kg.pcs = c->d_pcs;
         HIPCHK(c, hipMalloc(&c->d_csf, (size_t)g.nw * g.Lt * std::max<size_t>(pb.size(), 1) * sizeof(double2)));
         HIPCHK(c, hipMemset(c->d_csf, 0, (size_t)g.nw * g.Lt * std::max<size_t>(pb.size(), 1) * sizeof(double2)));
+        HIPCHK(c, hipMalloc(&c->d_cs_varies, (size_t)g.nw * sizeof(int)));
+        HIPCHK(c, hipMemset(c->d_cs_varies, 0, (size_t)g.nw * sizeof(int)));
+        c->ff.cs_varies = c->d_cs_varies;
+        c->ff.psites = c->d_psites; c->ff.pos = c->d_pos;
         c->ff.pbonds = c->d_pbonds; c->ff.poff = c->d_poff; c->ff.csf = c->d_csf; c->ff.ptotal = c->kg.ptotal; c->ff.threads = c->kg.threads;
         c->ff.enabled = (g.is_sym && g.ncol >= 1 && g.ncol <= kFdmColours && maxp <= 1024) ? 1 : 0;
         choose_chunking(c);
@@ -472,7 +514,7 @@ int smoqy_update_fields(smoqy_ctx *c, int w, const double *expV, const double *c
     if (int rc = upload_real_field(c, expV, c->d_expV + (size_t)w * g.Lt * g.N, g.N)) return rc;
     if (int rc = upload_real_field(c, ch, c->d_ch + (size_t)w * g.Lt * g.Nh, g.Nh)) return rc;
     if (int rc = upload_real_field(c, sh, c->d_sh + (size_t)w * g.Lt * g.Nh, g.Nh)) return rc;
-    launch_pack_csf(c->stream, c->d_ch + (size_t)w * g.Lt * g.Nh, c->d_sh + (size_t)w * g.Lt * g.Nh, c->d_psrc, c->d_csf + (size_t)w * g.Lt * c->kg.ptotal, g.Lt, g.Nh, c->kg.ptotal);
+    launch_pack_csf(c->stream, c->d_ch + (size_t)w * g.Lt * g.Nh, c->d_sh + (size_t)w * g.Lt * g.Nh, c->d_psrc, c->d_csf + (size_t)w * g.Lt * c->kg.ptotal, c->d_cs_varies + w, g.Lt, g.Lt, g.Nh, c->kg.ptotal);
     return check_launch(c, "update_fields");
 }
 
@@ -500,7 +542,7 @@ static int update_pi_range(smoqy_ctx *c, int w0, int nw, const double *V, const 
     const bool do_t = t && nT;
     launch_fields_from_path_integral(c->stream, V ? dV : nullptr, do_t ? dT : nullptr, c->d_stage_int, c->d_expV + (size_t)w0 * nV, c->d_ch + (size_t)w0 * nT, c->d_sh + (size_t)w0 * nT, nw * g.Lt, g.N, g.Nh,
                                      dtau, g.is_sym ? dtau / 2 : dtau);  // FermionDetMatrix.jl:220
-    if (do_t) launch_pack_csf(c->stream, c->d_ch + (size_t)w0 * nT, c->d_sh + (size_t)w0 * nT, c->d_psrc, c->d_csf + (size_t)w0 * g.Lt * c->kg.ptotal, nw * g.Lt, g.Nh, c->kg.ptotal);
+    if (do_t) launch_pack_csf(c->stream, c->d_ch + (size_t)w0 * nT, c->d_sh + (size_t)w0 * nT, c->d_psrc, c->d_csf + (size_t)w0 * g.Lt * c->kg.ptotal, c->d_cs_varies + w0, nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_launch(c, "update_from_path_integral");
 }
@@ -1095,11 +1137,28 @@ int smoqy_precond_apply(smoqy_ctx *c, void *out, const void *in, int sys0, int c
 
 // ---- conjugate gradient ---------------------------------------------------------------------------
 
+int smoqy_cg_use_graph(smoqy_ctx *c, int on)
+{
+    CHECK_CTX(c);
+    c->use_graph = on ? 1 : 0;
+    return 0;
+}
+
 int smoqy_cg_config(smoqy_ctx *c, int check_every)
 {
     CHECK_CTX(c);
     if (check_every < 1) FAIL(c, 1, "check_every must be >= 1");
     c->check_every = check_every;
+    return 0;
+}
+
+// one CG iteration: ConjugateGradient.jl:216-246
+static int cg_iteration(smoqy_ctx *c, const CgArgs &a, bool any_pre)
+{
+    if (int rc = matvec_dev(c, SMOQY_OP_MTM, c->cg_z, c->cg_p, c->part_pz, c->d_st, 0, c->g.nsys, true)) return rc;  // z = A p, partial p·Ap (:219)
+    launch_cg_update_xr(c->stream, a);                                                                             // :220-226
+    if (any_pre) if (int rc = precond_core(c, c->cg_r, c->cg_v, c->d_st, c->part_rz)) return rc;                 // z = P⁻¹ r, partial r·z (:237-240)
+    launch_cg_update_p(c->stream, a);                                                                              // :229-245
     return 0;
 }
 
@@ -1111,6 +1170,8 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
     for (int s = 0; s < g.nsys; ++s) {
         std::memset(&c->h_st[s], 0, sizeof(CgState));
         c->h_st[s].precond_on = (use_precond && c->pre[s / g.nrhs].active) ? 1 : 0;
+        c->h_st[s].tol = tol;
+        c->h_st[s].maxiter = maxiter;
         any_pre = any_pre || c->h_st[s].precond_on;
     }
     HIPCHK(c, hipMemcpyAsync(c->d_st, c->h_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyHostToDevice, c->stream));
@@ -1132,13 +1193,44 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
     if (int rc = check_launch(c, "cg setup")) return rc;
 
     int launched = 0;
+    int hint = 0, hslot = -1;
+    for (int q = 0; q < 4; ++q)
+        if (c->hint_tol[q] > 0 && std::fabs(std::log(c->hint_tol[q] / tol)) < 0.7) { hint = c->hint_iters[q]; hslot = q; }
     while (launched < maxiter) {
-        const int burst = std::min(c->check_every, maxiter - launched);
+        int burst = std::min(c->check_every, maxiter - launched);
+        if (launched == 0 && hint > burst) burst = std::min(hint - 1, maxiter);
+        hipGraphExec_t gexec = nullptr;
+        if (c->use_graph) {
+            // one CG iteration captured once per (x, preconditioning, kernel configuration) and replayed:
+            // the inner loop is launch bound at small batch (6 short dependent kernels per iteration)
+            for (auto &gph : c->graphs)
+                if (gph.exec && gph.x == (const void *)x && gph.pre == (int)any_pre && gph.Tc == c->Tc && gph.ffast == c->ff.enabled && gph.kfast == c->kg.fast) gexec = gph.exec;
+            if (!gexec) {
+                smoqy_ctx::IterGraph &slot = c->graphs[c->graph_next];
+                c->graph_next = (c->graph_next + 1) % 4;
+                if (slot.exec) { (void)hipGraphExecDestroy(slot.exec); slot.exec = nullptr; }
+                if (slot.graph) { (void)hipGraphDestroy(slot.graph); slot.graph = nullptr; }
+                bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                int rc = 0;
+                if (ok) {
+                    rc = cg_iteration(c, a, any_pre);
+                    ok = (hipStreamEndCapture(c->stream, &slot.graph) == hipSuccess) && rc == 0 && slot.graph;
+                }
+                if (ok) ok = hipGraphInstantiate(&slot.exec, slot.graph, nullptr, nullptr, 0) == hipSuccess;
+                if (ok) {
+                    slot.x = x; slot.pre = any_pre; slot.Tc = c->Tc; slot.ffast = c->ff.enabled; slot.kfast = c->kg.fast;
+                    gexec = slot.exec;
+                } else {
+                    (void)hipGetLastError();
+                    if (slot.graph) { (void)hipGraphDestroy(slot.graph); slot.graph = nullptr; }
+                    slot.exec = nullptr;
+                    c->use_graph = 0;
+                }
+            }
+        }
         for (int it = 0; it < burst; ++it) {
-            if (int rc = matvec_dev(c, SMOQY_OP_MTM, c->cg_z, c->cg_p, c->part_pz, c->d_st, 0, g.nsys, true)) return rc;  // z = A p, partial p·Ap (:219)
-            launch_cg_update_xr(c->stream, a);                                                                          // :220-226
-            if (any_pre) if (int rc = precond_core(c, c->cg_r, c->cg_v, c->d_st, c->part_rz)) return rc;              // z = P⁻¹ r, partial r·z (:237-240)
-            launch_cg_update_p(c->stream, a);                                                                           // :229-245
+            if (gexec) HIPCHK(c, hipGraphLaunch(gexec, c->stream));
+            else if (int rc = cg_iteration(c, a, any_pre)) return rc;
         }
         launched += burst;
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
@@ -1147,6 +1239,19 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
         bool all_done = true;
         for (int s = 0; s < g.nsys; ++s) all_done = all_done && (c->h_st[s].done != 0);
         if (all_done) break;
+    }
+    {   // remember how long this tolerance took
+        int mx = 0;
+        for (int s = 0; s < g.nsys; ++s) mx = std::max(mx, c->h_st[s].iters);
+        if (hslot < 0) {
+            hslot = 0;
+            for (int q = 1; q < 4; ++q)
+                if (c->hint_tol[q] == 0 || c->hint_iters[q] < c->hint_iters[hslot]) hslot = c->hint_tol[q] == 0 ? q : hslot;
+            for (int q = 0; q < 4; ++q)
+                if (c->hint_tol[q] == 0) { hslot = q; break; }
+        }
+        c->hint_tol[hslot] = tol;
+        c->hint_iters[hslot] = mx;
     }
     launch_cg_finish(c->stream, a);  // x = Θᴴ x̃
     HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyDeviceToHost, c->stream));

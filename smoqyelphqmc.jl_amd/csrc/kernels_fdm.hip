@@ -219,12 +219,16 @@ size_t fdm_lds_bytes(int op, int N, int Tc)
 template <bool SYM, int OP>
 static void launch_one(hipStream_t st, const FdmArgs &a, size_t lds)
 {
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute((const void *)fdm_kernel<SYM, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        configured = true;
-    }
     hipLaunchKernelGGL((fdm_kernel<SYM, OP>), dim3((unsigned)(a.nchunk * a.sys_count)), dim3(kThreads), lds, st, a);
+}
+
+// raise the dynamic-LDS limit of every instantiation once, outside any stream capture
+template <bool SYM, int OP>
+static void configure_one() { (void)hipFuncSetAttribute((const void *)fdm_kernel<SYM, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); }
+void configure_fdm_kernels()
+{
+    configure_one<true, 0>(); configure_one<true, 1>(); configure_one<true, 2>(); configure_one<true, 3>();
+    configure_one<false, 0>(); configure_one<false, 1>(); configure_one<false, 2>(); configure_one<false, 3>();
 }
 
 void launch_fdm(hipStream_t st, int op, bool sym, const FdmArgs &a, size_t lds)

@@ -150,6 +150,9 @@ __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
 
     // ---- everything this workgroup needs from memory is requested here, up front ----
     Lane ln;
+    // hoppings that do not depend on τ (e.g. Holstein: t constant) are detected when the fields are
+    // packed; the lane then fetches its (cosh, sinh) pair once instead of once per slice
+    const bool cs_varies = ff.cs_varies[w] != 0;
 #pragma unroll
     for (int c = 0; c < kFdmColours; ++c) {
         ln.on[c] = false;
@@ -161,38 +164,59 @@ __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
                 ln.b[c] = ff.pbonds[idx];
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k)
-                    if (k < K1) ln.cs[c][k] = csf[(size_t)wrapl(fbase + k, Lt) * ff.ptotal + idx];
+                    if (k < K1 && (k == 0 || cs_varies)) ln.cs[c][k] = csf[(size_t)wrapl(fbase + k, Lt) * ff.ptotal + idx];
+                if (!cs_varies) {
+#pragma unroll
+                    for (int k = 1; k < KMAX; ++k) ln.cs[c][k] = ln.cs[c][0];
+                }
             }
         }
     }
+    const int2 s0 = ln.on[0] ? ff.psites[ff.poff[0] + (int)threadIdx.x] : make_int2(0, 0);
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         ln.di[k] = ln.dj[k] = 1.0;
         if (k < K1 && ln.on[0]) {
             const double *e = expV + (size_t)wrapl(fbase + k, Lt) * N;
-            ln.di[k] = e[ln.b[0].x];
-            ln.dj[k] = e[ln.b[0].y];
+            ln.di[k] = e[s0.x];
+            ln.dj[k] = e[s0.y];
         }
     }
-    const int2 bL = ln.b[NCOL - 1];
+    const int2 bL = ln.b[NCOL - 1];  // LDS positions of the lane's last-colour site pair
     const bool onL = ln.on[NCOL - 1];
+    const int2 sL = onL ? ff.psites[ff.poff[NCOL - 1] + (int)threadIdx.x] : make_int2(0, 0);  // ... and the site ids
     // the "v" of v ∓ B v at the lane's own (last-colour) site pair
+    // All but one of these slices are also among the slices staged into U (shifted by one), so only
+    // that one is gathered from memory; the others are picked out of LDS after the fill.
     double2 vi[KMAX], vj[KMAX];
     const int vbase = (OP == SMOQY_OP_MMT) ? l0 - 1 : l0;  // slice of vi[0]
+    constexpr int VSH = (OP == SMOQY_OP_M || OP == SMOQY_OP_MTM) ? 1 : -1;  // v[k] is U[k + VSH]
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         vi[k] = vj[k] = make_double2(0.0, 0.0);
-        if (k < K1 && onL) {
+        const int ku = k + VSH;
+        if (k < K1 && onL && (ku < 0 || ku >= K1)) {
             const double2 *row = in + (size_t)wrapl(vbase + k, Lt) * sstride;
-            vi[k] = row[bL.x];
-            vj[k] = row[bL.y];
+            vi[k] = row[sL.x];
+            vj[k] = row[sL.y];
         }
     }
     for (int idx = threadIdx.x; idx < K1 * N; idx += blockDim.x) {
         const int k = idx / N, i = idx - k * N;
-        U[idx] = in[(size_t)wrapl(ubase + k, Lt) * sstride + i];
+        U[(size_t)k * N + ff.pos[i]] = in[(size_t)wrapl(ubase + k, Lt) * sstride + i];
     }
     __syncthreads();
+    if (onL) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int ku = k + VSH;
+            if (k < K1 && ku >= 0 && ku < K1) {
+                vi[k] = U[(size_t)ku * N + bL.x];
+                vj[k] = U[(size_t)ku * N + bL.y];
+            }
+        }
+    }
+    __syncthreads();  // the first stage overwrites U at other lanes' sites
 
     double2 ri[KMAX], rj[KMAX];
     double2 acc = make_double2(0.0, 0.0);
@@ -206,11 +230,11 @@ __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
                 const bool wrap = (OP == SMOQY_OP_M) ? (l == 0) : (l == Lt - 1);
                 const double2 oi = hopcomb(vi[k], ri[k], wrap, OP == SMOQY_OP_MT, a), oj = hopcomb(vj[k], rj[k], wrap, OP == SMOQY_OP_MT, a);
                 double2 *row = out + (size_t)l * sstride;
-                row[bL.x] = oi;
+                row[sL.x] = oi;
                 acc.x += vi[k].x * oi.x + vi[k].y * oi.y;
                 acc.y += vi[k].x * oi.y - vi[k].y * oi.x;
                 if (bL.y != bL.x) {
-                    row[bL.y] = oj;
+                    row[sL.y] = oj;
                     acc.x += vj[k].x * oj.x + vj[k].y * oj.y;
                     acc.y += vj[k].x * oj.y - vj[k].y * oj.x;
                 }
@@ -256,11 +280,11 @@ __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
                 const double2 oi = hopcomb(bi, ri[k], wrap, OP == SMOQY_OP_MTM, a), oj = hopcomb(bj, rj[k], wrap, OP == SMOQY_OP_MTM, a);
                 const double2 pi = (OP == SMOQY_OP_MTM) ? vi[k] : vi[k + 1], pj = (OP == SMOQY_OP_MTM) ? vj[k] : vj[k + 1];
                 double2 *row = out + (size_t)l * sstride;
-                row[bL.x] = oi;
+                row[sL.x] = oi;
                 acc.x += pi.x * oi.x + pi.y * oi.y;
                 acc.y += pi.x * oi.y - pi.y * oi.x;
                 if (bL.y != bL.x) {
-                    row[bL.y] = oj;
+                    row[sL.y] = oj;
                     acc.x += pj.x * oj.x + pj.y * oj.y;
                     acc.y += pj.x * oj.y - pj.y * oj.x;
                 }
@@ -314,24 +338,33 @@ void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff
     }
 }
 
-// pack cosh/sinh into the padded interleaved table csf[l][idx] = (c, s) (self bonds: (1, 0))
-__global__ void pack_csf_kernel(const double *__restrict__ ch, const double *__restrict__ sh, const int *__restrict__ psrc, double2 *__restrict__ csf, int Lt, int Nh, int ptotal)
+// pack cosh/sinh into the padded interleaved table csf[l][idx] = (c, s) (self bonds: (1, 0)) and note
+// per walker whether the hoppings depend on τ at all (Lt = nwalkers * Lt1 slices in a row)
+__global__ void pack_csf_kernel(const double *__restrict__ ch, const double *__restrict__ sh, const int *__restrict__ psrc, double2 *__restrict__ csf, int *__restrict__ cs_varies, int Lt, int Lt1, int Nh,
+                                int ptotal)
 {
     const size_t tot = (size_t)Lt * ptotal;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
         const int l = (int)(idx / ptotal), j = (int)(idx - (size_t)l * ptotal);
         const int h = psrc[j];
-        csf[idx] = h >= 0 ? make_double2(ch[(size_t)l * Nh + h], sh[(size_t)l * Nh + h]) : make_double2(1.0, 0.0);
+        double2 v = make_double2(1.0, 0.0);
+        if (h >= 0) {
+            v = make_double2(ch[(size_t)l * Nh + h], sh[(size_t)l * Nh + h]);
+            const int w = l / Lt1, lf = w * Lt1;  // first slice of this walker
+            if (v.x != ch[(size_t)lf * Nh + h] || v.y != sh[(size_t)lf * Nh + h]) cs_varies[w] = 1;  // benign race: every writer stores 1
+        }
+        csf[idx] = v;
     }
 }
 
-void launch_pack_csf(hipStream_t st, const double *ch, const double *sh, const int *psrc, double2 *csf, int Lt, int Nh, int ptotal)
+void launch_pack_csf(hipStream_t st, const double *ch, const double *sh, const int *psrc, double2 *csf, int *cs_varies, int Lt, int Lt1, int Nh, int ptotal)
 {
     const size_t tot = (size_t)Lt * ptotal;
     if (tot == 0) return;
+    (void)hipMemsetAsync(cs_varies, 0, sizeof(int) * (size_t)(Lt / Lt1), st);
     int blocks = (int)((tot + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(pack_csf_kernel, dim3(blocks), dim3(256), 0, st, ch, sh, psrc, csf, Lt, Nh, ptotal);
+    hipLaunchKernelGGL(pack_csf_kernel, dim3(blocks), dim3(256), 0, st, ch, sh, psrc, csf, cs_varies, Lt, Lt1, Nh, ptotal);
 }
 
 }  // namespace smoqy

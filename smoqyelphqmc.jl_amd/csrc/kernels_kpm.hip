@@ -106,13 +106,17 @@ void launch_tau_means(hipStream_t st, const KpmGeom &kg, const double *expV, con
 // register-resident bond program of one lane
 // ---------------------------------------------------------------------------------------------
 struct LaneBonds {
-    int2 b[kMaxColours];
+    int2 b[kMaxColours];  // LDS positions
+    int2 s0, sL;          // site ids of the first / last colour's bond
     double2 cs[kMaxColours];
     bool on[kMaxColours];
 };
 
 __device__ __forceinline__ void load_lane_bonds(LaneBonds &lb, const KpmGeom &kg, int w, int ncol)
 {
+    lb.s0 = lb.sL = make_int2(0, 0);
+    if (ncol >= 1 && kg.poff[0] + (int)threadIdx.x < kg.poff[1]) lb.s0 = kg.psites[kg.poff[0] + (int)threadIdx.x];
+    if (ncol >= 1 && kg.poff[ncol - 1] + (int)threadIdx.x < kg.poff[ncol]) lb.sL = kg.psites[kg.poff[ncol - 1] + (int)threadIdx.x];
 #pragma unroll
     for (int c = 0; c < kMaxColours; ++c) {
         lb.on[c] = false;
@@ -143,7 +147,7 @@ __device__ __forceinline__ void load_lane_bonds(LaneBonds &lb, const KpmGeom &kg
 // W <- B W where B = Sym B̄ (MODE 0), Asym B̄ = D̄Γ̄ (MODE 1) or Asym B̄ᵀB̄ = Γ̄ᵀD̄²Γ̄ (MODE 2); plain form
 // used by Lanczos (no basis change)
 template <int MODE>
-__device__ __forceinline__ void bbar_apply_regs(double2 *W, const LaneBonds &lb, int ncol, int N, const double *__restrict__ dbar)
+__device__ __forceinline__ void bbar_apply_regs(double2 *W, const LaneBonds &lb, int ncol, int N, const double *__restrict__ dbar, const int *__restrict__ pos)
 {
     if (MODE == 0) {
 #pragma unroll
@@ -152,7 +156,7 @@ __device__ __forceinline__ void bbar_apply_regs(double2 *W, const LaneBonds &lb,
         // C₁ D̄ C₁ fused (colour 0 is padded to cover every site)
         if (lb.on[0]) {
             const double2 a = W[lb.b[0].x], d = W[lb.b[0].y];
-            const double di = dbar[lb.b[0].x], dj = dbar[lb.b[0].y];
+            const double di = dbar[lb.s0.x], dj = dbar[lb.s0.y];
             double2 x = lin2(lb.cs[0].x, a, lb.cs[0].y, d), y = lin2(lb.cs[0].x, d, lb.cs[0].y, a);
             x = make_double2(di * x.x, di * x.y);
             y = make_double2(dj * y.x, dj * y.y);
@@ -169,7 +173,8 @@ __device__ __forceinline__ void bbar_apply_regs(double2 *W, const LaneBonds &lb,
             if (c < ncol) PLAIN_STAGE(c)
         for (int i = threadIdx.x; i < N; i += blockDim.x) {
             const double d = (MODE == 2) ? dbar[i] * dbar[i] : dbar[i];
-            W[i] = make_double2(d * W[i].x, d * W[i].y);
+            const int q = pos[i];
+            W[q] = make_double2(d * W[q].x, d * W[q].y);
         }
         __syncthreads();
         if (MODE == 2) {
@@ -342,10 +347,10 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
 #pragma unroll
     for (int c = 0; c < kMaxColours; ++c)
         if (c == cl) { bL = lb.b[c]; onL = lb.on[c]; }
-    const double di = lb.on[0] ? dbar[lb.b[0].x] : 1.0, dj = lb.on[0] ? dbar[lb.b[0].y] : 1.0;
-    const double dLi = onL ? dbar[bL.x] : 1.0, dLj = onL ? dbar[bL.y] : 1.0;
+    const double di = lb.on[0] ? dbar[lb.s0.x] : 1.0, dj = lb.on[0] ? dbar[lb.s0.y] : 1.0;
+    const double dLi = onL ? dbar[lb.sL.x] : 1.0, dLj = onL ? dbar[lb.sL.y] : 1.0;
     double2 vi = make_double2(0, 0), vj = vi;
-    if (onL) { vi = v[bL.x]; vj = v[bL.y]; }
+    if (onL) { vi = v[lb.sL.x]; vj = v[lb.sL.y]; }
     const double2 vi0 = vi, vj0 = vj;
     // expansion coefficients go to LDS once: no global load (and no vmcnt wait) inside the chain
     double2 *CF = W + N, *CF2 = CF + k.maxorder;
@@ -368,11 +373,11 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
     if (onL) {
         vi = make_double2(k.scale * vi.x, k.scale * vi.y);
         vj = make_double2(k.scale * vj.x, k.scale * vj.y);
-        v[bL.x] = vi;
+        v[lb.sL.x] = vi;
         acc.x += vi0.x * vi.x + vi0.y * vi.y;
         acc.y += vi0.x * vi.y - vi0.y * vi.x;
         if (bL.y != bL.x) {
-            v[bL.y] = vj;
+            v[lb.sL.y] = vj;
             acc.x += vj0.x * vj.x + vj0.y * vj.y;
             acc.y += vj0.x * vj.y - vj0.y * vj.x;
         }
@@ -505,11 +510,6 @@ __global__ void __launch_bounds__(kThreads) cheb_generic_kernel(KpmArgs k)
 
 void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
 {
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute((const void *)cheb_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        configured = true;
-    }
     if (kg.fast) {
         const size_t lds = sizeof(double2) * ((size_t)k.N + 2 * (size_t)k.maxorder);
         if (k.is_sym) hipLaunchKernelGGL((cheb_fast_kernel<true>), dim3((unsigned)(k.Lt * k.nsys)), dim3(kg.threads), lds, st, k, kg);
@@ -540,13 +540,14 @@ __global__ void __launch_bounds__(1024) lanczos_kernel(KpmArgs k, KpmGeom kg, in
     double acc = 0;
     for (int i = threadIdx.x; i < N; i += blockDim.x) acc += randvec[i] * randvec[i];
     const double nrm = sqrt(block_sum_real(acc, red));
-    for (int i = threadIdx.x; i < N; i += blockDim.x) { VK[i] = make_double2(randvec[i] / nrm, 0.0); VKM[i] = make_double2(0.0, 0.0); }
+    // the fast path works in LDS-position order (a permutation: dot products are unaffected)
+    for (int i = threadIdx.x; i < N; i += blockDim.x) { VK[FAST ? kg.pos[i] : i] = make_double2(randvec[i] / nrm, 0.0); VKM[i] = make_double2(0.0, 0.0); }
     __syncthreads();
     double bprev = 0.0;
     for (int s = 0; s < nsteps; ++s) {
         for (int i = threadIdx.x; i < N; i += blockDim.x) W[i] = VK[i];
         __syncthreads();
-        if (FAST) bbar_apply_regs<MODE>(W, lb, k.ncol, N, dbar);
+        if (FAST) bbar_apply_regs<MODE>(W, lb, k.ncol, N, dbar, kg.pos);
         else bbar_apply<MODE>(W, N, k.ncol, k.bonds, k.col_off, dbar, cbar, sbar);
         acc = 0;
         for (int i = threadIdx.x; i < N; i += blockDim.x) acc += VK[i].x * W[i].x;
@@ -571,14 +572,16 @@ __global__ void __launch_bounds__(1024) lanczos_kernel(KpmArgs k, KpmGeom kg, in
     }
 }
 
+// raise the dynamic-LDS limit of the generic kernels once, outside any stream capture
+void configure_kpm_kernels()
+{
+    (void)hipFuncSetAttribute((const void *)cheb_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute((const void *)lanczos_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute((const void *)lanczos_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+}
+
 void launch_lanczos(hipStream_t st, const KpmArgs &k, const KpmGeom &kg, int w0, int nw, const double *randvec, int nsteps, double *alpha, double *beta, bool use_BtB)
 {
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute((const void *)lanczos_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        (void)hipFuncSetAttribute((const void *)lanczos_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        configured = true;
-    }
     const size_t lds = sizeof(double2) * 3 * (size_t)k.N;
     const int threads = kg.fast ? kg.threads : kThreads;
     if (kg.fast) {

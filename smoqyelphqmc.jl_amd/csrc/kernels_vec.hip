@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(kThreads) cg_update_p_kernel(CgArgs a)
     if (a.st[sys].done) return;
     const double rr = reduce_partials(a.part_rr + (size_t)sys * a.nchunk, a.nchunk, red);
     const double eps = sqrt(rr) / sqrt(a.st[sys].normb2);
-    const bool conv = eps < a.tol;
+    const bool conv = eps < a.st[sys].tol;
     if (!conv) {
         const double2 rz = a.use_precond ? reduce_partials(a.part_rz + (size_t)sys * a.rz_stride, a.nrz, red) : make_double2(rr, 0.0);
         const double2 beta = cdiv(rz, make_double2(a.st[sys].rho_re, a.st[sys].rho_im));
@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(kThreads) cg_update_p_kernel(CgArgs a)
             s.eps = eps;
             s.iters += 1;
             if (conv) s.done = 1;
-            else if (s.iters >= a.maxiter) s.done = 2;
+            else if (s.iters >= s.maxiter) s.done = 2;
         }
     }
 }

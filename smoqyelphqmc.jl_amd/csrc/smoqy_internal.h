@@ -37,7 +37,8 @@ struct CgState {
     int iters;          // completed iterations
     int done;           // 0 running, 1 converged, 2 maxiter reached
     int precond_on;     // this system's walker has an active preconditioner
-    int pad;
+    int maxiter;        // stop criteria live here (not in kernel arguments) so a captured iteration can be replayed
+    double tol;
 };
 
 struct FdmArgs {
@@ -74,7 +75,10 @@ struct KpmArgs {
 // geometry of the KPM fast path: per-colour bond lists padded with identity self bonds (i, i) so
 // that every colour covers all N sites; lane t of a workgroup owns padded bond poff[c] + t
 struct KpmGeom {
-    const int2 *pbonds;  // [ptotal]
+    const int2 *pbonds;  // [ptotal] LDS positions of the two sites of each padded bond
+    const int2 *psites;  // [ptotal] the site ids themselves (global-memory addressing)
+    const int *pos;      // [N] site -> LDS position: first-colour x sites, then its y sites, so that on a
+                         // bipartite lattice the lanes of a wavefront touch consecutive 16-byte slots (no bank conflicts)
     const int *poff;     // [ncol + 1] (device)
     const int *psrc;     // [ptotal] source bond index, -1 for a self bond
     double2 *pcs;        // [nw][ptotal] tau-averaged (cosh, sinh) per padded bond
@@ -85,9 +89,12 @@ struct KpmGeom {
 
 // geometry + packed hopping table of the register-resident FermionDetMatrix kernels
 struct FdmFast {
-    const int2 *pbonds;  // padded bond lists (shared with KpmGeom)
+    const int2 *pbonds;  // padded bond lists as LDS positions (shared with KpmGeom)
+    const int2 *psites;  // the same as site ids
+    const int *pos;      // [N] site -> LDS position
     const int *poff;     // [ncol + 1] (device)
     const double2 *csf;  // [nw][Lt][ptotal] (cosh, sinh) per padded bond, (1, 0) on self bonds
+    const int *cs_varies; // [nw] 0 when a walker's hoppings are the same on every time slice
     int ptotal;
     int threads;
     int enabled;
@@ -96,9 +103,11 @@ struct FdmFast {
 // ---- launchers (defined in the .hip files) -----------------------------------------------
 void launch_fdm(hipStream_t st, int op, bool sym, const FdmArgs &a, size_t lds_bytes);
 size_t fdm_lds_bytes(int op, int N, int Tc);
+void configure_fdm_kernels();
+void configure_kpm_kernels();
 bool fdm_fast_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
 void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff);
-void launch_pack_csf(hipStream_t st, const double *ch, const double *sh, const int *psrc, double2 *csf, int Lt, int Nh, int ptotal);
+void launch_pack_csf(hipStream_t st, const double *ch, const double *sh, const int *psrc, double2 *csf, int *cs_varies, int Lt, int Lt1, int Nh, int ptotal);
 
 void launch_transpose_in(hipStream_t st, const double2 *host_layout, double2 *dev_layout, int Lt, int N, int nsys, int sys0, int count);
 void launch_transpose_out(hipStream_t st, const double2 *dev_layout, double2 *host_layout, int Lt, int N, int nsys, int sys0, int count);

@@ -246,8 +246,10 @@ def test_kpm_preconditioner_state_and_apply(kind, is_sym, generic):
 
 
 @pytest.mark.parametrize("is_sym", [True, False])
-def test_cg_preconditioned(is_sym):
+@pytest.mark.parametrize("graph", [False, True])
+def test_cg_preconditioned(is_sym, graph):
     p = Problem("honeycomb_L4", is_sym, nwalkers=2, nrhs=2)
+    p.h.call("smoqy_cg_use_graph", int(graph))  # hipGraph replay of the captured iteration must not change anything
     b = p.rand(4, 10)
     Ps = []
     for w in range(2):
