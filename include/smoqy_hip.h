@@ -27,6 +27,7 @@
 #ifndef SMOQY_HIP_H
 #define SMOQY_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -57,6 +58,9 @@ const char *smoqy_last_error(const smoqy_ctx *ctx);
 /* adopt a caller-owned hipStream_t (pass NULL to return to the handle's own stream) */
 int smoqy_set_stream(smoqy_ctx *ctx, void *hip_stream);
 int smoqy_sync(smoqy_ctx *ctx);
+/* optional: page-locked host memory for arrays that are handed to the library repeatedly */
+int smoqy_host_alloc(smoqy_ctx *ctx, void **ptr, size_t bytes);
+int smoqy_host_free(smoqy_ctx *ctx, void *ptr);
 /* size(fdm) (src/FermionDetMatrix.jl:243): dims = {Ltau, N, Nh, ncolors, nwalkers, nrhs} */
 int smoqy_dims(const smoqy_ctx *ctx, int dims[6]);
 

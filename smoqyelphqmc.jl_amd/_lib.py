@@ -49,6 +49,8 @@ SIGNATURES = {
     "smoqy_destroy": [_p],
     "smoqy_set_stream": [_p, _p],
     "smoqy_sync": [_p],
+    "smoqy_host_alloc": [_p, C.POINTER(_p), C.c_size_t],
+    "smoqy_host_free": [_p, _p],
     "smoqy_dims": [_p, _pi],
     "smoqy_set_tau_chunk": [_p, _i],
     "smoqy_get_tau_chunk": [_p, _pi],
@@ -162,6 +164,9 @@ class Handle:
 
     def close(self):
         if getattr(self, "_h", None):
+            for p in getattr(self, "_pinned", []):
+                self.lib.smoqy_host_free(self._h, p)
+            self._pinned = []
             self.lib.smoqy_destroy(self._h)
             self._h = None
 
@@ -177,6 +182,17 @@ class Handle:
             raise SmoqyError(f"{name} failed ({rc}): " + (self.lib.smoqy_last_error(self._h) or b"").decode())
 
     # ---- small conveniences -------------------------------------------------------------------
+    def pinned_empty(self, shape, dtype=np.float64, order="C"):
+        """numpy array backed by page-locked host memory owned by this handle (freed on close)."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape))
+        p = _p()
+        self.call("smoqy_host_alloc", C.byref(p), max(n * dt.itemsize, 8))
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        buf = (C.c_char * (n * dt.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dt, count=n).reshape(shape, order=order)
+
     def vec_alloc(self) -> int:
         i = C.c_int(-1)
         self.call("smoqy_vec_alloc", C.byref(i))

@@ -446,6 +446,23 @@ int smoqy_set_stream(smoqy_ctx *c, void *s)
     return 0;
 }
 
+// page-locked host memory for arrays that cross the boundary repeatedly (fields, phonon positions):
+// transfers from it run at full PCIe rate
+int smoqy_host_alloc(smoqy_ctx *c, void **ptr, size_t bytes)
+{
+    CHECK_CTX(c);
+    HIPCHK(c, hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    return 0;
+}
+
+int smoqy_host_free(smoqy_ctx *c, void *ptr)
+{
+    CHECK_CTX(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipHostFree(ptr));
+    return 0;
+}
+
 int smoqy_sync(smoqy_ctx *c)
 {
     CHECK_CTX(c);
@@ -872,10 +889,10 @@ static void tridiag_extremes(const double *a, const double *b, int n, double &em
         hi = std::max(hi, a[i] + r);
     }
     double l = lo, h = hi;
-    for (int it = 0; it < 200; ++it) { const double m = 0.5 * (l + h); if (sturm(a, b, n, m) >= 1) h = m; else l = m; }
+    for (int it = 0; it < 64; ++it) { const double m = 0.5 * (l + h); if (sturm(a, b, n, m) >= 1) h = m; else l = m; }
     emin = 0.5 * (l + h);
     l = lo; h = hi;
-    for (int it = 0; it < 200; ++it) { const double m = 0.5 * (l + h); if (sturm(a, b, n, m) >= n) h = m; else l = m; }
+    for (int it = 0; it < 64; ++it) { const double m = 0.5 * (l + h); if (sturm(a, b, n, m) >= n) h = m; else l = m; }
     emax = 0.5 * (l + h);
 }
 
@@ -973,7 +990,8 @@ static int precond_update_range(smoqy_ctx *c, int w0, int nw, const double *rand
     HIPCHK(c, hipMemcpyAsync(c->d_rand, randvecs, (size_t)nw * g.N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     KpmArgs k = kpm_args(c, nullptr, nullptr);
     launch_lanczos(c->stream, k, c->kg, w0, nw, c->d_rand, n, c->d_lan, c->d_lan + (size_t)g.nw * 1024, !g.is_sym);
-    HIPCHK(c, hipMemcpyAsync(c->h_lan, c->d_lan, (size_t)g.nw * 2 * 1024 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(c->h_lan, 1024 * sizeof(double), c->d_lan, 1024 * sizeof(double), (size_t)n * sizeof(double), (size_t)nw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(c->h_lan + (size_t)g.nw * 1024, 1024 * sizeof(double), c->d_lan + (size_t)g.nw * 1024, 1024 * sizeof(double), (size_t)n * sizeof(double), (size_t)nw, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (int rc = check_launch(c, "precond_update")) return rc;
     for (int j = 0; j < nw; ++j) {

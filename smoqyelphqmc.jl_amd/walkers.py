@@ -55,16 +55,16 @@ class WalkerBatch:
         self.tol, self.tol_force, self.maxiter, self.Nt, self.drift = tol, float(np.sqrt(tol)), maxiter, Nt, drift  # tutorials/holstein_honeycomb.jl:591
         # stacked host storage: walker w's (Nph x Ltau) / (N x Ltau) / (Nh x Ltau) column-major arrays
         # are the transposed views xs[w].T etc., so the whole batch crosses the C ABI in one call
-        self.xs = np.empty((nwalkers, self.Lt, self.Nph))
-        self.Vs = np.empty((nwalkers, self.Lt, self.N))
-        self.ts = np.empty((nwalkers, self.Lt, self.Nh))
+        self.h = L.Handle(self.Lt, self.N, self.nt, self.colors, is_sym, nwalkers, 1, device)
+        self.xs = self.h.pinned_empty((nwalkers, self.Lt, self.Nph))   # page-locked: crosses the boundary on every field move
+        self.Vs = self.h.pinned_empty((nwalkers, self.Lt, self.N))
+        self.ts = self.h.pinned_empty((nwalkers, self.Lt, self.Nh))
         for w, m in enumerate(self.models):
             self.xs[w] = m.elph.x.T
             self.Vs[w] = m.fpi.V.T
             self.ts[w] = m.fpi.t.T
             m.elph.x, m.fpi.V, m.fpi.t = self.xs[w].T, self.Vs[w].T, self.ts[w].T
         self.hoppings_move = m0.kind != "holstein"  # Holstein: t is constant, only V follows the phonons
-        self.h = L.Handle(self.Lt, self.N, self.nt, self.colors, is_sym, nwalkers, 1, device)
         if check_every:
             self.h.call("smoqy_cg_config", int(check_every))
         if tau_chunk:
@@ -73,7 +73,7 @@ class WalkerBatch:
         self.pool = ThreadPoolExecutor(max_workers=max(1, min(host_threads, nwalkers)))
         # device-resident PFFCalculator state (src/PFFCalculator.jl:9-16): Φ, u, u′, u″
         self.phi, self.u, self.u1, self.u2 = (self.h.vec_alloc() for _ in range(4))
-        self._R = np.empty((self.Lt, self.N, nwalkers), dtype=np.complex128, order="F")
+        self._R = self.h.pinned_empty((self.Lt, self.N, nwalkers), dtype=np.complex128, order="F")
         self.stats = SweepStats()
         self.refresh_fields(first=True)
 
