@@ -124,6 +124,9 @@ int smoqy_lambda_apply(smoqy_ctx *ctx, int op, void *out, const void *in, const 
 
 int smoqy_fft_forward_v(smoqy_ctx *ctx, int id); /* lmul!(U, v): tau -> omega, unitary, antiperiodic */
 int smoqy_fft_inverse_v(smoqy_ctx *ctx, int id); /* ldiv!(U, v) */
+/* testing aid: 1 = use the rocFFT plans instead of the library's own fused tau-FFT kernels (which
+ * are the default whenever Ltau factors into 2, 3, 5, 7) */
+int smoqy_fft_use_rocfft(smoqy_ctx *ctx, int on);
 int smoqy_fft_forward(smoqy_ctx *ctx, void *inout, int sys0, int count);
 int smoqy_fft_inverse(smoqy_ctx *ctx, void *inout, int sys0, int count);
 

@@ -73,6 +73,7 @@ SIGNATURES = {
     "smoqy_lambda_get": [_p, _i, _p],
     "smoqy_lambda_apply_v": [_p, _i, _i, _i],
     "smoqy_lambda_apply": [_p, _i, _p, _p, _p, _i, _i],
+    "smoqy_fft_use_rocfft": [_p, _i],
     "smoqy_fft_forward_v": [_p, _i],
     "smoqy_fft_inverse_v": [_p, _i],
     "smoqy_fft_forward": [_p, _p, _i, _i],

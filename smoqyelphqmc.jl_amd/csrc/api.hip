@@ -70,6 +70,10 @@ struct smoqy_ctx {
     void *fft_work = nullptr;
     double2 *d_tw = nullptr;  // theta_l / sqrt(Lt)  (unitary FourierTransformer)
     double2 *d_th = nullptr;  // theta_l
+    double2 *d_wtab = nullptr;  // exp(-2 pi i q / Lt)
+    TfftArgs tf{};            // plan of the own tau-FFT
+    int tf_ok = 0, use_tfft = 1;
+    int pstride = 0;          // per-system stride of the partial-sum arrays
     // kpm
     double rbuf = 0.10, a1 = 1.0, a2 = 1.0;
     int nlanczos = 20;
@@ -214,7 +218,7 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->plan_f_oop) rocfft_plan_destroy(c->plan_f_oop);
     if (c->fft_info) rocfft_execution_info_destroy(c->fft_info);
     void *ptrs[] = {c->d_bonds, c->d_col_off, c->d_expV, c->d_ch, c->d_sh, c->d_lam, c->d_stage, c->d_stage_real, c->d_stage_int, c->scr[0], c->scr[1], c->scr[2], c->cg_r, c->cg_p,
-                    c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->fft_work, c->d_tw, c->d_th, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
+                    c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->fft_work, c->d_tw, c->d_th, c->d_wtab, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
                     c->d_rand, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -237,7 +241,7 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) FAIL(c, 4, "this library is built for gfx950 (MI355X) only; device %d is %s", c->device, prop.gcnArchName);
     static std::once_flag cfg_once;
-    std::call_once(cfg_once, [] { configure_fdm_kernels(); configure_kpm_kernels(); });
+    std::call_once(cfg_once, [] { configure_fdm_kernels(); configure_kpm_kernels(); configure_tfft_kernels(); });
     HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIPCHK(c, hipEventCreate(&c->ev0));
@@ -285,7 +289,8 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     for (auto &s : c->scr) { HIPCHK(c, hipMalloc(&s, ve * sizeof(double2))); HIPCHK(c, hipMemset(s, 0, ve * sizeof(double2))); }
     double2 **cgv[] = {&c->cg_r, &c->cg_p, &c->cg_z, &c->cg_v};
     for (auto p : cgv) { HIPCHK(c, hipMalloc(p, ve * sizeof(double2))); HIPCHK(c, hipMemset(*p, 0, ve * sizeof(double2))); }
-    const size_t np = (size_t)g.nsys * g.Lt;  // nchunk <= Lt
+    c->pstride = std::max(g.Lt, (g.N + 3) / 4);  // room for Lt (per-frequency), nchunk and per-site-tile partials
+    const size_t np = (size_t)g.nsys * c->pstride;
     HIPCHK(c, hipMalloc(&c->part_pz, np * sizeof(double2)));
     HIPCHK(c, hipMalloc(&c->part_rz, np * sizeof(double2)));
     HIPCHK(c, hipMalloc(&c->part_c, np * sizeof(double2)));
@@ -326,6 +331,16 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
             FFTCHK(c, rocfft_execution_info_set_work_buffer(c->fft_info, c->fft_work, wsz));
         }
         FFTCHK(c, rocfft_execution_info_set_stream(c->fft_info, c->stream));
+    }
+
+    {   // own tau-FFT (kernels_tfft.hip) when Lt factors into 2, 3, 5, 7
+        c->tf_ok = tfft_plan(g.Lt, g.N, c->tf) ? 1 : 0;
+        c->tf.nsys = g.nsys;
+        std::vector<double2> wt((size_t)g.Lt);
+        for (int q = 0; q < g.Lt; ++q) wt[q] = make_double2(std::cos(2.0 * M_PI * q / g.Lt), -std::sin(2.0 * M_PI * q / g.Lt));
+        HIPCHK(c, hipMalloc(&c->d_wtab, wt.size() * sizeof(double2)));
+        HIPCHK(c, hipMemcpy(c->d_wtab, wt.data(), wt.size() * sizeof(double2), hipMemcpyHostToDevice));
+        c->tf.wtab = c->d_wtab;
     }
 
     // KPM preconditioner state
@@ -819,6 +834,14 @@ int smoqy_lambda_apply(smoqy_ctx *c, int op, void *out, const void *in, const do
 static int fft_dev(smoqy_ctx *c, double2 *v, bool inverse)
 {
     const Geometry &g = c->g;
+    if (c->tf_ok && c->use_tfft) {  // twiddle fused into the transform's load / store
+        TfftArgs t = c->tf;
+        t.src = v; t.dst = v;
+        t.pre_tw = inverse ? nullptr : c->d_tw;   // FourierTransformer.jl:46-47
+        t.post_tw = inverse ? c->d_tw : nullptr;  // :60-61 (1/Lτ of the inverse = the two 1/√Lτ factors)
+        launch_tfft(c->stream, inverse ? 1 : 0, t);
+        return check_launch(c, "fft");
+    }
     void *buf[1] = {v};
     if (!inverse) {
         launch_fft_twiddle(c->stream, v, c->d_tw, g.Lt, g.N, g.nsys, 0);  // FourierTransformer.jl:46
@@ -828,6 +851,13 @@ static int fft_dev(smoqy_ctx *c, double2 *v, bool inverse)
         launch_fft_twiddle(c->stream, v, c->d_tw, g.Lt, g.N, g.nsys, 1);  // :61 with the 1/Lτ folded in
     }
     return check_launch(c, "fft");
+}
+
+int smoqy_fft_use_rocfft(smoqy_ctx *c, int on)
+{
+    CHECK_CTX(c);
+    c->use_tfft = on ? 0 : 1;
+    return 0;
 }
 
 int smoqy_fft_forward_v(smoqy_ctx *c, int id)
@@ -1112,13 +1142,22 @@ int smoqy_precond_set(smoqy_ctx *c, int w, int active, const double *bounds, con
 // Parseval partials of src·v per (system, ω).
 static int precond_core(smoqy_ctx *c, const double2 *src, double2 *v, const CgState *cg, double2 *part_rz)
 {
+    const bool own = c->tf_ok && c->use_tfft;
     void *in[1] = {(void *)src}, *out[1] = {v};
-    if (src == v) FFTCHK(c, rocfft_execute(c->plan_f, out, nullptr, c->fft_info));      // KPMPreconditioner.jl:375
+    if (own) {
+        TfftArgs t = c->tf;
+        t.src = src; t.dst = v; t.pre_tw = nullptr; t.post_tw = nullptr;
+        launch_tfft(c->stream, 0, t);                                                   // KPMPreconditioner.jl:375
+    } else if (src == v) FFTCHK(c, rocfft_execute(c->plan_f, out, nullptr, c->fft_info));
     else FFTCHK(c, rocfft_execute(c->plan_f_oop, in, out, c->fft_info));
     KpmArgs k = kpm_args(c, v, cg);
     k.part_rz = part_rz;
     launch_cheb(c->stream, k, c->kg);                                                   // :381-400 (no transposes needed in this layout)
-    FFTCHK(c, rocfft_execute(c->plan_b, out, nullptr, c->fft_info));                    // :406
+    if (own) {
+        TfftArgs t = c->tf;
+        t.src = v; t.dst = v; t.pre_tw = nullptr; t.post_tw = nullptr;
+        launch_tfft(c->stream, 1, t);                                                   // :406
+    } else FFTCHK(c, rocfft_execute(c->plan_b, out, nullptr, c->fft_info));
     return check_launch(c, "precond_core");
 }
 
@@ -1174,6 +1213,22 @@ int smoqy_cg_config(smoqy_ctx *c, int check_every)
 static int cg_iteration(smoqy_ctx *c, const CgArgs &a, bool any_pre)
 {
     if (int rc = matvec_dev(c, SMOQY_OP_MTM, c->cg_z, c->cg_p, c->part_pz, c->d_st, 0, c->g.nsys, true)) return rc;  // z = A p, partial p·Ap (:219)
+    if (any_pre && c->tf_ok && c->use_tfft) {
+        // four launches per iteration: the tau-FFT kernels absorb the BLAS-1 updates (kernels_tfft.hip)
+        TfftArgs t = c->tf;
+        t.x = a.x; t.r = a.r; t.p = a.p; t.z = a.z; t.dst = a.v;
+        t.part_rz = a.part_rz; t.nrz = a.nrz; t.rz_stride = a.rz_stride;
+        t.part_pz = a.part_pz; t.npz = a.nchunk; t.pz_stride = a.nchunk;
+        t.part_rr = a.part_rr; t.nrr = t.ntile; t.rr_stride = c->pstride;
+        t.st = a.st;
+        launch_tfft(c->stream, 2, t);                      // :220-226 + FFT of the new residual (v̂ lands in v)
+        KpmArgs k = kpm_args(c, c->cg_v, c->d_st);
+        k.part_rz = c->part_rz;
+        launch_cheb(c->stream, k, c->kg);                  // :237 in frequency space, partial r·z by Parseval
+        t.src = a.v;
+        launch_tfft(c->stream, 3, t);                      // inverse FFT + :229-245
+        return check_launch(c, "cg iteration");
+    }
     launch_cg_update_xr(c->stream, a);                                                                             // :220-226
     if (any_pre) if (int rc = precond_core(c, c->cg_r, c->cg_v, c->d_st, c->part_rz)) return rc;                 // z = P⁻¹ r, partial r·z (:237-240)
     launch_cg_update_p(c->stream, a);                                                                              // :229-245

@@ -1,0 +1,325 @@
+// Imaginary-time FFT for the slice-major device layout, fused with the CG vector updates (gfx950).
+//
+// Reference: FourierTransformer (src/FourierTransformer.jl:39-64) inside the KPM preconditioner
+// (src/KPMPreconditioner.jl:375, 406) and the BLAS-1 lines of cg_solve!
+// (src/IterativeSolvers/ConjugateGradient.jl:219-245).
+//
+// Layout v[l][s][i]: a workgroup owns a tile of SB consecutive sites of one system for ALL Lτ
+// slices (SB·16 = 128/256 contiguous bytes per slice), keeps it in LDS and runs a Stockham
+// auto-sort FFT over τ with radix 2/3/4/5/7/8 passes (ping-pong between two LDS images; lanes run
+// over (butterfly, site) with the site index fastest, so every LDS access is a run of whole
+// 256-byte bank rows — conflict free).  Because a tile holds every τ of its sites, everything that
+// is elementwise around the transform is fused into the same pass over memory:
+//
+//   forward  (MODE_FWD_CG):  α = (r·z)/(p·Ap);  x += α p;  r -= α Ap;  partial |r|²;  v̂ = FFT r
+//                            (replaces cg_update_xr + the rocFFT forward transform)
+//   inverse  (MODE_INV_CG):  stop test on |r|/|b|;  β = (r·z)new/(r·z)old;  p = FFT⁻¹ v̂ + β p
+//                            (replaces the rocFFT inverse transform + cg_update_p; z is never stored)
+//
+// The CG runs in the twiddled basis (kernels_vec.hip), so no θ factors appear here; the plain
+// modes take optional pre/post twiddle tables for the stand-alone FourierTransformer API.
+// Lengths with a prime factor above 7 stay on rocFFT.
+#include "smoqy_internal.h"
+
+namespace smoqy {
+
+namespace {
+
+__device__ __forceinline__ double2 cm(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+// multiply by -i (forward) or +i (inverse)
+__device__ __forceinline__ double2 mul_mi(double2 a, bool inv) { return inv ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x); }
+
+template <int R>
+__device__ __forceinline__ void dft(double2 (&v)[R], const double2 *__restrict__ wt, int Lt, bool inv)
+{
+    double2 o[R];
+    const int step = Lt / R;
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+        double2 acc = v[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+            double2 w = wt[((r * s) % R) * step];
+            if (inv) w.y = -w.y;
+            acc = cadd(acc, cm(v[r], w));
+        }
+        o[s] = acc;
+    }
+#pragma unroll
+    for (int s = 0; s < R; ++s) v[s] = o[s];
+}
+
+template <>
+__device__ __forceinline__ void dft<2>(double2 (&v)[2], const double2 *__restrict__, int, bool)
+{
+    const double2 a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+}
+
+template <>
+__device__ __forceinline__ void dft<4>(double2 (&v)[4], const double2 *__restrict__, int, bool inv)
+{
+    const double2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]), c = cadd(v[1], v[3]), d = mul_mi(csub(v[1], v[3]), inv);
+    v[0] = cadd(a, c);
+    v[1] = cadd(b, d);
+    v[2] = csub(a, c);
+    v[3] = csub(b, d);
+}
+
+template <>
+__device__ __forceinline__ void dft<8>(double2 (&v)[8], const double2 *__restrict__, int, bool inv)
+{
+    // two radix-4 transforms on the even / odd inputs, then one radix-2 stage with the 8th roots
+    double2 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+    dft<4>(e, nullptr, 0, inv);
+    dft<4>(o, nullptr, 0, inv);
+    const double h = 0.70710678118654752440;
+    // w8^1 = (1 -/+ i)/√2, w8^2 = -/+ i, w8^3 = (-1 -/+ i)/√2   (forward / inverse)
+    const double2 t1 = inv ? make_double2(h * (o[1].x - o[1].y), h * (o[1].x + o[1].y)) : make_double2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));
+    const double2 t2 = mul_mi(o[2], inv);
+    const double2 t3 = inv ? make_double2(-h * (o[3].x + o[3].y), h * (o[3].x - o[3].y)) : make_double2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));
+    v[0] = cadd(e[0], o[0]); v[4] = csub(e[0], o[0]);
+    v[1] = cadd(e[1], t1);   v[5] = csub(e[1], t1);
+    v[2] = cadd(e[2], t2);   v[6] = csub(e[2], t2);
+    v[3] = cadd(e[3], t3);   v[7] = csub(e[3], t3);
+}
+
+// one Stockham pass of radix R: in/out are LDS images [Lt][SB]
+template <int R>
+__device__ __forceinline__ void stockham_pass(const double2 *__restrict__ in, double2 *__restrict__ out, const double2 *__restrict__ wt, int Lt, int SB, int Ns, bool inv)
+{
+    const int stride = Lt / R, nb = stride * SB, tw_step = Lt / (Ns * R);
+    for (int idx = threadIdx.x; idx < nb; idx += blockDim.x) {
+        const int j = idx / SB, sb = idx - j * SB;
+        const int k = j % Ns;
+        double2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double2 x = in[(size_t)(j + r * stride) * SB + sb];
+            if (r > 0 && k > 0) {
+                double2 w = wt[r * k * tw_step];
+                if (inv) w.y = -w.y;
+                x = cm(x, w);
+            }
+            v[r] = x;
+        }
+        dft<R>(v, wt, Lt, inv);
+        const int j0 = (j / Ns) * Ns * R + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) out[(size_t)(j0 + r * Ns) * SB + sb] = v[r];
+    }
+    __syncthreads();
+}
+
+// runs all passes; returns the buffer that holds the result
+__device__ __forceinline__ double2 *stockham(double2 *A, double2 *B, const double2 *wt, const TfftArgs &a, bool inv)
+{
+    int Ns = 1;
+    double2 *src = A, *dst = B;
+    for (int f = 0; f < a.nfac; ++f) {
+        const int R = a.fac[f];
+        switch (R) {
+            case 2: stockham_pass<2>(src, dst, wt, a.Lt, a.SB, Ns, inv); break;
+            case 3: stockham_pass<3>(src, dst, wt, a.Lt, a.SB, Ns, inv); break;
+            case 4: stockham_pass<4>(src, dst, wt, a.Lt, a.SB, Ns, inv); break;
+            case 5: stockham_pass<5>(src, dst, wt, a.Lt, a.SB, Ns, inv); break;
+            case 7: stockham_pass<7>(src, dst, wt, a.Lt, a.SB, Ns, inv); break;
+            default: stockham_pass<8>(src, dst, wt, a.Lt, a.SB, Ns, inv); break;
+        }
+        Ns *= R;
+        double2 *t = src; src = dst; dst = t;
+    }
+    return src;
+}
+
+__device__ __forceinline__ double wsum_t(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// workgroup sum of a (re, im) pair broadcast to all threads; red >= 18 doubles
+__device__ __forceinline__ double2 bsum(double2 v, double *red)
+{
+    v.x = wsum_t(v.x);
+    v.y = wsum_t(v.y);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) { red[2 * wave] = v.x; red[2 * wave + 1] = v.y; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double2 t = make_double2(0.0, 0.0);
+        for (int w = 0; w < nwave; ++w) { t.x += red[2 * w]; t.y += red[2 * w + 1]; }
+        red[16] = t.x;
+        red[17] = t.y;
+    }
+    __syncthreads();
+    return make_double2(red[16], red[17]);
+}
+
+__device__ __forceinline__ double2 reduce_c(const double2 *part, int n, double *red)
+{
+    double2 t = make_double2(0.0, 0.0);
+    for (int c = threadIdx.x; c < n; c += blockDim.x) { t.x += part[c].x; t.y += part[c].y; }
+    return bsum(t, red);
+}
+
+__device__ __forceinline__ double reduce_r(const double *part, int n, double *red)
+{
+    double2 t = make_double2(0.0, 0.0);
+    for (int c = threadIdx.x; c < n; c += blockDim.x) t.x += part[c];
+    return bsum(t, red).x;
+}
+
+__device__ __forceinline__ double2 cdivt(double2 a, double2 b)
+{
+    const double d = b.x * b.x + b.y * b.y;
+    return make_double2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
+}
+
+enum { MODE_PLAIN_FWD = 0, MODE_PLAIN_INV = 1, MODE_FWD_CG = 2, MODE_INV_CG = 3 };
+
+template <int MODE>
+__global__ void __launch_bounds__(256) tfft_kernel(TfftArgs a)
+{
+    extern __shared__ double2 lds[];
+    __shared__ double red[18];
+    const int Lt = a.Lt, SB = a.SB, N = a.N;
+    double2 *A = lds, *B = A + (size_t)Lt * SB, *WT = B + (size_t)Lt * SB;
+    const int tile = blockIdx.x % a.ntile, sys = blockIdx.x / a.ntile;
+    constexpr bool CG = (MODE == MODE_FWD_CG || MODE == MODE_INV_CG);
+    if (CG && a.st[sys].done) return;
+    const int i0 = tile * SB, ns = min(SB, N - i0);
+    const size_t sstride = (size_t)a.nsys * N;
+    const size_t base = (size_t)sys * N + i0;
+    for (int q = threadIdx.x; q < Lt; q += blockDim.x) WT[q] = a.wtab[q];
+    constexpr bool INV = (MODE == MODE_PLAIN_INV || MODE == MODE_INV_CG);
+
+    if (MODE == MODE_FWD_CG) {
+        // ConjugateGradient.jl:219-226 on this tile, then the forward transform of the new residual
+        const double2 rz = reduce_c(a.part_rz + (size_t)sys * a.rz_stride, a.nrz, red);
+        const double2 pz = reduce_c(a.part_pz + (size_t)sys * a.pz_stride, a.npz, red);
+        const double2 alpha = cdivt(rz, pz);
+        double acc = 0.0;
+        for (int idx = threadIdx.x; idx < Lt * SB; idx += blockDim.x) {
+            const int l = idx / SB, sb = idx - l * SB;
+            double2 rv = make_double2(0.0, 0.0);
+            if (sb < ns) {
+                const size_t off = (size_t)l * sstride + base + sb;
+                const double2 pv = a.p[off], zv = a.z[off];
+                double2 xv = a.x[off];
+                rv = a.r[off];
+                const double2 ap = cm(alpha, pv), az = cm(alpha, zv);
+                xv = cadd(xv, ap);
+                rv = csub(rv, az);
+                a.x[off] = xv;
+                a.r[off] = rv;
+                acc += rv.x * rv.x + rv.y * rv.y;
+            }
+            A[idx] = rv;
+        }
+        const double2 t = bsum(make_double2(acc, 0.0), red);  // also the barrier that publishes A and WT
+        if (threadIdx.x == 0) {
+            a.part_rr[(size_t)sys * a.rr_stride + tile] = t.x;
+            if (tile == 0) { a.st[sys].rho_re = rz.x; a.st[sys].rho_im = rz.y; }
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < Lt * SB; idx += blockDim.x) {
+            const int l = idx / SB, sb = idx - l * SB;
+            double2 x = make_double2(0.0, 0.0);
+            if (sb < ns) {
+                x = a.src[(size_t)l * sstride + base + sb];
+                if (a.pre_tw) x = cm(x, a.pre_tw[l]);
+            }
+            A[idx] = x;
+        }
+        __syncthreads();
+    }
+
+    const double2 *res = stockham(A, B, WT, a, INV);
+
+    if (MODE == MODE_INV_CG) {
+        // ConjugateGradient.jl:229-245: stop test on the unpreconditioned residual, then p = z + β p
+        const double rr = reduce_r(a.part_rr + (size_t)sys * a.rr_stride, a.nrr, red);
+        const double eps = sqrt(rr) / sqrt(a.st[sys].normb2);
+        const bool conv = eps < a.st[sys].tol;
+        if (!conv) {
+            const double2 rz = reduce_c(a.part_rz + (size_t)sys * a.rz_stride, a.nrz, red);
+            const double2 beta = cdivt(rz, make_double2(a.st[sys].rho_re, a.st[sys].rho_im));
+            for (int idx = threadIdx.x; idx < Lt * SB; idx += blockDim.x) {
+                const int l = idx / SB, sb = idx - l * SB;
+                if (sb < ns) {
+                    const size_t off = (size_t)l * sstride + base + sb;
+                    const double2 bp = cm(beta, a.p[off]);
+                    a.p[off] = cadd(res[idx], bp);
+                }
+            }
+        }
+        if (threadIdx.x == 0 && tile == 0) {
+            CgState &s = a.st[sys];
+            s.eps = eps;
+            s.iters += 1;
+            if (conv) s.done = 1;
+            else if (s.iters >= s.maxiter) s.done = 2;
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < Lt * SB; idx += blockDim.x) {
+            const int l = idx / SB, sb = idx - l * SB;
+            if (sb < ns) {
+                double2 x = res[idx];
+                if (a.post_tw) { const double2 w = a.post_tw[l]; x = cm(x, make_double2(w.x, -w.y)); }
+                a.dst[(size_t)l * sstride + base + sb] = x;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool tfft_plan(int Lt, int N, TfftArgs &a)
+{
+    a.Lt = Lt; a.N = N; a.nfac = 0;
+    int m = Lt;
+    const int pref[] = {8, 4, 2, 5, 3, 7};
+    for (int R : pref)
+        while (m % R == 0 && a.nfac < 16) { a.fac[a.nfac++] = R; m /= R; }
+    if (m != 1) return false;
+    // fewer, larger passes: a trailing (8, 2) pair reads better as (4, 4)
+    for (int f = 0; f + 1 < a.nfac; ++f)
+        if (a.fac[f] == 8 && a.fac[f + 1] == 2) { a.fac[f] = 4; a.fac[f + 1] = 4; }
+    a.SB = 16;
+    while (a.SB > 4 && (2 * (size_t)Lt * a.SB + Lt) * sizeof(double2) > 64 * 1024) a.SB /= 2;
+    if ((2 * (size_t)Lt * a.SB + Lt) * sizeof(double2) > 150 * 1024) return false;
+    a.ntile = (N + a.SB - 1) / a.SB;
+    return true;
+}
+
+static void configure_tfft()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    (void)hipFuncSetAttribute((const void *)tfft_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    (void)hipFuncSetAttribute((const void *)tfft_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    (void)hipFuncSetAttribute((const void *)tfft_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    (void)hipFuncSetAttribute((const void *)tfft_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+}
+
+void configure_tfft_kernels() { configure_tfft(); }
+
+void launch_tfft(hipStream_t st, int mode, const TfftArgs &a)
+{
+    const size_t lds = (2 * (size_t)a.Lt * a.SB + a.Lt) * sizeof(double2);
+    const dim3 grid((unsigned)(a.ntile * a.nsys)), block(256);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((tfft_kernel<0>), grid, block, lds, st, a); break;
+        case 1: hipLaunchKernelGGL((tfft_kernel<1>), grid, block, lds, st, a); break;
+        case 2: hipLaunchKernelGGL((tfft_kernel<2>), grid, block, lds, st, a); break;
+        default: hipLaunchKernelGGL((tfft_kernel<3>), grid, block, lds, st, a); break;
+    }
+}
+
+}  // namespace smoqy

@@ -145,4 +145,25 @@ void launch_cg_update_xr(hipStream_t s, const CgArgs &a);
 void launch_cg_update_p(hipStream_t s, const CgArgs &a);
 void launch_cg_finish(hipStream_t s, const CgArgs &a);
 
+// own tau-FFT (kernels_tfft.hip): Stockham passes over LDS site tiles, optionally fused with the CG updates
+struct TfftArgs {
+    int Lt, N, nsys, SB, ntile, nfac;
+    int fac[16];
+    const double2 *wtab;                  // [Lt] exp(-2 pi i q / Lt)
+    // plain modes (0 forward, 1 inverse): dst = FFT(pre_tw * src) * conj(post_tw)
+    const double2 *src;
+    double2 *dst;
+    const double2 *pre_tw, *post_tw;
+    // CG modes (2: x/r update + forward, 3: inverse + stop test + p update)
+    double2 *x, *r, *p;
+    const double2 *z;
+    const double2 *part_rz, *part_pz;
+    double *part_rr;
+    int nrz, rz_stride, npz, pz_stride, nrr, rr_stride;
+    CgState *st;
+};
+bool tfft_plan(int Lt, int N, TfftArgs &a);
+void configure_tfft_kernels();
+void launch_tfft(hipStream_t st, int mode, const TfftArgs &a);
+
 }  // namespace smoqy

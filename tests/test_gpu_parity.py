@@ -160,9 +160,11 @@ def test_lambda_ops():
     assert relerr(out[:, :, 0], orc.lambda_apply(lams[0], v[:, :, 1], "ldivT")) < 1e-14
 
 
-@pytest.mark.parametrize("kind", ["honeycomb", "square", "chain", "honeycomb_L4"])
-def test_fourier_transformer(kind):
+@pytest.mark.parametrize("kind", ["honeycomb", "square", "chain", "honeycomb_L4", "square_L6", "chain_L24"])  # Ltau = 10, 7, 9, 40, 12, 16
+@pytest.mark.parametrize("rocfft", [False, True])
+def test_fourier_transformer(kind, rocfft):
     p = Problem(kind, True, nwalkers=1, nrhs=2)
+    p.h.call("smoqy_fft_use_rocfft", int(rocfft))  # own Stockham kernels vs the rocFFT plans
     v = p.rand(2, 6)
     ft = orc.OracleFT(p.Lt, p.N)
     w = v.copy(order="F")
@@ -247,8 +249,10 @@ def test_kpm_preconditioner_state_and_apply(kind, is_sym, generic):
 
 @pytest.mark.parametrize("is_sym", [True, False])
 @pytest.mark.parametrize("graph", [False, True])
-def test_cg_preconditioned(is_sym, graph):
+@pytest.mark.parametrize("rocfft", [False, True])
+def test_cg_preconditioned(is_sym, graph, rocfft):
     p = Problem("honeycomb_L4", is_sym, nwalkers=2, nrhs=2)
+    p.h.call("smoqy_fft_use_rocfft", int(rocfft))  # fused tau-FFT iteration vs the rocFFT + BLAS-1 kernels
     p.h.call("smoqy_cg_use_graph", int(graph))  # hipGraph replay of the captured iteration must not change anything
     b = p.rand(4, 10)
     Ps = []
