@@ -39,10 +39,10 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="holstein_honeycomb_L16_Ltau128")
-    ap.add_argument("--walkers-per-gpu", type=int, default=32)
-    ap.add_argument("--streams", type=int, default=2, help="concurrent lock-step batches per GPU (one HIP stream + host thread each)")
+    ap.add_argument("--walkers-per-gpu", type=int, default=64)
+    ap.add_argument("--streams", type=int, default=4, help="concurrent lock-step batches per GPU (one HIP stream + host thread each)")
     ap.add_argument("--tau-chunk", type=int, default=0)
     ap.add_argument("--check-every", type=int, default=0)
     ap.add_argument("--matvec-reps", type=int, default=400)
