@@ -74,14 +74,21 @@ class WalkerBatch:
         # device-resident PFFCalculator state (src/PFFCalculator.jl:9-16): Φ, u, u′, u″
         self.phi, self.u, self.u1, self.u2 = (self.h.vec_alloc() for _ in range(4))
         self._R = self.h.pinned_empty((self.Lt, self.N, nwalkers), dtype=np.complex128, order="F")
+        self._tmp = np.empty_like(self.xs)
         self.stats = SweepStats()
         self.refresh_fields(first=True)
 
     # ---- field plumbing -------------------------------------------------------------------------
     def refresh_fields(self, first: bool = False):
         """update!(fdm, fpi) and update_Λ! for every walker from its current phonon field."""
-        for m in self.models:
-            m.refresh_from_x()
+        if self.models[0].kind == "holstein":
+            # V = α x - μ for the whole batch in one pass (what SyntheticModel.refresh_from_x does per walker)
+            np.multiply(self.xs, self.models[0].alpha, out=self.Vs)
+            if self.models[0].mu != 0.0:
+                self.Vs -= self.models[0].mu
+        else:
+            for m in self.models:
+                m.refresh_from_x()
         t_all = L.ptr(self.ts) if (first or self.hoppings_move) else None
         self.h.call("smoqy_update_from_path_integral_all", L.ptr(self.Vs), t_all, L.ptr(self.perm), C.c_double(self.dtau))
         hol = self.models[0].elph.holstein
@@ -141,7 +148,8 @@ class WalkerBatch:
         self.h.call("smoqy_matvec_v", L.OP_MT, self.u1, self.u2)             # Mᵀ AΨ
 
     def drift_fields(self, pis, step):
-        self.xs += step * pis
+        np.multiply(pis, step, out=self._tmp)
+        np.add(self.xs, self._tmp, out=self.xs)
         self.refresh_fields()
 
     def _momentum(self):
