@@ -102,6 +102,13 @@ int smoqy_matvec_force_generic(smoqy_ctx *ctx, int on);
 /* host form: `count` vectors starting at system sys0 (fields of walker sys/nrhs); out == in allowed */
 int smoqy_matvec(smoqy_ctx *ctx, int op, void *out, const void *in, int sys0, int count);
 
+/* checkerboard_lmul! (inverse = 0) / checkerboard_ldiv! (inverse = 1) with the `transposed` flag and a
+ * colour interval [color_first, color_first + ncolors) (0-based), in place
+ * (src/checkerboard_matrix_multiply.jl:26-72, 98-145; `interval = checkerboard_colors[color]` at
+ * src/fermion_det_matrix_dervative.jl:54-62) */
+int smoqy_checkerboard_v(smoqy_ctx *ctx, int id, int inverse, int transposed, int color_first, int ncolors);
+int smoqy_checkerboard(smoqy_ctx *ctx, void *inout, int inverse, int transposed, int color_first, int ncolors, int sys0, int count);
+
 /* ---- Holstein shift matrix Λ ---------------------------------------------------------- */
 
 /* set Λ (Ltau x N) of one walker from the host (what update_Λ! produced, :2-44) */

@@ -67,6 +67,8 @@ SIGNATURES = {
     "smoqy_matvec_v": [_p, _i, _i, _i],
     "smoqy_matvec_force_generic": [_p, _i],
     "smoqy_matvec": [_p, _i, _p, _p, _i, _i],
+    "smoqy_checkerboard_v": [_p, _i, _i, _i, _i, _i],
+    "smoqy_checkerboard": [_p, _p, _i, _i, _i, _i, _i, _i],
     "smoqy_lambda_set": [_p, _i, _p],
     "smoqy_lambda_update": [_p, _i, _p, _i, _d, _i, _p, _p, _p, _p, _p],
     "smoqy_lambda_update_all": [_p, _p, _i, _d, _i, _p, _p, _p, _p, _p],

@@ -173,6 +173,43 @@ def lmul_MMt(fdm, v):
     mul_MMt(v, fdm, v)
 
 
+# ---- checkerboard multiplies -----------------------------------------------------------------------
+
+def _interval_to_colours(fdm, interval):
+    """A reference `interval` is a bond range; the calls on the hot path and in the force code pass
+    either everything or one colour (`checkerboard_colors[color]`).  Returns (first colour, count)."""
+    if interval is None:
+        return 0, len(fdm.checkerboard_colors)
+    lo, hi = interval.start, interval.stop - 1
+    first = [k for k, r in enumerate(fdm.checkerboard_colors) if r.start == lo]
+    last = [k for k, r in enumerate(fdm.checkerboard_colors) if r.stop - 1 == hi]
+    if not first or not last or last[0] < first[0]:
+        raise ValueError("interval must be a union of consecutive checkerboard colours")
+    return first[0], last[0] - first[0] + 1
+
+
+def checkerboard_lmul(v, fdm, transposed=False, interval=None):
+    """checkerboard_lmul!(v, neighbor_table, coshΔτt, sinhΔτt; transposed, interval)
+    (src/checkerboard_matrix_multiply.jl:26-72) with the matrix's own tables."""
+    c0, nc = _interval_to_colours(fdm, interval)
+    a = L.writable_state(v, fdm.Lt, fdm.N)
+    fdm.handle.call("smoqy_checkerboard", L.ptr(a), 0, int(transposed), c0, nc, 0, 1)
+
+
+def checkerboard_ldiv(v, fdm, transposed=False, interval=None):
+    """checkerboard_ldiv! (src/checkerboard_matrix_multiply.jl:98-145)."""
+    c0, nc = _interval_to_colours(fdm, interval)
+    a = L.writable_state(v, fdm.Lt, fdm.N)
+    fdm.handle.call("smoqy_checkerboard", L.ptr(a), 1, int(transposed), c0, nc, 0, 1)
+
+
+def checkerboard_mul(vp, v, fdm, transposed=False, interval=None):
+    """checkerboard_mul!: copy then lmul (src/checkerboard_matrix_multiply.jl:2-22)."""
+    o = L.writable_state(vp, fdm.Lt, fdm.N)
+    o[...] = np.asarray(v).reshape(o.shape, order="F")
+    checkerboard_lmul(o, fdm, transposed, interval)
+
+
 # ---- FourierTransformer ------------------------------------------------------------------------------
 
 class FourierTransformer:

@@ -117,8 +117,9 @@ struct smoqy_ctx {
         if (_s != rocfft_status_success) FAIL(ctx, 3, "rocFFT error %d at %s:%d (%s)", (int)_s, __FILE__, __LINE__, #expr); \
     } while (0)
 
-#define CHECK_CTX(ctx) \
-    if (!(ctx)) return 1
+#define CHECK_CTX(ctx)            \
+    if (!(ctx)) return 1;         \
+    (void)hipSetDevice((ctx)->device)
 
 static int check_vec(smoqy_ctx *c, int id)
 {
@@ -731,6 +732,30 @@ int smoqy_matvec(smoqy_ctx *c, int op, void *out, const void *in, int sys0, int 
     if (int rc = upload_into(c, c->scr[1], in, sys0, count)) return rc;
     if (int rc = matvec_dev(c, op, c->scr[2], c->scr[1], nullptr, nullptr, sys0, count)) return rc;
     return download_from(c, c->scr[2], out, sys0, count);
+}
+
+// checkerboard_lmul! / checkerboard_ldiv! on a colour interval, in place (src/checkerboard_matrix_multiply.jl:26-145)
+int smoqy_checkerboard_v(smoqy_ctx *c, int id, int inverse, int transposed, int color_first, int ncolors)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, id)) return rc;
+    if (color_first < 0 || ncolors < 0 || color_first + ncolors > c->g.ncol) FAIL(c, 1, "colour interval [%d, %d) outside 0..%d", color_first, color_first + ncolors, c->g.ncol);
+    FdmArgs a = fdm_args(c, c->vecs[id], c->vecs[id], nullptr, nullptr, 0, c->g.nsys);
+    launch_checkerboard(c->stream, a, inverse, transposed, color_first, ncolors);
+    return check_launch(c, "checkerboard");
+}
+
+int smoqy_checkerboard(smoqy_ctx *c, void *inout, int inverse, int transposed, int color_first, int ncolors, int sys0, int count)
+{
+    CHECK_CTX(c);
+    CHECK_RANGE(c, sys0, count);
+    if (color_first < 0 || ncolors < 0 || color_first + ncolors > c->g.ncol) FAIL(c, 1, "colour interval [%d, %d) outside 0..%d", color_first, color_first + ncolors, c->g.ncol);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = upload_into(c, c->scr[1], inout, sys0, count)) return rc;
+    FdmArgs a = fdm_args(c, c->scr[1], c->scr[1], nullptr, nullptr, sys0, count);
+    launch_checkerboard(c->stream, a, inverse, transposed, color_first, ncolors);
+    if (int rc = check_launch(c, "checkerboard")) return rc;
+    return download_from(c, c->scr[1], inout, sys0, count);
 }
 
 // ---- Λ ------------------------------------------------------------------------------------------

@@ -210,6 +210,56 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// stand-alone checkerboard_lmul! / checkerboard_ldiv! on a colour interval
+// (src/checkerboard_matrix_multiply.jl:26-72, 98-145): in place on a device vector, one workgroup per
+// (tau-chunk, system), slices staged through LDS exactly like the fused kernels.
+// lmul, not transposed: colours first..last;  transposed: last..first (:45-47)
+// ldiv (factor [[c,-s],[-s,c]]), not transposed: last..first (:118-120);  transposed: first..last
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) checkerboard_kernel(FdmArgs a, int inverse, int transposed, int col0, int ncols)
+{
+    extern __shared__ double2 U[];
+    const int chunk = blockIdx.x % a.nchunk, sys = a.sys_first + blockIdx.x / a.nchunk;
+    const int w = sys / a.nrhs, Lt = a.Lt, N = a.N;
+    const int l0 = chunk * a.Tc, nk = min(a.Tc, Lt - l0);
+    const double *ch = a.ch + (size_t)w * Lt * a.Nh, *sh = a.sh + (size_t)w * Lt * a.Nh;
+    const size_t sstride = (size_t)a.nsys * N;
+    double2 *v = a.out + (size_t)sys * N;
+    for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {
+        const int k = idx / N, i = idx - k * N;
+        U[idx] = v[(size_t)(l0 + k) * sstride + i];
+    }
+    __syncthreads();
+    const bool reversed = (transposed != 0) != (inverse != 0);
+    for (int q = 0; q < ncols; ++q) {
+        const int c = reversed ? col0 + ncols - 1 - q : col0 + q;
+        const int cb = a.col_off[c], ce = a.col_off[c + 1];
+        for (int h = cb + (int)threadIdx.x; h < ce; h += (int)blockDim.x) {
+            const int2 b = a.bonds[h];
+            for (int k = 0; k < nk; ++k) {
+                const double cc = ch[(size_t)(l0 + k) * a.Nh + h];
+                const double ss = inverse ? -sh[(size_t)(l0 + k) * a.Nh + h] : sh[(size_t)(l0 + k) * a.Nh + h];
+                double2 *row = U + (size_t)k * N;
+                const double2 x = row[b.x], y = row[b.y];
+                row[b.x] = make_double2(cc * x.x + ss * y.x, cc * x.y + ss * y.y);
+                row[b.y] = make_double2(cc * y.x + ss * x.x, cc * y.y + ss * x.y);
+            }
+        }
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {
+        const int k = idx / N, i = idx - k * N;
+        v[(size_t)(l0 + k) * sstride + i] = U[idx];
+    }
+}
+
+void launch_checkerboard(hipStream_t st, const FdmArgs &a, int inverse, int transposed, int col0, int ncols)
+{
+    const size_t lds = sizeof(double2) * (size_t)a.N * (size_t)a.Tc;
+    hipLaunchKernelGGL(checkerboard_kernel, dim3((unsigned)(a.nchunk * a.sys_count)), dim3(kThreads), lds, st, a, inverse, transposed, col0, ncols);
+}
+
 size_t fdm_lds_bytes(int op, int N, int Tc)
 {
     const bool fused = (op == SMOQY_OP_MTM || op == SMOQY_OP_MMT);
@@ -227,6 +277,7 @@ template <bool SYM, int OP>
 static void configure_one() { (void)hipFuncSetAttribute((const void *)fdm_kernel<SYM, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); }
 void configure_fdm_kernels()
 {
+    (void)hipFuncSetAttribute((const void *)checkerboard_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     configure_one<true, 0>(); configure_one<true, 1>(); configure_one<true, 2>(); configure_one<true, 3>();
     configure_one<false, 0>(); configure_one<false, 1>(); configure_one<false, 2>(); configure_one<false, 3>();
 }

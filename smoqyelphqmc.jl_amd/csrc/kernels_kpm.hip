@@ -297,9 +297,12 @@ __device__ __forceinline__ double2 block_sum_cplx(double2 v, double *red)
     return make_double2(re, im);
 }
 
-template <bool SYM>
+// NCOL > 0 fixes the number of colours at compile time (the per-stage colour tests fold away);
+// NCOL = 0 reads it at run time.
+template <bool SYM, int NCOL>
 __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
 {
+    const int ncol = NCOL > 0 ? NCOL : k.ncol;
     extern __shared__ double2 lds[];
     __shared__ double red[17];
     double2 *W = lds;
@@ -339,9 +342,9 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
     const double emin = k.bounds[2 * w], emax = k.bounds[2 * w + 1];
     const double avg = 0.5 * (emax + emin), imag_ = 1.0 / (0.5 * (emax - emin));
     LaneBonds lb;
-    load_lane_bonds(lb, kg, w, k.ncol);
+    load_lane_bonds(lb, kg, w, ncol);
     const double *dbar = k.dbar + (size_t)w * N;
-    const int cl = k.ncol - 1;
+    const int cl = ncol - 1;
     int2 bL = make_int2(0, 0);
     bool onL = false;
 #pragma unroll
@@ -363,11 +366,11 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
     }
     __syncthreads();
     if (SYM) {
-        kpm_poly_regs<true>(W, lb, k.ncol, CF, n, avg, imag_, di, dj, dLi, dLj, vi, vj);  // :394
+        kpm_poly_regs<true>(W, lb, ncol, CF, n, avg, imag_, di, dj, dLi, dLj, vi, vj);  // :394
     } else {
-        kpm_poly_regs<false>(W, lb, k.ncol, CF2, n2, avg, imag_, di, dj, dLi, dLj, vi, vj);
+        kpm_poly_regs<false>(W, lb, ncol, CF2, n2, avg, imag_, di, dj, dLi, dLj, vi, vj);
         __syncthreads();
-        kpm_poly_regs<false>(W, lb, k.ncol, CF, n, avg, imag_, di, dj, dLi, dLj, vi, vj);
+        kpm_poly_regs<false>(W, lb, ncol, CF, n, avg, imag_, di, dj, dLi, dLj, vi, vj);
     }
     double2 acc = make_double2(0.0, 0.0);
     if (onL) {
@@ -512,8 +515,26 @@ void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
 {
     if (kg.fast) {
         const size_t lds = sizeof(double2) * ((size_t)k.N + 2 * (size_t)k.maxorder);
-        if (k.is_sym) hipLaunchKernelGGL((cheb_fast_kernel<true>), dim3((unsigned)(k.Lt * k.nsys)), dim3(kg.threads), lds, st, k, kg);
-        else hipLaunchKernelGGL((cheb_fast_kernel<false>), dim3((unsigned)(k.Lt * k.nsys)), dim3(kg.threads), lds, st, k, kg);
+        const dim3 grid((unsigned)(k.Lt * k.nsys)), block((unsigned)kg.threads);
+#define CHEB_LAUNCH(S_, C_) hipLaunchKernelGGL((cheb_fast_kernel<S_, C_>), grid, block, lds, st, k, kg)
+        if (k.is_sym) {
+            switch (k.ncol) {
+                case 1: CHEB_LAUNCH(true, 1); break;
+                case 2: CHEB_LAUNCH(true, 2); break;
+                case 3: CHEB_LAUNCH(true, 3); break;
+                case 4: CHEB_LAUNCH(true, 4); break;
+                default: CHEB_LAUNCH(true, 0); break;
+            }
+        } else {
+            switch (k.ncol) {
+                case 1: CHEB_LAUNCH(false, 1); break;
+                case 2: CHEB_LAUNCH(false, 2); break;
+                case 3: CHEB_LAUNCH(false, 3); break;
+                case 4: CHEB_LAUNCH(false, 4); break;
+                default: CHEB_LAUNCH(false, 0); break;
+            }
+        }
+#undef CHEB_LAUNCH
     } else {
         const size_t lds = sizeof(double2) * 4 * (size_t)k.N;
         hipLaunchKernelGGL(cheb_generic_kernel, dim3((unsigned)(k.Lt * k.nsys)), dim3(kThreads), lds, st, k);

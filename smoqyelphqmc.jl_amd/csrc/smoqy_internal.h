@@ -103,6 +103,7 @@ struct FdmFast {
 // ---- launchers (defined in the .hip files) -----------------------------------------------
 void launch_fdm(hipStream_t st, int op, bool sym, const FdmArgs &a, size_t lds_bytes);
 size_t fdm_lds_bytes(int op, int N, int Tc);
+void launch_checkerboard(hipStream_t st, const FdmArgs &a, int inverse, int transposed, int col0, int ncols);
 void configure_fdm_kernels();
 void configure_kpm_kernels();
 bool fdm_fast_supported(const FdmArgs &a, const FdmFast &ff, bool sym);

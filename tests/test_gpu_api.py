@@ -221,3 +221,26 @@ def test_errors_surface_as_exceptions(setup):
     b[0, 0] = np.nan
     with pytest.raises(sq.api.L.SmoqyError):
         sq.ldiv(np.zeros_like(b), fdm, b, tol=1e-10, maxiter=50)
+
+
+def test_checkerboard_entry_points(setup):
+    """checkerboard_lmul!/ldiv!/mul! with `transposed` and a colour `interval`
+    (src/checkerboard_matrix_multiply.jl:2-145) against the oracle."""
+    m, fdm, o, is_sym = setup
+    v = rand_vec(12, 18, 21)
+    for tr in (False, True):
+        w = v.copy(order="F")
+        sq.checkerboard_lmul(w, fdm, transposed=tr)
+        assert relerr(w, o.checkerboard(v, transposed=tr)) < 1e-14
+        sq.checkerboard_ldiv(w, fdm, transposed=tr)  # inverse of the same product
+        assert relerr(w, v) < 1e-13
+        w = v.copy(order="F")
+        sq.checkerboard_ldiv(w, fdm, transposed=tr)
+        assert relerr(w, o.checkerboard(v, transposed=tr, inverse=True)) < 1e-14
+        for col in fdm.checkerboard_colors:  # one colour at a time, as the force code does
+            w = v.copy(order="F")
+            sq.checkerboard_lmul(w, fdm, transposed=tr, interval=col)
+            assert relerr(w, o.checkerboard(v, transposed=tr, interval=(col.start - 1, col.stop - 1))) < 1e-14
+    out = np.zeros_like(v)
+    sq.checkerboard_mul(out, v, fdm, transposed=True)
+    assert relerr(out, o.checkerboard(v, transposed=True)) < 1e-14
