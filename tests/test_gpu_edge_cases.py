@@ -1,0 +1,171 @@
+"""Edge cases of the C ABI on the GPU: degenerate sizes, missing bonds, mixed active / inactive
+preconditioners in one batch, iteration limits, and the generic (fallback) kernels on a
+decomposition with more colours than the register-resident kernels hold."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import smoqyelphqmc_amd as sq
+from smoqyelphqmc_amd import _lib as L
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+lat = sq.lattice
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def make(nt_raw, Lt, N, is_sym=True, seed=0, nw=1, nrhs=1, vscale=1.0):
+    g = np.random.default_rng(seed)
+    nt, perm, colors = lat.checkerboard_decomposition(nt_raw)
+    Nh = nt.shape[1]
+    h = L.Handle(Lt, N, nt, colors, is_sym, nw, nrhs)
+    oracles = []
+    for w in range(nw):
+        V = np.asfortranarray(vscale * g.standard_normal((N, Lt)))
+        t = np.asfortranarray(1.0 + 0.3 * g.standard_normal((Nh, Lt)))
+        expV, ch, sh = orc.update_fields(V, t, perm, 0.05, is_sym)
+        h.call("smoqy_update_from_path_integral", w, L.ptr(V), L.ptr(t), L.ptr(perm), C.c_double(0.05))
+        oracles.append(orc.OracleFDM(nt, expV, ch, sh, is_sym))
+    return h, oracles, nt, colors
+
+
+def rand(Lt, N, count, seed):
+    g = np.random.default_rng(seed)
+    return np.asfortranarray(g.standard_normal((Lt, N, count)) + 1j * g.standard_normal((Lt, N, count)))
+
+
+def solve(h, b, tol, maxiter, pre):
+    n = b.shape[2]
+    x = np.zeros_like(b)
+    it = np.zeros(n, dtype=np.int32)
+    eps = np.zeros(n)
+    h.call("smoqy_cg_solve", L.ptr(x), L.ptr(b), 1, 0, n, C.c_double(tol), maxiter, pre, L.ptr(it), L.ptr(eps))
+    return x, it, eps
+
+
+@pytest.mark.parametrize("Lt", [1, 2, 3])
+@pytest.mark.parametrize("is_sym", [True, False])
+def test_tiny_time_extent(Lt, is_sym):
+    h, o, *_ = make(lat.chain_neighbor_table(4), Lt, 4, is_sym)
+    v = rand(Lt, 4, 1, 1)
+    for op, fn in ((L.OP_M, o[0].mul_M), (L.OP_MT, o[0].mul_Mt), (L.OP_MTM, o[0].mul_MtM), (L.OP_MMT, o[0].mul_MMt)):
+        out = np.zeros_like(v)
+        h.call("smoqy_matvec", op, L.ptr(out), L.ptr(v), 0, 1)
+        assert relerr(out[:, :, 0], fn(v[:, :, 0])) < 1e-13
+    x, it, eps = solve(h, v, 1e-12, 500, 0)
+    xo, ito, _ = o[0].cg_solve(v[:, :, 0], tol=1e-12, maxiter=500)
+    assert relerr(x[:, :, 0], xo) < 1e-10 and abs(int(it[0]) - ito) <= 1
+
+
+def test_single_bond_and_no_bonds():
+    h, o, *_ = make(np.array([[1], [2]], dtype=np.int64), 6, 2)
+    v = rand(6, 2, 1, 2)
+    out = np.zeros_like(v)
+    h.call("smoqy_matvec", L.OP_MTM, L.ptr(out), L.ptr(v), 0, 1)
+    assert relerr(out[:, :, 0], o[0].mul_MtM(v[:, :, 0])) < 1e-13
+    # no hoppings at all: M is the atomic-limit operator, B_l = diag(exp(-ΔτV_l))
+    hb, ob, *_ = make(np.zeros((2, 0), dtype=np.int64), 5, 3)
+    w = rand(5, 3, 1, 3)
+    hb.call("smoqy_matvec", L.OP_MTM, L.ptr(out := np.zeros_like(w)), L.ptr(w), 0, 1)
+    assert relerr(out[:, :, 0], ob[0].mul_MtM(w[:, :, 0])) < 1e-13
+    x, it, eps = solve(hb, w, 1e-12, 200, 0)
+    assert relerr(ob[0].mul_MtM(x[:, :, 0]), w[:, :, 0]) < 1e-10
+
+
+def test_many_colours_use_the_generic_kernels():
+    """A star graph needs one colour per bond: 7 colours > the 4 (FermionDetMatrix) / 6 (KPM) that the
+    register-resident kernels hold, so every launch goes through the generic path."""
+    N = 8
+    star = np.array([[1] * (N - 1), list(range(2, N + 1))], dtype=np.int64)
+    h, o, nt, colors = make(star, 24, N, True, seed=4, vscale=0.3)
+    assert colors.shape[1] == N - 1
+    v = rand(24, N, 1, 5)
+    out = np.zeros_like(v)
+    h.call("smoqy_matvec", L.OP_MTM, L.ptr(out), L.ptr(v), 0, 1)
+    assert relerr(out[:, :, 0], o[0].mul_MtM(v[:, :, 0])) < 1e-13
+    rv = np.random.default_rng(6).standard_normal(N)
+    P = orc.OracleKPM(o[0], n=6)
+    P.update(rv)
+    h.call("smoqy_precond_config", C.c_double(0.10), 6, C.c_double(1.0), C.c_double(1.0))
+    h.call("smoqy_precond_update", 0, L.ptr(rv))
+    x, it, eps = solve(h, v, 1e-11, 2000, 1)
+    xo, ito, _ = o[0].cg_solve(v[:, :, 0], precond=P if P.active else None, tol=1e-11, maxiter=2000)
+    assert relerr(x[:, :, 0], xo) < 1e-9 and abs(int(it[0]) - ito) <= 2
+
+
+def test_mixed_active_and_inactive_preconditioners():
+    """Walker 1 gets on-site energies wild enough that the Lanczos bounds fail the sanity test
+    (src/KPMPreconditioner.jl:573): its preconditioner must act as the identity while walker 0's works."""
+    nt_raw = lat.honeycomb_neighbor_table(3)
+    g = np.random.default_rng(7)
+    nt, perm, colors = lat.checkerboard_decomposition(nt_raw)
+    Lt, N, Nh = 16, 18, nt.shape[1]
+    h = L.Handle(Lt, N, nt, colors, True, 2, 1)
+    oracles, pre = [], []
+    for w, vs in enumerate((1.0, 40.0)):
+        V = np.asfortranarray(vs * g.standard_normal((N, Lt)))
+        t = np.asfortranarray(np.ones((Nh, Lt)))
+        expV, ch, sh = orc.update_fields(V, t, perm, 0.05, True)
+        h.call("smoqy_update_from_path_integral", w, L.ptr(V), L.ptr(t), L.ptr(perm), C.c_double(0.05))
+        o = orc.OracleFDM(nt, expV, ch, sh, True)
+        rv = g.standard_normal(N)
+        P = orc.OracleKPM(o)
+        P.update(rv)
+        h.call("smoqy_precond_update", w, L.ptr(rv))
+        oracles.append(o)
+        pre.append(P)
+    assert pre[0].active and not pre[1].active
+    act = [C.c_int(0), C.c_int(0)]
+    for w in range(2):
+        h.call("smoqy_precond_get", w, C.byref(act[w]), None, None, None, None, None)
+    assert act[0].value == 1 and act[1].value == 0
+    v = rand(Lt, N, 2, 8)
+    out = np.zeros_like(v)
+    h.call("smoqy_precond_apply", L.ptr(out), L.ptr(v), 0, 2)
+    assert relerr(out[:, :, 0], pre[0].apply(v[:, :, 0])) < 1e-11
+    assert relerr(out[:, :, 1], v[:, :, 1]) < 1e-13          # identity
+    x, it, eps = solve(h, v, 1e-9, 20000, 1)
+    for w in range(2):
+        xo, ito, _ = oracles[w].cg_solve(v[:, :, w], precond=pre[w] if pre[w].active else None, tol=1e-9, maxiter=20000)
+        assert abs(int(it[w]) - ito) <= max(3, ito // 10)  # ~1e4 iterations on the ill-conditioned walker: rounding-order sensitive
+        assert relerr(oracles[w].mul_MtM(x[:, :, w]), v[:, :, w]) < 1e-8
+
+
+def test_iteration_limits_and_zero_rhs():
+    h, o, *_ = make(lat.honeycomb_neighbor_table(2), 8, 8)
+    b = rand(8, 8, 1, 9)
+    x, it, eps = solve(h, b, 1e-12, 0, 0)      # maxiter = 0: nothing done, (0 == maxiter, eps0)
+    assert it[0] == 0 and abs(eps[0] - 1.0) < 1e-14 and np.all(x == 0)
+    x, it, eps = solve(h, b, 1e-30, 7, 0)      # unreachable tolerance: (maxiter, eps) without an error
+    assert it[0] == 7 and eps[0] > 0
+    x, it, eps = solve(h, np.zeros_like(b), 1e-10, 50, 0)  # b = 0 -> x = 0
+    assert it[0] == 0 and np.all(x == 0)
+
+
+def test_multi_rhs_with_preconditioner():
+    m = lat.holstein_honeycomb(4, 40)
+    nt, perm, colors = lat.checkerboard_decomposition(m.fpi.neighbor_table)
+    h = L.Handle(40, 32, nt, colors, True, 1, 5)
+    h.call("smoqy_update_from_path_integral", 0, L.ptr(m.fpi.V), L.ptr(m.fpi.t), L.ptr(perm), C.c_double(m.fpi.dtau))
+    expV, ch, sh = orc.update_fields(m.fpi.V, m.fpi.t, perm, m.fpi.dtau, True)
+    o = orc.OracleFDM(nt, expV, ch, sh, True)
+    rv = np.random.default_rng(10).standard_normal(32)
+    P = orc.OracleKPM(o)
+    P.update(rv)
+    h.call("smoqy_precond_update", 0, L.ptr(rv))
+    b = rand(40, 32, 5, 11)
+    b[:, :, 3] *= 1e-6                     # very different scales / convergence times in one batch
+    x, it, eps = solve(h, b, 1e-10, 10000, 1)
+    for s in range(5):
+        xo, ito, _ = o.cg_solve(b[:, :, s], precond=P, tol=1e-10, maxiter=10000)
+        assert abs(int(it[s]) - ito) <= 2 and relerr(x[:, :, s], xo) < 1e-8
+    # sub-range host call: only systems 1..2 are touched
+    x2 = np.zeros((40, 32, 2), dtype=complex, order="F")
+    it2 = np.zeros(2, dtype=np.int32)
+    e2 = np.zeros(2)
+    h.call("smoqy_cg_solve", L.ptr(x2), L.ptr(np.asfortranarray(b[:, :, 1:3])), 1, 1, 2, C.c_double(1e-10), 10000, 1, L.ptr(it2), L.ptr(e2))
+    assert relerr(x2, x[:, :, 1:3]) < 1e-9
