@@ -178,6 +178,39 @@ int smoqy_cg_config(smoqy_ctx *ctx, int check_every);
  * default: not faster on MI355X at the sizes measured) */
 int smoqy_cg_use_graph(smoqy_ctx *ctx, int on);
 
+/* ---- force terms of the pseudofermion action (handles with nrhs = 1) ------ */
+
+/* Flattened electron-phonon couplings, i.e. what mul_νRe∂M∂x! / mul_νRe∂Λ∂x! read from
+ * ElectronPhononParameters (src/fermion_det_matrix_dervative.jl:207-213, 257-262;
+ * src/holstein_shift_matrix.jl:165-166).  Ids are 1-based.  s_bond[c] is the position n of coupling
+ * c's hopping in the colour-sorted neighbour table (checkerboard_perm[n] == hopping,
+ * hopping_to_couplings[hopping] ∋ c).  finite_mass[p] = isfinite(M[p]). */
+typedef struct {
+    int Nph;
+    double dtau;
+    const int32_t *finite_mass;
+    int Nholstein;
+    const double *h_alpha, *h_alpha2, *h_alpha3, *h_alpha4;
+    const int64_t *h_coupling_to_phonon, *h_coupling_to_site;
+    const int32_t *h_ph_sym;
+    int Nssh;
+    const double *s_alpha, *s_alpha2, *s_alpha3, *s_alpha4;
+    const int64_t *s_coupling_to_phonon; /* 2 x Nssh */
+    const int64_t *s_bond;
+} smoqy_couplings;
+
+int smoqy_force_set_couplings(smoqy_ctx *ctx, const smoqy_couplings *cp);
+/* phonon fields of every walker, Nph x Ltau x nwalkers (call after each move of x) */
+int smoqy_force_set_phonons(smoqy_ctx *ctx, const double *x_all);
+/* mul_νRe∂M∂x!(out, ν, u, v, fdm, elph) (src/fermion_det_matrix_dervative.jl:2-186): out is
+ * Nph x Ltau x nwalkers on the host and is accumulated into, like the reference's ∂Sf∂x */
+int smoqy_force_dMdx_v(smoqy_ctx *ctx, double nu, int u, int v, double *out);
+/* mul_νRe∂Λ∂x!(out, ν, u′, u, Λ, elph) (src/holstein_shift_matrix.jl:156-201) with the stored Λ */
+int smoqy_force_dLdx_v(smoqy_ctx *ctx, double nu, int up, int u, double *out);
+/* the tail of calculate_derivative_fermionic_action! (src/PFFCalculator.jl:146-155) from Ψ:
+ * ΛΨ, AΨ = MΛΨ, out += -2 Re<AΨ|∂M/∂x|ΛΨ>, MᵀAΨ, out += -2 Re<MᵀAΨ|∂Λ/∂x|Ψ> */
+int smoqy_force_v(smoqy_ctx *ctx, int psi, double *out);
+
 /* ---- measurement aids (bench.py) -------------------------------------------------------- */
 
 /* HIP events on the handle's stream */

@@ -245,3 +245,51 @@ def tridiag_extremes(a, b):
     lo, hi = C.c_double(0), C.c_double(0)
     lib().orc_tridiag_extremes(_p(a), _p(b), len(a), C.byref(lo), C.byref(hi))
     return lo.value, hi.value
+
+
+# ---- force terms -----------------------------------------------------
+
+class _ElphStruct(C.Structure):
+    _fields_ = [("Nph", C.c_int), ("x", C.c_void_p), ("dtau", C.c_double), ("finite_mass", C.c_void_p),
+                ("Nhol", C.c_int), ("ha", C.c_void_p), ("ha2", C.c_void_p), ("ha3", C.c_void_p), ("ha4", C.c_void_p),
+                ("h_c2p", C.c_void_p), ("h_c2s", C.c_void_p), ("h_phsym", C.c_void_p),
+                ("Nssh", C.c_int), ("sa", C.c_void_p), ("sa2", C.c_void_p), ("sa3", C.c_void_p), ("sa4", C.c_void_p),
+                ("s_c2p", C.c_void_p), ("s_bond", C.c_void_p)]
+
+
+class OracleElph:
+    """Flattened electron-phonon couplings for the force terms (what the Julia shim would build from
+    ``ElectronPhononParameters``: holstein_parameters_up, ssh_parameters_up, phonon masses)."""
+
+    def __init__(self, couplings):
+        c = couplings
+        f = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+        self.x = np.asfortranarray(c.x, dtype=np.float64)
+        self.keep = [self.x, f(c.finite_mass, np.int32), f(c.h_alpha, np.float64), f(c.h_alpha2, np.float64), f(c.h_alpha3, np.float64), f(c.h_alpha4, np.float64),
+                     f(c.h_c2p, np.int64), f(c.h_c2s, np.int64), f(c.h_phsym, np.int32), f(c.s_alpha, np.float64), f(c.s_alpha2, np.float64), f(c.s_alpha3, np.float64),
+                     f(c.s_alpha4, np.float64), np.asfortranarray(c.s_c2p, dtype=np.int64), f(c.s_bond, np.int64)]
+        k = self.keep
+        self.s = _ElphStruct(self.x.shape[0], _p(k[0]), c.dtau, _p(k[1]), len(k[2]), _p(k[2]), _p(k[3]), _p(k[4]), _p(k[5]), _p(k[6]), _p(k[7]), _p(k[8]),
+                             len(k[9]), _p(k[9]), _p(k[10]), _p(k[11]), _p(k[12]), _p(k[13]), _p(k[14]))
+
+
+def mul_dMdx(fdm: OracleFDM, elph: OracleElph, colors, nu, u, v, out=None):
+    """mul_νRe∂M∂x! (src/fermion_det_matrix_dervative.jl:2-186); returns / accumulates (Nph, Ltau)."""
+    Lt, N = fdm.Lt, fdm.N
+    u = fvec(u).reshape(Lt, N, order="F")
+    v = fvec(v).reshape(Lt, N, order="F")
+    out = np.zeros((elph.x.shape[0], Lt), order="F") if out is None else out
+    cols = np.asfortranarray(colors, dtype=np.int64)
+    lib().orc_mul_dMdx(fdm._h, C.byref(elph.s), _p(cols), int(cols.shape[1]), C.c_double(nu), _p(u), _p(v), _p(out))
+    return out
+
+
+def mul_dLdx(elph: OracleElph, Lam, nu, up, u, out=None):
+    """mul_νRe∂Λ∂x! (src/holstein_shift_matrix.jl:156-201)."""
+    Lam = np.asfortranarray(Lam, dtype=np.float64)
+    Lt, N = Lam.shape
+    up = fvec(up).reshape(Lt, N, order="F")
+    u = fvec(u).reshape(Lt, N, order="F")
+    out = np.zeros((elph.x.shape[0], Lt), order="F") if out is None else out
+    lib().orc_mul_dLdx(C.byref(elph.s), _p(Lam), Lt, N, C.c_double(nu), _p(up), _p(u), _p(out))
+    return out

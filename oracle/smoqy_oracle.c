@@ -668,3 +668,128 @@ void orc_fdm_destroy(orc_fdm *f)
     if (!f) return;
     free(f->tmp1); free(f->tmp2); free(f);
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* force terms — src/fermion_det_matrix_dervative.jl:2-290, src/holstein_shift_matrix.jl:156-201 */
+/* (SURVEY.md §8(f) rank 1).  Couplings are passed flattened:                             */
+/*   Holstein coupling c: phonon h_c2p[c], site h_c2s[c] (1-based), polynomial α..α4       */
+/*   SSH coupling c: phonons s_c2p[2c], s_c2p[2c+1], acting on checkerboard bond s_bond[c]  */
+/*     (1-based index into the colour-sorted neighbour table, i.e. n with perm[n] = hopping) */
+/* finite_mass[p] = isfinite(M[p]).  out is Nph x Ltau column-major and is accumulated into. */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    int Nph;
+    const double *x;
+    double dtau;
+    const int32_t *finite_mass;
+    int Nhol;
+    const double *ha, *ha2, *ha3, *ha4;
+    const int64_t *h_c2p, *h_c2s;
+    const int32_t *h_phsym;
+    int Nssh;
+    const double *sa, *sa2, *sa3, *sa4;
+    const int64_t *s_c2p, *s_bond;
+} orc_elph;
+
+/* _mul_νReΔτ∂Kc∂x! — :189-245, for the bonds [h0, h1) of one colour */
+static void dKc_dx(const orc_fdm *f, const orc_elph *e, double nu, const cplx *up, const cplx *vp, double dtau_k, int h0, int h1, double *out)
+{
+    int Lt = f->Lt;
+    for (int c = 0; c < e->Nssh; ++c) {
+        int n = (int)e->s_bond[c] - 1;
+        if (n < h0 || n >= h1) continue;
+        int p = (int)e->s_c2p[2 * c] - 1, pp = (int)e->s_c2p[2 * c + 1] - 1;
+        int i = (int)f->nt[2 * n] - 1, j = (int)f->nt[2 * n + 1] - 1;
+        for (int l = 0; l < Lt; ++l) {
+            double dx = e->x[pp + (size_t)e->Nph * l] - e->x[p + (size_t)e->Nph * l];
+            double dK = dtau_k * (e->sa[c] + 2 * e->sa2[c] * dx + 3 * e->sa3[c] * dx * dx + 4 * e->sa4[c] * dx * dx * dx);
+            double val = nu * creal(conj(up[IDX(l, j, Lt)]) * dK * vp[IDX(l, i, Lt)] + conj(up[IDX(l, i, Lt)]) * dK * vp[IDX(l, j, Lt)]);
+            if (e->finite_mass[p]) out[p + (size_t)e->Nph * l] -= val;
+            if (e->finite_mass[pp]) out[pp + (size_t)e->Nph * l] += val;
+        }
+    }
+}
+
+/* _mul_νReΔτ∂V∂x! — :249-289 */
+static void dV_dx(const orc_fdm *f, const orc_elph *e, double nu, const cplx *up, const cplx *vp, double *out)
+{
+    int Lt = f->Lt;
+    for (int c = 0; c < e->Nhol; ++c) {
+        int p = (int)e->h_c2p[c] - 1, i = (int)e->h_c2s[c] - 1;
+        if (!e->finite_mass[p]) continue;
+        for (int l = 0; l < Lt; ++l) {
+            double xx = e->x[p + (size_t)e->Nph * l];
+            double dV = e->dtau * (e->ha[c] + 2 * e->ha2[c] * xx + 3 * e->ha3[c] * xx * xx + 4 * e->ha4[c] * xx * xx * xx);
+            out[p + (size_t)e->Nph * l] += nu * creal(conj(up[IDX(l, i, Lt)]) * dV * vp[IDX(l, i, Lt)]);
+        }
+    }
+}
+
+/* mul_νRe∂M∂x! — Sym :2-113, Asym :116-186.  colors: 2 x ncol, 1-based inclusive bond ranges. */
+void orc_mul_dMdx(const orc_fdm *f, const orc_elph *e, const int64_t *colors, int ncol, double nu, const cplx *u, const cplx *v, double *out)
+{
+    int Lt = f->Lt, N = f->N;
+    size_t V = (size_t)Lt * N;
+    cplx *vp = f->tmp1, *up = f->tmp2;
+    for (int i = 0; i < N; ++i) { /* circshift + sign :27-30 / :140-143 */
+        vp[IDX(0, i, Lt)] = v[IDX(Lt - 1, i, Lt)];
+        for (int l = 1; l < Lt; ++l) vp[IDX(l, i, Lt)] = -v[IDX(l - 1, i, Lt)];
+    }
+    if (f->is_sym) {
+        orc_checkerboard_lmul(vp, Lt, N, f->nt, f->ch, f->sh, 1, 0, f->Nh);      /* :33 */
+        for (size_t k = 0; k < V; ++k) vp[k] *= f->expV[k];                       /* :36 */
+        orc_checkerboard_lmul(vp, Lt, N, f->nt, f->ch, f->sh, 0, 0, f->Nh);      /* :39 */
+        memcpy(up, u, V * sizeof(cplx));                                           /* :42 */
+        if (e->Nssh > 0) {
+            for (int c = ncol - 1; c >= 0; --c) {                                 /* :50-63 */
+                int h0 = (int)colors[2 * c] - 1, h1 = (int)colors[2 * c + 1];
+                dKc_dx(f, e, -nu, up, vp, e->dtau / 2, h0, h1, out);
+                orc_checkerboard_lmul(up, Lt, N, f->nt, f->ch, f->sh, 0, h0, h1);
+                orc_checkerboard_ldiv(vp, Lt, N, f->nt, f->ch, f->sh, 0, h0, h1);
+            }
+        } else {                                                                   /* :64-75 */
+            orc_checkerboard_lmul(up, Lt, N, f->nt, f->ch, f->sh, 1, 0, f->Nh);
+            orc_checkerboard_ldiv(vp, Lt, N, f->nt, f->ch, f->sh, 1, 0, f->Nh);   /* transposed = true, as in the reference */
+        }
+        if (e->Nhol > 0) dV_dx(f, e, -nu, up, vp, out);                            /* :81-84 */
+        for (size_t k = 0; k < V; ++k) { up[k] *= f->expV[k]; vp[k] *= 1.0 / f->expV[k]; } /* :87, :90 */
+        if (e->Nssh > 0) {
+            for (int c = 0; c < ncol; ++c) {                                      /* :95-109 */
+                int h0 = (int)colors[2 * c] - 1, h1 = (int)colors[2 * c + 1];
+                dKc_dx(f, e, -nu, up, vp, e->dtau / 2, h0, h1, out);
+                orc_checkerboard_lmul(up, Lt, N, f->nt, f->ch, f->sh, 0, h0, h1);
+                orc_checkerboard_ldiv(vp, Lt, N, f->nt, f->ch, f->sh, 0, h0, h1);
+            }
+        }
+    } else {
+        orc_checkerboard_lmul(vp, Lt, N, f->nt, f->ch, f->sh, 0, 0, f->Nh);      /* :146 */
+        for (size_t k = 0; k < V; ++k) vp[k] *= f->expV[k];                       /* :149 */
+        memcpy(up, u, V * sizeof(cplx));                                           /* :152 */
+        if (e->Nhol > 0) dV_dx(f, e, -nu, up, vp, out);                            /* :158-161 */
+        if (e->Nssh > 0) {                                                         /* :166-183 */
+            for (size_t k = 0; k < V; ++k) { up[k] = f->expV[k] * up[k]; vp[k] = vp[k] / f->expV[k]; }
+            for (int c = ncol - 1; c >= 0; --c) {
+                int h0 = (int)colors[2 * c] - 1, h1 = (int)colors[2 * c + 1];
+                dKc_dx(f, e, -nu, up, vp, e->dtau, h0, h1, out);
+                orc_checkerboard_lmul(up, Lt, N, f->nt, f->ch, f->sh, 0, h0, h1);
+                orc_checkerboard_ldiv(vp, Lt, N, f->nt, f->ch, f->sh, 1, h0, h1);
+            }
+        }
+    }
+}
+
+/* mul_νRe∂Λ∂x! — src/holstein_shift_matrix.jl:156-201 */
+void orc_mul_dLdx(const orc_elph *e, const double *Lam, int Lt, int N, double nu, const cplx *up, const cplx *u, double *out)
+{
+    (void)N;
+    for (int c = 0; c < e->Nhol; ++c) {
+        if (!e->h_phsym[c]) continue;
+        int p = (int)e->h_c2p[c] - 1, site = (int)e->h_c2s[c] - 1;
+        for (int l = 0; l < Lt; ++l) {
+            double xx = e->x[p + (size_t)e->Nph * l];
+            double dL = e->dtau * (e->ha[c] + 3 * e->ha3[c] * xx * xx) / 2 * Lam[IDX(l, site, Lt)]; /* :192 */
+            int lm = (l == 0) ? Lt - 1 : l - 1;                                                    /* mod1(l-1, Lτ) */
+            out[p + (size_t)e->Nph * l] += nu * creal(conj(up[IDX(lm, site, Lt)]) * dL * u[IDX(l, site, Lt)]); /* :193 */
+        }
+    }
+}

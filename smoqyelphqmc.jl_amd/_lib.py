@@ -93,6 +93,11 @@ SIGNATURES = {
     "smoqy_cg_solve": [_p, _p, _p, _i, _i, _i, _d, _i, _i, _p, _p],
     "smoqy_cg_config": [_p, _i],
     "smoqy_cg_use_graph": [_p, _i],
+    "smoqy_force_set_couplings": [_p, _p],
+    "smoqy_force_set_phonons": [_p, _p],
+    "smoqy_force_dMdx_v": [_p, _d, _i, _i, _p],
+    "smoqy_force_dLdx_v": [_p, _d, _i, _i, _p],
+    "smoqy_force_v": [_p, _i, _p],
     "smoqy_timer_start": [_p],
     "smoqy_timer_stop": [_p, _pd],
     "smoqy_bench_matvec": [_p, _i, _i, _i, _i, _pd],
@@ -147,6 +152,26 @@ def writable_state(a, Lt, N, count=1):
     if not b.flags.writeable:
         raise ValueError("output vector is read-only")
     return b
+
+
+class CouplingsStruct(C.Structure):
+    """``smoqy_couplings`` of include/smoqy_hip.h."""
+
+    _fields_ = [("Nph", C.c_int), ("dtau", C.c_double), ("finite_mass", C.c_void_p), ("Nholstein", C.c_int), ("h_alpha", C.c_void_p), ("h_alpha2", C.c_void_p),
+                ("h_alpha3", C.c_void_p), ("h_alpha4", C.c_void_p), ("h_coupling_to_phonon", C.c_void_p), ("h_coupling_to_site", C.c_void_p), ("h_ph_sym", C.c_void_p),
+                ("Nssh", C.c_int), ("s_alpha", C.c_void_p), ("s_alpha2", C.c_void_p), ("s_alpha3", C.c_void_p), ("s_alpha4", C.c_void_p), ("s_coupling_to_phonon", C.c_void_p),
+                ("s_bond", C.c_void_p)]
+
+
+def couplings_struct(fc):
+    """Build a ``smoqy_couplings`` from a ``lattice.ForceCouplings``; returns (struct, keep-alive list)."""
+    f = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+    k = [f(fc.finite_mass, np.int32), f(fc.h_alpha, np.float64), f(fc.h_alpha2, np.float64), f(fc.h_alpha3, np.float64), f(fc.h_alpha4, np.float64), f(fc.h_c2p, np.int64),
+         f(fc.h_c2s, np.int64), f(fc.h_phsym, np.int32), f(fc.s_alpha, np.float64), f(fc.s_alpha2, np.float64), f(fc.s_alpha3, np.float64), f(fc.s_alpha4, np.float64),
+         np.asfortranarray(fc.s_c2p, dtype=np.int64), f(fc.s_bond, np.int64)]
+    s = CouplingsStruct(int(np.shape(fc.x)[0]), float(fc.dtau), ptr(k[0]), len(k[1]), ptr(k[1]), ptr(k[2]), ptr(k[3]), ptr(k[4]), ptr(k[5]), ptr(k[6]), ptr(k[7]), len(k[8]), ptr(k[8]),
+                        ptr(k[9]), ptr(k[10]), ptr(k[11]), ptr(k[12]), ptr(k[13]))
+    return s, k
 
 
 class Handle:

@@ -508,3 +508,69 @@ def calculate_fermionic_action(pff_calculator: PFFCalculator, electron_phonon_pa
     if np.sqrt(tol) < abs(Sf.imag / Sf.real):
         warnings.warn(f"Complex Fermionic Action Encountered. Sf={Sf} tol={tol}")
     return Sf.real, int(iters[0]), float(eps[0])
+
+
+# ---- force terms -------------------------------------------------------------------
+
+def set_force_couplings(fermion_det_matrix: FermionDetMatrix, couplings):
+    """Hand the flattened electron-phonon couplings (``lattice.ForceCouplings``) to the device once;
+    what the reference reads from ``ElectronPhononParameters`` inside the force routines."""
+    s, keep = L.couplings_struct(couplings)
+    fermion_det_matrix.handle.call("smoqy_force_set_couplings", C.byref(s))
+    fermion_det_matrix._force_couplings = couplings
+    set_force_phonons(fermion_det_matrix, couplings.x)
+
+
+def set_force_phonons(fermion_det_matrix: FermionDetMatrix, x):
+    """Refresh the device copy of the phonon fields ``x`` (Nph x Ltau) after they moved."""
+    xx = np.asfortranarray(x, dtype=np.float64)
+    fermion_det_matrix.handle.call("smoqy_force_set_phonons", L.ptr(xx))
+
+
+def _tmp_vecs(fdm, n):
+    if not hasattr(fdm, "_tmp_ids"):
+        fdm._tmp_ids = []
+    while len(fdm._tmp_ids) < n:
+        fdm._tmp_ids.append(fdm.handle.vec_alloc())
+    return fdm._tmp_ids[:n]
+
+
+def mul_nuRe_dMdx(νRedMdx, ν, u, v, fermion_det_matrix, elph=None):
+    """mul_νRe∂M∂x! (``∂`` is not a Python identifier character, hence the ASCII name): accumulates ν·Re⟨u|∂M/∂x|v⟩ into the
+    ``Nph x Ltau`` array (src/fermion_det_matrix_dervative.jl:2-186).  The couplings must have been
+    set with ``set_force_couplings``."""
+    fdm, h = fermion_det_matrix, fermion_det_matrix.handle
+    iu, iv = _tmp_vecs(fdm, 2)
+    h.vec_upload(iu, L.as_state(u, h.Lt, h.N))
+    h.vec_upload(iv, L.as_state(v, h.Lt, h.N))
+    out = νRedMdx if (νRedMdx.flags.f_contiguous and νRedMdx.dtype == np.float64) else np.asfortranarray(νRedMdx, dtype=np.float64)
+    h.call("smoqy_force_dMdx_v", C.c_double(ν), iu, iv, L.ptr(out))
+    if out is not νRedMdx:
+        νRedMdx[...] = out
+
+
+def mul_nuRe_dLdx(νRedΛdx, ν, up, u, Λ, fermion_det_matrix):
+    """mul_νRe∂Λ∂x!(νRe∂Λ∂x, ν, u′, u, Λ, elph) (src/holstein_shift_matrix.jl:156-201)."""
+    fdm, h = fermion_det_matrix, fermion_det_matrix.handle
+    iu, iv = _tmp_vecs(fdm, 2)
+    h.vec_upload(iu, L.as_state(up, h.Lt, h.N))
+    h.vec_upload(iv, L.as_state(u, h.Lt, h.N))
+    lam = np.asfortranarray(Λ, dtype=np.float64)
+    h.call("smoqy_lambda_set", 0, L.ptr(lam))
+    out = νRedΛdx if (νRedΛdx.flags.f_contiguous and νRedΛdx.dtype == np.float64) else np.asfortranarray(νRedΛdx, dtype=np.float64)
+    h.call("smoqy_force_dLdx_v", C.c_double(ν), iu, iv, L.ptr(out))
+    if out is not νRedΛdx:
+        νRedΛdx[...] = out
+
+
+
+def calculate_derivative_fermionic_action(dSfdx, pff_calculator: PFFCalculator, electron_phonon_parameters, fermion_det_matrix, preconditioner=I, rng=None, tol=None, maxiter=None):
+    """calculate_derivative_fermionic_action! (src/PFFCalculator.jl:119-157): returns
+    ``(Sf, iters, ϵ)`` and accumulates ∂S_f/∂x into ``dSfdx`` (``Nph x Ltau``)."""
+    Sf, iters, eps = calculate_fermionic_action(pff_calculator, electron_phonon_parameters, fermion_det_matrix, preconditioner, rng, tol, maxiter)
+    set_force_phonons(fermion_det_matrix, fermion_det_matrix._force_couplings.x)
+    out = dSfdx if (dSfdx.flags.f_contiguous and dSfdx.dtype == np.float64) else np.asfortranarray(dSfdx, dtype=np.float64)
+    pff_calculator.handle.call("smoqy_force_v", pff_calculator._u, L.ptr(out))
+    if out is not dSfdx:
+        dSfdx[...] = out
+    return Sf, iters, eps

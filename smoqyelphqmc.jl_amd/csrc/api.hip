@@ -91,6 +91,15 @@ struct smoqy_ctx {
     int *d_poff = nullptr, *d_psrc = nullptr;
     double2 *d_pcs = nullptr;
     double *h_lan = nullptr;  // pinned [nw][2][1024]
+    // force terms
+    struct ForceState {
+        bool set = false;
+        int Nph = 0, Nhol = 0, Nssh = 0, Q = 0;
+        double dtau = 0;
+        void *blob = nullptr;   // one device allocation holding every coupling table
+        double *d_x = nullptr, *d_contrib = nullptr, *d_out = nullptr, *h_out = nullptr;
+        ForceArgs tmpl{};
+    } force;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -227,6 +236,9 @@ int smoqy_destroy(smoqy_ctx *c)
         if (v) (void)hipFree(v);
     if (c->h_st) (void)hipHostFree(c->h_st);
     if (c->h_lan) (void)hipHostFree(c->h_lan);
+    if (c->force.h_out) (void)hipHostFree(c->force.h_out);
+    for (void *q : {c->force.blob, (void *)c->force.d_x, (void *)c->force.d_contrib, (void *)c->force.d_out})
+        if (q) (void)hipFree(q);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -242,7 +254,7 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) FAIL(c, 4, "this library is built for gfx950 (MI355X) only; device %d is %s", c->device, prop.gcnArchName);
     static std::once_flag cfg_once;
-    std::call_once(cfg_once, [] { configure_fdm_kernels(); configure_kpm_kernels(); configure_tfft_kernels(); });
+    std::call_once(cfg_once, [] { configure_fdm_kernels(); configure_kpm_kernels(); configure_tfft_kernels(); configure_force_kernels(); });
     HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIPCHK(c, hipEventCreate(&c->ev0));
@@ -1399,6 +1411,175 @@ int smoqy_cg_solve(smoqy_ctx *c, void *x, const void *b, int x_is_b, int sys0, i
         if (eps) eps[k] = ep[sys0 + k];
     }
     return download_from(c, c->scr[2], x, sys0, count);
+}
+
+// ---- force terms ----------------------------------------------------------------------------------------
+
+int smoqy_force_set_couplings(smoqy_ctx *c, const smoqy_couplings *cp)
+{
+    CHECK_CTX(c);
+    const Geometry &g = c->g;
+    if (g.nrhs != 1) FAIL(c, 1, "the force entry points need a handle with nrhs = 1");
+    if (!cp || cp->Nph < 0 || cp->Nholstein < 0 || cp->Nssh < 0) FAIL(c, 1, "invalid couplings");
+    auto &F = c->force;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (void *q : {F.blob, (void *)F.d_x, (void *)F.d_contrib, (void *)F.d_out})
+        if (q) (void)hipFree(q);
+    if (F.h_out) (void)hipHostFree(F.h_out);
+    F = smoqy_ctx::ForceState{};
+    const int Nph = cp->Nph, Nhol = cp->Nholstein, Nssh = cp->Nssh;
+    const int Q = 2 * Nhol + 2 * Nssh;
+    // integer tables
+    std::vector<int> h_c2p(Nhol), h_c2s(Nhol), h_ps(Nhol), s_c2p(2 * (size_t)Nssh), bond_ptr((size_t)g.Nh + 1, 0), bond_cpl((size_t)Nssh);
+    for (int k = 0; k < Nhol; ++k) {
+        const int64_t p = cp->h_coupling_to_phonon[k], i = cp->h_coupling_to_site[k];
+        if (p < 1 || p > Nph || i < 1 || i > g.N) FAIL(c, 1, "holstein coupling %d: phonon %lld / site %lld out of range", k + 1, (long long)p, (long long)i);
+        h_c2p[k] = (int)p - 1; h_c2s[k] = (int)i - 1; h_ps[k] = cp->h_ph_sym[k] ? 1 : 0;
+    }
+    for (int k = 0; k < Nssh; ++k) {
+        const int64_t p = cp->s_coupling_to_phonon[2 * k], pp = cp->s_coupling_to_phonon[2 * k + 1], n = cp->s_bond[k];
+        if (p < 1 || p > Nph || pp < 1 || pp > Nph || n < 1 || n > g.Nh) FAIL(c, 1, "ssh coupling %d: phonons %lld, %lld / bond %lld out of range", k + 1, (long long)p, (long long)pp, (long long)n);
+        s_c2p[2 * k] = (int)p - 1; s_c2p[2 * k + 1] = (int)pp - 1;
+        bond_ptr[n]++;  // counts, shifted by one
+    }
+    for (int h = 0; h < g.Nh; ++h) bond_ptr[h + 1] += bond_ptr[h];
+    {
+        std::vector<int> fill(bond_ptr.begin(), bond_ptr.end() - 1);
+        for (int k = 0; k < Nssh; ++k) bond_cpl[fill[(int)cp->s_bond[k] - 1]++] = k;  // coupling order within a bond = ascending c (hopping_to_couplings order)
+    }
+    // phonon -> contribution slots, in the order the reference adds them: dK pass 0/1 (bond order), dV, dΛ
+    std::vector<std::vector<std::pair<int, double>>> lists((size_t)Nph);
+    for (int k = 0; k < Nssh; ++k)
+        for (int pass = 0; pass < 2; ++pass) {
+            const int slot = Nhol + 2 * k + pass;
+            if (cp->finite_mass[s_c2p[2 * k]]) lists[s_c2p[2 * k]].push_back({slot, -1.0});          // :229-231
+            if (cp->finite_mass[s_c2p[2 * k + 1]]) lists[s_c2p[2 * k + 1]].push_back({slot, +1.0});  // :233-235
+        }
+    for (int k = 0; k < Nhol; ++k) {
+        if (cp->finite_mass[h_c2p[k]]) lists[h_c2p[k]].push_back({k, 1.0});                          // :274
+        lists[h_c2p[k]].push_back({Nhol + 2 * Nssh + k, 1.0});                                        // holstein_shift_matrix.jl:193
+    }
+    std::vector<int> ph_ptr((size_t)Nph + 1, 0), ph_slot;
+    std::vector<double> ph_sign;
+    for (int p = 0; p < Nph; ++p) {
+        for (auto &e : lists[p]) { ph_slot.push_back(e.first); ph_sign.push_back(e.second); }
+        ph_ptr[p + 1] = (int)ph_slot.size();
+    }
+    // one blob: [ints | doubles]
+    const size_t n_int = h_c2p.size() + h_c2s.size() + h_ps.size() + s_c2p.size() + bond_ptr.size() + bond_cpl.size() + ph_ptr.size() + ph_slot.size();
+    const size_t n_dbl = 4 * (size_t)Nhol + 4 * (size_t)Nssh + ph_sign.size();
+    const size_t int_bytes = ((n_int * sizeof(int) + 15) / 16) * 16;
+    HIPCHK(c, hipMalloc(&F.blob, int_bytes + n_dbl * sizeof(double) + 16));
+    std::vector<int> ib;
+    ib.reserve(n_int);
+    auto put_i = [&](const std::vector<int> &v) { const size_t off = ib.size(); ib.insert(ib.end(), v.begin(), v.end()); return (const int *)F.blob + off; };
+    ForceArgs &t = F.tmpl;
+    t = ForceArgs{};
+    t.h_c2p = put_i(h_c2p); t.h_c2s = put_i(h_c2s); t.h_phsym = put_i(h_ps); t.s_c2p = put_i(s_c2p);
+    t.bond_ptr = put_i(bond_ptr); t.bond_cpl = put_i(bond_cpl); t.ph_ptr = put_i(ph_ptr); t.ph_slot = put_i(ph_slot);
+    std::vector<double> db;
+    db.reserve(n_dbl);
+    const double *dbase = (const double *)((const char *)F.blob + int_bytes);
+    auto put_d = [&](const double *src, size_t n) { const size_t off = db.size(); db.insert(db.end(), src, src + n); return dbase + off; };
+    t.h_alpha = put_d(cp->h_alpha, Nhol); t.h_alpha2 = put_d(cp->h_alpha2, Nhol); t.h_alpha3 = put_d(cp->h_alpha3, Nhol); t.h_alpha4 = put_d(cp->h_alpha4, Nhol);
+    t.s_alpha = put_d(cp->s_alpha, Nssh); t.s_alpha2 = put_d(cp->s_alpha2, Nssh); t.s_alpha3 = put_d(cp->s_alpha3, Nssh); t.s_alpha4 = put_d(cp->s_alpha4, Nssh);
+    t.ph_sign = put_d(ph_sign.data(), ph_sign.size());
+    if (!ib.empty()) HIPCHK(c, hipMemcpy(F.blob, ib.data(), ib.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (!db.empty()) HIPCHK(c, hipMemcpy((char *)F.blob + int_bytes, db.data(), db.size() * sizeof(double), hipMemcpyHostToDevice));
+    const size_t nx = (size_t)g.nw * g.Lt * std::max(Nph, 1);
+    HIPCHK(c, hipMalloc(&F.d_x, nx * sizeof(double)));
+    HIPCHK(c, hipMemset(F.d_x, 0, nx * sizeof(double)));
+    HIPCHK(c, hipMalloc(&F.d_out, nx * sizeof(double)));
+    HIPCHK(c, hipHostMalloc(&F.h_out, nx * sizeof(double)));
+    HIPCHK(c, hipMalloc(&F.d_contrib, (size_t)g.nw * g.Lt * std::max(Q, 1) * sizeof(double)));
+    F.Nph = Nph; F.Nhol = Nhol; F.Nssh = Nssh; F.Q = Q; F.dtau = cp->dtau; F.set = true;
+    return 0;
+}
+
+int smoqy_force_set_phonons(smoqy_ctx *c, const double *x_all)
+{
+    CHECK_CTX(c);
+    if (!c->force.set) FAIL(c, 1, "call smoqy_force_set_couplings first");
+    const size_t nx = (size_t)c->g.nw * c->g.Lt * c->force.Nph;
+    if (nx) HIPCHK(c, hipMemcpyAsync(c->force.d_x, x_all, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static ForceArgs force_args(smoqy_ctx *c, double nu, const double2 *u, const double2 *v)
+{
+    const Geometry &g = c->g;
+    ForceArgs a = c->force.tmpl;
+    a.Lt = g.Lt; a.N = g.N; a.Nh = g.Nh; a.ncol = g.ncol; a.nsys = g.nsys; a.nrhs = g.nrhs; a.nw = g.nw;
+    a.Tc = 1; a.nchunk = g.Lt;  // one slice per workgroup: the kernel keeps two N-vectors per slice in LDS
+    a.bonds = c->d_bonds; a.col_off = c->d_col_off; a.expV = c->d_expV; a.ch = c->d_ch; a.sh = c->d_sh; a.lam = c->d_lam;
+    a.u = u; a.v = v; a.nu = nu; a.dtau = c->force.dtau;
+    a.Nph = c->force.Nph; a.Nhol = c->force.Nhol; a.Nssh = c->force.Nssh; a.Q = c->force.Q;
+    a.x = c->force.d_x; a.contrib = c->force.d_contrib;
+    return a;
+}
+
+// reduce the contribution slots into d_out (+=), bring it to the host and add it to `out`
+static int force_finish(smoqy_ctx *c, const ForceArgs &a, double *out, bool fetch)
+{
+    launch_force_reduce(c->stream, a, c->force.d_out);
+    if (!fetch) return check_launch(c, "force");
+    const size_t nx = (size_t)c->g.nw * c->g.Lt * c->force.Nph;
+    HIPCHK(c, hipMemcpyAsync(c->force.h_out, c->force.d_out, nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int rc = check_launch(c, "force")) return rc;
+    for (size_t k = 0; k < nx; ++k) out[k] += c->force.h_out[k];
+    return 0;
+}
+
+static int force_begin(smoqy_ctx *c)
+{
+    if (!c->force.set) FAIL(c, 1, "call smoqy_force_set_couplings first");
+    const size_t nx = (size_t)c->g.nw * c->g.Lt * std::max(c->force.Nph, 1);
+    HIPCHK(c, hipMemsetAsync(c->force.d_out, 0, nx * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->force.d_contrib, 0, (size_t)c->g.nw * c->g.Lt * std::max(c->force.Q, 1) * sizeof(double), c->stream));
+    return 0;
+}
+
+int smoqy_force_dMdx_v(smoqy_ctx *c, double nu, int u, int v, double *out)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, u)) return rc;
+    if (int rc = check_vec(c, v)) return rc;
+    if (int rc = force_begin(c)) return rc;
+    ForceArgs a = force_args(c, nu, c->vecs[u], c->vecs[v]);
+    if (sizeof(double2) * 2 * (size_t)a.N > 160 * 1024 - 256) FAIL(c, 5, "N = %d does not fit the force kernel's LDS tile", a.N);
+    launch_dmdx(c->stream, a, c->g.is_sym != 0);
+    return force_finish(c, a, out, true);
+}
+
+int smoqy_force_dLdx_v(smoqy_ctx *c, double nu, int up, int u, double *out)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, up)) return rc;
+    if (int rc = check_vec(c, u)) return rc;
+    if (int rc = force_begin(c)) return rc;
+    ForceArgs a = force_args(c, nu, c->vecs[up], c->vecs[u]);
+    launch_dldx(c->stream, a);
+    return force_finish(c, a, out, true);
+}
+
+int smoqy_force_v(smoqy_ctx *c, int psi, double *out)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, psi)) return rc;
+    if (int rc = force_begin(c)) return rc;
+    const Geometry &g = c->g;
+    double2 *Psi = c->vecs[psi], *LPsi = c->scr[1], *APsi = c->scr[2], *MtAPsi = c->scr[0];
+    launch_lambda_apply(c->stream, SMOQY_LAMBDA_MUL, LPsi, Psi, c->d_lam, g.Lt, g.N, g.nsys, g.nrhs, -1);           // ΛΨ            PFFCalculator.jl:146
+    if (int rc = matvec_dev(c, SMOQY_OP_M, APsi, LPsi, nullptr, nullptr, 0, g.nsys)) return rc;                      // AΨ = MΛΨ      :148
+    ForceArgs a = force_args(c, -2.0, APsi, LPsi);
+    if (sizeof(double2) * 2 * (size_t)a.N > 160 * 1024 - 256) FAIL(c, 5, "N = %d does not fit the force kernel's LDS tile", a.N);
+    launch_dmdx(c->stream, a, g.is_sym != 0);                                                                        // -2 Re<AΨ|∂M/∂x|ΛΨ>   :150
+    if (int rc = matvec_dev(c, SMOQY_OP_MT, MtAPsi, APsi, nullptr, nullptr, 0, g.nsys)) return rc;                   // MᵀAΨ          :153
+    ForceArgs b = force_args(c, -2.0, MtAPsi, Psi);
+    launch_dldx(c->stream, b);                                                                                       // -2 Re<MᵀAΨ|∂Λ/∂x|Ψ>  :155
+    return force_finish(c, b, out, true);
 }
 
 // ---- measurement aids -------------------------------------------------------------------------------

@@ -1,0 +1,218 @@
+// Force terms of the pseudofermion action for gfx950 (SURVEY.md §8(f), rank 1 "next" row):
+//   mul_νRe∂M∂x!   src/fermion_det_matrix_dervative.jl:2-113 (Sym), :116-186 (Asym)
+//   _mul_νReΔτ∂Kc∂x! :189-245,  _mul_νReΔτ∂V∂x! :249-289
+//   mul_νRe∂Λ∂x!   src/holstein_shift_matrix.jl:156-201
+//
+// Like the matvec, the derivative is independent slice by slice once v[l-1] has been shifted in:
+// a workgroup owns a tau-chunk of one system, holds |u'> and |v'> in LDS and walks the checkerboard
+// colours exactly in the reference's order (lmul on u', ldiv on v', one colour at a time, lane =
+// bond).  Every (coupling, slice) writes its value to its own slot of a contribution buffer and a
+// second kernel sums the slots that feed one phonon in a fixed order — no atomics, bit-reproducible.
+// This runs once per HMC step (not per CG iteration), so it uses the generic memory-resident bond
+// tables rather than the register-resident machinery of the matvec.
+#include "smoqy_internal.h"
+
+namespace smoqy {
+
+namespace {
+
+__device__ __forceinline__ int wrapf(int l, int Lt) { return l >= Lt ? l - Lt : (l < 0 ? l + Lt : l); }
+
+// one colour: optional SSH accumulation, then u' <- C u', v' <- C⁻¹ v'  (:53-62 / :98-108 / :170-182)
+__device__ __forceinline__ void colour_step(const ForceArgs &a, double2 *UP, double2 *VP, int nk, int l0, int w, int c, const double *ch, const double *sh, bool accumulate, int pass,
+                                            double dtau_k, double nu, bool apply_u, bool apply_v)
+{
+    const int N = a.N, Lt = a.Lt;
+    for (int h = a.col_off[c] + (int)threadIdx.x; h < a.col_off[c + 1]; h += (int)blockDim.x) {
+        const int2 b = a.bonds[h];
+        for (int k = 0; k < nk; ++k) {
+            const int l = l0 + k;
+            double2 *ur = UP + (size_t)k * N, *vr = VP + (size_t)k * N;
+            const double2 ui = ur[b.x], uj = ur[b.y], vi = vr[b.x], vj = vr[b.y];
+            if (accumulate) {
+                const double *xs = a.x + ((size_t)w * Lt + l) * a.Nph;
+                for (int q = a.bond_ptr[h]; q < a.bond_ptr[h + 1]; ++q) {
+                    const int cpl = a.bond_cpl[q];
+                    const int p = a.s_c2p[2 * cpl], pp = a.s_c2p[2 * cpl + 1];
+                    const double dx = xs[pp] - xs[p];                                                            // :223
+                    const double dK = dtau_k * (a.s_alpha[cpl] + 2 * a.s_alpha2[cpl] * dx + 3 * a.s_alpha3[cpl] * dx * dx + 4 * a.s_alpha4[cpl] * dx * dx * dx);  // :225
+                    // ν Re[conj(u'_j) dK v'_i + conj(u'_i) conj(dK) v'_j]                                        // :227
+                    const double val = nu * dK * ((uj.x * vi.x + uj.y * vi.y) + (ui.x * vj.x + ui.y * vj.y));
+                    a.contrib[((size_t)w * Lt + l) * a.Q + a.Nhol + 2 * cpl + pass] = val;
+                }
+            }
+            const double cc = ch[(size_t)l * a.Nh + h], ss = sh[(size_t)l * a.Nh + h];
+            if (apply_u) {
+                ur[b.x] = make_double2(cc * ui.x + ss * uj.x, cc * ui.y + ss * uj.y);
+                ur[b.y] = make_double2(cc * uj.x + ss * ui.x, cc * uj.y + ss * ui.y);
+            }
+            if (apply_v) {
+                vr[b.x] = make_double2(cc * vi.x - ss * vj.x, cc * vi.y - ss * vj.y);
+                vr[b.y] = make_double2(cc * vj.x - ss * vi.x, cc * vj.y - ss * vi.y);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// plain colour on one array (building B v)
+__device__ __forceinline__ void colour_plain(const ForceArgs &a, double2 *X, int nk, int l0, int c, const double *ch, const double *sh)
+{
+    const int N = a.N;
+    for (int h = a.col_off[c] + (int)threadIdx.x; h < a.col_off[c + 1]; h += (int)blockDim.x) {
+        const int2 b = a.bonds[h];
+        for (int k = 0; k < nk; ++k) {
+            const double cc = ch[(size_t)(l0 + k) * a.Nh + h], ss = sh[(size_t)(l0 + k) * a.Nh + h];
+            double2 *r = X + (size_t)k * N;
+            const double2 x = r[b.x], y = r[b.y];
+            r[b.x] = make_double2(cc * x.x + ss * y.x, cc * x.y + ss * y.y);
+            r[b.y] = make_double2(cc * y.x + ss * x.x, cc * y.y + ss * x.y);
+        }
+    }
+    __syncthreads();
+}
+
+template <bool SYM>
+__global__ void __launch_bounds__(kThreads) dmdx_kernel(ForceArgs a)
+{
+    extern __shared__ double2 lds[];
+    const int chunk = blockIdx.x % a.nchunk, sys = blockIdx.x / a.nchunk;
+    const int w = sys / a.nrhs, Lt = a.Lt, N = a.N;
+    const int l0 = chunk * a.Tc, nk = min(a.Tc, Lt - l0);
+    double2 *UP = lds, *VP = lds + (size_t)a.Tc * N;
+    const double *expV = a.expV + (size_t)w * Lt * N, *ch = a.ch + (size_t)w * Lt * a.Nh, *sh = a.sh + (size_t)w * Lt * a.Nh;
+    const size_t sstride = (size_t)a.nsys * N;
+    const double2 *u = a.u + (size_t)sys * N, *v = a.v + (size_t)sys * N;
+    const double nu = -a.nu;  // the reference passes -ν to the helpers (:52, :83, :97, :160, :173)
+    // v'[l] = ∓ v[l-1] (+ on the first slice), u'[l] = u[l]     (:27-30, :42 / :140-143, :152)
+    for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {
+        const int k = idx / N, i = idx - k * N, l = l0 + k;
+        const double2 x = v[(size_t)wrapf(l - 1, Lt) * sstride + i];
+        VP[idx] = (l == 0) ? x : make_double2(-x.x, -x.y);
+        UP[idx] = u[(size_t)l * sstride + i];
+    }
+    __syncthreads();
+    if (SYM) {
+        for (int c = a.ncol - 1; c >= 0; --c) colour_plain(a, VP, nk, l0, c, ch, sh);              // :33
+        for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {                              // :36
+            const int k = idx / N, i = idx - k * N;
+            const double d = expV[(size_t)(l0 + k) * N + i];
+            VP[idx] = make_double2(d * VP[idx].x, d * VP[idx].y);
+        }
+        __syncthreads();
+        for (int c = 0; c < a.ncol; ++c) colour_plain(a, VP, nk, l0, c, ch, sh);                   // :39
+        if (a.Nssh > 0) {
+            for (int c = a.ncol - 1; c >= 0; --c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, true, 0, a.dtau / 2, nu, true, true);  // :50-63
+        } else {
+            // |u'> := Γᵀ|u'> (colours last..first), |v'> := checkerboard_ldiv!(transposed = true) = colours
+            // first..last with inverted factors, exactly as the reference does it (:66-74)
+            for (int c = a.ncol - 1; c >= 0; --c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, false, 0, 0.0, 0.0, true, false);
+            for (int c = 0; c < a.ncol; ++c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, false, 0, 0.0, 0.0, false, true);
+        }
+    } else {
+        for (int c = 0; c < a.ncol; ++c) colour_plain(a, VP, nk, l0, c, ch, sh);                   // :146
+        for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {                              // :149
+            const int k = idx / N, i = idx - k * N;
+            const double d = expV[(size_t)(l0 + k) * N + i];
+            VP[idx] = make_double2(d * VP[idx].x, d * VP[idx].y);
+        }
+        __syncthreads();
+    }
+    // Holstein term  -ν Re[<u'|Δτ ∂V/∂x|v'>]   (:81-84 / :158-161)
+    for (int idx = threadIdx.x; idx < nk * a.Nhol; idx += blockDim.x) {
+        const int k = idx / a.Nhol, c = idx - k * a.Nhol, l = l0 + k;
+        const int p = a.h_c2p[c], i = a.h_c2s[c];
+        const double xx = a.x[((size_t)w * Lt + l) * a.Nph + p];
+        const double dV = a.dtau * (a.h_alpha[c] + 2 * a.h_alpha2[c] * xx + 3 * a.h_alpha3[c] * xx * xx + 4 * a.h_alpha4[c] * xx * xx * xx);  // :280
+        const double2 uu = UP[(size_t)k * N + i], vv = VP[(size_t)k * N + i];
+        a.contrib[((size_t)w * Lt + l) * a.Q + c] = nu * dV * (uu.x * vv.x + uu.y * vv.y);           // :282
+    }
+    if (a.Nssh > 0) {
+        // u' *= exp(-ΔτV), v' /= exp(-ΔτV)   (:87, :90 / :168, :170)
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {
+            const int k = idx / N, i = idx - k * N;
+            const double d = expV[(size_t)(l0 + k) * N + i], di = 1.0 / d;
+            UP[idx] = make_double2(d * UP[idx].x, d * UP[idx].y);
+            VP[idx] = SYM ? make_double2(di * VP[idx].x, di * VP[idx].y) : make_double2(VP[idx].x / d, VP[idx].y / d);
+        }
+        __syncthreads();
+        if (SYM) {
+            for (int c = 0; c < a.ncol; ++c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, true, 1, a.dtau / 2, nu, true, true);     // :95-109
+        } else {
+            for (int c = a.ncol - 1; c >= 0; --c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, true, 0, a.dtau, nu, true, true);    // :172-183
+        }
+    }
+}
+
+// mul_νRe∂Λ∂x!  (src/holstein_shift_matrix.jl:156-201): up = Mᵀ A Ψ, u = Ψ
+__global__ void dldx_kernel(ForceArgs a)
+{
+    const size_t tot = (size_t)a.nsys * a.Lt * a.Nhol;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % a.Nhol);
+        const int l = (int)((idx / a.Nhol) % a.Lt), sys = (int)(idx / ((size_t)a.Nhol * a.Lt));
+        const int w = sys / a.nrhs;
+        double val = 0.0;
+        if (a.h_phsym[c]) {
+            const int p = a.h_c2p[c], site = a.h_c2s[c];
+            const double xx = a.x[((size_t)w * a.Lt + l) * a.Nph + p];
+            const double dL = a.dtau * (a.h_alpha[c] + 3 * a.h_alpha3[c] * xx * xx) / 2 * a.lam[((size_t)w * a.Lt + l) * a.N + site];  // :192
+            const int lm = (l == 0) ? a.Lt - 1 : l - 1;
+            const size_t sstride = (size_t)a.nsys * a.N;
+            const double2 x = a.u[(size_t)lm * sstride + (size_t)sys * a.N + site], y = a.v[(size_t)l * sstride + (size_t)sys * a.N + site];
+            val = a.nu * dL * (x.x * y.x + x.y * y.y);                                                                                 // :193
+        }
+        a.contrib[((size_t)w * a.Lt + l) * a.Q + a.Nhol + 2 * a.Nssh + c] = val;
+    }
+}
+
+// out[w][l][p] += Σ sign · contrib over the slots that feed phonon p, in list order
+__global__ void force_reduce_kernel(ForceArgs a, double *out)
+{
+    const size_t tot = (size_t)a.nw * a.Lt * a.Nph;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(idx % a.Nph);
+        const size_t wl = idx / a.Nph;
+        const double *cb = a.contrib + wl * a.Q;
+        double acc = 0.0;
+        for (int q = a.ph_ptr[p]; q < a.ph_ptr[p + 1]; ++q) acc += a.ph_sign[q] * cb[a.ph_slot[q]];
+        out[idx] += acc;
+    }
+}
+
+}  // namespace
+
+void configure_force_kernels()
+{
+    (void)hipFuncSetAttribute((const void *)dmdx_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute((const void *)dmdx_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+}
+
+void launch_dmdx(hipStream_t st, const ForceArgs &a, bool sym)
+{
+    const size_t lds = sizeof(double2) * 2 * (size_t)a.Tc * a.N;
+    const dim3 grid((unsigned)(a.nchunk * a.nsys));
+    if (sym) hipLaunchKernelGGL((dmdx_kernel<true>), grid, dim3(kThreads), lds, st, a);
+    else hipLaunchKernelGGL((dmdx_kernel<false>), grid, dim3(kThreads), lds, st, a);
+}
+
+void launch_dldx(hipStream_t st, const ForceArgs &a)
+{
+    const size_t tot = (size_t)a.nsys * a.Lt * a.Nhol;
+    if (tot == 0) return;
+    int blocks = (int)((tot + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(dldx_kernel, dim3(blocks), dim3(256), 0, st, a);
+}
+
+void launch_force_reduce(hipStream_t st, const ForceArgs &a, double *out)
+{
+    const size_t tot = (size_t)a.nw * a.Lt * a.Nph;
+    if (tot == 0) return;
+    int blocks = (int)((tot + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(force_reduce_kernel, dim3(blocks), dim3(256), 0, st, a, out);
+}
+
+}  // namespace smoqy

@@ -146,6 +146,30 @@ void launch_cg_update_xr(hipStream_t s, const CgArgs &a);
 void launch_cg_update_p(hipStream_t s, const CgArgs &a);
 void launch_cg_finish(hipStream_t s, const CgArgs &a);
 
+// force terms (kernels_force.hip)
+struct ForceArgs {
+    int Lt, N, Nh, ncol, nsys, nrhs, nw, Tc, nchunk;
+    const int2 *bonds;
+    const int *col_off;
+    const double *expV, *ch, *sh, *lam;
+    const double2 *u, *v;
+    double nu, dtau;
+    int Nph, Nhol, Nssh, Q;             // Q = Nhol (dV) + 2 Nssh (dK, two passes) + Nhol (dΛ) contribution slots per (walker, slice)
+    const double *x;                    // [nw][Lt][Nph]
+    const int *h_c2p, *h_c2s, *h_phsym;
+    const double *h_alpha, *h_alpha2, *h_alpha3, *h_alpha4;
+    const int *s_c2p;                   // [Nssh][2]
+    const double *s_alpha, *s_alpha2, *s_alpha3, *s_alpha4;
+    const int *bond_ptr, *bond_cpl;     // CSR: checkerboard bond -> SSH couplings
+    const int *ph_ptr, *ph_slot;        // CSR: phonon -> contribution slots
+    const double *ph_sign;
+    double *contrib;                    // [nw][Lt][Q]
+};
+void configure_force_kernels();
+void launch_dmdx(hipStream_t st, const ForceArgs &a, bool sym);
+void launch_dldx(hipStream_t st, const ForceArgs &a);
+void launch_force_reduce(hipStream_t st, const ForceArgs &a, double *out);
+
 // own tau-FFT (kernels_tfft.hip): Stockham passes over LDS site tiles, optionally fused with the CG updates
 struct TfftArgs {
     int Lt, N, nsys, SB, ntile, nfac;

@@ -127,6 +127,31 @@ class ElectronPhononParameters:
 
 
 @dataclass
+class ForceCouplings:
+    """Flattened couplings the force terms need (src/fermion_det_matrix_dervative.jl:189-289,
+    src/holstein_shift_matrix.jl:156-201): what a shim extracts from SmoQyDQMC's
+    ``holstein_parameters_up`` / ``ssh_parameters_up`` / ``phonon_parameters.M``.  All ids 1-based.
+    ``s_bond[c]`` is the position of coupling c's hopping in the colour-sorted neighbour table."""
+
+    x: np.ndarray            # (Nph, Ltau)
+    dtau: float
+    finite_mass: np.ndarray  # (Nph,) isfinite(M)
+    h_alpha: np.ndarray
+    h_alpha2: np.ndarray
+    h_alpha3: np.ndarray
+    h_alpha4: np.ndarray
+    h_c2p: np.ndarray
+    h_c2s: np.ndarray
+    h_phsym: np.ndarray
+    s_alpha: np.ndarray
+    s_alpha2: np.ndarray
+    s_alpha3: np.ndarray
+    s_alpha4: np.ndarray
+    s_c2p: np.ndarray        # (2, Nssh)
+    s_bond: np.ndarray       # (Nssh,)
+
+
+@dataclass
 class SyntheticModel:
     name: str
     fpi: FermionPathIntegral
@@ -135,6 +160,36 @@ class SyntheticModel:
     mu: float
     kind: str  # "holstein" | "ossh" | "bssh"
     meta: dict = field(default_factory=dict)
+
+    def force_couplings(self, perm) -> ForceCouplings:
+        """Couplings of this model in the flattened form the force entry points take.  ``perm`` is the
+        checkerboard permutation (sorted bond n is model hopping perm[n])."""
+        x = self.elph.x
+        z = np.zeros(0)
+        zi = np.zeros(0, dtype=np.int64)
+        inv = np.empty(len(perm), dtype=np.int64)
+        inv[np.asarray(perm) - 1] = np.arange(1, len(perm) + 1)  # model hopping h -> sorted position n
+        if self.kind == "holstein":
+            hol = self.elph.holstein
+            n = len(hol.alpha)
+            return ForceCouplings(x, self.elph.dtau, np.ones(x.shape[0], dtype=np.int32), hol.alpha, np.zeros(n), hol.alpha3, np.zeros(n), hol.coupling_to_phonon, hol.coupling_to_site,
+                                  np.asarray(hol.ph_sym_form, dtype=np.int32), z, z, z, z, np.zeros((2, 0), dtype=np.int64), zi)
+        Nh = self.fpi.t.shape[0]
+        a = np.full(Nh, self.alpha)
+        zz = np.zeros(Nh)
+        if self.kind == "bssh":
+            # one finite-mass phonon per bond plus an infinite-mass partner pinned at 0 (how SmoQyDQMC
+            # expresses a bond mode as a difference of two modes): rows 0..Nh-1 = x, last row = 0
+            xe = np.asfortranarray(np.vstack([x, np.zeros((1, x.shape[1]))]))
+            fm = np.ones(Nh + 1, dtype=np.int32)
+            fm[Nh] = 0
+            c2p = np.vstack([np.full(Nh, Nh + 1), np.arange(1, Nh + 1)]).astype(np.int64)
+            return ForceCouplings(xe, self.elph.dtau, fm, z, z, z, z, zi, zi, np.zeros(0, dtype=np.int32), a, zz, zz, zz, c2p, inv[np.arange(Nh)])
+        # optical SSH: x / y polarised mode on every site; +x bonds couple the x modes, +y bonds the y modes
+        nt, N = self.fpi.neighbor_table, self.fpi.N
+        off = np.where(np.arange(Nh) < Nh // 2, 0, N)
+        c2p = np.vstack([nt[0] + off, nt[1] + off]).astype(np.int64)
+        return ForceCouplings(x, self.elph.dtau, np.ones(x.shape[0], dtype=np.int32), z, z, z, z, zi, zi, np.zeros(0, dtype=np.int32), a, zz, zz, zz, c2p, inv[np.arange(Nh)])
 
     def refresh_from_x(self):
         """Recompute ``V`` / ``t`` of the path integral from the current phonon field ``x``

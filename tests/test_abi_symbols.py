@@ -13,7 +13,7 @@ from smoqyelphqmc_amd import _lib as L
 def declared_symbols():
     txt = open(L.HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(smoqy_[a-z_0-9]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(smoqy_[A-Za-z_0-9]+)\s*\(", txt)))
 
 
 def test_library_builds_and_exports_every_declared_symbol():
