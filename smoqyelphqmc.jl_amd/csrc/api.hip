@@ -810,6 +810,9 @@ static int lambda_update_range(smoqy_ctx *c, int w0, int nw, const double *x, in
         last[site] = k;
     }
     if (nx) HIPCHK(c, hipMemcpyAsync(c->d_stage_real, x, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // the force kernels read the same phonon fields: keep their device copy in step (no second transfer)
+    if (nx && c->force.set && c->force.Nph == Nph)
+        HIPCHK(c, hipMemcpyAsync(c->force.d_x + (size_t)w0 * g.Lt * Nph, c->d_stage_real, nx * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     if (ncoup) {
         HIPCHK(c, hipMemcpyAsync(c->d_stage_real + nx, alpha, (size_t)ncoup * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_stage_real + nx + ncoup, alpha3, (size_t)ncoup * sizeof(double), hipMemcpyHostToDevice, c->stream));

@@ -13,12 +13,11 @@ reference call stack:
 
   sample_pseudofermion_fields!   Φ = Λᵀ Mᵀ R                        src/PFFCalculator.jl:56-76
   calculate_fermionic_action!    Ψ = Λ⁻¹ (MᵀM)⁻¹ Λ⁻ᵀ Φ, S = Φ·Ψ     src/PFFCalculator.jl:79-116
-  force operator applies         ΛΨ, M ΛΨ, Mᵀ M ΛΨ                   src/PFFCalculator.jl:146-153
+  force (∂S_f/∂x)                ΛΨ, MΛΨ, ∂M/∂x, MᵀMΛΨ, ∂Λ/∂x        src/PFFCalculator.jl:146-155
   update!(fdm, fpi)              exp/cosh/sinh refresh               src/FermionDetMatrix.jl:208-236
   update_preconditioner!         B̄ means, Lanczos, KPM coefficients  src/KPMPreconditioner.jl:554-597
 
-What is NOT part of the hot path (SmoQyDQMC's EFA leapfrog, the bosonic action, the force
-contractions ∂M/∂x — SURVEY.md §8(f)) is replaced by a synthetic drift of the phonon field
+What is NOT part of the hot path (SmoQyDQMC's EFA leapfrog and bosonic action) is replaced by a synthetic drift of the phonon field
 ``x ← x + δ·π`` with a fixed random "momentum" π, so successive solves see slowly moving
 fields like an HMC trajectory does.  Random numbers are drawn on the host, one generator per
 walker (the reference's rng stays on the host).
@@ -75,6 +74,17 @@ class WalkerBatch:
         self.phi, self.u, self.u1, self.u2 = (self.h.vec_alloc() for _ in range(4))
         self._R = self.h.pinned_empty((self.Lt, self.N, nwalkers), dtype=np.complex128, order="F")
         self._tmp = np.empty_like(self.xs)
+        # force terms (src/PFFCalculator.jl:146-155): couplings go to the device once
+        self.force_couplings = m0.force_couplings(self.perm)
+        self._cs, self._cs_keep = L.couplings_struct(self.force_couplings)
+        self.h.call("smoqy_force_set_couplings", C.byref(self._cs))
+        self.Nph_force = int(self.force_couplings.x.shape[0])
+        if self.Nph_force != self.Nph:  # bond-SSH: one extra infinite-mass partner mode pinned at zero
+            self.xs_force = self.h.pinned_empty((nwalkers, self.Lt, self.Nph_force))
+            self.xs_force[...] = 0.0
+        else:
+            self.xs_force = self.xs
+        self.dSdx = self.h.pinned_empty((nwalkers, self.Lt, self.Nph_force))
         self.stats = SweepStats()
         self.refresh_fields(first=True)
 
@@ -96,8 +106,12 @@ class WalkerBatch:
             self.h.call("smoqy_lambda_update_all", L.ptr(self.xs), self.Nph, C.c_double(self.dtau), len(hol.alpha), L.ptr(np.ascontiguousarray(hol.coupling_to_phonon, dtype=np.int64)),
                         L.ptr(np.ascontiguousarray(hol.coupling_to_site, dtype=np.int64)), L.ptr(np.ascontiguousarray(hol.alpha, dtype=np.float64)), L.ptr(np.ascontiguousarray(hol.alpha3, dtype=np.float64)),
                         L.ptr(np.ascontiguousarray(hol.ph_sym_form, dtype=np.int32)))
-        elif first:
-            self.h.call("smoqy_lambda_update_all", None, 0, C.c_double(self.dtau), 0, None, None, None, None, None)
+        else:
+            if first:
+                self.h.call("smoqy_lambda_update_all", None, 0, C.c_double(self.dtau), 0, None, None, None, None, None)
+            if self.xs_force is not self.xs:
+                self.xs_force[:, :, : self.Nph] = self.xs
+            self.h.call("smoqy_force_set_phonons", L.ptr(self.xs_force))  # Holstein models share the Λ upload instead
 
     def update_preconditioner(self):
         # randn!(rng, v) at KPMPreconditioner.jl:634, one start vector per walker
@@ -140,12 +154,13 @@ class WalkerBatch:
         self.stats.iters_sum += int(iters.sum())
         return sf.real, iters, eps
 
-    def force_operator_applies(self):
-        """The operator applies of calculate_derivative_fermionic_action! that belong to the hot
-        path (src/PFFCalculator.jl:146, 148, 153); the ∂M/∂x contractions are out of scope."""
-        self.h.call("smoqy_lambda_apply_v", L.LAMBDA_MUL, self.u1, self.u)   # ΛΨ
-        self.h.call("smoqy_matvec_v", L.OP_M, self.u2, self.u1)              # AΨ = M ΛΨ
-        self.h.call("smoqy_matvec_v", L.OP_MT, self.u1, self.u2)             # Mᵀ AΨ
+    def fermionic_force(self):
+        """The tail of calculate_derivative_fermionic_action! (src/PFFCalculator.jl:146-155):
+        ΛΨ, AΨ = MΛΨ, -2 Re⟨AΨ|∂M/∂x|ΛΨ⟩, MᵀAΨ, -2 Re⟨MᵀAΨ|∂Λ/∂x|Ψ⟩ — on the device; the force array
+        (Nph x Ltau per walker) comes back to the host, where the reference's leapfrog consumes it."""
+        self.dSdx[...] = 0.0
+        self.h.call("smoqy_force_v", self.u, L.ptr(self.dSdx))
+        return self.dSdx
 
     def drift_fields(self, pis, step):
         np.multiply(pis, step, out=self._tmp)
@@ -171,7 +186,7 @@ class WalkerBatch:
         pis = self._momentum()
         for _ in range(self.Nt):
             self.calculate_fermionic_action(self.tol_force)
-            self.force_operator_applies()
+            self.fermionic_force()
             self.drift_fields(pis, self.drift / self.Nt)
         last = self.calculate_fermionic_action(self.tol)
         self.drift_fields(pis, -self.drift)      # reject: restore x

@@ -124,3 +124,30 @@ def test_config1_against_oracle_end_to_end():
     assert relerr(batch.h.vec_download(batch.u), psi) < 1e-8
     sf = batch.h.vec_dot(batch.phi, batch.u)[0]
     assert abs(sf - np.vdot(phi, psi)) < 1e-8 * abs(sf)
+
+
+@pytest.mark.parametrize("name", ["holstein_honeycomb_L4_Ltau40", "bssh_chain_L256_Ltau200"])
+def test_sweep_force_matches_oracle(name):
+    """The force the synthetic sweep computes after each solve (WalkerBatch.fermionic_force) against the
+    oracle's restatement of src/PFFCalculator.jl:146-155 on the same Ψ, per walker."""
+    batch = WalkerBatch(name, nwalkers=2)
+    batch.sample_pseudofermion_fields()
+    batch.calculate_fermionic_action(1e-10)
+    dS = batch.fermionic_force().copy()
+    Psi = batch.h.vec_download(batch.u)
+    for w, m in enumerate(batch.models):
+        expV, ch, sh = orc.update_fields(m.fpi.V, m.fpi.t, batch.perm, m.fpi.dtau, True)
+        o = orc.OracleFDM(batch.nt, expV, ch, sh, True)
+        fc = m.force_couplings(batch.perm)
+        e = orc.OracleElph(fc)
+        hol = m.elph.holstein
+        if hol is not None:
+            Lam = orc.update_lambda(batch.Lt, batch.N, m.elph.x, m.elph.dtau, hol.coupling_to_phonon, hol.coupling_to_site, hol.alpha, hol.alpha3, hol.ph_sym_form)
+        else:
+            Lam = orc.update_lambda(batch.Lt, batch.N, m.elph.x, m.elph.dtau, [], [], [], [], [])
+        P = Psi[:, :, w]
+        LP = orc.lambda_apply(Lam, P, "mul")
+        AP = o.mul_M(LP)
+        want = orc.mul_dMdx(o, e, batch.colors, -2.0, AP, LP)
+        orc.mul_dLdx(e, Lam, -2.0, o.mul_Mt(AP), P, want)
+        assert np.abs(dS[w].T - want).max() < 1e-10 * np.abs(want).max()
