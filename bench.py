@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--matvec-reps", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch-scan", action="store_true", help="also report matvec GB/s vs batch size")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="rehearsal of the N>1 control flow on a one-GPU box: every rank uses cuda:0 and the barrier / MAX reduction run over gloo")
     return ap.parse_args()
 
 
@@ -116,10 +118,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    dev = 0 if args.rehearse_one_gpu else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 
     import numpy as np
 
@@ -136,7 +142,7 @@ def main():
         raise SystemExit("--walkers-per-gpu must be a multiple of --streams")
     mine = walker_range(rank, world, wpg)  # walkers [rank*wpg, (rank+1)*wpg): no overlap between ranks, no exchange
     per = wpg // S
-    batches = [WalkerBatch(args.workload, nwalkers=per, walker0=mine.start + s * per, device=local_rank, check_every=args.check_every or None, tau_chunk=args.tau_chunk or None) for s in range(S)]
+    batches = [WalkerBatch(args.workload, nwalkers=per, walker0=mine.start + s * per, device=dev, check_every=args.check_every or None, tau_chunk=args.tau_chunk or None) for s in range(S)]
     batch = batches[0]
     pool = ThreadPoolExecutor(S) if S > 1 else None
 
@@ -161,7 +167,7 @@ def main():
     t0 = time.perf_counter()
     run(args.steps)
     fence()
-    elapsed = reduce_max_time(time.perf_counter() - t0, device="cuda")
+    elapsed = reduce_max_time(time.perf_counter() - t0, device="cpu" if args.rehearse_one_gpu else "cuda")
     value = aggregate_throughput(wpg * args.steps, world, elapsed)
 
     if rank == 0:
@@ -207,7 +213,7 @@ def main():
         if args.batch_scan:
             scan = []
             for nb in (1, 2, 4, 8, 16, 32, 64):
-                hb = L.Handle(batch.Lt, batch.N, batch.nt, batch.colors, True, nb, 1, local_rank)
+                hb = L.Handle(batch.Lt, batch.N, batch.nt, batch.colors, True, nb, 1, dev)
                 for w in range(nb):
                     m = batch.models[w % per]
                     hb.call("smoqy_update_from_path_integral", w, L.ptr(m.fpi.V), L.ptr(m.fpi.t), L.ptr(batch.perm), L.C.c_double(m.fpi.dtau))
