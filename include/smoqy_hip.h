@@ -210,6 +210,21 @@ int smoqy_force_dLdx_v(smoqy_ctx *ctx, double nu, int up, int u, double *out);
 /* the tail of calculate_derivative_fermionic_action! (src/PFFCalculator.jl:146-155) from Ψ:
  * ΛΨ, AΨ = MΛΨ, out += -2 Re<AΨ|∂M/∂x|ΛΨ>, MᵀAΨ, out += -2 Re<MᵀAΨ|∂Λ/∂x|Ψ> */
 int smoqy_force_v(smoqy_ctx *ctx, int psi, double *out);
+/* the same force, stored (not accumulated) into out — the first line of the HMC step is fill!(∂S∂x, 0)
+ * (src/EFAPFFHMCUpdater.jl:160), so the transfer can land in the caller's array directly */
+int smoqy_force_store_v(smoqy_ctx *ctx, int psi, double *out);
+
+/* ---- device-side update! from the phonon fields ------------------- */
+
+/* bare on-site energies V⁰ (N) and hoppings t⁰ (Nh, FermionPathIntegral order) — what
+ * SmoQyDQMC.update!(fermion_path_integral, elph, x, -1) leaves behind (src/EFAPFFHMCUpdater.jl:148, 200);
+ * perm is the 1-based checkerboard permutation.  Needs smoqy_force_set_couplings. */
+int smoqy_set_bare_model(smoqy_ctx *ctx, const double *V0, const double *t0, const int64_t *perm);
+/* SmoQyDQMC.update!(fermion_path_integral, elph, x, +1); update!(fdm, fpi); update_Λ! for every walker
+ * from ONE upload of x (Nph x Ltau x nwalkers): V = V⁰ + Σ(αx+α₂x²+α₃x³+α₄x⁴), t = t⁰ - Σ(αΔx+…),
+ * then src/FermionDetMatrix.jl:208-236 and src/holstein_shift_matrix.jl:2-44 on the device
+ * (call sites src/EFAPFFHMCUpdater.jl:148-152, 200-205).  Also refreshes the force kernels' x. */
+int smoqy_update_from_phonons_all(smoqy_ctx *ctx, const double *x_all);
 
 /* ---- measurement aids (bench.py) -------------------------------------------------------- */
 

@@ -293,3 +293,25 @@ def mul_dLdx(elph: OracleElph, Lam, nu, up, u, out=None):
     out = np.zeros((elph.x.shape[0], Lt), order="F") if out is None else out
     lib().orc_mul_dLdx(C.byref(elph.s), _p(Lam), Lt, N, C.c_double(nu), _p(up), _p(u), _p(out))
     return out
+
+
+def fields_from_phonons(c, V0, t0, perm):
+    """``SmoQyDQMC.update!(fermion_path_integral, elph, x, +1)`` on a bare path integral — the source is
+    not under /root/reference, so the functional forms are the antiderivatives of what the reference
+    differentiates: ``∂V_i/∂x_p = α + 2α₂x + 3α₃x² + 4α₄x³`` (src/fermion_det_matrix_dervative.jl:281) and
+    ``∂K_ji/∂Δx`` of the same form with ``K = -t``, ``Δx = x[p′] - x[p]`` (:229-233).  Pinned by the
+    finite-difference test in tests/test_oracle_phonon_fields.py.  ``c`` is a ForceCouplings-like object;
+    returns ``V`` (N x Ltau) and ``t`` (Nh x Ltau, FermionPathIntegral hopping order)."""
+    x = np.asarray(c.x, dtype=np.float64)
+    Lt = x.shape[1]
+    V = np.repeat(np.asarray(V0, dtype=np.float64)[:, None], Lt, axis=1)
+    t = np.repeat(np.asarray(t0, dtype=np.float64)[:, None], Lt, axis=1)
+    for k in range(len(c.h_alpha)):
+        xp = x[int(c.h_c2p[k]) - 1]
+        V[int(c.h_c2s[k]) - 1] += c.h_alpha[k] * xp + c.h_alpha2[k] * xp**2 + c.h_alpha3[k] * xp**3 + c.h_alpha4[k] * xp**4
+    s_c2p = np.asarray(c.s_c2p)
+    for k in range(len(c.s_alpha)):
+        dx = x[int(s_c2p[1, k]) - 1] - x[int(s_c2p[0, k]) - 1]
+        h = int(perm[int(c.s_bond[k]) - 1]) - 1  # sorted bond n is model hopping perm[n]
+        t[h] -= c.s_alpha[k] * dx + c.s_alpha2[k] * dx**2 + c.s_alpha3[k] * dx**3 + c.s_alpha4[k] * dx**4
+    return np.asfortranarray(V), np.asfortranarray(t)

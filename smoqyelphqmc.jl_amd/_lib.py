@@ -98,6 +98,9 @@ SIGNATURES = {
     "smoqy_force_dMdx_v": [_p, _d, _i, _i, _p],
     "smoqy_force_dLdx_v": [_p, _d, _i, _i, _p],
     "smoqy_force_v": [_p, _i, _p],
+    "smoqy_force_store_v": [_p, _i, _p],
+    "smoqy_set_bare_model": [_p, _p, _p, _p],
+    "smoqy_update_from_phonons_all": [_p, _p],
     "smoqy_timer_start": [_p],
     "smoqy_timer_stop": [_p, _pd],
     "smoqy_bench_matvec": [_p, _i, _i, _i, _i, _pd],

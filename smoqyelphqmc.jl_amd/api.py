@@ -527,6 +527,22 @@ def set_force_phonons(fermion_det_matrix: FermionDetMatrix, x):
     fermion_det_matrix.handle.call("smoqy_force_set_phonons", L.ptr(xx))
 
 
+def set_bare_model(fermion_det_matrix: FermionDetMatrix, V0, t0, perm):
+    """Bare on-site energies ``V0`` (N) and hoppings ``t0`` (Nh, FermionPathIntegral order): what
+    ``SmoQyDQMC.update!(fermion_path_integral, elph, x, -1)`` leaves in the path integral
+    (src/EFAPFFHMCUpdater.jl:148, 200).  Needed once before ``update_from_phonons``."""
+    h = fermion_det_matrix.handle
+    h.call("smoqy_set_bare_model", L.ptr(np.ascontiguousarray(V0, dtype=np.float64)), L.ptr(np.ascontiguousarray(t0, dtype=np.float64)), L.ptr(np.ascontiguousarray(perm, dtype=np.int64)))
+
+
+def update_from_phonons(fermion_det_matrix: FermionDetMatrix, x):
+    """``update!(fermion_path_integral, elph, x, +1); update!(fermion_det_matrix, fermion_path_integral);
+    update_Λ!`` in one device pass from the phonon fields ``x`` (Nph x Ltau), as at
+    src/EFAPFFHMCUpdater.jl:200-205 — the host never forms V, t or Λ."""
+    xx = np.asfortranarray(x, dtype=np.float64)
+    fermion_det_matrix.handle.call("smoqy_update_from_phonons_all", L.ptr(xx))
+
+
 def _tmp_vecs(fdm, n):
     if not hasattr(fdm, "_tmp_ids"):
         fdm._tmp_ids = []

@@ -98,6 +98,8 @@ struct smoqy_ctx {
         double dtau = 0;
         void *blob = nullptr;   // one device allocation holding every coupling table
         double *d_x = nullptr, *d_contrib = nullptr, *d_out = nullptr, *h_out = nullptr;
+        double *d_bare = nullptr;  // [V⁰ (N) | t⁰ in checkerboard order (Nh)]
+        bool bare_set = false, t_done = false;
         ForceArgs tmpl{};
     } force;
     // timing
@@ -1426,7 +1428,7 @@ int smoqy_force_set_couplings(smoqy_ctx *c, const smoqy_couplings *cp)
     if (!cp || cp->Nph < 0 || cp->Nholstein < 0 || cp->Nssh < 0) FAIL(c, 1, "invalid couplings");
     auto &F = c->force;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (void *q : {F.blob, (void *)F.d_x, (void *)F.d_contrib, (void *)F.d_out})
+    for (void *q : {F.blob, (void *)F.d_x, (void *)F.d_contrib, (void *)F.d_out, (void *)F.d_bare})
         if (q) (void)hipFree(q);
     if (F.h_out) (void)hipHostFree(F.h_out);
     F = smoqy_ctx::ForceState{};
@@ -1468,8 +1470,16 @@ int smoqy_force_set_couplings(smoqy_ctx *c, const smoqy_couplings *cp)
         for (auto &e : lists[p]) { ph_slot.push_back(e.first); ph_sign.push_back(e.second); }
         ph_ptr[p + 1] = (int)ph_slot.size();
     }
+    // site -> Holstein couplings (coupling order within a site, like the reference's loop over c)
+    std::vector<int> site_ptr((size_t)g.N + 1, 0), site_cpl((size_t)Nhol);
+    for (int k = 0; k < Nhol; ++k) site_ptr[h_c2s[k] + 1]++;
+    for (int i = 0; i < g.N; ++i) site_ptr[i + 1] += site_ptr[i];
+    {
+        std::vector<int> fill(site_ptr.begin(), site_ptr.end() - 1);
+        for (int k = 0; k < Nhol; ++k) site_cpl[fill[h_c2s[k]]++] = k;
+    }
     // one blob: [ints | doubles]
-    const size_t n_int = h_c2p.size() + h_c2s.size() + h_ps.size() + s_c2p.size() + bond_ptr.size() + bond_cpl.size() + ph_ptr.size() + ph_slot.size();
+    const size_t n_int = h_c2p.size() + h_c2s.size() + h_ps.size() + s_c2p.size() + bond_ptr.size() + bond_cpl.size() + ph_ptr.size() + ph_slot.size() + site_ptr.size() + site_cpl.size();
     const size_t n_dbl = 4 * (size_t)Nhol + 4 * (size_t)Nssh + ph_sign.size();
     const size_t int_bytes = ((n_int * sizeof(int) + 15) / 16) * 16;
     HIPCHK(c, hipMalloc(&F.blob, int_bytes + n_dbl * sizeof(double) + 16));
@@ -1480,6 +1490,7 @@ int smoqy_force_set_couplings(smoqy_ctx *c, const smoqy_couplings *cp)
     t = ForceArgs{};
     t.h_c2p = put_i(h_c2p); t.h_c2s = put_i(h_c2s); t.h_phsym = put_i(h_ps); t.s_c2p = put_i(s_c2p);
     t.bond_ptr = put_i(bond_ptr); t.bond_cpl = put_i(bond_cpl); t.ph_ptr = put_i(ph_ptr); t.ph_slot = put_i(ph_slot);
+    t.site_ptr = put_i(site_ptr); t.site_cpl = put_i(site_cpl);
     std::vector<double> db;
     db.reserve(n_dbl);
     const double *dbase = (const double *)((const char *)F.blob + int_bytes);
@@ -1495,6 +1506,7 @@ int smoqy_force_set_couplings(smoqy_ctx *c, const smoqy_couplings *cp)
     HIPCHK(c, hipMalloc(&F.d_out, nx * sizeof(double)));
     HIPCHK(c, hipHostMalloc(&F.h_out, nx * sizeof(double)));
     HIPCHK(c, hipMalloc(&F.d_contrib, (size_t)g.nw * g.Lt * std::max(Q, 1) * sizeof(double)));
+    HIPCHK(c, hipMalloc(&F.d_bare, ((size_t)g.N + g.Nh + 1) * sizeof(double)));
     F.Nph = Nph; F.Nhol = Nhol; F.Nssh = Nssh; F.Q = Q; F.dtau = cp->dtau; F.set = true;
     return 0;
 }
@@ -1567,9 +1579,9 @@ int smoqy_force_dLdx_v(smoqy_ctx *c, double nu, int up, int u, double *out)
     return force_finish(c, a, out, true);
 }
 
-int smoqy_force_v(smoqy_ctx *c, int psi, double *out)
+// ΛΨ, AΨ = MΛΨ, ∂M/∂x term, MᵀAΨ, ∂Λ/∂x term; leaves the force of every walker in force.d_out
+static int force_device(smoqy_ctx *c, int psi)
 {
-    CHECK_CTX(c);
     if (int rc = check_vec(c, psi)) return rc;
     if (int rc = force_begin(c)) return rc;
     const Geometry &g = c->g;
@@ -1582,7 +1594,69 @@ int smoqy_force_v(smoqy_ctx *c, int psi, double *out)
     if (int rc = matvec_dev(c, SMOQY_OP_MT, MtAPsi, APsi, nullptr, nullptr, 0, g.nsys)) return rc;                   // MᵀAΨ          :153
     ForceArgs b = force_args(c, -2.0, MtAPsi, Psi);
     launch_dldx(c->stream, b);                                                                                       // -2 Re<MᵀAΨ|∂Λ/∂x|Ψ>  :155
-    return force_finish(c, b, out, true);
+    return force_finish(c, b, nullptr, false);
+}
+
+int smoqy_force_v(smoqy_ctx *c, int psi, double *out)
+{
+    CHECK_CTX(c);
+    if (int rc = force_device(c, psi)) return rc;
+    const size_t nx = (size_t)c->g.nw * c->g.Lt * c->force.Nph;
+    HIPCHK(c, hipMemcpyAsync(c->force.h_out, c->force.d_out, nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int rc = check_launch(c, "force")) return rc;
+    for (size_t k = 0; k < nx; ++k) out[k] += c->force.h_out[k];
+    return 0;
+}
+
+int smoqy_set_bare_model(smoqy_ctx *c, const double *V0, const double *t0, const int64_t *perm)
+{
+    CHECK_CTX(c);
+    if (!c->force.set) FAIL(c, 1, "call smoqy_force_set_couplings first");
+    if (!V0 || (c->g.Nh && (!t0 || !perm))) FAIL(c, 1, "V0, t0 and perm must be given");
+    const Geometry &g = c->g;
+    std::vector<double> b((size_t)g.N + g.Nh);
+    for (int i = 0; i < g.N; ++i) b[i] = V0[i];
+    for (int n = 0; n < g.Nh; ++n) {
+        if (perm[n] < 1 || perm[n] > g.Nh) FAIL(c, 1, "perm[%d] = %lld out of range", n + 1, (long long)perm[n]);
+        b[(size_t)g.N + n] = t0[perm[n] - 1];  // FermionDetMatrix.jl:224-228: sorted bond n is model hopping perm[n]
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->force.d_bare, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->force.bare_set = true;
+    c->force.t_done = false;
+    return 0;
+}
+
+int smoqy_update_from_phonons_all(smoqy_ctx *c, const double *x_all)
+{
+    CHECK_CTX(c);
+    auto &F = c->force;
+    if (!F.set || !F.bare_set) FAIL(c, 1, "call smoqy_force_set_couplings and smoqy_set_bare_model first");
+    const Geometry &g = c->g;
+    const size_t nx = (size_t)g.nw * g.Lt * F.Nph;
+    if (nx) {
+        if (!x_all) FAIL(c, 1, "x_all is NULL");
+        HIPCHK(c, hipMemcpyAsync(F.d_x, x_all, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    ForceArgs a = force_args(c, 0.0, nullptr, nullptr);
+    const bool do_t = g.Nh > 0 && (F.Nssh > 0 || !F.t_done);  // hoppings that no phonon couples to are refreshed once
+    launch_phonon_fields(c->stream, a, F.d_bare, F.d_bare + g.N, c->d_expV, c->d_ch, c->d_sh, c->d_lam, g.is_sym ? F.dtau / 2 : F.dtau, do_t);
+    if (do_t) launch_pack_csf(c->stream, c->d_ch, c->d_sh, c->d_psrc, c->d_csf, c->d_cs_varies, g.nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal);
+    F.t_done = true;
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // x_all is the caller's again
+    return check_launch(c, "update_from_phonons");
+}
+
+int smoqy_force_store_v(smoqy_ctx *c, int psi, double *out)
+{
+    CHECK_CTX(c);
+    if (!out) FAIL(c, 1, "out is NULL");
+    if (int rc = force_device(c, psi)) return rc;
+    const size_t nx = (size_t)c->g.nw * c->g.Lt * c->force.Nph;
+    if (nx) HIPCHK(c, hipMemcpyAsync(out, c->force.d_out, nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_launch(c, "force");
 }
 
 // ---- measurement aids -------------------------------------------------------------------------------

@@ -181,6 +181,48 @@ __global__ void force_reduce_kernel(ForceArgs a, double *out)
     }
 }
 
+
+// Device-side update!(fermion_path_integral, elph, x, ±1) + update!(fdm, fpi) + update_Λ!.
+// SmoQyDQMC's update! is not under /root/reference; the functional forms follow from the derivatives the
+// reference takes of them: ∂V_i/∂x_p = α + 2α₂x + 3α₃x² + 4α₄x³ (src/fermion_det_matrix_dervative.jl:281) gives
+// V_i = V⁰_i + Σ_c (αx + α₂x² + α₃x³ + α₄x⁴), and ∂K_ji/∂Δx of the same form with K = -t (:233) gives
+// t_h = t⁰_h - Σ_c (αΔx + α₂Δx² + α₃Δx³ + α₄Δx⁴), Δx = x[p′] - x[p].  Then FermionDetMatrix.jl:217, :230-231
+// and holstein_shift_matrix.jl:11-12, :37 exactly as fields_kernel / lambda_couple_kernel do them.
+__global__ void phonon_fields_kernel(ForceArgs a, const double *__restrict__ V0, const double *__restrict__ t0s, double *__restrict__ expV, double *__restrict__ ch, double *__restrict__ sh,
+                                     double *__restrict__ lam, double dtau_k, int do_t)
+{
+    const size_t nV = (size_t)a.nw * a.Lt * a.N, nT = do_t ? (size_t)a.nw * a.Lt * a.Nh : 0;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nV + nT; idx += (size_t)gridDim.x * blockDim.x) {
+        if (idx < nV) {
+            const int i = (int)(idx % a.N);
+            const size_t wl = idx / a.N;
+            const double *x = a.x + wl * a.Nph;
+            double V = V0[i], L = (wl % a.Lt == 0) ? 1.0 : -1.0;
+            for (int q = a.site_ptr[i]; q < a.site_ptr[i + 1]; ++q) {
+                const int c = a.site_cpl[q];
+                const double xp = x[a.h_c2p[c]];
+                V += (((a.h_alpha4[c] * xp + a.h_alpha3[c]) * xp + a.h_alpha2[c]) * xp + a.h_alpha[c]) * xp;
+                if (a.h_phsym[c]) L *= exp(a.dtau * (a.h_alpha[c] * xp + a.h_alpha3[c] * xp * xp * xp) / 2);
+            }
+            expV[idx] = exp(-a.dtau * V);
+            lam[idx] = L;
+        } else {
+            const size_t j = idx - nV;
+            const int n = (int)(j % a.Nh);
+            const double *x = a.x + (j / a.Nh) * a.Nph;
+            double tt = t0s[n];
+            for (int q = a.bond_ptr[n]; q < a.bond_ptr[n + 1]; ++q) {
+                const int c = a.bond_cpl[q];
+                const double dx = x[a.s_c2p[2 * c + 1]] - x[a.s_c2p[2 * c]];
+                tt -= (((a.s_alpha4[c] * dx + a.s_alpha3[c]) * dx + a.s_alpha2[c]) * dx + a.s_alpha[c]) * dx;
+            }
+            const double arg = dtau_k * fabs(tt);
+            ch[j] = cosh(arg);
+            sh[j] = (tt > 0 ? 1.0 : (tt < 0 ? -1.0 : 0.0)) * sinh(arg);
+        }
+    }
+}
+
 }  // namespace
 
 void configure_force_kernels()
@@ -213,6 +255,15 @@ void launch_force_reduce(hipStream_t st, const ForceArgs &a, double *out)
     int blocks = (int)((tot + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(force_reduce_kernel, dim3(blocks), dim3(256), 0, st, a, out);
+}
+
+void launch_phonon_fields(hipStream_t st, const ForceArgs &a, const double *V0, const double *t0s, double *expV, double *ch, double *sh, double *lam, double dtau_k, bool do_t)
+{
+    const size_t tot = (size_t)a.nw * a.Lt * (a.N + (do_t ? a.Nh : 0));
+    if (tot == 0) return;
+    int blocks = (int)((tot + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(phonon_fields_kernel, dim3(blocks), dim3(256), 0, st, a, V0, t0s, expV, ch, sh, lam, dtau_k, do_t ? 1 : 0);
 }
 
 }  // namespace smoqy

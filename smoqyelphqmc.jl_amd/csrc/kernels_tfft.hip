@@ -21,6 +21,8 @@
 // Lengths with a prime factor above 7 stay on rocFFT.
 #include "smoqy_internal.h"
 
+#include <cstdlib>
+
 namespace smoqy {
 
 namespace {
@@ -198,28 +200,46 @@ __global__ void __launch_bounds__(256) tfft_kernel(TfftArgs a)
     for (int q = threadIdx.x; q < Lt; q += blockDim.x) WT[q] = a.wtab[q];
     constexpr bool INV = (MODE == MODE_PLAIN_INV || MODE == MODE_INV_CG);
 
+    // 256 % SB == 0, so a lane keeps one site column sb and walks slices l0, l0 + lstep, ...
+    const int sb = threadIdx.x % SB, l0 = threadIdx.x / SB, lstep = blockDim.x / SB;
+    const bool act = sb < ns;
+    constexpr int U = 4;  // slices in flight per lane: all loads of a batch are issued before its first store
+
     if (MODE == MODE_FWD_CG) {
         // ConjugateGradient.jl:219-226 on this tile, then the forward transform of the new residual
+        double2 pv[U], zv[U], xv[U], rv[U];
+        auto load = [&](int l) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int lu = l + u * lstep;
+                if (act && lu < Lt) {
+                    const size_t off = (size_t)lu * sstride + base + sb;
+                    pv[u] = a.p[off]; zv[u] = a.z[off]; xv[u] = a.x[off]; rv[u] = a.r[off];
+                }
+            }
+        };
+        load(l0);  // in flight while the two scalar reductions below run
         const double2 rz = reduce_c(a.part_rz + (size_t)sys * a.rz_stride, a.nrz, red);
         const double2 pz = reduce_c(a.part_pz + (size_t)sys * a.pz_stride, a.npz, red);
         const double2 alpha = cdivt(rz, pz);
         double acc = 0.0;
-        for (int idx = threadIdx.x; idx < Lt * SB; idx += blockDim.x) {
-            const int l = idx / SB, sb = idx - l * SB;
-            double2 rv = make_double2(0.0, 0.0);
-            if (sb < ns) {
-                const size_t off = (size_t)l * sstride + base + sb;
-                const double2 pv = a.p[off], zv = a.z[off];
-                double2 xv = a.x[off];
-                rv = a.r[off];
-                const double2 ap = cm(alpha, pv), az = cm(alpha, zv);
-                xv = cadd(xv, ap);
-                rv = csub(rv, az);
-                a.x[off] = xv;
-                a.r[off] = rv;
-                acc += rv.x * rv.x + rv.y * rv.y;
+        for (int l = l0; l < Lt; l += U * lstep) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int lu = l + u * lstep;
+                if (lu < Lt) {
+                    double2 rn = make_double2(0.0, 0.0);
+                    if (act) {
+                        const size_t off = (size_t)lu * sstride + base + sb;
+                        a.x[off] = cadd(xv[u], cm(alpha, pv[u]));
+                        rn = csub(rv[u], cm(alpha, zv[u]));
+                        a.r[off] = rn;
+                        acc += rn.x * rn.x + rn.y * rn.y;
+                    }
+                    A[lu * SB + sb] = rn;
+                }
             }
-            A[idx] = rv;
+            if (l + U * lstep < Lt) load(l + U * lstep);
         }
         const double2 t = bsum(make_double2(acc, 0.0), red);  // also the barrier that publishes A and WT
         if (threadIdx.x == 0) {
@@ -249,12 +269,19 @@ __global__ void __launch_bounds__(256) tfft_kernel(TfftArgs a)
         if (!conv) {
             const double2 rz = reduce_c(a.part_rz + (size_t)sys * a.rz_stride, a.nrz, red);
             const double2 beta = cdivt(rz, make_double2(a.st[sys].rho_re, a.st[sys].rho_im));
-            for (int idx = threadIdx.x; idx < Lt * SB; idx += blockDim.x) {
-                const int l = idx / SB, sb = idx - l * SB;
-                if (sb < ns) {
-                    const size_t off = (size_t)l * sstride + base + sb;
-                    const double2 bp = cm(beta, a.p[off]);
-                    a.p[off] = cadd(res[idx], bp);
+            if (act) {
+                for (int l = l0; l < Lt; l += U * lstep) {
+                    double2 pv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int lu = l + u * lstep;
+                        if (lu < Lt) pv[u] = a.p[(size_t)lu * sstride + base + sb];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int lu = l + u * lstep;
+                        if (lu < Lt) a.p[(size_t)lu * sstride + base + sb] = cadd(res[lu * SB + sb], cm(beta, pv[u]));
+                    }
                 }
             }
         }
@@ -291,6 +318,10 @@ bool tfft_plan(int Lt, int N, TfftArgs &a)
     for (int f = 0; f + 1 < a.nfac; ++f)
         if (a.fac[f] == 8 && a.fac[f + 1] == 2) { a.fac[f] = 4; a.fac[f + 1] = 4; }
     a.SB = 16;
+    if (const char *e = getenv("SMOQY_TFFT_SB")) {  // tuning knob: sites per tile (4, 8 or 16)
+        const int v = atoi(e);
+        if (v == 4 || v == 8 || v == 16) a.SB = v;
+    }
     while (a.SB > 4 && (2 * (size_t)Lt * a.SB + Lt) * sizeof(double2) > 64 * 1024) a.SB /= 2;
     if ((2 * (size_t)Lt * a.SB + Lt) * sizeof(double2) > 150 * 1024) return false;
     a.ntile = (N + a.SB - 1) / a.SB;

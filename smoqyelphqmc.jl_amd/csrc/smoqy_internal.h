@@ -162,6 +162,7 @@ struct ForceArgs {
     const double *s_alpha, *s_alpha2, *s_alpha3, *s_alpha4;
     const int *bond_ptr, *bond_cpl;     // CSR: checkerboard bond -> SSH couplings
     const int *ph_ptr, *ph_slot;        // CSR: phonon -> contribution slots
+    const int *site_ptr, *site_cpl;     // CSR: site -> Holstein couplings, in coupling order
     const double *ph_sign;
     double *contrib;                    // [nw][Lt][Q]
 };
@@ -169,6 +170,8 @@ void configure_force_kernels();
 void launch_dmdx(hipStream_t st, const ForceArgs &a, bool sym);
 void launch_dldx(hipStream_t st, const ForceArgs &a);
 void launch_force_reduce(hipStream_t st, const ForceArgs &a, double *out);
+// V(x), t(x) -> expV, cosh, sinh (+ Λ) for every walker from the device copy of the phonon fields
+void launch_phonon_fields(hipStream_t st, const ForceArgs &a, const double *V0, const double *t0s, double *expV, double *ch, double *sh, double *lam, double dtau_k, bool do_t);
 
 // own tau-FFT (kernels_tfft.hip): Stockham passes over LDS site tiles, optionally fused with the CG updates
 struct TfftArgs {

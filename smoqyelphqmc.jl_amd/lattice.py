@@ -191,6 +191,11 @@ class SyntheticModel:
         c2p = np.vstack([nt[0] + off, nt[1] + off]).astype(np.int64)
         return ForceCouplings(x, self.elph.dtau, np.ones(x.shape[0], dtype=np.int32), z, z, z, z, zi, zi, np.zeros(0, dtype=np.int32), a, zz, zz, zz, c2p, inv[np.arange(Nh)])
 
+    def bare_model(self):
+        """(V0, t0): the path integral with the phonon contribution removed, i.e. what
+        ``SmoQyDQMC.update!(fermion_path_integral, elph, x, -1)`` leaves (src/EFAPFFHMCUpdater.jl:148)."""
+        return np.full(self.fpi.N, -self.mu), np.ones(self.fpi.t.shape[0])
+
     def refresh_from_x(self):
         """Recompute ``V`` / ``t`` of the path integral from the current phonon field ``x``
         (what SmoQyDQMC's ``update!(fermion_path_integral, …, x, ±1)`` does at

@@ -43,7 +43,7 @@ class SweepStats:
 
 class WalkerBatch:
     def __init__(self, workload: str, nwalkers: int = 1, walker0: int = 0, is_sym: bool = True, device: int = -1, tol: float = 1e-10, maxiter: int = 10_000, Nt: int = 24,
-                 drift: float = 0.02, check_every: int | None = None, tau_chunk: int | None = None, smooth: bool = False, host_threads: int = 8):
+                 drift: float = 0.02, check_every: int | None = None, tau_chunk: int | None = None, smooth: bool = False, host_threads: int = 8, device_update: bool = True):
         self.models = [lat.CONFIGS[workload](walker=walker0 + w, smooth=smooth) for w in range(nwalkers)]
         m0 = self.models[0]
         self.workload = workload
@@ -85,12 +85,22 @@ class WalkerBatch:
         else:
             self.xs_force = self.xs
         self.dSdx = self.h.pinned_empty((nwalkers, self.Lt, self.Nph_force))
+        # device-side update! from x: the host sends x only, V / t / Λ are formed on the device
+        self.device_update = device_update
+        if device_update:
+            V0, t0 = m0.bare_model()
+            self.h.call("smoqy_set_bare_model", L.ptr(V0), L.ptr(t0), L.ptr(self.perm))
         self.stats = SweepStats()
         self.refresh_fields(first=True)
 
     # ---- field plumbing -------------------------------------------------------------------------
     def refresh_fields(self, first: bool = False):
         """update!(fdm, fpi) and update_Λ! for every walker from its current phonon field."""
+        if self.device_update:
+            if self.xs_force is not self.xs:
+                self.xs_force[:, :, : self.Nph] = self.xs
+            self.h.call("smoqy_update_from_phonons_all", L.ptr(self.xs_force))
+            return
         if self.models[0].kind == "holstein":
             # V = α x - μ for the whole batch in one pass (what SyntheticModel.refresh_from_x does per walker)
             np.multiply(self.xs, self.models[0].alpha, out=self.Vs)
@@ -158,13 +168,17 @@ class WalkerBatch:
         """The tail of calculate_derivative_fermionic_action! (src/PFFCalculator.jl:146-155):
         ΛΨ, AΨ = MΛΨ, -2 Re⟨AΨ|∂M/∂x|ΛΨ⟩, MᵀAΨ, -2 Re⟨MᵀAΨ|∂Λ/∂x|Ψ⟩ — on the device; the force array
         (Nph x Ltau per walker) comes back to the host, where the reference's leapfrog consumes it."""
-        self.dSdx[...] = 0.0
-        self.h.call("smoqy_force_v", self.u, L.ptr(self.dSdx))
+        self.h.call("smoqy_force_store_v", self.u, L.ptr(self.dSdx))  # fill!(∂S∂x, 0) + accumulate == store (EFAPFFHMCUpdater.jl:160-165)
         return self.dSdx
 
     def drift_fields(self, pis, step):
         np.multiply(pis, step, out=self._tmp)
         np.add(self.xs, self._tmp, out=self.xs)
+        self.refresh_fields()
+
+    def drift_by(self, dx):
+        """x += dx with a precomputed increment (one pass over the fields)."""
+        np.add(self.xs, dx, out=self.xs)
         self.refresh_fields()
 
     def _momentum(self):
@@ -184,10 +198,11 @@ class WalkerBatch:
         # HMC trajectory (src/EFAPFFHMCUpdater.jl:102-276)
         self.sample_pseudofermion_fields()
         pis = self._momentum()
+        dx = pis * (self.drift / self.Nt)
         for _ in range(self.Nt):
             self.calculate_fermionic_action(self.tol_force)
             self.fermionic_force()
-            self.drift_fields(pis, self.drift / self.Nt)
+            self.drift_by(dx)
         last = self.calculate_fermionic_action(self.tol)
         self.drift_fields(pis, -self.drift)      # reject: restore x
         self.stats.action = float(np.sum(last[0]))
