@@ -24,6 +24,8 @@
 // colour than 1024.
 #include "smoqy_internal.h"
 
+#include <cstdlib>
+
 namespace smoqy {
 
 __device__ __forceinline__ double wsum_k(double v)
@@ -391,6 +393,210 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// owner-computes Chebyshev kernel (Sym, 2..kMaxColours colours)
+// ---------------------------------------------------------------------------------------------
+// cheb_fast_kernel pays one LDS round trip + barrier per colour stage (2L-2 per Chebyshev step) because a stage
+// reads its pair, updates it and writes it back for the next colour's lanes.  Here lane j OWNS the two sites of
+// the j-th padded bond of colour q for the whole chain and updates both of them itself in every stage: a stage
+// of colour q is pure register arithmetic, and a stage of another colour needs one exchange (own values to
+// LDS, barrier, read the two mates) followed by  a' = c·a + s·mate(a)  for each own site with that site's bond.
+// q is a colour that occurs twice per step (colour 1 for L >= 3; colour 0 for L = 2), which leaves 2L-4 (L >= 3)
+// or 1 (L = 2) exchanges per step — two instead of four on the honeycomb lattice.  The fused C₁D̄C₁ stage
+// recomputes the mate's intermediate value (same bond, mate's d̄) instead of fetching it.  Exchanges ping-pong
+// between two LDS images, so each costs a single barrier.  Arithmetic per site is identical to cheb_fast_kernel.
+template <int NCOL>
+__global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
+{
+    static_assert(NCOL >= 2, "single-colour decompositions use cheb_fast_kernel");
+    constexpr int Q = NCOL >= 3 ? 1 : 0, CL = NCOL - 1;
+    extern __shared__ double2 lds[];
+    __shared__ double red[17];
+    const int N = k.N, Lt = k.Lt, T = blockDim.x, j = threadIdx.x;
+    double2 *Wb[2] = {lds, lds + 2 * T};
+    double2 *CF = lds + 4 * T;
+    const int sys = blockIdx.x % k.nsys, rank = blockIdx.x / k.nsys;
+    const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);  // heaviest orders first, rank-major
+    const int w = sys / k.nrhs;
+    if (k.cg && k.cg[sys].done) return;
+    double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
+    double2 *prz = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride + om : nullptr;
+    const int Lo2 = (Lt + 1) / 2;
+    const int slot = om >= Lo2 ? Lt - om - 1 : om;  // :387
+    const bool act = k.active[w] != 0;
+    const int n = act ? k.order[(size_t)w * k.nslot + slot] : 1;
+    const double2 *coefs = k.coefs + ((size_t)w * k.nslot + slot) * k.maxorder;
+    if (n <= 1) {  // single-term expansion: scalar multiply (:398)
+        const double f = k.scale * (act ? coefs[0].x : 1.0);
+        double acc = 0.0;
+        for (int i = j; i < N; i += T) {
+            const double2 x = v[i];
+            v[i] = make_double2(f * x.x, f * x.y);
+            acc += f * (x.x * x.x + x.y * x.y);
+        }
+        if (prz) {
+            const double t = block_sum_real(acc, red);
+            if (j == 0) *prz = make_double2(t, 0.0);
+        }
+        return;
+    }
+    const double emin = k.bounds[2 * w], emax = k.bounds[2 * w + 1];
+    const double avg = 0.5 * (emax + emin), imag_ = 1.0 / (0.5 * (emax - emin));
+    const bool on = j < kg.own_n;
+    const int *own = kg.own;
+    // lane program: own sites, their LDS slots, and per colour the mates' slots and the two bonds' (c̄, s̄)
+    int sx = 0, sy = 0, ox = j, oy = j;
+    int px[NCOL], py[NCOL];
+    double2 cx[NCOL], cy[NCOL];
+    double dx = 1.0, dy = 1.0, dmx = 1.0, dmy = 1.0;
+    const double *dbar = k.dbar + (size_t)w * N;
+    const double2 *pcs = kg.pcs + (size_t)w * kg.ptotal;
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) { px[c] = py[c] = j; cx[c] = cy[c] = make_double2(1.0, 0.0); }
+    double2 ax = make_double2(0.0, 0.0), ay = ax;
+    if (on) {
+        sx = own[j]; sy = own[T + j];
+        oy = (sy != sx) ? T + j : j;
+        dx = dbar[sx]; dy = dbar[sy];
+        dmx = dbar[own[2 * T + j]]; dmy = dbar[own[3 * T + j]];
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            px[c] = own[(4 + 4 * c + 0) * T + j];
+            py[c] = own[(4 + 4 * c + 1) * T + j];
+            cx[c] = pcs[own[(4 + 4 * c + 2) * T + j]];
+            cy[c] = pcs[own[(4 + 4 * c + 3) * T + j]];
+        }
+        ax = v[sx]; ay = v[sy];
+    }
+    const double2 v0x = ax, v0y = ay;
+    for (int i = j; i < n; i += T) CF[i] = coefs[i];  // coefficients in LDS: no global load inside the chain
+    int buf = 0;
+    // own values -> LDS image, barrier, the two mates of colour c_ come back in (mx_, my_)
+#define OWN_EXCHANGE(c_, mx_, my_)                       \
+    {                                                    \
+        double2 *Wc = Wb[buf];                           \
+        buf ^= 1;                                        \
+        if (on) { Wc[ox] = ax; Wc[oy] = ay; }            \
+        __syncthreads();                                 \
+        mx_ = Wc[px[c_]];                                \
+        my_ = Wc[py[c_]];                                \
+    }
+#define OWN_STAGE(c_)                                                        \
+    {                                                                        \
+        if (c_ == Q) {                                                       \
+            const double2 t_ = lin2(cx[Q].x, ax, cx[Q].y, ay);               \
+            ay = lin2(cx[Q].x, ay, cx[Q].y, ax);                             \
+            ax = t_;                                                         \
+        } else {                                                             \
+            double2 mx_, my_;                                                \
+            OWN_EXCHANGE(c_, mx_, my_)                                       \
+            ax = lin2(cx[c_].x, ax, cx[c_].y, mx_);                          \
+            ay = lin2(cy[c_].x, ay, cy[c_].y, my_);                          \
+        }                                                                    \
+    }
+    // into the basis α̃ = C_L α (see cheb_fast_kernel)
+    {
+        double2 mx, my;
+        OWN_EXCHANGE(CL, mx, my)
+        ax = lin2(cx[CL].x, ax, cx[CL].y, mx);
+        ay = lin2(cy[CL].x, ay, cy[CL].y, my);
+    }
+    const double qcx = cx[CL].x * cx[CL].x + cx[CL].y * cx[CL].y, qsx = 2.0 * cx[CL].x * cx[CL].y;  // C_L²
+    const double qcy = cy[CL].x * cy[CL].x + cy[CL].y * cy[CL].y, qsy = 2.0 * cy[CL].x * cy[CL].y;
+    double2 a1x = ax, a1y = ay, a2x = make_double2(0, 0), a2y = a2x, accx = a2x, accy = a2x;
+    __syncthreads();  // CF visible
+    for (int kk = 1; kk < n; ++kk) {
+        const double2 ck = CF[kk];
+#pragma unroll
+        for (int c = NCOL - 2; c >= 1; --c) OWN_STAGE(c)
+        if (Q == 0) {  // C₁ D̄ C₁ in registers
+            double2 x = lin2(cx[0].x, ax, cx[0].y, ay), y = lin2(cx[0].x, ay, cx[0].y, ax);
+            x = make_double2(dx * x.x, dx * x.y);
+            y = make_double2(dy * y.x, dy * y.y);
+            ax = lin2(cx[0].x, x, cx[0].y, y);
+            ay = lin2(cx[0].x, y, cx[0].y, x);
+        } else {       // one exchange; the mate's value after C₁ and D̄ is recomputed here (same bond, its own d̄)
+            double2 mx, my;
+            OWN_EXCHANGE(0, mx, my)
+            double2 x = lin2(cx[0].x, ax, cx[0].y, mx), xm = lin2(cx[0].x, mx, cx[0].y, ax);
+            double2 y = lin2(cy[0].x, ay, cy[0].y, my), ym = lin2(cy[0].x, my, cy[0].y, ay);
+            x = make_double2(dx * x.x, dx * x.y);
+            xm = make_double2(dmx * xm.x, dmx * xm.y);
+            y = make_double2(dy * y.x, dy * y.y);
+            ym = make_double2(dmy * ym.x, dmy * ym.y);
+            ax = lin2(cx[0].x, x, cx[0].y, xm);
+            ay = lin2(cy[0].x, y, cy[0].y, ym);
+        }
+#pragma unroll
+        for (int c = 1; c <= NCOL - 2; ++c) OWN_STAGE(c)
+        double2 xi, xj;
+        {
+            double2 mx, my;
+            OWN_EXCHANGE(CL, mx, my)
+            xi = lin2(qcx, ax, qsx, mx);
+            xj = lin2(qcy, ay, qsy, my);
+        }
+        // three-term recurrence on the lane's own sites (kpm_lmul!)
+        double2 a3x, a3y;
+        if (kk == 1) {
+            a3x = make_double2((xi.x - avg * a1x.x) * imag_, (xi.y - avg * a1x.y) * imag_);
+            a3y = make_double2((xj.x - avg * a1y.x) * imag_, (xj.y - avg * a1y.y) * imag_);
+            const double2 c0 = CF[0];
+            const double2 t0x = cmulk(c0, a1x), t0y = cmulk(c0, a1y), t1x = cmulk(ck, a3x), t1y = cmulk(ck, a3y);
+            accx = make_double2(t0x.x + t1x.x, t0x.y + t1x.y);
+            accy = make_double2(t0y.x + t1y.x, t0y.y + t1y.y);
+        } else {
+            a3x = make_double2(2.0 * (xi.x - avg * a2x.x) * imag_ - a1x.x, 2.0 * (xi.y - avg * a2x.y) * imag_ - a1x.y);
+            a3y = make_double2(2.0 * (xj.x - avg * a2y.x) * imag_ - a1y.x, 2.0 * (xj.y - avg * a2y.y) * imag_ - a1y.y);
+            const double2 tx = cmulk(ck, a3x), ty = cmulk(ck, a3y);
+            accx = make_double2(accx.x + tx.x, accx.y + tx.y);
+            accy = make_double2(accy.x + ty.x, accy.y + ty.y);
+            a1x = a2x; a1y = a2y;
+        }
+        a2x = a3x; a2y = a3y;
+        ax = a3x; ay = a3y;
+    }
+    // back to the original basis: C_L⁻¹ on the accumulated sum
+    {
+        ax = accx; ay = accy;
+        double2 mx, my;
+        OWN_EXCHANGE(CL, mx, my)
+        const double idx_ = 1.0 / (cx[CL].x * cx[CL].x - cx[CL].y * cx[CL].y), idy_ = 1.0 / (cy[CL].x * cy[CL].x - cy[CL].y * cy[CL].y);
+        ax = make_double2((cx[CL].x * accx.x - cx[CL].y * mx.x) * idx_, (cx[CL].x * accx.y - cx[CL].y * mx.y) * idx_);
+        ay = make_double2((cy[CL].x * accy.x - cy[CL].y * my.x) * idy_, (cy[CL].x * accy.y - cy[CL].y * my.y) * idy_);
+    }
+#undef OWN_STAGE
+#undef OWN_EXCHANGE
+    double2 acc = make_double2(0.0, 0.0);
+    if (on) {
+        ax = make_double2(k.scale * ax.x, k.scale * ax.y);
+        ay = make_double2(k.scale * ay.x, k.scale * ay.y);
+        v[sx] = ax;
+        acc.x += v0x.x * ax.x + v0x.y * ax.y;
+        acc.y += v0x.x * ax.y - v0x.y * ax.x;
+        if (sy != sx) {
+            v[sy] = ay;
+            acc.x += v0y.x * ay.x + v0y.y * ay.y;
+            acc.y += v0y.x * ay.y - v0y.y * ay.x;
+        }
+    }
+    if (prz) {
+        const double2 t = block_sum_cplx(acc, red);
+        if (j == 0) *prz = t;
+    }
+}
+
+static int cheb_own_enabled()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("SMOQY_CHEB_OWN");  // A/B switch for measurements; default on
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // generic fallback (any number of colours / sites): bond tables read from memory each stage
 // ---------------------------------------------------------------------------------------------
@@ -517,7 +723,18 @@ void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
         const size_t lds = sizeof(double2) * ((size_t)k.N + 2 * (size_t)k.maxorder);
         const dim3 grid((unsigned)(k.Lt * k.nsys)), block((unsigned)kg.threads);
 #define CHEB_LAUNCH(S_, C_) hipLaunchKernelGGL((cheb_fast_kernel<S_, C_>), grid, block, lds, st, k, kg)
-        if (k.is_sym) {
+        if (k.is_sym && k.ncol >= 2 && k.ncol <= 6 && kg.own && cheb_own_enabled()) {
+            const size_t olds = sizeof(double2) * (4 * (size_t)kg.threads + (size_t)k.maxorder);
+#define OWN_LAUNCH(C_) hipLaunchKernelGGL((cheb_own_kernel<C_>), grid, block, olds, st, k, kg)
+            switch (k.ncol) {
+                case 2: OWN_LAUNCH(2); break;
+                case 3: OWN_LAUNCH(3); break;
+                case 4: OWN_LAUNCH(4); break;
+                case 5: OWN_LAUNCH(5); break;
+                default: OWN_LAUNCH(6); break;
+            }
+#undef OWN_LAUNCH
+        } else if (k.is_sym) {
             switch (k.ncol) {
                 case 1: CHEB_LAUNCH(true, 1); break;
                 case 2: CHEB_LAUNCH(true, 2); break;

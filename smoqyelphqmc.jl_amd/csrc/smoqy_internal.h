@@ -85,6 +85,12 @@ struct KpmGeom {
     int ptotal;
     int threads;         // workgroup size = padded bonds per colour rounded up to a wavefront
     int fast;            // 0: use the generic kernels
+    // owner-computes layout of the Sym Chebyshev kernel: lane j keeps the two sites of the j-th padded bond of
+    // colour own_q in registers for the whole chain.  own is [(4 + 4 ncol)][threads] ints: the lane's two site ids,
+    // the site ids of their colour-0 mates, then per colour the LDS slots of the two mates and the padded-bond
+    // indices (into pcs) of the two bonds.
+    const int *own;
+    int own_q, own_n;
 };
 
 // geometry + packed hopping table of the register-resident FermionDetMatrix kernels
