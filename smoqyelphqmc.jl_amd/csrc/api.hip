@@ -88,7 +88,7 @@ struct smoqy_ctx {
     int *d_cs_varies = nullptr;
     int2 *d_pbonds = nullptr, *d_psites = nullptr;
     int *d_pos = nullptr;
-    int *d_poff = nullptr, *d_psrc = nullptr, *d_own = nullptr;
+    int *d_poff = nullptr, *d_psrc = nullptr, *d_own = nullptr, *d_own_f = nullptr;
     double2 *d_pcs = nullptr;
     double *h_lan = nullptr;  // pinned [nw][2][1024]
     // force terms
@@ -231,7 +231,7 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->fft_info) rocfft_execution_info_destroy(c->fft_info);
     void *ptrs[] = {c->d_bonds, c->d_col_off, c->d_expV, c->d_ch, c->d_sh, c->d_lam, c->d_stage, c->d_stage_real, c->d_stage_int, c->scr[0], c->scr[1], c->scr[2], c->cg_r, c->cg_p,
                     c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->fft_work, c->d_tw, c->d_th, c->d_wtab, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
-                    c->d_rand, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own};
+                    c->d_rand, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (double2 *v : c->vecs)
@@ -418,36 +418,46 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
         c->kg.psites = c->d_psites; c->kg.pos = c->d_pos;
         c->kg.pbonds = c->d_pbonds; c->kg.poff = c->d_poff; c->kg.psrc = c->d_psrc; c->kg.pcs = c->d_pcs;
         if (c->kg.fast) {
-            // owner-computes tables (cheb_own_kernel): the owned colour is one that is applied twice per Chebyshev
-            // step, so that its two stages need no exchange at all
-            const int q = g.ncol >= 3 ? 1 : 0, T = c->kg.threads, nb = poff[q + 1] - poff[q];
+            // owner-computes tables: the owned colour is one that is applied twice (per Chebyshev step in
+            // cheb_own_kernel, per B apply in fdm_own_kernel), so that its two stages need no exchange at all
+            const int T = c->kg.threads;
             std::vector<std::vector<int>> mate((size_t)g.ncol, std::vector<int>((size_t)g.N)), bidx((size_t)g.ncol, std::vector<int>((size_t)g.N));
             for (int col = 0; col < g.ncol; ++col)
                 for (int k = poff[col]; k < poff[col + 1]; ++k) {
                     mate[col][pb[k].x] = pb[k].y; mate[col][pb[k].y] = pb[k].x;
                     bidx[col][pb[k].x] = bidx[col][pb[k].y] = k;
                 }
-            std::vector<int> slot((size_t)g.N, 0);
-            for (int j = 0; j < nb; ++j) {
-                const int2 b = pb[(size_t)poff[q] + j];
-                slot[b.x] = j;
-                if (b.y != b.x) slot[b.y] = T + j;
-            }
-            std::vector<int> own((size_t)(4 + 4 * g.ncol) * T, 0);
-            for (int j = 0; j < nb; ++j) {
-                const int2 b = pb[(size_t)poff[q] + j];
-                own[0 * (size_t)T + j] = b.x; own[1 * (size_t)T + j] = b.y;
-                own[2 * (size_t)T + j] = mate[0][b.x]; own[3 * (size_t)T + j] = mate[0][b.y];
-                for (int col = 0; col < g.ncol; ++col) {
-                    own[(size_t)(4 + 4 * col + 0) * T + j] = slot[mate[col][b.x]];
-                    own[(size_t)(4 + 4 * col + 1) * T + j] = slot[mate[col][b.y]];
-                    own[(size_t)(4 + 4 * col + 2) * T + j] = bidx[col][b.x];
-                    own[(size_t)(4 + 4 * col + 3) * T + j] = bidx[col][b.y];
+            auto build_own = [&](int q, int **dptr, int *nb_out) -> int {
+                const int nb = poff[q + 1] - poff[q];
+                std::vector<int> slot((size_t)g.N, 0);
+                for (int j = 0; j < nb; ++j) {
+                    const int2 b = pb[(size_t)poff[q] + j];
+                    slot[b.x] = j;
+                    if (b.y != b.x) slot[b.y] = T + j;
                 }
-            }
-            HIPCHK(c, hipMalloc(&c->d_own, own.size() * sizeof(int)));
-            HIPCHK(c, hipMemcpy(c->d_own, own.data(), own.size() * sizeof(int), hipMemcpyHostToDevice));
-            c->kg.own = c->d_own; c->kg.own_q = q; c->kg.own_n = nb;
+                std::vector<int> own((size_t)(4 + 4 * g.ncol) * T, 0);
+                for (int j = 0; j < nb; ++j) {
+                    const int2 b = pb[(size_t)poff[q] + j];
+                    own[0 * (size_t)T + j] = b.x; own[1 * (size_t)T + j] = b.y;
+                    own[2 * (size_t)T + j] = mate[0][b.x]; own[3 * (size_t)T + j] = mate[0][b.y];
+                    for (int col = 0; col < g.ncol; ++col) {
+                        own[(size_t)(4 + 4 * col + 0) * T + j] = slot[mate[col][b.x]];
+                        own[(size_t)(4 + 4 * col + 1) * T + j] = slot[mate[col][b.y]];
+                        own[(size_t)(4 + 4 * col + 2) * T + j] = bidx[col][b.x];
+                        own[(size_t)(4 + 4 * col + 3) * T + j] = bidx[col][b.y];
+                    }
+                }
+                HIPCHK(c, hipMalloc(dptr, own.size() * sizeof(int)));
+                HIPCHK(c, hipMemcpy(*dptr, own.data(), own.size() * sizeof(int), hipMemcpyHostToDevice));
+                *nb_out = nb;
+                return 0;
+            };
+            const int q_cheb = g.ncol >= 3 ? 1 : 0, q_fdm = g.ncol >= 2 ? 1 : 0;
+            if (int rc = build_own(q_cheb, &c->d_own, &c->kg.own_n)) return rc;
+            c->kg.own = c->d_own; c->kg.own_q = q_cheb;
+            if (q_fdm == q_cheb) { c->d_own_f = c->d_own; c->ff.own_n = c->kg.own_n; }
+            else if (int rc = build_own(q_fdm, &c->d_own_f, &c->ff.own_n)) return rc;
+            c->ff.own = c->d_own_f;
         }
         HIPCHK(c, hipMalloc(&c->d_csf, (size_t)g.nw * g.Lt * std::max<size_t>(pb.size(), 1) * sizeof(double2)));
         HIPCHK(c, hipMemset(c->d_csf, 0, (size_t)g.nw * g.Lt * std::max<size_t>(pb.size(), 1) * sizeof(double2)));
@@ -752,7 +762,8 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
         a.hop_im = -std::sin(M_PI / c->g.Lt);
         a.antiperiodic = 0;
     }
-    if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_fast(c->stream, op, a, c->ff);
+    if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_own(c->stream, op, a, c->ff);
+    else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_fast(c->stream, op, a, c->ff);
     else launch_fdm(c->stream, op, c->g.is_sym != 0, a, fdm_lds_bytes(op, c->g.N, c->Tc));
     return check_launch(c, "matvec");
 }

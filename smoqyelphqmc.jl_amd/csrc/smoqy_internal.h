@@ -104,6 +104,8 @@ struct FdmFast {
     int ptotal;
     int threads;
     int enabled;
+    const int *own;      // owner-computes tables (layout as KpmGeom::own) for owned colour 1 (0 when there is one colour)
+    int own_n;
 };
 
 // ---- launchers (defined in the .hip files) -----------------------------------------------
@@ -114,6 +116,8 @@ void configure_fdm_kernels();
 void configure_kpm_kernels();
 bool fdm_fast_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
 void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff);
+bool fdm_own_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
+void launch_fdm_own(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff);
 void launch_pack_csf(hipStream_t st, const double *ch, const double *sh, const int *psrc, double2 *csf, int *cs_varies, int Lt, int Lt1, int Nh, int ptotal);
 
 void launch_transpose_in(hipStream_t st, const double2 *host_layout, double2 *dev_layout, int Lt, int N, int nsys, int sys0, int count);

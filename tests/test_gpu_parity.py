@@ -91,6 +91,26 @@ def test_matvec_all_ops(kind, is_sym, Tc, generic):
         assert relerr(out[:, :, 0], fn(v[:, :, 0])) < OP_TOL, (kind, is_sym, Tc, op)
 
 
+@pytest.mark.parametrize("kind", ["honeycomb", "square", "chain"])
+@pytest.mark.parametrize("Tc", [1, 2])
+def test_matvec_large_batch_uses_the_lds_resident_kernel(kind, Tc):
+    """More than 8 systems per launch dispatch the Sym operator to the LDS-resident kernel (kernels_fdm_fast.hip),
+    up to 8 to the owner-computes kernel (kernels_fdm_own.hip): both against the oracle, and against each other."""
+    p = Problem(kind, True, nwalkers=3, nrhs=4)  # 12 systems
+    p.h.call("smoqy_set_tau_chunk", Tc)
+    v = p.rand(12, 8)
+    a, b = p.h.vec_alloc(), p.h.vec_alloc()
+    p.h.vec_upload(a, v)
+    for op, name in ((L.OP_M, "mul_M"), (L.OP_MT, "mul_Mt"), (L.OP_MTM, "mul_MtM"), (L.OP_MMT, "mul_MMt")):
+        p.h.call("smoqy_matvec_v", op, b, a)
+        big = p.h.vec_download(b)
+        for s in (0, 5, 11):
+            assert relerr(big[:, :, s], getattr(p.oracles[s // 4], name)(v[:, :, s])) < OP_TOL, (kind, Tc, name, s)
+        small = np.zeros((p.Lt, p.N, 2), dtype=complex, order="F")  # 2 systems: owner-computes kernel
+        p.h.call("smoqy_matvec", op, L.ptr(small), L.ptr(np.asfortranarray(v[:, :, 6:8])), 6, 2)
+        assert relerr(small, big[:, :, 6:8]) < 4e-15
+
+
 def test_matvec_in_place_and_batched():
     p = Problem("honeycomb", True, nwalkers=2, nrhs=2)
     v = p.rand(4, 4)
