@@ -226,6 +226,21 @@ int smoqy_set_bare_model(smoqy_ctx *ctx, const double *V0, const double *t0, con
  * (call sites src/EFAPFFHMCUpdater.jl:148-152, 200-205).  Also refreshes the force kernels' x. */
 int smoqy_update_from_phonons_all(smoqy_ctx *ctx, const double *x_all);
 
+/* ---- GreensEstimator ------------------------------------------------ */
+
+/* copy one walker's fields (expnΔτV, cosh, sinh, Λ) from another handle of the same lattice on the same device:
+ * a measurement handle created with nrhs = Nrv follows the sampling handle without a host round trip
+ * (update_greens_estimator!(ge, fermion_det_matrix, …), src/Measurements/GreensEstimator.jl:125-175) */
+int smoqy_copy_fields(smoqy_ctx *dst, int dst_walker, smoqy_ctx *src, int src_walker);
+/* unit cell and lattice of the model geometry (GreensEstimator constructor :76-99): n orbitals per cell,
+ * D <= 2 directions of extent L[d]; site = orbital + n * cell, cell = c1 + L1 * c2 (column-major) */
+int smoqy_ge_config(smoqy_ctx *ctx, int n_orbitals, int D, const int64_t *L);
+/* measure_GΔ0!(…, greens_estimator, (a, b)) (:179-233): G(Δ,0) averaged over translations and over the
+ * handle's nrhs random vectors, from GR = M⁻¹R (vector gr) and R (vector r, conjugated on the fly as Rt).
+ * out is complex (Lτ+1) x L... x nwalkers, the reference's CΔ0 array per walker, before
+ * add_contraction_to_correlation! permutes τ to the last axis (:712-726).  a, b are 1-based orbitals. */
+int smoqy_ge_measure_GD0(smoqy_ctx *ctx, int gr, int r, int a, int b, void *out);
+
 /* ---- measurement aids (bench.py) -------------------------------------------------------- */
 
 /* HIP events on the handle's stream */

@@ -101,6 +101,9 @@ SIGNATURES = {
     "smoqy_force_store_v": [_p, _i, _p],
     "smoqy_set_bare_model": [_p, _p, _p, _p],
     "smoqy_update_from_phonons_all": [_p, _p],
+    "smoqy_copy_fields": [_p, _i, _p, _i],
+    "smoqy_ge_config": [_p, _i, _i, _p],
+    "smoqy_ge_measure_GD0": [_p, _i, _i, _i, _i, _p],
     "smoqy_timer_start": [_p],
     "smoqy_timer_stop": [_p, _pd],
     "smoqy_bench_matvec": [_p, _i, _i, _i, _i, _pd],
@@ -187,6 +190,7 @@ class Handle:
         self.Lt, self.N, self.Nh, self.ncol = int(Lt), int(N), int(nt.shape[1]) if nt.ndim == 2 else 0, int(cr.shape[1]) if cr.ndim == 2 else 0
         self.is_sym, self.nw, self.nrhs = bool(is_sym), int(nwalkers), int(nrhs)
         self.nsys = self.nw * self.nrhs
+        self.device = int(device)
         h = _p()
         rc = self.lib.smoqy_create(C.byref(h), self.Lt, self.N, self.Nh, self.ncol, ptr(nt), ptr(cr), int(self.is_sym), 0, self.nw, self.nrhs, int(device))
         if rc != 0:

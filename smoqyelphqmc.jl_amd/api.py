@@ -590,3 +590,85 @@ def calculate_derivative_fermionic_action(dSfdx, pff_calculator: PFFCalculator, 
     if out is not dSfdx:
         dSfdx[...] = out
     return Sf, iters, eps
+
+
+# ---- GreensEstimator ------------------------------------------------------------
+
+class GreensEstimator:
+    """GreensEstimator(fermion_det_matrix, model_geometry; Nrv, preconditioner, rng, maxiter, tol),
+    src/Measurements/GreensEstimator.jl:10-121.  ``model_geometry`` is anything with ``unit_cell.n`` and
+    ``lattice.L``, or the pair ``(n, L)``.  The ``Nrv`` solves of ``update_greens_estimator!`` run as ONE batched
+    solve on a second handle created with ``nrhs = Nrv`` that follows the sampling handle's fields device to device;
+    ``GR`` and ``Rt`` (shape ``(Lτ, n, L..., Nrv)``, the reference's arrays) come back to the host for the contractions
+    that stay there, while ``measure_GΔ0`` contracts them on the device."""
+
+    def __init__(self, fermion_det_matrix: FermionDetMatrix, model_geometry, Nrv=10, preconditioner=I, rng=None, maxiter=None, tol=None):
+        fdm = fermion_det_matrix
+        if hasattr(model_geometry, "unit_cell"):
+            n, Ls = int(model_geometry.unit_cell.n), tuple(int(x) for x in model_geometry.lattice.L)
+        else:
+            n, Ls = int(model_geometry[0]), tuple(int(x) for x in model_geometry[1])
+        self.Nrv, self.n, self.L = int(Nrv), n, Ls
+        self.N = int(np.prod(Ls))                     # unit cells (:84)
+        self.V = fdm.Lt * fdm.N                       # :86
+        self.Lτ = self.V // (n * self.N)              # :88
+        if n * self.N != fdm.N:
+            raise ValueError("unit cell / lattice do not match the FermionDetMatrix")
+        self.handle = L.Handle(fdm.Lt, fdm.N, fdm.checkerboard_neighbor_table, fdm._colors, fdm.is_sym, 1, self.Nrv, fdm.handle.device)
+        self.handle.call("smoqy_ge_config", n, len(Ls), L.ptr(np.asarray(Ls, dtype=np.int64)))
+        self._r, self._gr, self._mtr = (self.handle.vec_alloc() for _ in range(3))   # Rt, GR, MtR (:91-93); GR starts at zero
+        shape = (self.Lτ, n) + Ls + (self.Nrv,)
+        self.Rt = np.zeros(shape, dtype=np.complex128, order="F")
+        self.GR = np.zeros(shape, dtype=np.complex128, order="F")
+        self._pre_cfg = None
+        update_greens_estimator(self, fdm, preconditioner=preconditioner, rng=rng, maxiter=maxiter, tol=tol)  # :111-118
+
+    @property
+    def CΔ0_shape(self):
+        return (self.Lτ + 1,) + self.L
+
+
+def update_greens_estimator(greens_estimator: GreensEstimator, fermion_det_matrix: FermionDetMatrix, preconditioner=I, rng=None, maxiter=None, tol=None):
+    """update_greens_estimator!(ge, fdm; preconditioner, rng, maxiter, tol), src/Measurements/GreensEstimator.jl:125-175.
+    Returns the average iteration count.  All ``Nrv`` right-hand sides advance in one batched CG."""
+    ge, fdm, h = greens_estimator, fermion_det_matrix, greens_estimator.handle
+    rng = rng if rng is not None else np.random.default_rng()
+    maxiter = fdm.cgs.maxiter if maxiter is None else int(maxiter)
+    tol = fdm.cgs.tol if tol is None else float(tol)
+    h.call("smoqy_copy_fields", 0, fdm.handle._h, 0)
+    # randn!(rng, R); R ./= abs.(R)  (:141-142), one V-vector per random vector, in the reference's memory order
+    R = np.empty((fdm.Lt, fdm.N, ge.Nrv), dtype=np.complex128, order="F")
+    flat = R.reshape(-1, order="F").view(np.float64)
+    rng.standard_normal(out=flat)
+    R /= np.abs(R)
+    use_pre = isinstance(preconditioner, KPMPreconditioner)
+    if use_pre:  # update_preconditioner!(preconditioner, fdm, rng)  (:150), on the measurement handle
+        cfg = (preconditioner.rbuf, preconditioner.n, preconditioner.a1 / (2 if fdm.is_sym else 1), preconditioner.a2)
+        if ge._pre_cfg != cfg:
+            h.call("smoqy_precond_config", C.c_double(cfg[0]), int(cfg[1]), C.c_double(cfg[2]), C.c_double(cfg[3]))
+            ge._pre_cfg = cfg
+        rv = np.ascontiguousarray(rng.standard_normal(fdm.N))
+        h.call("smoqy_precond_update", 0, L.ptr(rv))
+    h.vec_upload(ge._r, R)
+    h.call("smoqy_matvec_v", L.OP_MT, ge._mtr, ge._r)                    # mul_Mt!(MtR, fdm, R′)   :157
+    iters = np.zeros(ge.Nrv, dtype=np.int32)
+    eps = np.zeros(ge.Nrv)
+    h.call("smoqy_cg_solve_v", ge._gr, ge._mtr, C.c_double(tol), maxiter, int(use_pre), L.ptr(iters), L.ptr(eps))  # ldiv!(GR′, fdm, MtR)  :159-165 (GR′ is the initial guess)
+    shape = ge.GR.shape
+    ge.GR[...] = h.vec_download(ge._gr).reshape(shape, order="F")
+    ge.Rt[...] = np.conj(R).reshape(shape, order="F")                    # :171
+    return float(iters.mean())
+
+
+def measure_GΔ0(correlation, greens_estimator: GreensEstimator, orbitals):
+    """measure_GΔ0!(correlation, ge, (a, b)), src/Measurements/GreensEstimator.jl:179-233: adds the translation-averaged
+    G(Δ,0) (shape ``L... x (Lτ+1)``) to ``correlation``; the cross-correlations run on the device."""
+    ge, h = greens_estimator, greens_estimator.handle
+    a, b = (int(x) for x in orbitals)
+    out = np.zeros(ge.CΔ0_shape, dtype=np.complex128, order="F")
+    h.call("smoqy_ge_measure_GD0", ge._gr, ge._r, a, b, L.ptr(out))
+    correlation += np.moveaxis(out, 0, -1)                               # add_contraction_to_correlation!  :712-726
+    return None
+
+
+measure_GD0 = measure_GΔ0

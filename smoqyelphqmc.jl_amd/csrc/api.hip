@@ -102,6 +102,16 @@ struct smoqy_ctx {
         bool bare_set = false, t_done = false;
         ForceArgs tmpl{};
     } force;
+    // GreensEstimator contractions
+    struct GeState {
+        bool set = false;
+        int n_orb = 0, D = 0, Nc = 0;
+        size_t n2 = 0;  // 2 Lτ · Nc, the size of one aperiodic array
+        rocfft_plan fwd_sys = nullptr, inv_sys = nullptr, inv_w = nullptr;
+        rocfft_execution_info info = nullptr;
+        void *work = nullptr;
+        double2 *A = nullptr, *B = nullptr, *P = nullptr, *out = nullptr;
+    } ge;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -216,6 +226,17 @@ extern "C" {
 
 const char *smoqy_last_error(const smoqy_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+static void ge_release(smoqy_ctx *c)
+{
+    auto &G = c->ge;
+    for (rocfft_plan p : {G.fwd_sys, G.inv_sys, G.inv_w})
+        if (p) rocfft_plan_destroy(p);
+    if (G.info) rocfft_execution_info_destroy(G.info);
+    for (void *q : {G.work, (void *)G.A, (void *)G.B, (void *)G.P, (void *)G.out})
+        if (q) (void)hipFree(q);
+    G = smoqy_ctx::GeState{};
+}
+
 int smoqy_destroy(smoqy_ctx *c)
 {
     if (!c) return 0;
@@ -225,6 +246,7 @@ int smoqy_destroy(smoqy_ctx *c)
         if (gph.exec) (void)hipGraphExecDestroy(gph.exec);
         if (gph.graph) (void)hipGraphDestroy(gph.graph);
     }
+    ge_release(c);
     if (c->plan_f) rocfft_plan_destroy(c->plan_f);
     if (c->plan_b) rocfft_plan_destroy(c->plan_b);
     if (c->plan_f_oop) rocfft_plan_destroy(c->plan_f_oop);
@@ -1700,6 +1722,99 @@ int smoqy_force_store_v(smoqy_ctx *c, int psi, double *out)
     if (nx) HIPCHK(c, hipMemcpyAsync(out, c->force.d_out, nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_launch(c, "force");
+}
+
+
+// ---- GreensEstimator -----------------------------------------------------------
+
+int smoqy_copy_fields(smoqy_ctx *dst, int dst_walker, smoqy_ctx *src, int src_walker)
+{
+    CHECK_CTX(dst);
+    if (!src) FAIL(dst, 1, "source handle is NULL");
+    CHECK_WALKER(dst, dst_walker);
+    if (src_walker < 0 || src_walker >= src->g.nw) FAIL(dst, 1, "source walker %d out of range", src_walker);
+    const Geometry &a = dst->g, &b = src->g;
+    if (a.Lt != b.Lt || a.N != b.N || a.Nh != b.Nh || a.ncol != b.ncol || a.is_sym != b.is_sym || dst->kg.ptotal != src->kg.ptotal || dst->device != src->device)
+        FAIL(dst, 1, "smoqy_copy_fields needs two handles of the same lattice, propagator form and device");
+    HIPCHK(dst, hipStreamSynchronize(src->stream));  // the source's fields are final
+    const size_t nV = (size_t)a.Lt * a.N, nT = (size_t)a.Lt * a.Nh, nP = (size_t)a.Lt * dst->kg.ptotal;
+    HIPCHK(dst, hipMemcpyAsync(dst->d_expV + dst_walker * nV, src->d_expV + src_walker * nV, nV * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+    HIPCHK(dst, hipMemcpyAsync(dst->d_lam + dst_walker * nV, src->d_lam + src_walker * nV, nV * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+    if (nT) {
+        HIPCHK(dst, hipMemcpyAsync(dst->d_ch + dst_walker * nT, src->d_ch + src_walker * nT, nT * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+        HIPCHK(dst, hipMemcpyAsync(dst->d_sh + dst_walker * nT, src->d_sh + src_walker * nT, nT * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+    }
+    if (nP) HIPCHK(dst, hipMemcpyAsync(dst->d_csf + dst_walker * nP, src->d_csf + src_walker * nP, nP * sizeof(double2), hipMemcpyDeviceToDevice, dst->stream));
+    HIPCHK(dst, hipMemcpyAsync(dst->d_cs_varies + dst_walker, src->d_cs_varies + src_walker, sizeof(int), hipMemcpyDeviceToDevice, dst->stream));
+    HIPCHK(dst, hipStreamSynchronize(dst->stream));
+    return 0;
+}
+
+int smoqy_ge_config(smoqy_ctx *c, int n_orbitals, int D, const int64_t *Ldims)
+{
+    CHECK_CTX(c);
+    const Geometry &g = c->g;
+    if (n_orbitals < 1 || D < 1 || !Ldims) FAIL(c, 1, "invalid unit cell / lattice description");
+    if (D > 2) FAIL(c, 5, "GreensEstimator contractions need a (D+1)-dimensional transform; rocFFT plans stop at 3 dimensions (D = %d)", D);
+    size_t Nc = 1;
+    for (int d = 0; d < D; ++d) {
+        if (Ldims[d] < 1) FAIL(c, 1, "L[%d] = %lld", d, (long long)Ldims[d]);
+        Nc *= (size_t)Ldims[d];
+    }
+    if ((size_t)n_orbitals * Nc != (size_t)g.N) FAIL(c, 1, "n_orbitals * prod(L) = %zu does not match N = %d", (size_t)n_orbitals * Nc, g.N);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ge_release(c);
+    auto &G = c->ge;
+    G.n_orb = n_orbitals; G.D = D; G.Nc = (int)Nc; G.n2 = 2 * (size_t)g.Lt * Nc;
+    std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+    size_t len[3] = {2 * (size_t)g.Lt, 1, 1};  // τ fastest, then the lattice directions: the reference's (2Lτ, L...) column-major arrays (:91-92)
+    for (int d = 0; d < D; ++d) len[1 + d] = (size_t)Ldims[d];
+    FFTCHK(c, rocfft_plan_create(&G.fwd_sys, rocfft_placement_inplace, rocfft_transform_type_complex_forward, rocfft_precision_double, (size_t)D + 1, len, (size_t)g.nsys, nullptr));
+    FFTCHK(c, rocfft_plan_create(&G.inv_sys, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, rocfft_precision_double, (size_t)D + 1, len, (size_t)g.nsys, nullptr));
+    FFTCHK(c, rocfft_plan_create(&G.inv_w, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, rocfft_precision_double, (size_t)D + 1, len, (size_t)g.nw, nullptr));
+    size_t wsz = 0;
+    for (rocfft_plan p : {G.fwd_sys, G.inv_sys, G.inv_w}) {
+        size_t w1 = 0;
+        FFTCHK(c, rocfft_plan_get_work_buffer_size(p, &w1));
+        wsz = std::max(wsz, w1);
+    }
+    FFTCHK(c, rocfft_execution_info_create(&G.info));
+    if (wsz) {
+        HIPCHK(c, hipMalloc(&G.work, wsz));
+        FFTCHK(c, rocfft_execution_info_set_work_buffer(G.info, G.work, wsz));
+    }
+    FFTCHK(c, rocfft_execution_info_set_stream(G.info, c->stream));
+    HIPCHK(c, hipMalloc(&G.A, (size_t)g.nsys * G.n2 * sizeof(double2)));
+    HIPCHK(c, hipMalloc(&G.B, (size_t)g.nsys * G.n2 * sizeof(double2)));
+    HIPCHK(c, hipMalloc(&G.P, (size_t)g.nw * G.n2 * sizeof(double2)));
+    HIPCHK(c, hipMalloc(&G.out, (size_t)g.nw * Nc * ((size_t)g.Lt + 1) * sizeof(double2)));
+    G.set = true;
+    return 0;
+}
+
+int smoqy_ge_measure_GD0(smoqy_ctx *c, int gr, int r, int a, int b, void *out)
+{
+    CHECK_CTX(c);
+    auto &G = c->ge;
+    if (!G.set) FAIL(c, 1, "call smoqy_ge_config first");
+    if (int rc = check_vec(c, gr)) return rc;
+    if (int rc = check_vec(c, r)) return rc;
+    if (a < 1 || a > G.n_orb || b < 1 || b > G.n_orb) FAIL(c, 1, "orbitals (%d, %d) out of range 1..%d", a, b, G.n_orb);
+    if (!out) FAIL(c, 1, "out is NULL");
+    const Geometry &g = c->g;
+    FFTCHK(c, rocfft_execution_info_set_stream(G.info, c->stream));
+    launch_ge_gather(c->stream, c->vecs[gr], G.A, g.Lt, g.N, g.nsys, G.n_orb, a - 1, G.Nc, 0);   // _aperiodic_copyto!(A, GR_a_i)   :213
+    launch_ge_gather(c->stream, c->vecs[r], G.B, g.Lt, g.N, g.nsys, G.n_orb, b - 1, G.Nc, 1);    // _aperiodic_copyto!(B, Rt_b_i), Rt = conj(R)  :214, :171
+    void *bufA[1] = {G.A}, *bufB[1] = {G.B}, *bufP[1] = {G.P};
+    FFTCHK(c, rocfft_execute(G.fwd_sys, bufA, nullptr, G.info));                                  // mul!(a, pfft!, a)   :686
+    FFTCHK(c, rocfft_execute(G.inv_sys, bufB, nullptr, G.info));                                  // mul!(b, pifft!, b)  :687 (1/n folded into the scale below)
+    launch_ge_product(c->stream, G.A, G.B, G.P, G.n2, g.nrhs, g.nw);                              // a .* b, summed over the random vectors  :692, :205-217
+    FFTCHK(c, rocfft_execute(G.inv_w, bufP, nullptr, G.info));                                    // mul!(a, pifft!, a)  :695
+    const double scale = 1.0 / ((double)G.n2 * (double)G.n2 * (double)g.nrhs);
+    launch_ge_finalize_gd0(c->stream, G.P, G.out, g.Lt, G.Nc, g.nw, scale, a == b);               // :697-705, :219-227
+    HIPCHK(c, hipMemcpyAsync(out, G.out, (size_t)g.nw * G.Nc * ((size_t)g.Lt + 1) * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_launch(c, "ge_measure_GD0");
 }
 
 // ---- measurement aids -------------------------------------------------------------------------------

@@ -183,6 +183,11 @@ void launch_force_reduce(hipStream_t st, const ForceArgs &a, double *out);
 // V(x), t(x) -> expV, cosh, sinh (+ Λ) for every walker from the device copy of the phonon fields
 void launch_phonon_fields(hipStream_t st, const ForceArgs &a, const double *V0, const double *t0s, double *expV, double *ch, double *sh, double *lam, double dtau_k, bool do_t);
 
+// GreensEstimator contractions (kernels_greens.hip)
+void launch_ge_gather(hipStream_t st, const double2 *v, double2 *A, int Lt, int N, int nsys, int n_orb, int orb, int Nc, int conj);
+void launch_ge_product(hipStream_t st, const double2 *Ah, const double2 *Bh, double2 *P, size_t n2, int nrhs, int nw);
+void launch_ge_finalize_gd0(hipStream_t st, const double2 *S, double2 *out, int Lt, int Nc, int nw, double scale, int same_orbital);
+
 // own tau-FFT (kernels_tfft.hip): Stockham passes over LDS site tiles, optionally fused with the CG updates
 struct TfftArgs {
     int Lt, N, nsys, SB, ntile, nfac;

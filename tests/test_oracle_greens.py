@@ -1,0 +1,58 @@
+"""Known-answer test of the oracle's GreensEstimator contractions (oracle/greens.py, restating
+src/Measurements/GreensEstimator.jl:179-233, 656-708): with a complete unit-modulus orthogonal set of random vectors
+the stochastic estimate is exact and must equal the translational average of the dense G = M⁻¹ from its definition."""
+import numpy as np
+import pytest
+
+import smoqyelphqmc_amd as sq
+from oracle import dense, greens, oracle as orc
+
+lat = sq.lattice
+
+
+def dense_G(m, is_sym=True):
+    nt, perm, colors = lat.checkerboard_decomposition(m.fpi.neighbor_table)
+    expV, ch, sh = orc.update_fields(m.fpi.V, m.fpi.t, perm, m.fpi.dtau, is_sym)
+    M, _ = dense.dense_M(nt, expV, ch, sh, is_sym)
+    return np.linalg.inv(M)
+
+
+@pytest.mark.parametrize("kind", ["honeycomb", "chain", "square"])
+def test_measure_GD0_is_exact_for_a_complete_set_of_vectors(kind):
+    if kind == "honeycomb":
+        m, n, Ls = lat.holstein_honeycomb(2, 3), 2, (2, 2)
+    elif kind == "chain":
+        m, n, Ls = lat.bssh_chain(6, 4), 1, (6,)
+    else:
+        m, n, Ls = lat.ossh_square(2, 3), 1, (2, 2)
+    Lt, N = m.fpi.Ltau, m.fpi.N
+    V = Lt * N
+    G = dense_G(m)
+    k = np.arange(V)
+    R = np.exp(2j * np.pi * np.outer(k, k) / V)          # unit modulus, R Rᴴ = V·I
+    GR = (G @ R).reshape((Lt, n) + Ls + (V,), order="F")  # M⁻¹ R, one column per vector  (:152-168)
+    Rt = np.conj(R).reshape((Lt, n) + Ls + (V,), order="F")  # :171
+    for a in range(1, n + 1):
+        for b in range(1, n + 1):
+            got = greens.measure_GD0(GR, Rt, a, b)
+            want = greens.exact_GD0(G, Lt, n, Ls, a, b)
+            assert np.abs(got - want).max() < 1e-12 * max(1.0, np.abs(want).max()), (kind, a, b)
+
+
+def test_translational_average_against_direct_sums():
+    g = np.random.default_rng(5)
+    a = g.standard_normal((6, 3, 4)) + 1j * g.standard_normal((6, 3, 4))
+    b = g.standard_normal((6, 3, 4)) + 1j * g.standard_normal((6, 3, 4))
+    S = greens.translational_average(np.zeros((4, 3, 4), dtype=complex), a.copy(), b.copy())  # Lτ = 3 rows of a 6-row array
+    n = a.size
+    for r in [(0, 0, 0), (1, 2, 3), (2, 1, 0)]:
+        want = sum(a[(i + r[0]) % 6, (j + r[1]) % 3, (k + r[2]) % 4] * b[i, j, k] for i in range(6) for j in range(3) for k in range(4)) / n
+        assert abs(S[r] - want) < 1e-13
+    assert np.allclose(S[3], S[0])
+
+
+def test_add_contraction_moves_tau_last():
+    c = np.zeros((2, 3, 5), dtype=complex)
+    x = np.arange(30).reshape(5, 2, 3).astype(complex)
+    greens.add_contraction_to_correlation(c, x, 2.0)
+    assert c[1, 2, 4] == 2 * x[4, 1, 2]
