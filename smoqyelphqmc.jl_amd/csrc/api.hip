@@ -1342,6 +1342,8 @@ static int cg_iteration(smoqy_ctx *c, const CgArgs &a, bool any_pre)
     return 0;
 }
 
+constexpr int kGraphIters = 4;  // iterations per captured graph (smoqy_cg_use_graph)
+
 static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, double tol, int maxiter, int use_precond, int *iters, double *eps)
 {
     const Geometry &g = c->g;
@@ -1381,8 +1383,8 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
         if (launched == 0 && hint > burst) burst = std::min(hint - 1, maxiter);
         hipGraphExec_t gexec = nullptr;
         if (c->use_graph) {
-            // one CG iteration captured once per (x, preconditioning, kernel configuration) and replayed:
-            // the inner loop is launch bound at small batch (6 short dependent kernels per iteration)
+            // kGraphIters CG iterations captured once per (x, preconditioning, kernel configuration) and replayed:
+            // the inner loop is launch bound at small batch (4 short dependent kernels per iteration)
             for (auto &gph : c->graphs)
                 if (gph.exec && gph.x == (const void *)x && gph.pre == (int)any_pre && gph.Tc == c->Tc && gph.ffast == c->ff.enabled && gph.kfast == c->kg.fast) gexec = gph.exec;
             if (!gexec) {
@@ -1393,7 +1395,7 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
                 bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
                 int rc = 0;
                 if (ok) {
-                    rc = cg_iteration(c, a, any_pre);
+                    for (int q = 0; q < kGraphIters && rc == 0; ++q) rc = cg_iteration(c, a, any_pre);
                     ok = (hipStreamEndCapture(c->stream, &slot.graph) == hipSuccess) && rc == 0 && slot.graph;
                 }
                 if (ok) ok = hipGraphInstantiate(&slot.exec, slot.graph, nullptr, nullptr, 0) == hipSuccess;
@@ -1408,9 +1410,13 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
                 }
             }
         }
-        for (int it = 0; it < burst; ++it) {
-            if (gexec) HIPCHK(c, hipGraphLaunch(gexec, c->stream));
-            else if (int rc = cg_iteration(c, a, any_pre)) return rc;
+        if (gexec) {
+            // whole graphs only: iterations past convergence or maxiter are workgroups that exit on their first load
+            burst = ((burst + kGraphIters - 1) / kGraphIters) * kGraphIters;
+            for (int it = 0; it < burst; it += kGraphIters) HIPCHK(c, hipGraphLaunch(gexec, c->stream));
+        } else {
+            for (int it = 0; it < burst; ++it)
+                if (int rc = cg_iteration(c, a, any_pre)) return rc;
         }
         launched += burst;
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyDeviceToHost, c->stream));

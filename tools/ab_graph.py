@@ -2,7 +2,7 @@ import sys, time
 sys.path.insert(0, '.')
 import torch
 from smoqyelphqmc_amd.walkers import WalkerBatch
-for nw in (1, 4, 16):
+for nw in (1, 4):
     for g in (0, 1, 0, 1):
         b = WalkerBatch("holstein_honeycomb_L16_Ltau128", nwalkers=nw)
         b.h.call("smoqy_cg_use_graph", g)
