@@ -230,6 +230,18 @@ def main():
                 scan.append(best)
                 hb.close()
             extra["matvec_batch_scan"] = scan
+        # the literal BASELINE.json configuration — ONE walker per GPU — next to the batched headline figure (outside the timed region)
+        one = WalkerBatch(args.workload, nwalkers=1, walker0=mine.start, device=dev)
+        one.sweep()
+        one.h.call("smoqy_sync")
+        t1 = time.perf_counter()
+        for _ in range(2):
+            one.sweep()
+        one.h.call("smoqy_sync")
+        ms_one = (time.perf_counter() - t1) / 2 * 1e3
+        one.h.close()
+        extra["single_walker"] = {"walkers_per_gpu": 1, "sweeps_per_s": 1e3 / ms_one, "ms_per_sweep": ms_one,
+                                  "note": "one walker on one stream: the launch-latency regime (4 dependent launches per CG iteration)"}
         cpu = None if args.no_cpu_baseline else cpu_baseline(args.workload, batch.tol, batch.Nt)
         out = {
             "metric": "QMC sweeps/sec (27 preconditioned CG solves per sweep) + FermionDetMatrix matvec GB/s vs HBM roofline, fp64",

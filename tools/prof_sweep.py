@@ -3,7 +3,8 @@ sys.path.insert(0, '.')
 import torch
 from smoqyelphqmc_amd.walkers import WalkerBatch
 nw = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-b = WalkerBatch("holstein_honeycomb_L16_Ltau128", nwalkers=nw)
+wl = sys.argv[2] if len(sys.argv) > 2 else "holstein_honeycomb_L16_Ltau128"
+b = WalkerBatch(wl, nwalkers=nw)
 b.sweep()
 import smoqyelphqmc_amd._lib as L
 import collections

@@ -2,7 +2,8 @@ import sys, time, cProfile, pstats
 sys.path.insert(0, '.')
 from smoqyelphqmc_amd.walkers import WalkerBatch
 nw = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-b = WalkerBatch("holstein_honeycomb_L16_Ltau128", nwalkers=nw)
+wl = sys.argv[2] if len(sys.argv) > 2 else "holstein_honeycomb_L16_Ltau128"
+b = WalkerBatch(wl, nwalkers=nw)
 b.sweep(); b.sweep()
 t0 = time.perf_counter(); b.sweep(); b.h.call("smoqy_sync"); print("sweep ms", 1e3 * (time.perf_counter() - t0))
 pr = cProfile.Profile(); pr.enable(); b.sweep(); b.h.call("smoqy_sync"); pr.disable()

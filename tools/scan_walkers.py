@@ -7,7 +7,7 @@ import torch  # noqa: F401  (same HIP runtime as bench.py)
 from smoqyelphqmc_amd.walkers import WalkerBatch
 
 workload = sys.argv[1] if len(sys.argv) > 1 else "holstein_honeycomb_L16_Ltau128"
-combos = [(1, 1), (8, 1), (16, 1), (32, 2), (64, 4), (128, 4)]
+combos = [(1, 1), (16, 1), (64, 4)]
 for wpg, S in combos:
     bs = [WalkerBatch(workload, nwalkers=wpg // S, walker0=s * (wpg // S)) for s in range(S)]
     def run(n):
