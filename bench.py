@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--check-every", type=int, default=0)
     ap.add_argument("--matvec-reps", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true", help="run only the isolated roofline leg (for a rocprofv3 pass whose kernel average must match roofline.avg_launch_us)")
     ap.add_argument("--batch-scan", action="store_true", help="also report matvec GB/s vs batch size")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="rehearsal of the N>1 control flow on a one-GPU box: every rank uses cuda:0 and the barrier / MAX reduction run over gloo")
@@ -160,15 +161,27 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if args.roofline_only:
+        args.warmup, args.steps = 0, 0
     run(args.warmup)
     for b in batches:
         b.stats.solves = b.stats.iters_sum = 0
+        # roofline: the dominant kernel's launches inside the timed region are sampled with HIP events on the stream
+        # they run on (every 8th full-batch fused MᵀM launch of the CG loop)
+        b.h.call("smoqy_matvec_timing", 8, 4096)
     fence()
     t0 = time.perf_counter()
     run(args.steps)
     fence()
     elapsed = reduce_max_time(time.perf_counter() - t0, device="cpu" if args.rehearse_one_gpu else "cuda")
-    value = aggregate_throughput(wpg * args.steps, world, elapsed)
+    value = aggregate_throughput(wpg * args.steps, world, elapsed) if args.steps else 0.0
+    insitu_us, insitu_n = 0.0, 0
+    for b in batches:
+        us, n = L.C.c_double(0.0), L.C.c_int(0)
+        b.h.call("smoqy_matvec_timing_read", L.C.byref(us), L.C.byref(n))
+        insitu_us += us.value * n.value
+        insitu_n += n.value
+    insitu_us = insitu_us / insitu_n if insitu_n else None
 
     if rank == 0:
         # --- roofline of the dominant kernel: fused MᵀM apply ------------------------------------
@@ -194,6 +207,10 @@ def main():
                 traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/r01_pmc_traffic_fdm_mtm.json"
         except (OSError, ValueError, KeyError):
             pass
+        # `achieved` is the kernel with the GPU to itself (back-to-back launches on the handle's stream, HIP events on that
+        # stream; `python bench.py --roofline-only` repeats exactly this leg for rocprofv3).  `in_timed_region` is the same
+        # kernel sampled with event pairs while S streams share the GPU: those brackets contain the dependency gap to the
+        # neighbouring launches and the time slices of the other streams' kernels, so they describe the mix, not the kernel.
         roofline = {
             "bound": "hbm",
             "kernel": "fdm_fast_kernel<3, MtM> (fused MᵀM apply)",
@@ -205,9 +222,15 @@ def main():
             "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg,
             "avg_launch_us": per_launch_s * 1e6,
+            "launches": args.matvec_reps,
             "systems_per_launch": per,
             "tau_chunk": tc.value,
-            "note": "working set is L2/Infinity-Cache resident at this size; fraction is algorithmic bytes over wall time, see DESIGN.md",
+            "in_timed_region": None if not insitu_us else {
+                "avg_launch_us": insitu_us, "achieved": alg / (insitu_us * 1e-6) / 1e9, "frac": alg / (insitu_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "launches_sampled": insitu_n, "concurrent_streams": S,
+                "note": "event pairs around every 8th MtM launch of the CG loops while all streams run; includes inter-launch gaps and the other streams' time slices",
+            },
+            "note": "working set is L2/Infinity-Cache resident at this size; fraction is algorithmic bytes over launch duration, see DESIGN.md",
         }
         extra = {}
         if args.batch_scan:
@@ -231,18 +254,20 @@ def main():
                 hb.close()
             extra["matvec_batch_scan"] = scan
         # the literal BASELINE.json configuration — ONE walker per GPU — next to the batched headline figure (outside the timed region)
-        one = WalkerBatch(args.workload, nwalkers=1, walker0=mine.start, device=dev)
-        one.sweep()
-        one.h.call("smoqy_sync")
-        t1 = time.perf_counter()
-        for _ in range(2):
+        if world == 1 and not args.roofline_only:
+            one = WalkerBatch(args.workload, nwalkers=1, walker0=mine.start, device=dev)
             one.sweep()
-        one.h.call("smoqy_sync")
-        ms_one = (time.perf_counter() - t1) / 2 * 1e3
-        one.h.close()
-        extra["single_walker"] = {"walkers_per_gpu": 1, "sweeps_per_s": 1e3 / ms_one, "ms_per_sweep": ms_one,
-                                  "note": "one walker on one stream: the launch-latency regime (4 dependent launches per CG iteration)"}
-        cpu = None if args.no_cpu_baseline else cpu_baseline(args.workload, batch.tol, batch.Nt)
+            one.h.call("smoqy_sync")
+            t1 = time.perf_counter()
+            for _ in range(2):
+                one.sweep()
+            one.h.call("smoqy_sync")
+            ms_one = (time.perf_counter() - t1) / 2 * 1e3
+            one.h.close()
+            extra["single_walker"] = {"walkers_per_gpu": 1, "sweeps_per_s": 1e3 / ms_one, "ms_per_sweep": ms_one,
+                                      "note": "one walker on one stream: the launch-latency regime (4 dependent launches per CG iteration)"}
+        # the CPU baseline is a rank-0, N = 1 measurement (it would only hold the other ranks at the final barrier)
+        cpu = None if (args.no_cpu_baseline or args.roofline_only or world > 1) else cpu_baseline(args.workload, batch.tol, batch.Nt)
         out = {
             "metric": "QMC sweeps/sec (27 preconditioned CG solves per sweep) + FermionDetMatrix matvec GB/s vs HBM roofline, fp64",
             "value": value,
@@ -250,7 +275,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": elapsed / args.steps * 1e3 if args.steps else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

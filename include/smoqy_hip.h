@@ -247,6 +247,10 @@ int smoqy_ge_measure_GD0(smoqy_ctx *ctx, int gr, int r, int a, int b, void *out)
 int smoqy_timer_start(smoqy_ctx *ctx);
 int smoqy_timer_stop(smoqy_ctx *ctx, double *ms);
 /* `reps` back-to-back launches of one matvec kernel between two HIP events; *ms = total */
+/* in-situ duration of the fused MᵀM launches inside the CG loop: every sample_every-th full-batch launch is bracketed
+ * by an event pair on the handle's stream (at most max_samples); _read synchronises, returns the mean and stops sampling */
+int smoqy_matvec_timing(smoqy_ctx *ctx, int sample_every, int max_samples);
+int smoqy_matvec_timing_read(smoqy_ctx *ctx, double *avg_us, int *samples);
 int smoqy_bench_matvec(smoqy_ctx *ctx, int op, int out, int in, int reps, double *ms);
 /* algorithmic bytes of one launch of `op` over all systems ((2S+F) per M / Mᵀ,
  * 2(2S+F) per MᵀM / MMᵀ, F counted once per walker) */

@@ -106,6 +106,8 @@ SIGNATURES = {
     "smoqy_ge_measure_GD0": [_p, _i, _i, _i, _i, _p],
     "smoqy_timer_start": [_p],
     "smoqy_timer_stop": [_p, _pd],
+    "smoqy_matvec_timing": [_p, _i, _i],
+    "smoqy_matvec_timing_read": [_p, _pd, _pi],
     "smoqy_bench_matvec": [_p, _i, _i, _i, _i, _pd],
     "smoqy_algorithmic_bytes": [_p, _i, _pd],
 }

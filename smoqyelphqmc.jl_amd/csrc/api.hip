@@ -114,6 +114,12 @@ struct smoqy_ctx {
     } ge;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // in-situ duration of the fused MᵀM launches of the CG loop (smoqy_matvec_timing): every `every`-th launch is
+    // bracketed by an event pair on the handle's stream; read back after the timed region
+    struct MvTiming {
+        int every = 0, seen = 0, used = 0;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    } mvt;
 
     size_t vec_elems() const { return (size_t)g.nsys * g.Lt * g.N; }
 };
@@ -263,6 +269,7 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->force.h_out) (void)hipHostFree(c->force.h_out);
     for (void *q : {c->force.blob, (void *)c->force.d_x, (void *)c->force.d_contrib, (void *)c->force.d_out})
         if (q) (void)hipFree(q);
+    for (auto &e : c->mvt.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -784,9 +791,13 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
         a.hop_im = -std::sin(M_PI / c->g.Lt);
         a.antiperiodic = 0;
     }
+    auto &T = c->mvt;
+    const bool sample = T.every > 0 && op == SMOQY_OP_MTM && count == c->g.nsys && T.used < (int)T.ev.size() && (T.seen++ % T.every) == 0;
+    if (sample) HIPCHK(c, hipEventRecord(T.ev[T.used].first, c->stream));
     if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_own(c->stream, op, a, c->ff);
     else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_fast(c->stream, op, a, c->ff);
     else launch_fdm(c->stream, op, c->g.is_sym != 0, a, fdm_lds_bytes(op, c->g.N, c->Tc));
+    if (sample) HIPCHK(c, hipEventRecord(T.ev[T.used++].second, c->stream));
     return check_launch(c, "matvec");
 }
 
@@ -1840,6 +1851,41 @@ int smoqy_timer_stop(smoqy_ctx *c, double *ms)
     float f = 0;
     HIPCHK(c, hipEventElapsedTime(&f, c->ev0, c->ev1));
     *ms = f;
+    return 0;
+}
+
+int smoqy_matvec_timing(smoqy_ctx *c, int sample_every, int max_samples)
+{
+    CHECK_CTX(c);
+    auto &T = c->mvt;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (sample_every < 0 || max_samples < 0 || max_samples > 65536) FAIL(c, 1, "invalid sampling parameters");
+    while ((int)T.ev.size() < max_samples) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIPCHK(c, hipEventCreate(&a));
+        HIPCHK(c, hipEventCreate(&b));
+        T.ev.push_back({a, b});
+    }
+    T.every = sample_every;
+    T.seen = T.used = 0;
+    return 0;
+}
+
+int smoqy_matvec_timing_read(smoqy_ctx *c, double *avg_us, int *samples)
+{
+    CHECK_CTX(c);
+    auto &T = c->mvt;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double sum = 0.0;
+    for (int k = 0; k < T.used; ++k) {
+        float f = 0;
+        HIPCHK(c, hipEventElapsedTime(&f, T.ev[k].first, T.ev[k].second));
+        sum += f;
+    }
+    if (avg_us) *avg_us = T.used ? 1e3 * sum / T.used : 0.0;
+    if (samples) *samples = T.used;
+    T.every = 0;
+    T.seen = T.used = 0;
     return 0;
 }
 
