@@ -241,6 +241,22 @@ int smoqy_ge_config(smoqy_ctx *ctx, int n_orbitals, int D, const int64_t *L);
  * add_contraction_to_correlation! permutes τ to the last axis (:712-726).  a, b are 1-based orbitals. */
 int smoqy_ge_measure_GD0(smoqy_ctx *ctx, int gr, int r, int a, int b, void *out);
 
+/* one factor of a four-point estimator: which solved/random vector, which orbital, the static displacement of
+ * ShiftedArrays.circshift(·, (0, -r..., 0)) (src/Measurements/GreensEstimator.jl:265-268), and whether it takes the
+ * first (n) or the second (m) random vector of a pair n < m */
+typedef struct {
+    int source;        /* 0: GR = M⁻¹R, 1: Rt = conj(R) */
+    int orbital;       /* 1-based */
+    int64_t shift[2];  /* r, unit cells */
+    int second;        /* 0: vector n of the pair, 1: vector m */
+} smoqy_ge_slot;
+/* the pair sum shared by measure_GΔ0_GΔ0!, measure_GΔΔ_G00! and measure_G0Δ_GΔ0! (:285-306, 439-460, 518-539):
+ *   CΔ0 = 1/Npairs Σ_{n<m} _measure_CΔ0!(slot0 ⊙ slot1 [⊙ tΔ], slot2 ⊙ slot3 [⊙ t0])        (:610-652, 677-708)
+ * over all pairs of the handle's nrhs random vectors, per walker.  tD / t0 are complex (Lτ x L...) weight arrays or
+ * NULL, conjugated when the flag is set (bconj, :729).  out is complex (Lτ+1) x L... x nwalkers; the scalar boundary
+ * terms at τ = 0 / τ = β (:312-382, 545-599) are left to the caller, who holds GR and Rt. */
+int smoqy_ge_measure_pairs(smoqy_ctx *ctx, int gr, int r, const smoqy_ge_slot *slots, const void *tD, int conj_tD, const void *t0, int conj_t0, void *out);
+
 /* ---- measurement aids (bench.py) -------------------------------------------------------- */
 
 /* HIP events on the handle's stream */

@@ -104,6 +104,7 @@ SIGNATURES = {
     "smoqy_copy_fields": [_p, _i, _p, _i],
     "smoqy_ge_config": [_p, _i, _i, _p],
     "smoqy_ge_measure_GD0": [_p, _i, _i, _i, _i, _p],
+    "smoqy_ge_measure_pairs": [_p, _i, _i, _p, _p, _i, _p, _i, _p],
     "smoqy_timer_start": [_p],
     "smoqy_timer_stop": [_p, _pd],
     "smoqy_matvec_timing": [_p, _i, _i],
@@ -180,6 +181,12 @@ def couplings_struct(fc):
     s = CouplingsStruct(int(np.shape(fc.x)[0]), float(fc.dtau), ptr(k[0]), len(k[1]), ptr(k[1]), ptr(k[2]), ptr(k[3]), ptr(k[4]), ptr(k[5]), ptr(k[6]), ptr(k[7]), len(k[8]), ptr(k[8]),
                         ptr(k[9]), ptr(k[10]), ptr(k[11]), ptr(k[12]), ptr(k[13]))
     return s, k
+
+
+class GeSlot(C.Structure):
+    """``smoqy_ge_slot`` of include/smoqy_hip.h."""
+
+    _fields_ = [("source", C.c_int), ("orbital", C.c_int), ("shift", C.c_int64 * 2), ("second", C.c_int)]
 
 
 class Handle:

@@ -672,3 +672,105 @@ def measure_GΔ0(correlation, greens_estimator: GreensEstimator, orbitals):
 
 
 measure_GD0 = measure_GΔ0
+
+
+# four-point estimators: the pair sums run on the device, the scalar boundary terms on the host arrays GR / Rt exactly as the
+# reference writes them (src/Measurements/GreensEstimator.jl:241-606)
+
+def _ge_pair_sum(ge: GreensEstimator, slots, tΔ, t0, conj_tΔ, conj_t0):
+    h = ge.handle
+    arr = (L.GeSlot * 4)()
+    for q, (source, orbital, shift, second) in enumerate(slots):
+        arr[q].source, arr[q].orbital, arr[q].second = int(source), int(orbital), int(second)
+        for d in range(2):
+            arr[q].shift[d] = int(shift[d]) if d < len(shift) else 0
+    wshape = (ge.Lτ,) + ge.L
+    keep = []
+
+    def weights(t):
+        if t is None:
+            return None
+        w = np.asfortranarray(np.broadcast_to(np.asarray(t), wshape), dtype=np.complex128)
+        keep.append(w)
+        return L.ptr(w)
+
+    out = np.zeros(ge.CΔ0_shape, dtype=np.complex128, order="F")
+    h.call("smoqy_ge_measure_pairs", ge._gr, ge._r, C.cast(arr, C.c_void_p), weights(tΔ), int(bool(conj_tΔ)), weights(t0), int(bool(conj_t0)), L.ptr(out))
+    return out
+
+
+def _bconj(x, flag):
+    return np.conj(x) if flag else x
+
+
+def _mod1(x, Ln):
+    return (int(x) - 1) % int(Ln)
+
+
+def _boundary_dot(ge, GRo, Rto, shift, tΔ, t0, conj_tΔ, conj_t0, tshift):
+    """Σ_rv Σ_i [bconj(tβ)·bconj(t0)]·circshift(GR_o, (0, shift...))[i]·Rt_o[i] / (Nrv·length)  — the scalar of :325-334 and its siblings."""
+    D = len(ge.L)
+    axes = tuple(range(1, 1 + D))
+    acc = 0.0
+    for i in range(ge.Nrv):
+        sh = np.roll(GRo[..., i], shift=tuple(int(s) for s in shift), axis=axes)
+        if tΔ is None and t0 is None:
+            acc += np.sum(sh * Rto[..., i]) / (ge.Nrv * sh.size)
+        else:
+            tb = np.roll(np.asarray(tΔ), shift=tuple(int(s) for s in tshift), axis=axes)
+            acc += np.sum(_bconj(tb, conj_tΔ) * _bconj(np.asarray(t0), conj_t0) * sh * Rto[..., i]) / (ge.Nrv * sh.size)
+    return acc
+
+
+def measure_GΔ0_GΔ0(correlation, greens_estimator: GreensEstimator, orbitals, r1, r2, r3, r4, coef, tΔ=None, t0=None, conj_tΔ=False, conj_t0=False):
+    """measure_GΔ0_GΔ0! (src/Measurements/GreensEstimator.jl:241-388): (GR_a^{r1} ⊙ GR_c^{r3}) ⋆ (Rt_b^{r2} ⊙ Rt_d^{r4}) over all pairs of
+    random vectors, plus the τ = β boundary terms."""
+    ge = greens_estimator
+    a, b, c, d = (int(x) for x in orbitals)
+    D, Ls, Lt = len(ge.L), ge.L, ge.Lτ
+    G = _ge_pair_sum(ge, [(0, a, r1, 0), (0, c, r3, 1), (1, b, r2, 0), (1, d, r4, 1)], tΔ, t0, conj_tΔ, conj_t0)  # :285-306
+    GR, Rt = ge.GR, ge.Rt
+    if a == b:   # :312-337
+        idx = (Lt,) + tuple(_mod1(1 - r1[k] + r2[k], Ls[k]) for k in range(D))
+        G[idx] -= _boundary_dot(ge, GR[:, c - 1], Rt[:, d - 1], [r1[k] - r2[k] - r3[k] + r4[k] for k in range(D)], tΔ, t0, conj_tΔ, conj_t0, [r1[k] - r2[k] for k in range(D)])
+    if c == d:   # :341-364
+        idx = (Lt,) + tuple(_mod1(1 - r3[k] + r4[k], Ls[k]) for k in range(D))
+        G[idx] -= _boundary_dot(ge, GR[:, a - 1], Rt[:, b - 1], [-r1[k] + r2[k] + r3[k] - r4[k] for k in range(D)], tΔ, t0, conj_tΔ, conj_t0, [r3[k] - r4[k] for k in range(D)])
+    if a == b and c == d and all((r2[k] - r1[k]) % Ls[k] == (r4[k] - r3[k]) % Ls[k] for k in range(D)):   # :367-382
+        idx = (Lt,) + tuple(_mod1(1 + r2[k] - r1[k], Ls[k]) for k in range(D))
+        if tΔ is None and t0 is None:
+            G[idx] += 1
+        else:
+            tb = np.roll(np.asarray(tΔ), shift=tuple(int(r1[k] - r2[k]) for k in range(D)), axis=tuple(range(1, 1 + D)))
+            G[idx] += np.sum(_bconj(tb, conj_tΔ) * _bconj(np.asarray(t0), conj_t0)) / tb.size
+    correlation += coef * np.moveaxis(G, 0, -1)   # :385
+    return None
+
+
+def measure_GΔΔ_G00(correlation, greens_estimator: GreensEstimator, orbitals, r1, r2, r3, r4, coef, tΔ=None, t0=None, conj_tΔ=False, conj_t0=False):
+    """measure_GΔΔ_G00! (:396-467): (GR_a^{r1} ⊙ Rt_b^{r2}) ⋆ (GR_c^{r3} ⊙ Rt_d^{r4}); no boundary terms."""
+    a, b, c, d = (int(x) for x in orbitals)
+    G = _ge_pair_sum(greens_estimator, [(0, a, r1, 0), (1, b, r2, 0), (0, c, r3, 1), (1, d, r4, 1)], tΔ, t0, conj_tΔ, conj_t0)
+    correlation += coef * np.moveaxis(G, 0, -1)
+    return None
+
+
+def measure_G0Δ_GΔ0(correlation, greens_estimator: GreensEstimator, orbitals, r1, r2, r3, r4, coef, tΔ=None, t0=None, conj_tΔ=False, conj_t0=False):
+    """measure_G0Δ_GΔ0! (:475-606): (Rt_b^{r2} ⊙ GR_c^{r3}) ⋆ (GR_a^{r1} ⊙ Rt_d^{r4}), boundary terms at τ = 0 and τ = β."""
+    ge = greens_estimator
+    a, b, c, d = (int(x) for x in orbitals)
+    D, Ls, Lt = len(ge.L), ge.L, ge.Lτ
+    G = _ge_pair_sum(ge, [(1, b, r2, 0), (0, c, r3, 1), (0, a, r1, 0), (1, d, r4, 1)], tΔ, t0, conj_tΔ, conj_t0)  # :518-539
+    GR, Rt = ge.GR, ge.Rt
+    sh = [-r1[k] + r2[k] - r3[k] + r4[k] for k in range(D)]
+    if a == b:   # :545-569, τ = 0
+        idx = (0,) + tuple(_mod1(1 + r1[k] - r2[k], Ls[k]) for k in range(D))
+        G[idx] -= _boundary_dot(ge, GR[:, c - 1], Rt[:, d - 1], sh, tΔ, t0, conj_tΔ, conj_t0, [-r1[k] + r2[k] for k in range(D)])
+    if c == d:   # :575-599, τ = β
+        idx = (Lt,) + tuple(_mod1(1 + r4[k] - r3[k], Ls[k]) for k in range(D))
+        G[idx] -= _boundary_dot(ge, GR[:, a - 1], Rt[:, b - 1], sh, tΔ, t0, conj_tΔ, conj_t0, [-r4[k] + r3[k] for k in range(D)])
+    correlation += coef * np.moveaxis(G, 0, -1)   # :603
+    return None
+
+
+measure_GD0_GD0, measure_GDD_G00, measure_G0D_GD0 = measure_GΔ0_GΔ0, measure_GΔΔ_G00, measure_G0Δ_GΔ0

@@ -107,10 +107,19 @@ struct smoqy_ctx {
         bool set = false;
         int n_orb = 0, D = 0, Nc = 0;
         size_t n2 = 0;  // 2 Lτ · Nc, the size of one aperiodic array
+        int Ld[2] = {1, 1};
         rocfft_plan fwd_sys = nullptr, inv_sys = nullptr, inv_w = nullptr;
         rocfft_execution_info info = nullptr;
         void *work = nullptr;
         double2 *A = nullptr, *B = nullptr, *P = nullptr, *out = nullptr;
+        // four-point estimators: periodic (Lτ, L...) transforms over all pairs of one walker's random vectors
+        size_t n1 = 0;  // Lτ · Nc
+        int npairs = 0;
+        rocfft_plan pfwd = nullptr, pinv = nullptr, pinv1 = nullptr;
+        rocfft_execution_info pinfo = nullptr;
+        void *pwork = nullptr;
+        double2 *S[4] = {nullptr, nullptr, nullptr, nullptr}, *X = nullptr, *Y = nullptr, *tw[2] = {nullptr, nullptr};
+        int2 *pairs = nullptr;
     } ge;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -235,10 +244,12 @@ const char *smoqy_last_error(const smoqy_ctx *ctx) { return ctx ? ctx->err.c_str
 static void ge_release(smoqy_ctx *c)
 {
     auto &G = c->ge;
-    for (rocfft_plan p : {G.fwd_sys, G.inv_sys, G.inv_w})
+    for (rocfft_plan p : {G.fwd_sys, G.inv_sys, G.inv_w, G.pfwd, G.pinv, G.pinv1})
         if (p) rocfft_plan_destroy(p);
     if (G.info) rocfft_execution_info_destroy(G.info);
-    for (void *q : {G.work, (void *)G.A, (void *)G.B, (void *)G.P, (void *)G.out})
+    if (G.pinfo) rocfft_execution_info_destroy(G.pinfo);
+    for (void *q : {G.work, (void *)G.A, (void *)G.B, (void *)G.P, (void *)G.out, G.pwork, (void *)G.S[0], (void *)G.S[1], (void *)G.S[2], (void *)G.S[3], (void *)G.X, (void *)G.Y, (void *)G.tw[0],
+                    (void *)G.tw[1], (void *)G.pairs})
         if (q) (void)hipFree(q);
     G = smoqy_ctx::GeState{};
 }
@@ -1783,6 +1794,7 @@ int smoqy_ge_config(smoqy_ctx *c, int n_orbitals, int D, const int64_t *Ldims)
     ge_release(c);
     auto &G = c->ge;
     G.n_orb = n_orbitals; G.D = D; G.Nc = (int)Nc; G.n2 = 2 * (size_t)g.Lt * Nc;
+    G.Ld[0] = (int)Ldims[0]; G.Ld[1] = D > 1 ? (int)Ldims[1] : 1;
     std::call_once(g_rocfft_once, [] { rocfft_setup(); });
     size_t len[3] = {2 * (size_t)g.Lt, 1, 1};  // τ fastest, then the lattice directions: the reference's (2Lτ, L...) column-major arrays (:91-92)
     for (int d = 0; d < D; ++d) len[1 + d] = (size_t)Ldims[d];
@@ -1805,8 +1817,78 @@ int smoqy_ge_config(smoqy_ctx *c, int n_orbitals, int D, const int64_t *Ldims)
     HIPCHK(c, hipMalloc(&G.B, (size_t)g.nsys * G.n2 * sizeof(double2)));
     HIPCHK(c, hipMalloc(&G.P, (size_t)g.nw * G.n2 * sizeof(double2)));
     HIPCHK(c, hipMalloc(&G.out, (size_t)g.nw * Nc * ((size_t)g.Lt + 1) * sizeof(double2)));
+    // four-point estimators: (Lτ, L...) periodic transforms (cfft!/cifft!, :95-98), batched over the pairs of random vectors
+    G.n1 = (size_t)g.Lt * Nc;
+    G.npairs = g.nrhs * (g.nrhs - 1) / 2;
+    if (G.npairs > 0) {
+        size_t plen[3] = {(size_t)g.Lt, 1, 1};
+        for (int d = 0; d < D; ++d) plen[1 + d] = (size_t)Ldims[d];
+        FFTCHK(c, rocfft_plan_create(&G.pfwd, rocfft_placement_inplace, rocfft_transform_type_complex_forward, rocfft_precision_double, (size_t)D + 1, plen, (size_t)G.npairs, nullptr));
+        FFTCHK(c, rocfft_plan_create(&G.pinv, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, rocfft_precision_double, (size_t)D + 1, plen, (size_t)G.npairs, nullptr));
+        FFTCHK(c, rocfft_plan_create(&G.pinv1, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, rocfft_precision_double, (size_t)D + 1, plen, 1, nullptr));
+        size_t pw = 0;
+        for (rocfft_plan p : {G.pfwd, G.pinv, G.pinv1}) {
+            size_t w1 = 0;
+            FFTCHK(c, rocfft_plan_get_work_buffer_size(p, &w1));
+            pw = std::max(pw, w1);
+        }
+        FFTCHK(c, rocfft_execution_info_create(&G.pinfo));
+        if (pw) {
+            HIPCHK(c, hipMalloc(&G.pwork, pw));
+            FFTCHK(c, rocfft_execution_info_set_work_buffer(G.pinfo, G.pwork, pw));
+        }
+        FFTCHK(c, rocfft_execution_info_set_stream(G.pinfo, c->stream));
+        for (int q = 0; q < 4; ++q) HIPCHK(c, hipMalloc(&G.S[q], (size_t)g.nsys * G.n1 * sizeof(double2)));
+        HIPCHK(c, hipMalloc(&G.X, (size_t)G.npairs * G.n1 * sizeof(double2)));
+        HIPCHK(c, hipMalloc(&G.Y, (size_t)G.npairs * G.n1 * sizeof(double2)));
+        for (int q = 0; q < 2; ++q) HIPCHK(c, hipMalloc(&G.tw[q], G.n1 * sizeof(double2)));
+        std::vector<int2> pr;
+        for (int n = 0; n + 1 < g.nrhs; ++n)
+            for (int m = n + 1; m < g.nrhs; ++m) pr.push_back(make_int2(n, m));  // :285-286
+        HIPCHK(c, hipMalloc(&G.pairs, pr.size() * sizeof(int2)));
+        HIPCHK(c, hipMemcpy(G.pairs, pr.data(), pr.size() * sizeof(int2), hipMemcpyHostToDevice));
+    }
     G.set = true;
     return 0;
+}
+
+int smoqy_ge_measure_pairs(smoqy_ctx *c, int gr, int r, const smoqy_ge_slot *slots, const void *tD, int conj_tD, const void *t0, int conj_t0, void *out)
+{
+    CHECK_CTX(c);
+    auto &G = c->ge;
+    if (!G.set) FAIL(c, 1, "call smoqy_ge_config first");
+    if (G.npairs < 1) FAIL(c, 1, "the pair estimators need nrhs >= 2 random vectors");
+    if (int rc = check_vec(c, gr)) return rc;
+    if (int rc = check_vec(c, r)) return rc;
+    if (!slots || !out) FAIL(c, 1, "slots / out is NULL");
+    const Geometry &g = c->g;
+    int second = 0;
+    for (int q = 0; q < 4; ++q) {
+        const smoqy_ge_slot &s = slots[q];
+        if (s.source < 0 || s.source > 1 || s.orbital < 1 || s.orbital > G.n_orb) FAIL(c, 1, "slot %d: source %d / orbital %d invalid", q, s.source, s.orbital);
+        if (s.second) second |= 1 << q;
+        launch_ge_slot_gather(c->stream, c->vecs[s.source ? r : gr], G.S[q], g.Lt, g.N, g.nsys, G.n_orb, s.orbital - 1, G.Nc, G.Ld[0], G.Ld[1], (int)(s.shift[0] % G.Ld[0]),
+                              G.D > 1 ? (int)(s.shift[1] % G.Ld[1]) : 0, s.source);  // Rt = conj(R)
+    }
+    if (tD) HIPCHK(c, hipMemcpyAsync(G.tw[0], tD, G.n1 * sizeof(double2), hipMemcpyHostToDevice, c->stream));
+    if (t0) HIPCHK(c, hipMemcpyAsync(G.tw[1], t0, G.n1 * sizeof(double2), hipMemcpyHostToDevice, c->stream));
+    FFTCHK(c, rocfft_execution_info_set_stream(G.pinfo, c->stream));
+    const size_t nout = (size_t)G.Nc * ((size_t)g.Lt + 1);
+    const double scale = 1.0 / ((double)G.n1 * (double)G.n1 * (double)G.npairs);  // two normalised inverse transforms, 1/Npairs (:306)
+    for (int w = 0; w < g.nw; ++w) {
+        const size_t off = (size_t)w * g.nrhs * G.n1;
+        launch_ge_pair_product(c->stream, G.S[0] + off, G.S[1] + off, G.S[2] + off, G.S[3] + off, G.X, G.Y, G.pairs, G.npairs, G.n1, second, tD ? G.tw[0] : nullptr, conj_tD,
+                               t0 ? G.tw[1] : nullptr, conj_t0);                              // :626-646
+        void *bx[1] = {G.X}, *by[1] = {G.Y}, *bp[1] = {G.P};
+        FFTCHK(c, rocfft_execute(G.pfwd, bx, nullptr, G.pinfo));                              // :686
+        FFTCHK(c, rocfft_execute(G.pinv, by, nullptr, G.pinfo));                              // :687
+        launch_ge_pair_reduce(c->stream, G.X, G.Y, G.P, G.npairs, G.n1);                      // :692, summed over the pairs
+        FFTCHK(c, rocfft_execute(G.pinv1, bp, nullptr, G.pinfo));                             // :695
+        launch_ge_finalize_pairs(c->stream, G.P, G.out + (size_t)w * nout, g.Lt, G.Nc, scale);  // :697-705
+    }
+    HIPCHK(c, hipMemcpyAsync(out, G.out, (size_t)g.nw * nout * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_launch(c, "ge_measure_pairs");
 }
 
 int smoqy_ge_measure_GD0(smoqy_ctx *c, int gr, int r, int a, int b, void *out)

@@ -66,6 +66,71 @@ __global__ void ge_finalize_gd0_kernel(const double2 *__restrict__ S, double2 *_
     }
 }
 
+// four-point estimators (:241-652): S[sys][c][τ] (τ = 0..Lτ-1 fastest) = the orbital-`orb` component of source v
+// (conj = 1: Rt = conj(R)) at cell c + r, i.e. ShiftedArrays.circshift(·, (0, -r..., 0)) of :265-268
+__global__ void ge_slot_gather_kernel(const double2 *__restrict__ v, double2 *__restrict__ S, int Lt, int N, int nsys, int n_orb, int orb, int Nc, int L1, int L2, int r1, int r2, int conj)
+{
+    const size_t tot = (size_t)nsys * Nc * Lt;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(idx % Lt);
+        const size_t q = idx / Lt;
+        const int c = (int)(q % Nc), sys = (int)(q / Nc);
+        const int c1 = c % L1, c2 = c / L1;
+        const int s1 = ((c1 + r1) % L1 + L1) % L1, s2 = ((c2 + r2) % L2 + L2) % L2;
+        double2 x = v[((size_t)l * nsys + sys) * N + orb + (size_t)n_orb * (s1 + (size_t)L1 * s2)];
+        if (conj) x.y = -x.y;
+        S[idx] = x;
+    }
+}
+
+__device__ __forceinline__ double2 cmul_g(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// X[p][k] = S0[i0(p)][k]·S1[i1(p)][k]·[tΔ[k]],  Y[p][k] = S2[i2(p)][k]·S3[i3(p)][k]·[t0[k]]  (_measure_CΔ0! :626-646) for
+// every pair p = (n < m) of one walker's random vectors; slot q takes vector m when bit q of `second` is set, n otherwise
+__global__ void ge_pair_product_kernel(const double2 *__restrict__ S0, const double2 *__restrict__ S1, const double2 *__restrict__ S2, const double2 *__restrict__ S3, double2 *__restrict__ X,
+                                       double2 *__restrict__ Y, const int2 *__restrict__ pairs, int npairs, size_t n1, int second, const double2 *__restrict__ tD, int conj_tD,
+                                       const double2 *__restrict__ t0, int conj_t0)
+{
+    const size_t tot = (size_t)npairs * n1;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t k = idx % n1;
+        const int2 nm = pairs[idx / n1];
+        const int i0 = (second & 1) ? nm.y : nm.x, i1 = (second & 2) ? nm.y : nm.x, i2 = (second & 4) ? nm.y : nm.x, i3 = (second & 8) ? nm.y : nm.x;
+        double2 x = cmul_g(S0[(size_t)i0 * n1 + k], S1[(size_t)i1 * n1 + k]);
+        double2 y = cmul_g(S2[(size_t)i2 * n1 + k], S3[(size_t)i3 * n1 + k]);
+        if (tD) { double2 w = tD[k]; if (conj_tD) w.y = -w.y; x = cmul_g(w, x); }
+        if (t0) { double2 w = t0[k]; if (conj_t0) w.y = -w.y; y = cmul_g(w, y); }
+        X[idx] = x;
+        Y[idx] = y;
+    }
+}
+
+// P[k] = Σ_p X̂[p][k]·Ỹ[p][k]  (the product of :692 summed over the pairs before the last transform)
+__global__ void ge_pair_reduce_kernel(const double2 *__restrict__ X, const double2 *__restrict__ Y, double2 *__restrict__ P, int npairs, size_t n1)
+{
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n1; k += (size_t)gridDim.x * blockDim.x) {
+        double2 acc = make_double2(0.0, 0.0);
+        for (int p = 0; p < npairs; ++p) {
+            const double2 t = cmul_g(X[(size_t)p * n1 + k], Y[(size_t)p * n1 + k]);
+            acc.x += t.x;
+            acc.y += t.y;
+        }
+        P[k] = acc;
+    }
+}
+
+// out[c][τ], τ = 0..Lτ: the periodic result on [0, β-Δτ] and its τ = 0 row repeated at τ = β (:697-705), scaled
+__global__ void ge_finalize_pairs_kernel(const double2 *__restrict__ S, double2 *__restrict__ out, int Lt, int Nc, double scale)
+{
+    const size_t L1 = (size_t)Lt + 1, tot = (size_t)Nc * L1;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % L1);
+        const size_t c = idx / L1;
+        const double2 x = S[c * (size_t)Lt + (t < Lt ? t : 0)];
+        out[idx] = make_double2(x.x * scale, x.y * scale);
+    }
+}
+
 int blocks_for(size_t tot)
 {
     size_t b = (tot + 255) / 256;
@@ -87,6 +152,27 @@ void launch_ge_product(hipStream_t st, const double2 *Ah, const double2 *Bh, dou
 void launch_ge_finalize_gd0(hipStream_t st, const double2 *S, double2 *out, int Lt, int Nc, int nw, double scale, int same_orbital)
 {
     hipLaunchKernelGGL(ge_finalize_gd0_kernel, dim3(blocks_for((size_t)nw * Nc * (Lt + 1))), dim3(256), 0, st, S, out, Lt, Nc, nw, scale, same_orbital);
+}
+
+void launch_ge_slot_gather(hipStream_t st, const double2 *v, double2 *S, int Lt, int N, int nsys, int n_orb, int orb, int Nc, int L1, int L2, int r1, int r2, int conj)
+{
+    hipLaunchKernelGGL(ge_slot_gather_kernel, dim3(blocks_for((size_t)nsys * Nc * Lt)), dim3(256), 0, st, v, S, Lt, N, nsys, n_orb, orb, Nc, L1, L2, r1, r2, conj);
+}
+
+void launch_ge_pair_product(hipStream_t st, const double2 *S0, const double2 *S1, const double2 *S2, const double2 *S3, double2 *X, double2 *Y, const int2 *pairs, int npairs, size_t n1, int second,
+                            const double2 *tD, int conj_tD, const double2 *t0, int conj_t0)
+{
+    hipLaunchKernelGGL(ge_pair_product_kernel, dim3(blocks_for((size_t)npairs * n1)), dim3(256), 0, st, S0, S1, S2, S3, X, Y, pairs, npairs, n1, second, tD, conj_tD, t0, conj_t0);
+}
+
+void launch_ge_pair_reduce(hipStream_t st, const double2 *X, const double2 *Y, double2 *P, int npairs, size_t n1)
+{
+    hipLaunchKernelGGL(ge_pair_reduce_kernel, dim3(blocks_for(n1)), dim3(256), 0, st, X, Y, P, npairs, n1);
+}
+
+void launch_ge_finalize_pairs(hipStream_t st, const double2 *S, double2 *out, int Lt, int Nc, double scale)
+{
+    hipLaunchKernelGGL(ge_finalize_pairs_kernel, dim3(blocks_for((size_t)Nc * (Lt + 1))), dim3(256), 0, st, S, out, Lt, Nc, scale);
 }
 
 }  // namespace smoqy

@@ -186,6 +186,11 @@ void launch_phonon_fields(hipStream_t st, const ForceArgs &a, const double *V0, 
 // GreensEstimator contractions (kernels_greens.hip)
 void launch_ge_gather(hipStream_t st, const double2 *v, double2 *A, int Lt, int N, int nsys, int n_orb, int orb, int Nc, int conj);
 void launch_ge_product(hipStream_t st, const double2 *Ah, const double2 *Bh, double2 *P, size_t n2, int nrhs, int nw);
+void launch_ge_slot_gather(hipStream_t st, const double2 *v, double2 *S, int Lt, int N, int nsys, int n_orb, int orb, int Nc, int L1, int L2, int r1, int r2, int conj);
+void launch_ge_pair_product(hipStream_t st, const double2 *S0, const double2 *S1, const double2 *S2, const double2 *S3, double2 *X, double2 *Y, const int2 *pairs, int npairs, size_t n1, int second,
+                            const double2 *tD, int conj_tD, const double2 *t0, int conj_t0);
+void launch_ge_pair_reduce(hipStream_t st, const double2 *X, const double2 *Y, double2 *P, int npairs, size_t n1);
+void launch_ge_finalize_pairs(hipStream_t st, const double2 *S, double2 *out, int Lt, int Nc, double scale);
 void launch_ge_finalize_gd0(hipStream_t st, const double2 *S, double2 *out, int Lt, int Nc, int nw, double scale, int same_orbital);
 
 // own tau-FFT (kernels_tfft.hip): Stockham passes over LDS site tiles, optionally fused with the CG updates

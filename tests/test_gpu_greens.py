@@ -93,3 +93,37 @@ def test_ge_errors():
     v = h.vec_alloc()
     with pytest.raises(L.SmoqyError):
         h.call("smoqy_ge_measure_GD0", v, v, 2, 1, L.ptr(np.zeros((10, 12), dtype=complex)))  # orbital out of range
+
+
+@pytest.mark.parametrize("kind", ["honeycomb", "chain"])
+@pytest.mark.parametrize("weights", [False, True])
+def test_four_point_estimators_against_oracle(kind, weights):
+    """measure_GΔ0_GΔ0!, measure_GΔΔ_G00!, measure_G0Δ_GΔ0! (pair sums on the device, boundary terms on the host arrays)
+    against the numpy restatement on the same GR, Rt — orbitals, displacements, weights and the δ-conditions varied."""
+    m, n, Ls = geometry(kind)
+    D = len(Ls)
+    fdm = sq.SymFermionDetMatrix(m.fpi, maxiter=5000, tol=1e-10)
+    ge = sq.GreensEstimator(fdm, (n, Ls), Nrv=5, rng=np.random.default_rng(4), maxiter=5000, tol=1e-10)
+    g = np.random.default_rng(6)
+    wshape = (ge.Lτ,) + Ls
+    tD = (g.standard_normal(wshape) + 1j * g.standard_normal(wshape)) if weights else None
+    t0 = (g.standard_normal(wshape) + 1j * g.standard_normal(wshape)) if weights else None
+    z = (0,) * D
+    cases = [((1, 1, 1, 1), z, z, z, z), ((1, n, n, 1), tuple([1] + [0] * (D - 1)), tuple([0] * (D - 1) + [2]), z, tuple([-1] * D)),
+             ((n, n, 1, 1), tuple([2] * D), tuple([1] * D), tuple([1] * D), z)]
+    fns = [(sq.measure_GΔ0_GΔ0, greens.measure_GD0_GD0), (sq.measure_GΔΔ_G00, greens.measure_GDD_G00), (sq.measure_G0Δ_GΔ0, greens.measure_G0D_GD0)]
+    for orbitals, r1, r2, r3, r4 in cases:
+        for dev_fn, ref_fn in fns:
+            for cflags in ((False, False), (True, False)) if weights else ((False, False),):
+                corr = np.full(Ls + (ge.Lτ + 1,), 0.5 + 0j)
+                dev_fn(corr, ge, orbitals, r1, r2, r3, r4, 0.7, tD, t0, *cflags)
+                ref = greens.add_contraction_to_correlation(np.full(Ls + (ge.Lτ + 1,), 0.5 + 0j), ref_fn(ge.GR, ge.Rt, orbitals, r1, r2, r3, r4, tD, t0, *cflags), 0.7)
+                assert np.abs(corr - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()), (kind, dev_fn.__name__, orbitals, r1, r2, r3, r4, cflags)
+
+
+def test_pair_estimator_needs_two_vectors():
+    m, n, Ls = geometry("chain")
+    fdm = sq.SymFermionDetMatrix(m.fpi, maxiter=5000, tol=1e-8)
+    ge = sq.GreensEstimator(fdm, (n, Ls), Nrv=1, rng=np.random.default_rng(4), maxiter=5000, tol=1e-8)
+    with pytest.raises(L.SmoqyError):
+        sq.measure_GΔΔ_G00(np.zeros(Ls + (ge.Lτ + 1,), dtype=complex), ge, (1, 1, 1, 1), (0,), (0,), (0,), (0,), 1.0)

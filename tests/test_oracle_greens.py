@@ -56,3 +56,60 @@ def test_add_contraction_moves_tau_last():
     x = np.arange(30).reshape(5, 2, 3).astype(complex)
     greens.add_contraction_to_correlation(c, x, 2.0)
     assert c[1, 2, 4] == 2 * x[4, 1, 2]
+
+
+def _random_ge(seed, Lt=3, n=2, Ls=(2, 3), Nrv=4):
+    g = np.random.default_rng(seed)
+    shape = (Lt, n) + Ls + (Nrv,)
+    GR = g.standard_normal(shape) + 1j * g.standard_normal(shape)
+    Rt = np.conj(greens.random_phases(g, shape))
+    return GR, Rt
+
+
+@pytest.mark.parametrize("weights", [False, True])
+def test_four_point_pair_sums_against_direct_sums(weights):
+    """The FFT-based pair sums of the three four-point estimators against plain periodic index arithmetic (the boundary
+    rows are excluded here: they are literal restatements of the reference's scalar updates)."""
+    GR, Rt = _random_ge(3)
+    Lt, Ls = 3, (2, 3)
+    orbitals, rs = (1, 2, 2, 1), ((1, 0), (0, 2), (1, 1), (0, 0))
+    g = np.random.default_rng(8)
+    tD = (g.standard_normal((Lt,) + Ls) + 1j * g.standard_normal((Lt,) + Ls)) if weights else None
+    t0 = (g.standard_normal((Lt,) + Ls) + 1j * g.standard_normal((Lt,) + Ls)) if weights else None
+    GRa, Rtb, GRc, Rtd = greens._views(GR, Rt, orbitals, rs)
+    cases = {
+        "GD0_GD0": (greens.measure_GD0_GD0, (GRa, GRc, Rtb, Rtd), (0, 1, 0, 1)),
+        "GDD_G00": (greens.measure_GDD_G00, (GRa, Rtb, GRc, Rtd), (0, 0, 1, 1)),
+        "G0D_GD0": (greens.measure_G0D_GD0, (Rtb, GRc, GRa, Rtd), (0, 1, 0, 1)),
+    }
+    for name, (fn, slots, second) in cases.items():
+        got = fn(GR, Rt, orbitals, *rs, tD, t0, False, False)
+        want = greens.pair_correlation_direct(*slots, second, tD, t0)
+        assert np.abs(got[1:Lt] - want[1:Lt]).max() < 1e-12, name   # rows 1..Lτ-1 carry no boundary terms
+        if name == "GDD_G00":
+            assert np.abs(got[:Lt] - want).max() < 1e-12 and np.abs(got[Lt] - want[0]).max() < 1e-12
+
+
+def test_four_point_estimators_approach_the_wick_products():
+    """Statistical sanity of the restated estimators, boundary terms included: with many random vectors
+    G(Δ,0)G(Δ,0) and G(Δ,Δ)G(0,0) approach the translation-averaged products of exact Green's functions."""
+    m = lat.bssh_chain(4, 3)
+    Lt, N, n, Ls = 3, 4, 1, (4,)
+    G = dense_G(m)
+    V = Lt * N
+    Nrv = 300
+    g = np.random.default_rng(11)
+    R = greens.random_phases(g, (V, Nrv))
+    GR = (G @ R).reshape((Lt, n) + Ls + (Nrv,), order="F")
+    Rt = np.conj(R).reshape((Lt, n) + Ls + (Nrv,), order="F")
+    G4 = G.reshape(Lt, N, Lt, N, order="F")
+
+    zero = (0,)
+    got = greens.measure_GDD_G00(GR, Rt, (1, 1, 1, 1), zero, zero, zero, zero)
+    # G(Δ,Δ)G(0,0) = 1/(Lτ N) Σ_{i,τ'} G(i+r, τ'+τ | i+r, τ'+τ) G(i, τ' | i, τ')  (equal-time on both sides, periodic in τ)
+    want = np.zeros((Lt, N), dtype=complex)
+    for tau in range(Lt):
+        for r in range(N):
+            want[tau, r] = sum(G4[(tp + tau) % Lt, (i + r) % N, (tp + tau) % Lt, (i + r) % N] * G4[tp, i, tp, i] for tp in range(Lt) for i in range(N)) / (Lt * N)
+    err = np.abs(got[:Lt] - want).max()
+    assert err < 0.03, err  # the exact values are 0.25 (half filling); measured 0.003-0.008 at 300 vectors
