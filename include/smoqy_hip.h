@@ -257,6 +257,11 @@ typedef struct {
  * terms at τ = 0 / τ = β (:312-382, 545-599) are left to the caller, who holds GR and Rt. */
 int smoqy_ge_measure_pairs(smoqy_ctx *ctx, int gr, int r, const smoqy_ge_slot *slots, const void *tD, int conj_tD, const void *t0, int conj_t0, void *out);
 
+/* the scalar those boundary terms subtract (e.g. :325-334): per walker
+ *   1/(Nrv·Lτ·Ncells) Σ_rv Σ_{τ,c} [bconj(circshift(tΔ, tshift)) · bconj(t0)] · circshift(GR_orbital_gr, shift) · Rt_orbital_r
+ * from the device-resident vectors (circshift(a, s)[c] = a[c - s]; tD = t0 = NULL drops the weights).  out: nwalkers complex. */
+int smoqy_ge_boundary_dot(smoqy_ctx *ctx, int gr, int r, int orbital_gr, int orbital_r, const int64_t *shift, const void *tD, int conj_tD, const int64_t *tshift, const void *t0, int conj_t0, void *out);
+
 /* ---- measurement aids (bench.py) -------------------------------------------------------- */
 
 /* HIP events on the handle's stream */

@@ -104,6 +104,7 @@ SIGNATURES = {
     "smoqy_copy_fields": [_p, _i, _p, _i],
     "smoqy_ge_config": [_p, _i, _i, _p],
     "smoqy_ge_measure_GD0": [_p, _i, _i, _i, _i, _p],
+    "smoqy_ge_boundary_dot": [_p, _i, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p],
     "smoqy_ge_measure_pairs": [_p, _i, _i, _p, _p, _i, _p, _i, _p],
     "smoqy_timer_start": [_p],
     "smoqy_timer_stop": [_p, _pd],

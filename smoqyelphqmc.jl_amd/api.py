@@ -674,8 +674,8 @@ def measure_GΔ0(correlation, greens_estimator: GreensEstimator, orbitals):
 measure_GD0 = measure_GΔ0
 
 
-# four-point estimators: the pair sums run on the device, the scalar boundary terms on the host arrays GR / Rt exactly as the
-# reference writes them (src/Measurements/GreensEstimator.jl:241-606)
+# four-point estimators (src/Measurements/GreensEstimator.jl:241-606): the pair sums and the scalar boundary terms are reduced on
+# the device from the resident GR and R; the mirror only decides which element of CΔ0 each boundary term goes to
 
 def _ge_pair_sum(ge: GreensEstimator, slots, tΔ, t0, conj_tΔ, conj_t0):
     h = ge.handle
@@ -707,19 +707,23 @@ def _mod1(x, Ln):
     return (int(x) - 1) % int(Ln)
 
 
-def _boundary_dot(ge, GRo, Rto, shift, tΔ, t0, conj_tΔ, conj_t0, tshift):
-    """Σ_rv Σ_i [bconj(tβ)·bconj(t0)]·circshift(GR_o, (0, shift...))[i]·Rt_o[i] / (Nrv·length)  — the scalar of :325-334 and its siblings."""
-    D = len(ge.L)
-    axes = tuple(range(1, 1 + D))
-    acc = 0.0
-    for i in range(ge.Nrv):
-        sh = np.roll(GRo[..., i], shift=tuple(int(s) for s in shift), axis=axes)
-        if tΔ is None and t0 is None:
-            acc += np.sum(sh * Rto[..., i]) / (ge.Nrv * sh.size)
-        else:
-            tb = np.roll(np.asarray(tΔ), shift=tuple(int(s) for s in tshift), axis=axes)
-            acc += np.sum(_bconj(tb, conj_tΔ) * _bconj(np.asarray(t0), conj_t0) * sh * Rto[..., i]) / (ge.Nrv * sh.size)
-    return acc
+def _boundary_dot(ge, orbital_gr, orbital_r, shift, tΔ, t0, conj_tΔ, conj_t0, tshift):
+    """Σ_rv Σ_i [bconj(tβ)·bconj(t0)]·circshift(GR_o, (0, shift...))[i]·Rt_o′[i] / (Nrv·length) — the scalar of :325-334 and its
+    siblings, reduced on the device from the resident GR and R."""
+    h = ge.handle
+    sh = np.zeros(2, dtype=np.int64)
+    ts = np.zeros(2, dtype=np.int64)
+    sh[: len(shift)] = shift
+    ts[: len(tshift)] = tshift
+    wshape = (ge.Lτ,) + ge.L
+    wD = w0 = None
+    if tΔ is not None or t0 is not None:
+        wD = np.asfortranarray(np.broadcast_to(np.asarray(1.0 if tΔ is None else tΔ), wshape), dtype=np.complex128)
+        w0 = np.asfortranarray(np.broadcast_to(np.asarray(1.0 if t0 is None else t0), wshape), dtype=np.complex128)
+    out = np.zeros(1, dtype=np.complex128)
+    h.call("smoqy_ge_boundary_dot", ge._gr, ge._r, int(orbital_gr), int(orbital_r), L.ptr(sh), None if wD is None else L.ptr(wD), int(bool(conj_tΔ)), L.ptr(ts),
+           None if w0 is None else L.ptr(w0), int(bool(conj_t0)), L.ptr(out))
+    return out[0]
 
 
 def measure_GΔ0_GΔ0(correlation, greens_estimator: GreensEstimator, orbitals, r1, r2, r3, r4, coef, tΔ=None, t0=None, conj_tΔ=False, conj_t0=False):
@@ -729,13 +733,12 @@ def measure_GΔ0_GΔ0(correlation, greens_estimator: GreensEstimator, orbitals, 
     a, b, c, d = (int(x) for x in orbitals)
     D, Ls, Lt = len(ge.L), ge.L, ge.Lτ
     G = _ge_pair_sum(ge, [(0, a, r1, 0), (0, c, r3, 1), (1, b, r2, 0), (1, d, r4, 1)], tΔ, t0, conj_tΔ, conj_t0)  # :285-306
-    GR, Rt = ge.GR, ge.Rt
     if a == b:   # :312-337
         idx = (Lt,) + tuple(_mod1(1 - r1[k] + r2[k], Ls[k]) for k in range(D))
-        G[idx] -= _boundary_dot(ge, GR[:, c - 1], Rt[:, d - 1], [r1[k] - r2[k] - r3[k] + r4[k] for k in range(D)], tΔ, t0, conj_tΔ, conj_t0, [r1[k] - r2[k] for k in range(D)])
+        G[idx] -= _boundary_dot(ge, c, d, [r1[k] - r2[k] - r3[k] + r4[k] for k in range(D)], tΔ, t0, conj_tΔ, conj_t0, [r1[k] - r2[k] for k in range(D)])
     if c == d:   # :341-364
         idx = (Lt,) + tuple(_mod1(1 - r3[k] + r4[k], Ls[k]) for k in range(D))
-        G[idx] -= _boundary_dot(ge, GR[:, a - 1], Rt[:, b - 1], [-r1[k] + r2[k] + r3[k] - r4[k] for k in range(D)], tΔ, t0, conj_tΔ, conj_t0, [r3[k] - r4[k] for k in range(D)])
+        G[idx] -= _boundary_dot(ge, a, b, [-r1[k] + r2[k] + r3[k] - r4[k] for k in range(D)], tΔ, t0, conj_tΔ, conj_t0, [r3[k] - r4[k] for k in range(D)])
     if a == b and c == d and all((r2[k] - r1[k]) % Ls[k] == (r4[k] - r3[k]) % Ls[k] for k in range(D)):   # :367-382
         idx = (Lt,) + tuple(_mod1(1 + r2[k] - r1[k], Ls[k]) for k in range(D))
         if tΔ is None and t0 is None:
@@ -761,14 +764,13 @@ def measure_G0Δ_GΔ0(correlation, greens_estimator: GreensEstimator, orbitals, 
     a, b, c, d = (int(x) for x in orbitals)
     D, Ls, Lt = len(ge.L), ge.L, ge.Lτ
     G = _ge_pair_sum(ge, [(1, b, r2, 0), (0, c, r3, 1), (0, a, r1, 0), (1, d, r4, 1)], tΔ, t0, conj_tΔ, conj_t0)  # :518-539
-    GR, Rt = ge.GR, ge.Rt
     sh = [-r1[k] + r2[k] - r3[k] + r4[k] for k in range(D)]
     if a == b:   # :545-569, τ = 0
         idx = (0,) + tuple(_mod1(1 + r1[k] - r2[k], Ls[k]) for k in range(D))
-        G[idx] -= _boundary_dot(ge, GR[:, c - 1], Rt[:, d - 1], sh, tΔ, t0, conj_tΔ, conj_t0, [-r1[k] + r2[k] for k in range(D)])
+        G[idx] -= _boundary_dot(ge, c, d, sh, tΔ, t0, conj_tΔ, conj_t0, [-r1[k] + r2[k] for k in range(D)])
     if c == d:   # :575-599, τ = β
         idx = (Lt,) + tuple(_mod1(1 + r4[k] - r3[k], Ls[k]) for k in range(D))
-        G[idx] -= _boundary_dot(ge, GR[:, a - 1], Rt[:, b - 1], sh, tΔ, t0, conj_tΔ, conj_t0, [-r4[k] + r3[k] for k in range(D)])
+        G[idx] -= _boundary_dot(ge, a, b, sh, tΔ, t0, conj_tΔ, conj_t0, [-r4[k] + r3[k] for k in range(D)])
     correlation += coef * np.moveaxis(G, 0, -1)   # :603
     return None
 

@@ -120,6 +120,7 @@ struct smoqy_ctx {
         void *pwork = nullptr;
         double2 *S[4] = {nullptr, nullptr, nullptr, nullptr}, *X = nullptr, *Y = nullptr, *tw[2] = {nullptr, nullptr};
         int2 *pairs = nullptr;
+        double2 *bpart = nullptr, *bout = nullptr;  // boundary-term partial sums
     } ge;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -249,7 +250,7 @@ static void ge_release(smoqy_ctx *c)
     if (G.info) rocfft_execution_info_destroy(G.info);
     if (G.pinfo) rocfft_execution_info_destroy(G.pinfo);
     for (void *q : {G.work, (void *)G.A, (void *)G.B, (void *)G.P, (void *)G.out, G.pwork, (void *)G.S[0], (void *)G.S[1], (void *)G.S[2], (void *)G.S[3], (void *)G.X, (void *)G.Y, (void *)G.tw[0],
-                    (void *)G.tw[1], (void *)G.pairs})
+                    (void *)G.tw[1], (void *)G.pairs, (void *)G.bpart, (void *)G.bout})
         if (q) (void)hipFree(q);
     G = smoqy_ctx::GeState{};
 }
@@ -1817,6 +1818,9 @@ int smoqy_ge_config(smoqy_ctx *c, int n_orbitals, int D, const int64_t *Ldims)
     HIPCHK(c, hipMalloc(&G.B, (size_t)g.nsys * G.n2 * sizeof(double2)));
     HIPCHK(c, hipMalloc(&G.P, (size_t)g.nw * G.n2 * sizeof(double2)));
     HIPCHK(c, hipMalloc(&G.out, (size_t)g.nw * Nc * ((size_t)g.Lt + 1) * sizeof(double2)));
+    HIPCHK(c, hipMalloc(&G.bpart, (size_t)g.nw * 64 * sizeof(double2)));
+    HIPCHK(c, hipMalloc(&G.bout, (size_t)g.nw * sizeof(double2)));
+    for (int q = 0; q < 2; ++q) HIPCHK(c, hipMalloc(&G.tw[q], (size_t)g.Lt * Nc * sizeof(double2)));
     // four-point estimators: (Lτ, L...) periodic transforms (cfft!/cifft!, :95-98), batched over the pairs of random vectors
     G.n1 = (size_t)g.Lt * Nc;
     G.npairs = g.nrhs * (g.nrhs - 1) / 2;
@@ -1841,7 +1845,6 @@ int smoqy_ge_config(smoqy_ctx *c, int n_orbitals, int D, const int64_t *Ldims)
         for (int q = 0; q < 4; ++q) HIPCHK(c, hipMalloc(&G.S[q], (size_t)g.nsys * G.n1 * sizeof(double2)));
         HIPCHK(c, hipMalloc(&G.X, (size_t)G.npairs * G.n1 * sizeof(double2)));
         HIPCHK(c, hipMalloc(&G.Y, (size_t)G.npairs * G.n1 * sizeof(double2)));
-        for (int q = 0; q < 2; ++q) HIPCHK(c, hipMalloc(&G.tw[q], G.n1 * sizeof(double2)));
         std::vector<int2> pr;
         for (int n = 0; n + 1 < g.nrhs; ++n)
             for (int m = n + 1; m < g.nrhs; ++m) pr.push_back(make_int2(n, m));  // :285-286
@@ -1914,6 +1917,32 @@ int smoqy_ge_measure_GD0(smoqy_ctx *c, int gr, int r, int a, int b, void *out)
     HIPCHK(c, hipMemcpyAsync(out, G.out, (size_t)g.nw * G.Nc * ((size_t)g.Lt + 1) * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_launch(c, "ge_measure_GD0");
+}
+
+int smoqy_ge_boundary_dot(smoqy_ctx *c, int gr, int r, int orbital_gr, int orbital_r, const int64_t *shift, const void *tD, int conj_tD, const int64_t *tshift, const void *t0, int conj_t0, void *out)
+{
+    CHECK_CTX(c);
+    auto &G = c->ge;
+    if (!G.set) FAIL(c, 1, "call smoqy_ge_config first");
+    if (int rc = check_vec(c, gr)) return rc;
+    if (int rc = check_vec(c, r)) return rc;
+    if (orbital_gr < 1 || orbital_gr > G.n_orb || orbital_r < 1 || orbital_r > G.n_orb) FAIL(c, 1, "orbitals (%d, %d) out of range 1..%d", orbital_gr, orbital_r, G.n_orb);
+    if (!shift || !out) FAIL(c, 1, "shift / out is NULL");
+    if ((tD == nullptr) != (t0 == nullptr)) FAIL(c, 1, "tD and t0 must be given together");
+    if (tD && !tshift) FAIL(c, 1, "tshift is NULL");
+    const Geometry &g = c->g;
+    const size_t n1 = (size_t)g.Lt * G.Nc;
+    if (tD) {
+        HIPCHK(c, hipMemcpyAsync(G.tw[0], tD, n1 * sizeof(double2), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(G.tw[1], t0, n1 * sizeof(double2), hipMemcpyHostToDevice, c->stream));
+    }
+    const double scale = 1.0 / ((double)g.nrhs * (double)n1);  // 1 / (Nrv · length), :327
+    launch_ge_boundary(c->stream, c->vecs[gr], c->vecs[r], G.bpart, G.bout, g.Lt, g.N, g.nsys, g.nrhs, G.n_orb, orbital_gr - 1, orbital_r - 1, G.Nc, G.Ld[0], G.Ld[1], (int)(shift[0] % G.Ld[0]),
+                       G.D > 1 ? (int)(shift[1] % G.Ld[1]) : 0, tD ? G.tw[0] : nullptr, conj_tD, tD ? (int)(tshift[0] % G.Ld[0]) : 0, (tD && G.D > 1) ? (int)(tshift[1] % G.Ld[1]) : 0,
+                       tD ? G.tw[1] : nullptr, conj_t0, 64, scale);
+    HIPCHK(c, hipMemcpyAsync(out, G.bout, (size_t)g.nw * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_launch(c, "ge_boundary_dot");
 }
 
 // ---- measurement aids -------------------------------------------------------------------------------

@@ -131,6 +131,54 @@ __global__ void ge_finalize_pairs_kernel(const double2 *__restrict__ S, double2 
     }
 }
 
+// scalar boundary terms of the four-point estimators (:325-334, 351-361, 556-566, 586-596): per walker
+//   Σ_rv Σ_{τ,c} [bconj(tΔ[τ, c - ts]) · bconj(t0[τ, c])] · GR_og[τ, c - sh, rv] · conj(R_or[τ, c, rv])
+// (circshift(a, s)[c] = a[c - s]).  One workgroup per (walker, slab); fixed-order tree reduction, no atomics.
+__global__ void ge_boundary_partial_kernel(const double2 *__restrict__ gr, const double2 *__restrict__ r, double2 *__restrict__ part, int Lt, int N, int nsys, int nrhs, int n_orb, int og, int orr, int Nc,
+                                           int L1, int L2, int sh1, int sh2, const double2 *__restrict__ tD, int conj_tD, int ts1, int ts2, const double2 *__restrict__ t0, int conj_t0, int nslab)
+{
+    __shared__ double2 red[256];
+    const int w = blockIdx.x / nslab, slab = blockIdx.x % nslab;
+    const size_t per = (size_t)nrhs * Nc * Lt;
+    double2 acc = make_double2(0.0, 0.0);
+    for (size_t idx = (size_t)slab * blockDim.x + threadIdx.x; idx < per; idx += (size_t)nslab * blockDim.x) {
+        const int l = (int)(idx % Lt);
+        const size_t q = idx / Lt;
+        const int c = (int)(q % Nc), sys = w * nrhs + (int)(q / Nc);
+        const int c1 = c % L1, c2 = c / L1;
+        const int g1 = ((c1 - sh1) % L1 + L1) % L1, g2 = ((c2 - sh2) % L2 + L2) % L2;
+        const double2 a = gr[((size_t)l * nsys + sys) * N + og + (size_t)n_orb * (g1 + (size_t)L1 * g2)];
+        double2 b = r[((size_t)l * nsys + sys) * N + orr + (size_t)n_orb * c];
+        b.y = -b.y;  // Rt = conj(R)
+        double2 t = cmul_g(a, b);
+        if (tD) {
+            const int u1 = ((c1 - ts1) % L1 + L1) % L1, u2 = ((c2 - ts2) % L2 + L2) % L2;
+            double2 x = tD[(size_t)(u1 + (size_t)L1 * u2) * Lt + l], y = t0[(size_t)c * Lt + l];
+            if (conj_tD) x.y = -x.y;
+            if (conj_t0) y.y = -y.y;
+            t = cmul_g(cmul_g(x, y), t);
+        }
+        acc.x += t.x;
+        acc.y += t.y;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s2 = blockDim.x / 2; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) { red[threadIdx.x].x += red[threadIdx.x + s2].x; red[threadIdx.x].y += red[threadIdx.x + s2].y; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ void ge_boundary_final_kernel(const double2 *__restrict__ part, double2 *__restrict__ out, int nslab, double scale)
+{
+    const int w = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    double2 t = make_double2(0.0, 0.0);
+    for (int k = 0; k < nslab; ++k) { t.x += part[(size_t)w * nslab + k].x; t.y += part[(size_t)w * nslab + k].y; }
+    out[w] = make_double2(t.x * scale, t.y * scale);
+}
+
 int blocks_for(size_t tot)
 {
     size_t b = (tot + 255) / 256;
@@ -168,6 +216,14 @@ void launch_ge_pair_product(hipStream_t st, const double2 *S0, const double2 *S1
 void launch_ge_pair_reduce(hipStream_t st, const double2 *X, const double2 *Y, double2 *P, int npairs, size_t n1)
 {
     hipLaunchKernelGGL(ge_pair_reduce_kernel, dim3(blocks_for(n1)), dim3(256), 0, st, X, Y, P, npairs, n1);
+}
+
+void launch_ge_boundary(hipStream_t st, const double2 *gr, const double2 *r, double2 *part, double2 *out, int Lt, int N, int nsys, int nrhs, int n_orb, int og, int orr, int Nc, int L1, int L2, int sh1, int sh2,
+                        const double2 *tD, int conj_tD, int ts1, int ts2, const double2 *t0, int conj_t0, int nslab, double scale)
+{
+    const int nw = nsys / nrhs;
+    hipLaunchKernelGGL(ge_boundary_partial_kernel, dim3((unsigned)(nw * nslab)), dim3(256), 0, st, gr, r, part, Lt, N, nsys, nrhs, n_orb, og, orr, Nc, L1, L2, sh1, sh2, tD, conj_tD, ts1, ts2, t0, conj_t0, nslab);
+    hipLaunchKernelGGL(ge_boundary_final_kernel, dim3((unsigned)nw), dim3(64), 0, st, part, out, nslab, scale);
 }
 
 void launch_ge_finalize_pairs(hipStream_t st, const double2 *S, double2 *out, int Lt, int Nc, double scale)

@@ -191,6 +191,8 @@ void launch_ge_pair_product(hipStream_t st, const double2 *S0, const double2 *S1
                             const double2 *tD, int conj_tD, const double2 *t0, int conj_t0);
 void launch_ge_pair_reduce(hipStream_t st, const double2 *X, const double2 *Y, double2 *P, int npairs, size_t n1);
 void launch_ge_finalize_pairs(hipStream_t st, const double2 *S, double2 *out, int Lt, int Nc, double scale);
+void launch_ge_boundary(hipStream_t st, const double2 *gr, const double2 *r, double2 *part, double2 *out, int Lt, int N, int nsys, int nrhs, int n_orb, int og, int orr, int Nc, int L1, int L2, int sh1, int sh2,
+                        const double2 *tD, int conj_tD, int ts1, int ts2, const double2 *t0, int conj_t0, int nslab, double scale);
 void launch_ge_finalize_gd0(hipStream_t st, const double2 *S, double2 *out, int Lt, int Nc, int nw, double scale, int same_orbital);
 
 // own tau-FFT (kernels_tfft.hip): Stockham passes over LDS site tiles, optionally fused with the CG updates
