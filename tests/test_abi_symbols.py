@@ -53,3 +53,21 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "smoqy_oracle" not in src, f
+
+
+def test_header_and_c_example_compile_as_plain_c(tmp_path):
+    """include/smoqy_hip.h is a C header (no C++ or torch types) and examples/c_abi_demo.c — the ccall sequence of INTEGRATION.md
+    written in C — builds against libsmoqy_hip.so with gcc -std=c99 (the run itself needs a GPU: tests/test_gpu_c_abi.py)."""
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(root, "include", "smoqy_hip.h")], check=True)
+    lib_dir = os.path.join(root, "smoqyelphqmc.jl_amd", "csrc")
+    out = tmp_path / "c_abi_demo"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_demo.c"), "-L" + lib_dir, "-lsmoqy_hip", "-lm",
+                    "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(out)], check=True)
+    assert out.exists()
