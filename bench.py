@@ -41,8 +41,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="holstein_honeycomb_L16_Ltau128")
-    ap.add_argument("--walkers-per-gpu", type=int, default=64)
-    ap.add_argument("--streams", type=int, default=4, help="concurrent lock-step batches per GPU (one HIP stream + host thread each)")
+    ap.add_argument("--walkers-per-gpu", type=int, default=96)
+    ap.add_argument("--streams", type=int, default=6, help="concurrent lock-step batches per GPU (one HIP stream + host thread each)")
     ap.add_argument("--tau-chunk", type=int, default=0)
     ap.add_argument("--check-every", type=int, default=0)
     ap.add_argument("--matvec-reps", type=int, default=400)
@@ -143,7 +143,8 @@ def main():
         raise SystemExit("--walkers-per-gpu must be a multiple of --streams")
     mine = walker_range(rank, world, wpg)  # walkers [rank*wpg, (rank+1)*wpg): no overlap between ranks, no exchange
     per = wpg // S
-    batches = [WalkerBatch(args.workload, nwalkers=per, walker0=mine.start + s * per, device=dev, check_every=args.check_every or None, tau_chunk=args.tau_chunk or None) for s in range(S)]
+    batches = [WalkerBatch(args.workload, nwalkers=per, walker0=mine.start + s * per, device=dev, check_every=args.check_every or None, tau_chunk=args.tau_chunk or None,
+                           host_threads=max(2, 16 // S)) for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
     batch = batches[0]
     pool = ThreadPoolExecutor(S) if S > 1 else None
 

@@ -1344,19 +1344,22 @@ static int cg_iteration(smoqy_ctx *c, const CgArgs &a, bool any_pre)
 {
     if (int rc = matvec_dev(c, SMOQY_OP_MTM, c->cg_z, c->cg_p, c->part_pz, c->d_st, 0, c->g.nsys, true)) return rc;  // z = A p, partial p·Ap (:219)
     if (any_pre && c->tf_ok && c->use_tfft) {
-        // four launches per iteration: the tau-FFT kernels absorb the BLAS-1 updates (kernels_tfft.hip)
+        // four launches per iteration: the tau-FFT kernels absorb the BLAS-1 updates (kernels_tfft.hip).  In this form a.r
+        // holds the residual in FREQUENCY space (r̂): the forward kernel updates it with α·FFT(Ap), the Chebyshev kernel reads
+        // it and writes ẑ into v (out of place), the inverse kernel turns ẑ into z and updates x and p.
         TfftArgs t = c->tf;
-        t.x = a.x; t.r = a.r; t.p = a.p; t.z = a.z; t.dst = a.v;
+        t.x = a.x; t.r = a.r; t.p = a.p; t.z = a.z;
         t.part_rz = a.part_rz; t.nrz = a.nrz; t.rz_stride = a.rz_stride;
         t.part_pz = a.part_pz; t.npz = a.nchunk; t.pz_stride = a.nchunk;
         t.part_rr = a.part_rr; t.nrr = t.ntile; t.rr_stride = c->pstride;
         t.st = a.st;
-        launch_tfft(c->stream, 2, t);                      // :220-226 + FFT of the new residual (v̂ lands in v)
-        KpmArgs k = kpm_args(c, c->cg_v, c->d_st);
+        launch_tfft(c->stream, 2, t);                      // :219-226: α, r̂ -= α FFT(Ap), |r|²
+        KpmArgs k = kpm_args(c, c->cg_r, c->d_st);
+        k.vout = c->cg_v;
         k.part_rz = c->part_rz;
         launch_cheb(c->stream, k, c->kg);                  // :237 in frequency space, partial r·z by Parseval
         t.src = a.v;
-        launch_tfft(c->stream, 3, t);                      // inverse FFT + :229-245
+        launch_tfft(c->stream, 3, t);                      // inverse FFT + x += α p + :229-245
         return check_launch(c, "cg iteration");
     }
     launch_cg_update_xr(c->stream, a);                                                                             // :220-226
@@ -1393,7 +1396,18 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
         if (int rc = matvec_dev(c, SMOQY_OP_MTM, c->cg_z, x, nullptr, nullptr, 0, g.nsys, true)) return rc;
     }
     launch_cg_init(c->stream, a, x_is_b);
-    if (any_pre) if (int rc = precond_core(c, c->cg_r, c->cg_v, nullptr, c->part_rz)) return rc;  // z0 = P⁻¹ r0 (:200)
+    if (any_pre && c->tf_ok && c->use_tfft) {
+        // fused iteration: the residual lives in frequency space from here on (r̂0 = FFT r0, in place), z0 = FFT⁻¹ P̂ r̂0 (:200)
+        TfftArgs t = c->tf;
+        t.src = c->cg_r; t.dst = c->cg_r; t.pre_tw = nullptr; t.post_tw = nullptr;
+        launch_tfft(c->stream, 0, t);
+        KpmArgs k = kpm_args(c, c->cg_r, nullptr);
+        k.vout = c->cg_v;
+        k.part_rz = c->part_rz;
+        launch_cheb(c->stream, k, c->kg);
+        t.src = c->cg_v; t.dst = c->cg_v;
+        launch_tfft(c->stream, 1, t);
+    } else if (any_pre) if (int rc = precond_core(c, c->cg_r, c->cg_v, nullptr, c->part_rz)) return rc;  // z0 = P⁻¹ r0 (:200)
     launch_cg_start(c->stream, a);
     if (int rc = check_launch(c, "cg setup")) return rc;
 

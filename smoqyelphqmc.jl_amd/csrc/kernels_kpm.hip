@@ -315,7 +315,8 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
     const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);  // heaviest orders first
     const int w = sys / k.nrhs;
     if (k.cg && k.cg[sys].done) return;
-    double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
+    const double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
+    double2 *vo = (k.vout ? k.vout : k.v) + ((size_t)om * k.nsys + sys) * N;
     double2 *prz = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride + om : nullptr;
     const int Lo2 = (Lt + 1) / 2;
     const int slot = SYM ? (om >= Lo2 ? Lt - om - 1 : om) : om;  // :387
@@ -332,7 +333,7 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
         double acc = 0.0;
         for (int i = threadIdx.x; i < N; i += blockDim.x) {
             const double2 x = v[i];
-            v[i] = make_double2(f * x.x, f * x.y);
+            vo[i] = make_double2(f * x.x, f * x.y);
             acc += f * (x.x * x.x + x.y * x.y);
         }
         if (prz) {
@@ -378,11 +379,11 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
     if (onL) {
         vi = make_double2(k.scale * vi.x, k.scale * vi.y);
         vj = make_double2(k.scale * vj.x, k.scale * vj.y);
-        v[lb.sL.x] = vi;
+        vo[lb.sL.x] = vi;
         acc.x += vi0.x * vi.x + vi0.y * vi.y;
         acc.y += vi0.x * vi.y - vi0.y * vi.x;
         if (bL.y != bL.x) {
-            v[lb.sL.y] = vj;
+            vo[lb.sL.y] = vj;
             acc.x += vj0.x * vj.x + vj0.y * vj.y;
             acc.y += vj0.x * vj.y - vj0.y * vj.x;
         }
@@ -420,7 +421,8 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
     const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);  // heaviest orders first, rank-major
     const int w = sys / k.nrhs;
     if (k.cg && k.cg[sys].done) return;
-    double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
+    const double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
+    double2 *vo = (k.vout ? k.vout : k.v) + ((size_t)om * k.nsys + sys) * N;
     double2 *prz = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride + om : nullptr;
     const int Lo2 = (Lt + 1) / 2;
     const int slot = om >= Lo2 ? Lt - om - 1 : om;  // :387
@@ -432,7 +434,7 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
         double acc = 0.0;
         for (int i = j; i < N; i += T) {
             const double2 x = v[i];
-            v[i] = make_double2(f * x.x, f * x.y);
+            vo[i] = make_double2(f * x.x, f * x.y);
             acc += f * (x.x * x.x + x.y * x.y);
         }
         if (prz) {
@@ -572,11 +574,11 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
     if (on) {
         ax = make_double2(k.scale * ax.x, k.scale * ax.y);
         ay = make_double2(k.scale * ay.x, k.scale * ay.y);
-        v[sx] = ax;
+        vo[sx] = ax;
         acc.x += v0x.x * ax.x + v0x.y * ax.y;
         acc.y += v0x.x * ax.y - v0x.y * ax.x;
         if (sy != sx) {
-            v[sy] = ay;
+            vo[sy] = ay;
             acc.x += v0y.x * ay.x + v0y.y * ay.y;
             acc.y += v0y.x * ay.y - v0y.y * ay.x;
         }
@@ -677,7 +679,8 @@ __global__ void __launch_bounds__(kThreads) cheb_generic_kernel(KpmArgs k)
     const double *dbar = k.dbar + (size_t)w * N, *cbar = k.cbar + (size_t)w * k.Nh, *sbar = k.sbar + (size_t)w * k.Nh;
     const double emin = k.bounds[2 * w], emax = k.bounds[2 * w + 1];
     const double avg = 0.5 * (emax + emin), mag = 0.5 * (emax - emin);
-    double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
+    const double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
+    double2 *vo = (k.vout ? k.vout : k.v) + ((size_t)om * k.nsys + sys) * N;
     double2 *prz = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride + om : nullptr;
     const int Lo2 = (Lt + 1) / 2;
     const bool act = k.active[w] != 0;
@@ -698,7 +701,7 @@ __global__ void __launch_bounds__(kThreads) cheb_generic_kernel(KpmArgs k)
         }
         for (int i = threadIdx.x; i < N; i += blockDim.x) {
             const double2 x = v[i], o = make_double2(k.scale * ACC[i].x, k.scale * ACC[i].y);
-            v[i] = o;
+            vo[i] = o;
             acc.x += x.x * o.x + x.y * o.y;
             acc.y += x.x * o.y - x.y * o.x;
         }
@@ -707,7 +710,7 @@ __global__ void __launch_bounds__(kThreads) cheb_generic_kernel(KpmArgs k)
         if (act) f *= k.is_sym ? coefs[0].x : (coefs[0].x * coefs[0].x + coefs[0].y * coefs[0].y);
         for (int i = threadIdx.x; i < N; i += blockDim.x) {
             const double2 x = v[i];
-            v[i] = make_double2(f * x.x, f * x.y);
+            vo[i] = make_double2(f * x.x, f * x.y);
             acc.x += f * (x.x * x.x + x.y * x.y);
         }
     }

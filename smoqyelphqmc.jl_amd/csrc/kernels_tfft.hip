@@ -11,10 +11,12 @@
 // 256-byte bank rows — conflict free).  Because a tile holds every τ of its sites, everything that
 // is elementwise around the transform is fused into the same pass over memory:
 //
-//   forward  (MODE_FWD_CG):  α = (r·z)/(p·Ap);  x += α p;  r -= α Ap;  partial |r|²;  v̂ = FFT r
-//                            (replaces cg_update_xr + the rocFFT forward transform)
-//   inverse  (MODE_INV_CG):  stop test on |r|/|b|;  β = (r·z)new/(r·z)old;  p = FFT⁻¹ v̂ + β p
-//                            (replaces the rocFFT inverse transform + cg_update_p; z is never stored)
+//   forward  (MODE_FWD_CG):  α = (r·z)/(p·Ap);  r̂ -= α FFT(Ap);  partial |r|² (Parseval)
+//   inverse  (MODE_INV_CG):  stop test on |r|/|b|;  x += α p;  β = (r·z)new/(r·z)old;  p = FFT⁻¹ ẑ + β p
+// The fused CG keeps the residual in FREQUENCY space only: the transform is linear, so r̂ ← r̂ - α·FFT(Ap) replaces
+// "update r, then transform it", the time-domain residual is never stored, and the x update moves next to the p update, which
+// reads the old search direction anyway.  One iteration then touches 12 vectors (MᵀM 2, forward 3, Chebyshev 2 out of place,
+// inverse 5) instead of 14; |r|² comes from Σ|r̂|²/Lτ and r·z from the Chebyshev kernel, both by Parseval.
 //
 // The CG runs in the twiddled basis (kernels_vec.hip), so no θ factors appear here; the plain
 // modes take optional pre/post twiddle tables for the stand-alone FourierTransformer API.
@@ -206,46 +208,9 @@ __global__ void __launch_bounds__(256) tfft_kernel(TfftArgs a)
     constexpr int U = 4;  // slices in flight per lane: all loads of a batch are issued before its first store
 
     if (MODE == MODE_FWD_CG) {
-        // ConjugateGradient.jl:219-226 on this tile, then the forward transform of the new residual
-        double2 pv[U], zv[U], xv[U], rv[U];
-        auto load = [&](int l) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int lu = l + u * lstep;
-                if (act && lu < Lt) {
-                    const size_t off = (size_t)lu * sstride + base + sb;
-                    pv[u] = a.p[off]; zv[u] = a.z[off]; xv[u] = a.x[off]; rv[u] = a.r[off];
-                }
-            }
-        };
-        load(l0);  // in flight while the two scalar reductions below run
-        const double2 rz = reduce_c(a.part_rz + (size_t)sys * a.rz_stride, a.nrz, red);
-        const double2 pz = reduce_c(a.part_pz + (size_t)sys * a.pz_stride, a.npz, red);
-        const double2 alpha = cdivt(rz, pz);
-        double acc = 0.0;
-        for (int l = l0; l < Lt; l += U * lstep) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int lu = l + u * lstep;
-                if (lu < Lt) {
-                    double2 rn = make_double2(0.0, 0.0);
-                    if (act) {
-                        const size_t off = (size_t)lu * sstride + base + sb;
-                        a.x[off] = cadd(xv[u], cm(alpha, pv[u]));
-                        rn = csub(rv[u], cm(alpha, zv[u]));
-                        a.r[off] = rn;
-                        acc += rn.x * rn.x + rn.y * rn.y;
-                    }
-                    A[lu * SB + sb] = rn;
-                }
-            }
-            if (l + U * lstep < Lt) load(l + U * lstep);
-        }
-        const double2 t = bsum(make_double2(acc, 0.0), red);  // also the barrier that publishes A and WT
-        if (threadIdx.x == 0) {
-            a.part_rr[(size_t)sys * a.rr_stride + tile] = t.x;
-            if (tile == 0) { a.st[sys].rho_re = rz.x; a.st[sys].rho_im = rz.y; }
-        }
+        // stage A p (in a.z) for the transform
+        for (int l = l0; l < Lt; l += lstep) A[l * SB + sb] = act ? a.z[(size_t)l * sstride + base + sb] : make_double2(0.0, 0.0);
+        __syncthreads();
     } else {
         for (int idx = threadIdx.x; idx < Lt * SB; idx += blockDim.x) {
             const int l = idx / SB, sb = idx - l * SB;
@@ -261,26 +226,70 @@ __global__ void __launch_bounds__(256) tfft_kernel(TfftArgs a)
 
     const double2 *res = stockham(A, B, WT, a, INV);
 
-    if (MODE == MODE_INV_CG) {
-        // ConjugateGradient.jl:229-245: stop test on the unpreconditioned residual, then p = z + β p
+    if (MODE == MODE_FWD_CG) {
+        // ConjugateGradient.jl:219-226 in frequency space: α = (r·z)/(p·Ap), r̂ -= α·FFT(Ap), |r|² = Σ|r̂|²/Lτ
+        const double2 rz = reduce_c(a.part_rz + (size_t)sys * a.rz_stride, a.nrz, red);
+        const double2 pz = reduce_c(a.part_pz + (size_t)sys * a.pz_stride, a.npz, red);
+        const double2 alpha = cdivt(rz, pz);
+        double acc = 0.0;
+        if (act) {
+            for (int l = l0; l < Lt; l += U * lstep) {
+                double2 rv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int lu = l + u * lstep;
+                    if (lu < Lt) rv[u] = a.r[(size_t)lu * sstride + base + sb];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int lu = l + u * lstep;
+                    if (lu < Lt) {
+                        const double2 rn = csub(rv[u], cm(alpha, res[lu * SB + sb]));
+                        a.r[(size_t)lu * sstride + base + sb] = rn;
+                        acc += rn.x * rn.x + rn.y * rn.y;
+                    }
+                }
+            }
+        }
+        const double2 t = bsum(make_double2(acc, 0.0), red);
+        if (threadIdx.x == 0) {
+            a.part_rr[(size_t)sys * a.rr_stride + tile] = t.x / Lt;
+            if (tile == 0) {
+                CgState &s = a.st[sys];
+                s.rho_re = rz.x; s.rho_im = rz.y;
+                s.alpha_re = alpha.x; s.alpha_im = alpha.y;
+            }
+        }
+    } else if (MODE == MODE_INV_CG) {
+        // ConjugateGradient.jl:220 (x += α p, deferred to here), :229-245: stop test on the unpreconditioned residual, p = z + β p
         const double rr = reduce_r(a.part_rr + (size_t)sys * a.rr_stride, a.nrr, red);
         const double eps = sqrt(rr) / sqrt(a.st[sys].normb2);
         const bool conv = eps < a.st[sys].tol;
+        const double2 alpha = make_double2(a.st[sys].alpha_re, a.st[sys].alpha_im);
+        double2 beta = make_double2(0.0, 0.0);
         if (!conv) {
             const double2 rz = reduce_c(a.part_rz + (size_t)sys * a.rz_stride, a.nrz, red);
-            const double2 beta = cdivt(rz, make_double2(a.st[sys].rho_re, a.st[sys].rho_im));
-            if (act) {
-                for (int l = l0; l < Lt; l += U * lstep) {
-                    double2 pv[U];
+            beta = cdivt(rz, make_double2(a.st[sys].rho_re, a.st[sys].rho_im));
+        }
+        if (act) {
+            for (int l = l0; l < Lt; l += U * lstep) {
+                double2 pv[U], xv[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int lu = l + u * lstep;
-                        if (lu < Lt) pv[u] = a.p[(size_t)lu * sstride + base + sb];
+                for (int u = 0; u < U; ++u) {
+                    const int lu = l + u * lstep;
+                    if (lu < Lt) {
+                        const size_t off = (size_t)lu * sstride + base + sb;
+                        pv[u] = a.p[off];
+                        xv[u] = a.x[off];
                     }
+                }
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int lu = l + u * lstep;
-                        if (lu < Lt) a.p[(size_t)lu * sstride + base + sb] = cadd(res[lu * SB + sb], cm(beta, pv[u]));
+                for (int u = 0; u < U; ++u) {
+                    const int lu = l + u * lstep;
+                    if (lu < Lt) {
+                        const size_t off = (size_t)lu * sstride + base + sb;
+                        a.x[off] = cadd(xv[u], cm(alpha, pv[u]));
+                        if (!conv) a.p[off] = cadd(res[lu * SB + sb], cm(beta, pv[u]));
                     }
                 }
             }

@@ -33,6 +33,7 @@ struct Geometry {
 struct CgState {
     double normb2;      // |b|^2
     double rho_re, rho_im;  // r.z of the current iteration
+    double alpha_re, alpha_im;  // α of the current iteration (the x update happens one kernel later than the r update)
     double eps;         // last relative residual
     int iters;          // completed iterations
     int done;           // 0 running, 1 converged, 2 maxiter reached
@@ -65,7 +66,8 @@ struct KpmArgs {
     const double *bounds;               // [w][2]
     const int *active;                  // [w]
     int nslot, maxorder;
-    double2 *v;                         // in place, slice(=frequency)-major
+    double2 *v;                         // input, slice(=frequency)-major
+    double2 *vout;                      // output; nullptr = in place
     const CgState *cg;
     double2 *part_rz;                   // optional [nsys][rz_stride]: Parseval partial of r·z per (system, ω)
     int rz_stride;
