@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--workload", default="holstein_honeycomb_L16_Ltau128")
     ap.add_argument("--walkers-per-gpu", type=int, default=96)
     ap.add_argument("--streams", type=int, default=6, help="concurrent lock-step batches per GPU (one HIP stream + host thread each)")
+    ap.add_argument("--solve-concurrency", type=int, default=3, help="at most this many batches inside the CG at once (0 = no limit)")
     ap.add_argument("--tau-chunk", type=int, default=0)
     ap.add_argument("--check-every", type=int, default=0)
     ap.add_argument("--matvec-reps", type=int, default=400)
@@ -146,6 +147,9 @@ def main():
     batches = [WalkerBatch(args.workload, nwalkers=per, walker0=mine.start + s * per, device=dev, check_every=args.check_every or None, tau_chunk=args.tau_chunk or None,
                            host_threads=max(2, 16 // S)) for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
     batch = batches[0]
+    if args.solve_concurrency > 0:
+        import threading
+        WalkerBatch.solve_gate = threading.Semaphore(args.solve_concurrency)
     pool = ThreadPoolExecutor(S) if S > 1 else None
 
     def run(nsweeps):

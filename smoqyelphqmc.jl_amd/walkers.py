@@ -42,6 +42,10 @@ class SweepStats:
 
 
 class WalkerBatch:
+    # optional threading.Semaphore shared by the batches of one GPU: bounds how many batches are inside the CG at once
+    # (the other batches' host work and transfers still overlap with them)
+    solve_gate = None
+
     def __init__(self, workload: str, nwalkers: int = 1, walker0: int = 0, is_sym: bool = True, device: int = -1, tol: float = 1e-10, maxiter: int = 10_000, Nt: int = 24,
                  drift: float = 0.02, check_every: int | None = None, tau_chunk: int | None = None, smooth: bool = False, host_threads: int = 8, device_update: bool = True):
         self.models = [lat.CONFIGS[workload](walker=walker0 + w, smooth=smooth) for w in range(nwalkers)]
@@ -157,7 +161,14 @@ class WalkerBatch:
         self.h.call("smoqy_lambda_apply_v", L.LAMBDA_LDIVT, self.u, self.phi)  # Ψ = Λ⁻ᵀ Φ   (:97)
         iters = np.zeros(self.nw, dtype=np.int32)
         eps = np.zeros(self.nw)
-        self.h.call("smoqy_cg_solve_v", self.u, self.u, C.c_double(tol), int(self.maxiter), int(bool(use_precond)), L.ptr(iters), L.ptr(eps))  # (:99)
+        gate = WalkerBatch.solve_gate
+        if gate is not None:
+            gate.acquire()
+        try:
+            self.h.call("smoqy_cg_solve_v", self.u, self.u, C.c_double(tol), int(self.maxiter), int(bool(use_precond)), L.ptr(iters), L.ptr(eps))  # (:99)
+        finally:
+            if gate is not None:
+                gate.release()
         self.h.call("smoqy_lambda_apply_v", L.LAMBDA_LDIV, self.u, self.u)   # Ψ = Λ⁻¹ Ψ   (:107)
         sf = self.h.vec_dot(self.phi, self.u)                                 # S = Φ·Ψ     (:109)
         self.stats.solves += self.nw
