@@ -1355,7 +1355,7 @@ static int cg_iteration(smoqy_ctx *c, const CgArgs &a, bool any_pre)
         t.st = a.st;
         launch_tfft(c->stream, 2, t);                      // :219-226: α, r̂ -= α FFT(Ap), |r|²
         KpmArgs k = kpm_args(c, c->cg_r, c->d_st);
-        k.vout = c->cg_v;
+        k.vout = c->cg_z;  // ẑ reuses the buffer of A p, which the forward kernel has consumed (one vector less in the cache-resident working set)
         k.part_rz = c->part_rz;
         launch_cheb(c->stream, k, c->kg);                  // :237 in frequency space, partial r·z by Parseval
         t.src = a.v;
@@ -1363,7 +1363,7 @@ static int cg_iteration(smoqy_ctx *c, const CgArgs &a, bool any_pre)
         return check_launch(c, "cg iteration");
     }
     launch_cg_update_xr(c->stream, a);                                                                             // :220-226
-    if (any_pre) if (int rc = precond_core(c, c->cg_r, c->cg_v, c->d_st, c->part_rz)) return rc;                 // z = P⁻¹ r, partial r·z (:237-240)
+    if (any_pre) if (int rc = precond_core(c, c->cg_r, c->cg_z, c->d_st, c->part_rz)) return rc;                 // z = P⁻¹ r (over A p, consumed), partial r·z (:237-240)
     launch_cg_update_p(c->stream, a);                                                                              // :229-245
     return 0;
 }
@@ -1386,7 +1386,8 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
 
     CgArgs a{};
     a.Lt = g.Lt; a.N = g.N; a.nsys = g.nsys; a.nrhs = g.nrhs; a.Tc = c->Tc; a.nchunk = c->nchunk;
-    a.x = x; a.r = c->cg_r; a.p = c->cg_p; a.z = c->cg_z; a.v = c->cg_v; a.th = c->d_th; a.b = b;
+    a.x = x; a.r = c->cg_r; a.p = c->cg_p; a.z = c->cg_z; a.th = c->d_th; a.b = b;
+    a.v = c->cg_z;  // z = P⁻¹ r shares the buffer of A p: their lifetimes do not overlap
     a.part_pz = c->part_pz; a.part_rz = c->part_rz; a.part_rr = c->part_rr; a.part_bb = c->part_bb;
     a.st = c->d_st; a.tol = tol; a.maxiter = maxiter; a.use_precond = any_pre ? 1 : 0;
     a.rz_stride = g.Lt; a.nrz = any_pre ? g.Lt : c->nchunk;
@@ -1402,12 +1403,12 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
         t.src = c->cg_r; t.dst = c->cg_r; t.pre_tw = nullptr; t.post_tw = nullptr;
         launch_tfft(c->stream, 0, t);
         KpmArgs k = kpm_args(c, c->cg_r, nullptr);
-        k.vout = c->cg_v;
+        k.vout = c->cg_z;
         k.part_rz = c->part_rz;
         launch_cheb(c->stream, k, c->kg);
-        t.src = c->cg_v; t.dst = c->cg_v;
+        t.src = c->cg_z; t.dst = c->cg_z;
         launch_tfft(c->stream, 1, t);
-    } else if (any_pre) if (int rc = precond_core(c, c->cg_r, c->cg_v, nullptr, c->part_rz)) return rc;  // z0 = P⁻¹ r0 (:200)
+    } else if (any_pre) if (int rc = precond_core(c, c->cg_r, c->cg_z, nullptr, c->part_rz)) return rc;  // z0 = P⁻¹ r0 (:200)
     launch_cg_start(c->stream, a);
     if (int rc = check_launch(c, "cg setup")) return rc;
 
