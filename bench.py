@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--check-every", type=int, default=0)
     ap.add_argument("--matvec-reps", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)  # child process of cpu_baseline: time the oracle sample for this walker
+    ap.add_argument("--cpu-tol", type=float, default=1e-10, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-nt", type=int, default=24, help=argparse.SUPPRESS)
     ap.add_argument("--roofline-only", action="store_true", help="run only the isolated roofline leg (for a rocprofv3 pass whose kernel average must match roofline.avg_launch_us)")
     ap.add_argument("--batch-scan", action="store_true", help="also report matvec GB/s vs batch size")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
@@ -56,6 +59,43 @@ def parse():
 
 
 def cpu_baseline(workload, tol, Nt):
+    """The CPU oracle on the host cores the box gives this process: ONE walker per core, as the reference's MPI mode runs it
+    (tutorials/holstein_honeycomb_mpi.jl) — every core times the same bounded sample (`cpu_sample`) in its own child process (no
+    GPU, no threads inside), all at once, so that memory-bandwidth contention between the walkers is part of the figure.
+    `value` is the aggregate over the cores; the single-core figure is reported next to it."""
+    import subprocess
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    single = cpu_sample(workload, tol, Nt, walker=0)
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(w), "--workload", workload, "--cpu-tol", repr(tol), "--cpu-nt", str(Nt)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for w in range(cores)]
+    rates = []
+    for pr in procs:
+        out, _ = pr.communicate(timeout=600)
+        try:
+            rates.append(float(json.loads(out.strip().splitlines()[-1])["value"]))
+        except (ValueError, IndexError, KeyError):
+            pass
+    if len(rates) != cores:  # a worker failed: fall back to the single-core measurement, labelled as such
+        return single
+    agg = dict(single)
+    agg.update({
+        "value": sum(rates),
+        "cores": cores,
+        "sample": f"{cores} walkers, one per core and all at once, each: " + single["sample"].split(": ", 1)[1],
+        "single_core_value": single["value"],
+        "per_core_min": min(rates),
+        "per_core_max": max(rates),
+    })
+    return agg
+
+
+def cpu_sample(workload, tol, Nt, walker=0):
     """Time the CPU oracle (single thread) on a bounded sample of the workload: one
     preconditioned action solve (tol) and one force solve (sqrt(tol)) of walker 0, each
     including the preconditioner update, extrapolated to the 27 solves of a sweep."""
@@ -65,12 +105,12 @@ def cpu_baseline(workload, tol, Nt):
     from oracle import oracle as orc
 
     lat = sq.lattice
-    m = lat.CONFIGS[workload](walker=0)
+    m = lat.CONFIGS[workload](walker=walker)
     nt, perm, colors = lat.checkerboard_decomposition(m.fpi.neighbor_table)
     expV, ch, sh = orc.update_fields(m.fpi.V, m.fpi.t, perm, m.fpi.dtau, True)
     o = orc.OracleFDM(nt, expV, ch, sh, True)
     P = orc.OracleKPM(o)
-    g = np.random.default_rng(1)
+    g = np.random.default_rng(1 + walker)
     Lt, N = expV.shape
     # the same right-hand side the sweep solves for: b = Λ⁻ᵀ Φ with Φ = Λᵀ Mᵀ R (src/PFFCalculator.jl:56-99)
     R = np.asfortranarray((g.standard_normal((Lt, N)) + 1j * g.standard_normal((Lt, N))) * np.sqrt(0.5))
@@ -102,7 +142,7 @@ def cpu_baseline(workload, tol, Nt):
         "unit": "sweeps/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"walker 0 of {workload}: 1 action solve (tol {tol:g}, {it_a} iters, {t_action:.2f} s) + 1 force solve (tol {np.sqrt(tol):g}, {it_f} iters, {t_force:.2f} s) "
+        "sample": f"walker {walker} of {workload}: 1 action solve (tol {tol:g}, {it_a} iters, {t_action:.2f} s) + 1 force solve (tol {np.sqrt(tol):g}, {it_f} iters, {t_force:.2f} s) "
         f"with the KPM preconditioner, single thread, extrapolated to 3 action + {Nt} force solves per sweep",
         "matvec_MtM_ms": t_mv * 1e3,
         "matvec_MtM_GBs": alg / t_mv / 1e9,
@@ -112,6 +152,9 @@ def cpu_baseline(workload, tol, Nt):
 
 def main():
     args = parse()
+    if args.cpu_worker >= 0:  # CPU-only child of cpu_baseline(): never touches the GPU
+        print(json.dumps(cpu_sample(args.workload, args.cpu_tol, args.cpu_nt, walker=args.cpu_worker)))
+        return
     import torch
     import torch.distributed as dist
 
