@@ -58,6 +58,30 @@ def parse():
     return ap.parse_args()
 
 
+def available_cores():
+    """Host cores this process may really use: the scheduler affinity capped by the cgroup CPU quota (a one-GPU box exposes every
+    core of the node but grants 16 cores' worth of time)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(workload, tol, Nt):
     """The CPU oracle on the host cores the box gives this process: ONE walker per core, as the reference's MPI mode runs it
     (tutorials/holstein_honeycomb_mpi.jl) — every core times the same bounded sample (`cpu_sample`) in its own child process (no
@@ -65,11 +89,7 @@ def cpu_baseline(workload, tol, Nt):
     `value` is the aggregate over the cores; the single-core figure is reported next to it."""
     import subprocess
 
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
+    cores = available_cores()
     single = cpu_sample(workload, tol, Nt, walker=0)
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(w), "--workload", workload, "--cpu-tol", repr(tol), "--cpu-nt", str(Nt)],
@@ -146,7 +166,8 @@ def cpu_sample(workload, tol, Nt, walker=0):
         f"with the KPM preconditioner, single thread, extrapolated to 3 action + {Nt} force solves per sweep",
         "matvec_MtM_ms": t_mv * 1e3,
         "matvec_MtM_GBs": alg / t_mv / 1e9,
-        "host_cores_available": os.cpu_count(),
+        "host_cores_available": available_cores(),
+        "host_cores_visible": os.cpu_count(),
     }
 
 
