@@ -50,7 +50,8 @@ enum { SMOQY_OP_M = 0, SMOQY_OP_MT = 1, SMOQY_OP_MTM = 2, SMOQY_OP_MMT = 3 };
  * checkerboard decomposition, which is an INPUT: neighbor_table is 2 x Nh (1-based, colour
  * sorted), color_ranges is 2 x ncolors (1-based inclusive first/last bond of each colour).
  * Bonds of one colour must touch disjoint sites (checked).  device_id < 0 = current device. */
-/* Limits: real hoppings only (is_complex_T must be 0), N <= 2556 sites (whole slices live in LDS / registers; error 5 beyond). */
+/* Limits: real hoppings only (is_complex_T must be 0).  Lattices of more than 2556 sites run on generic kernels that stage
+ * their time slices in global memory instead of LDS (functional, not tuned). */
 int smoqy_create(smoqy_ctx **out, int Ltau, int N, int Nh, int ncolors, const int64_t *neighbor_table,
                  const int64_t *color_ranges, int is_sym, int is_complex_T, int nwalkers, int nrhs, int device_id);
 int smoqy_destroy(smoqy_ctx *ctx);

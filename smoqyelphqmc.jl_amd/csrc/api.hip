@@ -48,6 +48,9 @@ struct smoqy_ctx {
     double2 *scr[3] = {nullptr, nullptr, nullptr};
     // cg
     double2 *cg_r = nullptr, *cg_p = nullptr, *cg_z = nullptr, *cg_v = nullptr;
+    // lattices beyond the LDS limit (N > 2556): global staging area of the generic kernels, 4 N-vectors per workgroup
+    double2 *d_big = nullptr;
+    size_t big_stride = 0;
     double2 *part_pz = nullptr, *part_rz = nullptr, *part_c = nullptr, *d_dot_out = nullptr;
     double *part_rr = nullptr, *part_bb = nullptr;
     CgState *d_st = nullptr, *h_st = nullptr;
@@ -174,6 +177,11 @@ static int check_launch(smoqy_ctx *c, const char *what)
 static void choose_chunking(smoqy_ctx *c)
 {
     const Geometry &g = c->g;
+    if (c->d_big) {  // global staging: one time slice per workgroup
+        c->Tc = 1;
+        c->nchunk = g.Lt;
+        return;
+    }
     if (!c->user_Tc) {
         // largest chunk that still gives >= 2 workgroups per CU and <= 64 KiB of LDS for the
         // fused MᵀM kernel; at small batch this degenerates to Tc = 1 (latency regime)
@@ -200,6 +208,7 @@ static FdmArgs fdm_args(smoqy_ctx *c, const double2 *in, double2 *out, double2 *
     a.in = in; a.out = out; a.partial = partial; a.cg = cg;
     a.sys_first = sys0; a.sys_count = count;
     a.hop_re = 1.0; a.hop_im = 0.0; a.antiperiodic = 1;  // the reference operator
+    a.scratch = c->d_big; a.scratch_stride = c->big_stride;
     return a;
 }
 
@@ -214,6 +223,7 @@ static KpmArgs kpm_args(smoqy_ctx *c, double2 *v, const CgState *cg)
     k.nslot = c->nslot; k.maxorder = c->maxorder;
     k.v = v; k.cg = cg;
     k.part_rz = nullptr; k.rz_stride = g.Lt; k.scale = 1.0 / (double)g.Lt;
+    k.scratch = c->d_big; k.scratch_stride = c->big_stride;
     return k;
 }
 
@@ -271,7 +281,7 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->fft_info) rocfft_execution_info_destroy(c->fft_info);
     void *ptrs[] = {c->d_bonds, c->d_col_off, c->d_expV, c->d_ch, c->d_sh, c->d_lam, c->d_stage, c->d_stage_real, c->d_stage_int, c->scr[0], c->scr[1], c->scr[2], c->cg_r, c->cg_p,
                     c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->fft_work, c->d_tw, c->d_th, c->d_wtab, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
-                    c->d_rand, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f};
+                    c->d_rand, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_big};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (double2 *v : c->vecs)
@@ -357,8 +367,15 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     HIPCHK(c, hipMemset(c->d_st, 0, (size_t)g.nsys * sizeof(CgState)));
     HIPCHK(c, hipHostMalloc(&c->h_st, (size_t)g.nsys * sizeof(CgState)));
     choose_chunking(c);
-    if (fdm_lds_bytes(SMOQY_OP_MTM, g.N, 1) > 160 * 1024 - 256)
-        FAIL(c, 5, "N = %d does not fit the LDS-resident slice kernels (max %d sites)", g.N, (int)((160 * 1024 - 256) / (4 * sizeof(double2))));
+    if (fdm_lds_bytes(SMOQY_OP_MTM, g.N, 1) > 160 * 1024 - 256) {
+        // slices too large for LDS: the generic kernels stage them in global memory instead (one time slice per workgroup);
+        // every workgroup of the largest launch (Lτ · nsys of them) gets room for four N-vectors
+        c->big_stride = 4 * (size_t)g.N;
+        HIPCHK(c, hipMalloc(&c->d_big, (size_t)g.Lt * g.nsys * c->big_stride * sizeof(double2)));
+        c->Tc = 1;
+        c->user_Tc = 1;
+        c->nchunk = g.Lt;
+    }
 
     // FourierTransformer: strided batched rocFFT along tau (stride nsys*N, distance 1)
     std::call_once(g_rocfft_once, [] { rocfft_setup(); });
@@ -594,6 +611,10 @@ int smoqy_set_tau_chunk(smoqy_ctx *c, int Tc)
 {
     CHECK_CTX(c);
     if (Tc <= 0) { c->user_Tc = false; choose_chunking(c); return 0; }
+    if (c->d_big) {
+        if (Tc != 1) FAIL(c, 1, "lattices beyond the LDS limit run with one time slice per workgroup");
+        return 0;
+    }
     if (fdm_lds_bytes(SMOQY_OP_MTM, c->g.N, Tc) > 160 * 1024 - 256) FAIL(c, 1, "tau chunk %d needs more than 160 KiB of LDS at N = %d", Tc, c->g.N);
     c->user_Tc = true;
     c->Tc = std::min(Tc, c->g.Lt);
@@ -808,7 +829,7 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
     if (sample) HIPCHK(c, hipEventRecord(T.ev[T.used].first, c->stream));
     if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_own(c->stream, op, a, c->ff);
     else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_fast(c->stream, op, a, c->ff);
-    else launch_fdm(c->stream, op, c->g.is_sym != 0, a, fdm_lds_bytes(op, c->g.N, c->Tc));
+    else launch_fdm(c->stream, op, c->g.is_sym != 0, a, c->d_big ? 0 : fdm_lds_bytes(op, c->g.N, c->Tc));
     if (sample) HIPCHK(c, hipEventRecord(T.ev[T.used++].second, c->stream));
     return check_launch(c, "matvec");
 }
@@ -1640,6 +1661,7 @@ static ForceArgs force_args(smoqy_ctx *c, double nu, const double2 *u, const dou
     a.u = u; a.v = v; a.nu = nu; a.dtau = c->force.dtau;
     a.Nph = c->force.Nph; a.Nhol = c->force.Nhol; a.Nssh = c->force.Nssh; a.Q = c->force.Q;
     a.x = c->force.d_x; a.contrib = c->force.d_contrib;
+    a.scratch = c->d_big; a.scratch_stride = c->big_stride;
     return a;
 }
 
@@ -1672,7 +1694,7 @@ int smoqy_force_dMdx_v(smoqy_ctx *c, double nu, int u, int v, double *out)
     if (int rc = check_vec(c, v)) return rc;
     if (int rc = force_begin(c)) return rc;
     ForceArgs a = force_args(c, nu, c->vecs[u], c->vecs[v]);
-    if (sizeof(double2) * 2 * (size_t)a.N > 160 * 1024 - 256) FAIL(c, 5, "N = %d does not fit the force kernel's LDS tile", a.N);
+    if (!c->d_big && sizeof(double2) * 2 * (size_t)a.N > 160 * 1024 - 256) FAIL(c, 5, "N = %d does not fit the force kernel's LDS tile", a.N);
     launch_dmdx(c->stream, a, c->g.is_sym != 0);
     return force_finish(c, a, out, true);
 }
@@ -1698,7 +1720,7 @@ static int force_device(smoqy_ctx *c, int psi)
     launch_lambda_apply(c->stream, SMOQY_LAMBDA_MUL, LPsi, Psi, c->d_lam, g.Lt, g.N, g.nsys, g.nrhs, -1);           // ΛΨ            PFFCalculator.jl:146
     if (int rc = matvec_dev(c, SMOQY_OP_M, APsi, LPsi, nullptr, nullptr, 0, g.nsys)) return rc;                      // AΨ = MΛΨ      :148
     ForceArgs a = force_args(c, -2.0, APsi, LPsi);
-    if (sizeof(double2) * 2 * (size_t)a.N > 160 * 1024 - 256) FAIL(c, 5, "N = %d does not fit the force kernel's LDS tile", a.N);
+    if (!c->d_big && sizeof(double2) * 2 * (size_t)a.N > 160 * 1024 - 256) FAIL(c, 5, "N = %d does not fit the force kernel's LDS tile", a.N);
     launch_dmdx(c->stream, a, g.is_sym != 0);                                                                        // -2 Re<AΨ|∂M/∂x|ΛΨ>   :150
     if (int rc = matvec_dev(c, SMOQY_OP_MT, MtAPsi, APsi, nullptr, nullptr, 0, g.nsys)) return rc;                   // MᵀAΨ          :153
     ForceArgs b = force_args(c, -2.0, MtAPsi, Psi);

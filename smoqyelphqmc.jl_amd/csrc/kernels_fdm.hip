@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
     const size_t sstride = (size_t)a.nsys * N;  // distance between time slices
     const double2 *in = a.in + (size_t)sys * N;
     double2 *out = a.out + (size_t)sys * N;
-    double2 *U = lds;
+    double2 *U = a.scratch ? a.scratch + (size_t)blockIdx.x * a.scratch_stride : lds;
     double2 acc = make_double2(0.0, 0.0);
 
     if (OP == SMOQY_OP_M) {
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
         }
     } else if (OP == SMOQY_OP_MTM) {
         // y = M v on slices l0 .. l0+nk (one halo slice), then out = Mᴴ y on l0 .. l0+nk-1
-        double2 *Y = lds + (size_t)(a.Tc + 1) * N;
+        double2 *Y = U + (size_t)(a.Tc + 1) * N;
         const int nk1 = nk + 1;
         for (int idx = threadIdx.x; idx < nk1 * N; idx += blockDim.x) {
             const int k = idx / N, i = idx - k * N;
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
         }
     } else {
         // MMᴴ: y = Mᴴ v on slices l0-1 .. l0+nk-1, then out = M y on l0 .. l0+nk-1
-        double2 *Y = lds + (size_t)(a.Tc + 1) * N;
+        double2 *Y = U + (size_t)(a.Tc + 1) * N;
         const int nk1 = nk + 1;
         for (int idx = threadIdx.x; idx < nk1 * N; idx += blockDim.x) {
             const int k = idx / N, i = idx - k * N;
@@ -219,7 +219,8 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads) checkerboard_kernel(FdmArgs a, int inverse, int transposed, int col0, int ncols)
 {
-    extern __shared__ double2 U[];
+    extern __shared__ double2 lds_cb[];
+    double2 *U = a.scratch ? a.scratch + (size_t)blockIdx.x * a.scratch_stride : lds_cb;
     const int chunk = blockIdx.x % a.nchunk, sys = a.sys_first + blockIdx.x / a.nchunk;
     const int w = sys / a.nrhs, Lt = a.Lt, N = a.N;
     const int l0 = chunk * a.Tc, nk = min(a.Tc, Lt - l0);
@@ -256,7 +257,7 @@ __global__ void __launch_bounds__(kThreads) checkerboard_kernel(FdmArgs a, int i
 
 void launch_checkerboard(hipStream_t st, const FdmArgs &a, int inverse, int transposed, int col0, int ncols)
 {
-    const size_t lds = sizeof(double2) * (size_t)a.N * (size_t)a.Tc;
+    const size_t lds = a.scratch ? 0 : sizeof(double2) * (size_t)a.N * (size_t)a.Tc;
     hipLaunchKernelGGL(checkerboard_kernel, dim3((unsigned)(a.nchunk * a.sys_count)), dim3(kThreads), lds, st, a, inverse, transposed, col0, ncols);
 }
 

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(kThreads) dmdx_kernel(ForceArgs a)
     const int chunk = blockIdx.x % a.nchunk, sys = blockIdx.x / a.nchunk;
     const int w = sys / a.nrhs, Lt = a.Lt, N = a.N;
     const int l0 = chunk * a.Tc, nk = min(a.Tc, Lt - l0);
-    double2 *UP = lds, *VP = lds + (size_t)a.Tc * N;
+    double2 *UP = a.scratch ? a.scratch + (size_t)blockIdx.x * a.scratch_stride : lds, *VP = UP + (size_t)a.Tc * N;
     const double *expV = a.expV + (size_t)w * Lt * N, *ch = a.ch + (size_t)w * Lt * a.Nh, *sh = a.sh + (size_t)w * Lt * a.Nh;
     const size_t sstride = (size_t)a.nsys * N;
     const double2 *u = a.u + (size_t)sys * N, *v = a.v + (size_t)sys * N;
@@ -233,7 +233,7 @@ void configure_force_kernels()
 
 void launch_dmdx(hipStream_t st, const ForceArgs &a, bool sym)
 {
-    const size_t lds = sizeof(double2) * 2 * (size_t)a.Tc * a.N;
+    const size_t lds = a.scratch ? 0 : sizeof(double2) * 2 * (size_t)a.Tc * a.N;
     const dim3 grid((unsigned)(a.nchunk * a.nsys));
     if (sym) hipLaunchKernelGGL((dmdx_kernel<true>), grid, dim3(kThreads), lds, st, a);
     else hipLaunchKernelGGL((dmdx_kernel<false>), grid, dim3(kThreads), lds, st, a);

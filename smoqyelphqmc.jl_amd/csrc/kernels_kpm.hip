@@ -671,7 +671,7 @@ __global__ void __launch_bounds__(kThreads) cheb_generic_kernel(KpmArgs k)
     extern __shared__ double2 lds[];
     __shared__ double red[17];
     const int N = k.N, Lt = k.Lt;
-    double2 *W = lds, *A1 = W + N, *A2 = A1 + N, *ACC = A2 + N;
+    double2 *W = k.scratch ? k.scratch + (size_t)blockIdx.x * k.scratch_stride : lds, *A1 = W + N, *A2 = A1 + N, *ACC = A2 + N;
     const int sys = blockIdx.x % k.nsys, rank = blockIdx.x / k.nsys;
     const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);
     const int w = sys / k.nrhs;
@@ -756,7 +756,7 @@ void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
         }
 #undef CHEB_LAUNCH
     } else {
-        const size_t lds = sizeof(double2) * 4 * (size_t)k.N;
+        const size_t lds = k.scratch ? 0 : sizeof(double2) * 4 * (size_t)k.N;
         hipLaunchKernelGGL(cheb_generic_kernel, dim3((unsigned)(k.Lt * k.nsys)), dim3(kThreads), lds, st, k);
     }
 }
@@ -771,7 +771,7 @@ __global__ void __launch_bounds__(1024) lanczos_kernel(KpmArgs k, KpmGeom kg, in
     extern __shared__ double2 lds[];
     __shared__ double red[17];
     const int N = k.N, w = w0 + blockIdx.x;
-    double2 *W = lds, *VK = W + N, *VKM = VK + N;
+    double2 *W = (!FAST && k.scratch) ? k.scratch + (size_t)blockIdx.x * k.scratch_stride : lds, *VK = W + N, *VKM = VK + N;
     const double *dbar = k.dbar + (size_t)w * N, *cbar = k.cbar + (size_t)w * k.Nh, *sbar = k.sbar + (size_t)w * k.Nh;
     randvec += (size_t)blockIdx.x * N;
     alpha += (size_t)blockIdx.x * 1024;
@@ -823,7 +823,7 @@ void configure_kpm_kernels()
 
 void launch_lanczos(hipStream_t st, const KpmArgs &k, const KpmGeom &kg, int w0, int nw, const double *randvec, int nsteps, double *alpha, double *beta, bool use_BtB)
 {
-    const size_t lds = sizeof(double2) * 3 * (size_t)k.N;
+    const size_t lds = (!kg.fast && k.scratch) ? 0 : sizeof(double2) * 3 * (size_t)k.N;
     const int threads = kg.fast ? kg.threads : kThreads;
     if (kg.fast) {
         if (use_BtB) hipLaunchKernelGGL((lanczos_kernel<2, true>), dim3(nw), dim3(threads), lds, st, k, kg, w0, randvec, nsteps, alpha, beta);

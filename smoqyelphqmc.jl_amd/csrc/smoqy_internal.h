@@ -54,6 +54,10 @@ struct FdmArgs {
     int sys_first, sys_count;  // systems [sys_first, sys_first + sys_count) are processed
     double hop_re, hop_im;     // phase on the inter-slice hop: 1 for the reference operator, exp(-iπ/Lτ) inside the CG
     int antiperiodic;          // 1: the wrap-around row carries the opposite sign (reference operator)
+    // lattices whose slices do not fit in LDS: the generic kernels stage their slices in this global scratch instead
+    // (scratch_stride elements per workgroup, L2-resident; same code, same barriers)
+    double2 *scratch;
+    size_t scratch_stride;
 };
 
 struct KpmArgs {
@@ -68,6 +72,8 @@ struct KpmArgs {
     int nslot, maxorder;
     double2 *v;                         // input, slice(=frequency)-major
     double2 *vout;                      // output; nullptr = in place
+    double2 *scratch;                   // see FdmArgs::scratch
+    size_t scratch_stride;
     const CgState *cg;
     double2 *part_rz;                   // optional [nsys][rz_stride]: Parseval partial of r·z per (system, ω)
     int rz_stride;
@@ -177,6 +183,8 @@ struct ForceArgs {
     const int *site_ptr, *site_cpl;     // CSR: site -> Holstein couplings, in coupling order
     const double *ph_sign;
     double *contrib;                    // [nw][Lt][Q]
+    double2 *scratch;                   // see FdmArgs::scratch
+    size_t scratch_stride;
 };
 void configure_force_kernels();
 void launch_dmdx(hipStream_t st, const ForceArgs &a, bool sym);
