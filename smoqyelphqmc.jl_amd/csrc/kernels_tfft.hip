@@ -327,11 +327,12 @@ bool tfft_plan(int Lt, int N, TfftArgs &a)
     for (int f = 0; f + 1 < a.nfac; ++f)
         if (a.fac[f] == 8 && a.fac[f + 1] == 2) { a.fac[f] = 4; a.fac[f + 1] = 4; }
     a.SB = 16;
-    if (const char *e = getenv("SMOQY_TFFT_SB")) {  // tuning knob: sites per tile (4, 8 or 16)
+    size_t lds_cap = 64 * 1024;  // two or more workgroups per CU
+    if (const char *e = getenv("SMOQY_TFFT_SB")) {  // tuning knob: sites per tile (4, 8 or 16), also lifts the LDS cap
         const int v = atoi(e);
-        if (v == 4 || v == 8 || v == 16) a.SB = v;
+        if (v == 4 || v == 8 || v == 16) { a.SB = v; lds_cap = 150 * 1024; }
     }
-    while (a.SB > 4 && (2 * (size_t)Lt * a.SB + Lt) * sizeof(double2) > 64 * 1024) a.SB /= 2;
+    while (a.SB > 4 && (2 * (size_t)Lt * a.SB + Lt) * sizeof(double2) > lds_cap) a.SB /= 2;
     if ((2 * (size_t)Lt * a.SB + Lt) * sizeof(double2) > 150 * 1024) return false;
     a.ntile = (N + a.SB - 1) / a.SB;
     return true;
