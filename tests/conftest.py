@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built artefacts (*.so are git-ignored): compile them once before collection.  This is a
+    build step, not a fallback — if hipcc is missing the library stays absent and the tests that need it fail loudly."""
+    lib = os.path.join(ROOT, "smoqyelphqmc.jl_amd", "csrc", "libsmoqy_hip.so")
+    if not os.path.exists(lib):
+        try:
+            import __graft_entry__
+
+            __graft_entry__.build()
+        except Exception as e:  # noqa: BLE001 - report and let the dependent tests fail on their own
+            print(f"[conftest] build() failed: {e}", file=sys.stderr)
+
+
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT
