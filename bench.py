@@ -337,6 +337,17 @@ def main():
                                       "note": "one walker on one stream: the launch-latency regime (4 dependent launches per CG iteration)"}
         # the CPU baseline is a rank-0, N = 1 measurement (it would only hold the other ranks at the final barrier)
         cpu = None if (args.no_cpu_baseline or args.roofline_only or world > 1) else cpu_baseline(args.workload, batch.tol, batch.Nt)
+        # the whole sweep against the roofline: algorithmic bytes of one preconditioned CG iteration per walker as SURVEY.md §8(d)
+        # counts them for the reference's pass structure — MᵀM 2(2S+F), forward and inverse FourierTransformer 2S each, the
+        # per-frequency Chebyshev apply 2S, the BLAS-1 lines 10S — times the iterations all walkers ran per second
+        V_ = batch.Lt * batch.N
+        S_, F_ = 16.0 * V_, 8.0 * V_ + 16.0 * batch.Lt * batch.Nh
+        it_bytes = 2 * (2 * S_ + F_) + 2 * S_ + 2 * S_ + 2 * S_ + 10 * S_
+        avg_iters = sum(b.stats.iters_sum for b in batches) / max(sum(b.stats.solves for b in batches), 1)
+        sweep_gbs = value * batch.solves_per_sweep * avg_iters * it_bytes / 1e9
+        extra["sweep_roofline"] = {"algorithmic_bytes_per_cg_iteration_per_walker": it_bytes, "achieved": sweep_gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS * world,
+                                   "frac": sweep_gbs / (HBM_PEAK_GBS * world),
+                                   "note": "CG iterations only (the solves are >85 % of the sweep); the fused kernels move 12 vectors per iteration where this count assumes 20S + 2F"}
         out = {
             "metric": "QMC sweeps/sec (27 preconditioned CG solves per sweep) + FermionDetMatrix matvec GB/s vs HBM roofline, fp64",
             "value": value,
