@@ -170,3 +170,19 @@ def test_multi_rhs_with_preconditioner():
     e2 = np.zeros(2)
     h.call("smoqy_cg_solve", L.ptr(x2), L.ptr(np.asfortranarray(b[:, :, 1:3])), 1, 1, 2, C.c_double(1e-10), 10000, 1, L.ptr(it2), L.ptr(e2))
     assert relerr(x2, x[:, :, 1:3]) < 1e-9
+
+
+def test_bitwise_reproducible_solves_and_force():
+    """No atomics anywhere on the path: every reduction is a fixed-order tree over fixed-order partials, so two runs on the
+    same inputs agree bit for bit — the solve (iterates, iteration counts, residuals) and the force."""
+    from smoqyelphqmc_amd.walkers import WalkerBatch
+
+    outs = []
+    for _ in range(2):
+        b = WalkerBatch("holstein_honeycomb_L4_Ltau40", nwalkers=3)
+        b.sample_pseudofermion_fields()
+        sf, iters, eps = b.calculate_fermionic_action(1e-10)
+        outs.append((b.h.vec_download(b.u).copy(), sf.copy(), iters.copy(), eps.copy(), b.fermionic_force().copy()))
+        b.h.close()
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
