@@ -244,3 +244,22 @@ def test_checkerboard_entry_points(setup):
     out = np.zeros_like(v)
     sq.checkerboard_mul(out, v, fdm, transposed=True)
     assert relerr(out, o.checkerboard(v, transposed=True)) < 1e-14
+
+
+@pytest.mark.parametrize("is_sym", [True, False])
+def test_kpm_ldiv_on_a_real_vector(is_sym):
+    """The real-vector ldiv! methods (src/KPMPreconditioner.jl:288-352, 417-485): same operator applied to a real vector."""
+    m = lat.holstein_honeycomb(4, 10)  # N = 32 > 20 Lanczos steps
+    fdm = (sq.SymFermionDetMatrix if is_sym else sq.AsymFermionDetMatrix)(m.fpi, maxiter=5000, tol=1e-10)
+    P = sq.KPMPreconditioner(fdm, rng=np.random.default_rng(5))
+    assert P.active
+    g = np.random.default_rng(6)
+    u = np.asfortranarray(g.standard_normal((10, 32)))
+    up = np.zeros_like(u)
+    sq.ldiv(up, P, u)
+    uc = np.asfortranarray(u.astype(complex))
+    upc = np.zeros_like(uc)
+    sq.ldiv(upc, P, uc)
+    assert np.abs(up - upc.real).max() < 1e-15 * np.abs(upc).max()
+    if is_sym:  # P⁻¹ is a real symmetric operator for real fields: nothing is lost in the real part
+        assert np.abs(upc.imag).max() < 1e-12 * np.abs(upc.real).max()
