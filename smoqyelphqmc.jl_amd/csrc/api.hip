@@ -289,7 +289,7 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->h_st) (void)hipHostFree(c->h_st);
     if (c->h_lan) (void)hipHostFree(c->h_lan);
     if (c->force.h_out) (void)hipHostFree(c->force.h_out);
-    for (void *q : {c->force.blob, (void *)c->force.d_x, (void *)c->force.d_contrib, (void *)c->force.d_out})
+    for (void *q : {c->force.blob, (void *)c->force.d_x, (void *)c->force.d_contrib, (void *)c->force.d_out, (void *)c->force.d_bare})
         if (q) (void)hipFree(q);
     for (auto &e : c->mvt.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
