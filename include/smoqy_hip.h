@@ -216,6 +216,14 @@ int smoqy_force_v(smoqy_ctx *ctx, int psi, double *out);
  * (src/EFAPFFHMCUpdater.jl:160), so the transfer can land in the caller's array directly */
 int smoqy_force_store_v(smoqy_ctx *ctx, int psi, double *out);
 
+/* calculate_derivative_fermionic_action! (src/PFFCalculator.jl:119-157) for every walker of the handle in ONE call, with the
+ * field update of the HMC step in front of it: [x_all != NULL: smoqy_update_from_phonons_all]; [randvec_all != NULL and
+ * use_precond: update_preconditioner!, src/FermionDetMatrix.jl:259]; Ψ = Λ⁻ᵀΦ; Ψ = (MᵀM)⁻¹Ψ from a zero initial guess (:99);
+ * Ψ = Λ⁻¹Ψ; Sf[w] = Re Φ·Ψ (:109); [dSdx != NULL: the force of smoqy_force_store_v].  Φ lives in vector phi, Ψ is left in
+ * vector psi.  One host synchronisation at the end besides those of the preconditioner update and the CG's convergence polls. */
+int smoqy_pff_step_v(smoqy_ctx *ctx, int phi, int psi, const double *x_all, const double *randvec_all, double tol, int maxiter, int use_precond,
+                     double *Sf, int *iters, double *eps, double *dSdx);
+
 /* ---- device-side update! from the phonon fields ------------------- */
 
 /* bare on-site energies V⁰ (N) and hoppings t⁰ (Nh, FermionPathIntegral order) — what

@@ -99,6 +99,7 @@ SIGNATURES = {
     "smoqy_force_dLdx_v": [_p, _d, _i, _i, _p],
     "smoqy_force_v": [_p, _i, _p],
     "smoqy_force_store_v": [_p, _i, _p],
+    "smoqy_pff_step_v": [_p, _i, _i, _p, _p, _d, _i, _i, _p, _p, _p, _p],
     "smoqy_set_bare_model": [_p, _p, _p, _p],
     "smoqy_update_from_phonons_all": [_p, _p],
     "smoqy_copy_fields": [_p, _i, _p, _i],

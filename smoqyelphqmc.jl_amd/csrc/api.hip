@@ -54,6 +54,7 @@ struct smoqy_ctx {
     double2 *part_pz = nullptr, *part_rz = nullptr, *part_c = nullptr, *d_dot_out = nullptr;
     double *part_rr = nullptr, *part_bb = nullptr;
     CgState *d_st = nullptr, *h_st = nullptr;
+    void *h_poll_dot = nullptr;  // pinned staging for per-system scalars (smoqy_pff_step_v)
     int check_every = 4;
     // iterations the previous solve at (about) the same tolerance needed: consecutive solves of an HMC
     // trajectory converge in nearly the same number of iterations, so the first burst runs that far
@@ -287,6 +288,7 @@ int smoqy_destroy(smoqy_ctx *c)
     for (double2 *v : c->vecs)
         if (v) (void)hipFree(v);
     if (c->h_st) (void)hipHostFree(c->h_st);
+    if (c->h_poll_dot) (void)hipHostFree(c->h_poll_dot);
     if (c->h_lan) (void)hipHostFree(c->h_lan);
     if (c->force.h_out) (void)hipHostFree(c->force.h_out);
     for (void *q : {c->force.blob, (void *)c->force.d_x, (void *)c->force.d_contrib, (void *)c->force.d_out, (void *)c->force.d_bare})
@@ -366,6 +368,7 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     HIPCHK(c, hipMalloc(&c->d_st, (size_t)g.nsys * sizeof(CgState)));
     HIPCHK(c, hipMemset(c->d_st, 0, (size_t)g.nsys * sizeof(CgState)));
     HIPCHK(c, hipHostMalloc(&c->h_st, (size_t)g.nsys * sizeof(CgState)));
+    HIPCHK(c, hipHostMalloc(&c->h_poll_dot, (size_t)g.nsys * sizeof(double2)));
     choose_chunking(c);
     if (fdm_lds_bytes(SMOQY_OP_MTM, g.N, 1) > 160 * 1024 - 256) {
         // slices too large for LDS: the generic kernels stage them in global memory instead (one time slice per workgroup);
@@ -1790,6 +1793,40 @@ int smoqy_force_store_v(smoqy_ctx *c, int psi, double *out)
     return check_launch(c, "force");
 }
 
+
+
+// ---- calculate_derivative_fermionic_action! in one call ---------------------------------------------------
+
+int smoqy_pff_step_v(smoqy_ctx *c, int phi, int psi, const double *x_all, const double *randvec_all, double tol, int maxiter, int use_precond, double *Sf, int *iters, double *eps, double *dSdx)
+{
+    CHECK_CTX(c);
+    if (int rc = check_vec(c, phi)) return rc;
+    if (int rc = check_vec(c, psi)) return rc;
+    if (phi == psi) FAIL(c, 1, "phi and psi must be different vectors");
+    const Geometry &g = c->g;
+    if (g.nrhs != 1) FAIL(c, 1, "smoqy_pff_step_v needs a handle with nrhs = 1");
+    if (dSdx && !c->force.set) FAIL(c, 1, "call smoqy_force_set_couplings first");
+    if (x_all) if (int rc = smoqy_update_from_phonons_all(c, x_all)) return rc;                          // EFAPFFHMCUpdater.jl:200-205
+    if (randvec_all && use_precond) if (int rc = precond_update_range(c, 0, g.nw, randvec_all)) return rc;  // FermionDetMatrix.jl:259
+    launch_lambda_apply(c->stream, SMOQY_LAMBDA_LDIVT, c->vecs[psi], c->vecs[phi], c->d_lam, g.Lt, g.N, g.nsys, g.nrhs, -1);  // Ψ = Λ⁻ᵀΦ  PFFCalculator.jl:97
+    HIPCHK(c, hipMemcpyAsync(c->scr[0], c->vecs[psi], c->vec_elems() * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    if (int rc = cg_dev(c, c->vecs[psi], c->scr[0], true, tol, maxiter, use_precond, iters, eps)) return rc;                   // ldiv!(Ψ, fdm, Ψ)  :99
+    launch_lambda_apply(c->stream, SMOQY_LAMBDA_LDIV, c->scr[0], c->vecs[psi], c->d_lam, g.Lt, g.N, g.nsys, g.nrhs, -1);       // Ψ = Λ⁻¹Ψ  :107
+    std::swap(c->scr[0], c->vecs[psi]);
+    launch_dot(c->stream, c->vecs[phi], c->vecs[psi], c->part_c, c->d_dot_out, g.Lt, g.N, g.nsys, c->Tc, c->nchunk);           // S_f = Φ·Ψ  :109
+    if (dSdx) {
+        if (int rc = force_device(c, psi)) return rc;                                                                           // :146-155
+        const size_t nx = (size_t)g.nw * g.Lt * c->force.Nph;
+        if (nx) HIPCHK(c, hipMemcpyAsync(dSdx, c->force.d_out, nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    double2 *hdot = reinterpret_cast<double2 *>(c->h_poll_dot);
+    HIPCHK(c, hipMemcpyAsync(hdot, c->d_dot_out, (size_t)g.nsys * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int rc = check_launch(c, "pff_step")) return rc;
+    if (Sf)
+        for (int w = 0; w < g.nw; ++w) Sf[w] = hdot[w].x;
+    return 0;
+}
 
 // ---- GreensEstimator -----------------------------------------------------------
 

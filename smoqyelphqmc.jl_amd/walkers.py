@@ -182,6 +182,31 @@ class WalkerBatch:
         self.h.call("smoqy_force_store_v", self.u, L.ptr(self.dSdx))  # fill!(∂S∂x, 0) + accumulate == store (EFAPFFHMCUpdater.jl:160-165)
         return self.dSdx
 
+    def pff_step(self, tol, moved: bool, want_force: bool, use_precond: bool = True):
+        """One HMC force evaluation in ONE library call (smoqy_pff_step_v): [update! from the moved x], update_preconditioner!,
+        Ψ = Λ⁻¹ (MᵀM)⁻¹ Λ⁻ᵀ Φ, S_f = Φ·Ψ and, if wanted, ∂S_f/∂x — calculate_derivative_fermionic_action!
+        (src/PFFCalculator.jl:119-157) behind src/EFAPFFHMCUpdater.jl:200-205.  Returns (S_f, iters, eps[, force])."""
+        if not self.device_update:
+            raise RuntimeError("pff_step needs the device-side update! (device_update=True)")
+        if moved and self.xs_force is not self.xs:
+            self.xs_force[:, :, : self.Nph] = self.xs
+        rv = np.ascontiguousarray(np.stack([g.standard_normal(self.N) for g in self.rng])) if use_precond else None  # randn!(rng, v), KPMPreconditioner.jl:634
+        sf = np.zeros(self.nw)
+        iters = np.zeros(self.nw, dtype=np.int32)
+        eps = np.zeros(self.nw)
+        gate = WalkerBatch.solve_gate
+        if gate is not None:
+            gate.acquire()
+        try:
+            self.h.call("smoqy_pff_step_v", self.phi, self.u, L.ptr(self.xs_force) if moved else None, None if rv is None else L.ptr(rv), C.c_double(tol), int(self.maxiter),
+                        int(bool(use_precond)), L.ptr(sf), L.ptr(iters), L.ptr(eps), L.ptr(self.dSdx) if want_force else None)
+        finally:
+            if gate is not None:
+                gate.release()
+        self.stats.solves += self.nw
+        self.stats.iters_sum += int(iters.sum())
+        return (sf, iters, eps, self.dSdx) if want_force else (sf, iters, eps)
+
     def drift_fields(self, pis, step):
         np.multiply(pis, step, out=self._tmp)
         np.add(self.xs, self._tmp, out=self.xs)
@@ -210,11 +235,18 @@ class WalkerBatch:
         self.sample_pseudofermion_fields()
         pis = self._momentum()
         dx = pis * (self.drift / self.Nt)
-        for _ in range(self.Nt):
-            self.calculate_fermionic_action(self.tol_force)
-            self.fermionic_force()
-            self.drift_by(dx)
-        last = self.calculate_fermionic_action(self.tol)
+        if self.device_update:
+            # every force evaluation is one library call; the field move of the previous step rides in front of it
+            for t in range(self.Nt):
+                self.pff_step(self.tol_force, moved=t > 0, want_force=True)
+                np.add(self.xs, dx, out=self.xs)      # stand-in for evolve_eom!
+            last = self.pff_step(self.tol, moved=True, want_force=False)
+        else:
+            for _ in range(self.Nt):
+                self.calculate_fermionic_action(self.tol_force)
+                self.fermionic_force()
+                self.drift_by(dx)
+            last = self.calculate_fermionic_action(self.tol)
         self.drift_fields(pis, -self.drift)      # reject: restore x
         self.stats.action = float(np.sum(last[0]))
         return last

@@ -110,3 +110,29 @@ def test_walker_batch_device_update_equals_host_update(name):
     out = np.zeros_like(b.dSdx)
     b.h.call("smoqy_force_v", b.u, L.ptr(out))
     np.testing.assert_allclose(fa_, out, rtol=0, atol=1e-9 * np.abs(out).max())
+
+
+@pytest.mark.parametrize("name", ["holstein_honeycomb_L4_Ltau40", "bssh_chain_L256_Ltau200"])
+def test_fused_pff_step_equals_the_separate_calls(name):
+    """smoqy_pff_step_v (update! + update_preconditioner! + action + force in one call) against the same sequence made of the
+    separate entry points, on identical inputs and random vectors: bit-identical."""
+    nw = 2
+    a = WalkerBatch(name, nwalkers=nw)
+    b = WalkerBatch(name, nwalkers=nw)
+    for wb in (a, b):
+        wb.sample_pseudofermion_fields()
+    dx = 0.01 * np.random.default_rng(1).standard_normal(a.xs.shape)
+    # separate calls
+    a.drift_by(dx)
+    sfa, ita, epa = a.calculate_fermionic_action(1e-8)
+    fa = a.fermionic_force().copy()
+    # fused
+    np.add(b.xs, dx, out=b.xs)
+    sfb, itb, epb, fb = b.pff_step(1e-8, moved=True, want_force=True)
+    assert np.array_equal(ita, itb) and np.array_equal(sfa, sfb) and np.array_equal(epa, epb)
+    assert np.array_equal(fa, fb)
+    assert np.array_equal(a.h.vec_download(a.u), b.h.vec_download(b.u))
+    # without a field move and without the force
+    sfa2, ita2, _ = a.calculate_fermionic_action(1e-10)
+    sfb2, itb2, _ = b.pff_step(1e-10, moved=False, want_force=False)
+    assert np.array_equal(ita2, itb2) and np.array_equal(sfa2, sfb2)
