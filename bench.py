@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--walkers-per-gpu", type=int, default=96)
     ap.add_argument("--streams", type=int, default=6, help="concurrent lock-step batches per GPU (one HIP stream + host thread each)")
     ap.add_argument("--solve-concurrency", type=int, default=3, help="at most this many batches inside the CG at once (0 = no limit)")
+    ap.add_argument("--measure-nrv", type=int, default=0, help="add update_greens_estimator! + measure_GΔ0! with this many random vectors to every sweep (27 + Nrv solves)")
     ap.add_argument("--tau-chunk", type=int, default=0)
     ap.add_argument("--check-every", type=int, default=0)
     ap.add_argument("--matvec-reps", type=int, default=400)
@@ -209,7 +210,7 @@ def main():
     mine = walker_range(rank, world, wpg)  # walkers [rank*wpg, (rank+1)*wpg): no overlap between ranks, no exchange
     per = wpg // S
     batches = [WalkerBatch(args.workload, nwalkers=per, walker0=mine.start + s * per, device=dev, check_every=args.check_every or None, tau_chunk=args.tau_chunk or None,
-                           host_threads=max(2, 16 // S)) for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
+                           host_threads=max(2, 16 // S), measure_nrv=args.measure_nrv) for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
     batch = batches[0]
     if args.solve_concurrency > 0:
         import threading

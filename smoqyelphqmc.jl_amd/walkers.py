@@ -47,7 +47,7 @@ class WalkerBatch:
     solve_gate = None
 
     def __init__(self, workload: str, nwalkers: int = 1, walker0: int = 0, is_sym: bool = True, device: int = -1, tol: float = 1e-10, maxiter: int = 10_000, Nt: int = 24,
-                 drift: float = 0.02, check_every: int | None = None, tau_chunk: int | None = None, smooth: bool = False, host_threads: int = 8, device_update: bool = True):
+                 drift: float = 0.02, check_every: int | None = None, tau_chunk: int | None = None, smooth: bool = False, host_threads: int = 8, device_update: bool = True, measure_nrv: int = 0):
         self.models = [lat.CONFIGS[workload](walker=walker0 + w, smooth=smooth) for w in range(nwalkers)]
         m0 = self.models[0]
         self.workload = workload
@@ -91,6 +91,7 @@ class WalkerBatch:
         self.dSdx = self.h.pinned_empty((nwalkers, self.Lt, self.Nph_force))
         # device-side update! from x: the host sends x only, V / t / Λ are formed on the device
         self.device_update = device_update
+        self.measure_nrv = int(measure_nrv)
         if device_update:
             V0, t0 = m0.bare_model()
             self.h.call("smoqy_set_bare_model", L.ptr(V0), L.ptr(t0), L.ptr(self.perm))
@@ -207,6 +208,45 @@ class WalkerBatch:
         self.stats.iters_sum += int(iters.sum())
         return (sf, iters, eps, self.dSdx) if want_force else (sf, iters, eps)
 
+    # ---- measurements (GreensEstimator) -----------------------------------------------
+    def measure_greens(self, Nrv: int = 10, orbitals=(1, 1), tol=None):
+        """update_greens_estimator! + measure_GΔ0! (src/Measurements/GreensEstimator.jl:125-233) for every walker of the batch:
+        nwalkers x Nrv right-hand sides advance in ONE batched CG on a follower handle; returns G(Δ,0) per walker
+        (shape (nwalkers, Lτ+1, L...)) and the iteration counts."""
+        meta = self.models[0].meta
+        if "L" not in meta:
+            raise ValueError("no lattice geometry recorded for this workload")
+        Lc = int(meta["L"])
+        n_orb = 2 if self.models[0].name.startswith("holstein_honeycomb") else 1
+        Ls = (Lc, Lc) if n_orb * Lc * Lc == self.N else (Lc,)
+        if getattr(self, "_ge", None) is None or self._ge[1] != Nrv:
+            hg = L.Handle(self.Lt, self.N, self.nt, self.colors, True, self.nw, Nrv, self.h.device)
+            hg.call("smoqy_ge_config", n_orb, len(Ls), L.ptr(np.asarray(Ls, dtype=np.int64)))
+            self._ge = (hg, Nrv, tuple(hg.vec_alloc() for _ in range(3)), hg.pinned_empty((self.Lt, self.N, self.nw * Nrv), dtype=np.complex128, order="F"))
+        hg, _, (r, gr, mtr), R = self._ge
+        for w in range(self.nw):
+            hg.call("smoqy_copy_fields", w, self.h._h, w)
+
+        def fill(w):  # randn!(rng, R); R ./= abs.(R)  (:141-142)
+            blk = R[:, :, w * Nrv : (w + 1) * Nrv]
+            flat = blk.reshape(-1, order="F").view(np.float64)
+            self.rng[w].standard_normal(out=flat)
+            np.divide(blk, np.abs(blk), out=blk)
+
+        list(self.pool.map(fill, range(self.nw)))
+        rv = np.ascontiguousarray(np.stack([g.standard_normal(self.N) for g in self.rng]))
+        hg.call("smoqy_precond_update_all", L.ptr(rv))                                  # :150
+        hg.vec_upload(r, R)
+        hg.call("smoqy_matvec_v", L.OP_MT, mtr, r)                                      # :157
+        iters = np.zeros(self.nw * Nrv, dtype=np.int32)
+        eps = np.zeros(self.nw * Nrv)
+        hg.call("smoqy_cg_solve_v", gr, mtr, C.c_double(self.tol if tol is None else tol), int(self.maxiter), 1, L.ptr(iters), L.ptr(eps))  # :159-165
+        out = np.zeros((self.nw, *reversed(Ls), self.Lt + 1), dtype=np.complex128)       # C order == (Lτ+1) x L... x nw column-major
+        hg.call("smoqy_ge_measure_GD0", gr, r, int(orbitals[0]), int(orbitals[1]), L.ptr(out))
+        self.stats.solves += self.nw * Nrv
+        self.stats.iters_sum += int(iters.sum())
+        return np.transpose(out, (0,) + tuple(range(out.ndim - 1, 0, -1))), iters
+
     def drift_fields(self, pis, step):
         np.multiply(pis, step, out=self._tmp)
         np.add(self.xs, self._tmp, out=self.xs)
@@ -249,8 +289,10 @@ class WalkerBatch:
             last = self.calculate_fermionic_action(self.tol)
         self.drift_fields(pis, -self.drift)      # reject: restore x
         self.stats.action = float(np.sum(last[0]))
+        if self.measure_nrv:
+            self.measure_greens(self.measure_nrv)   # make_measurements! -> update_greens_estimator! once per sweep (tutorials/holstein_honeycomb.jl:653-671)
         return last
 
     @property
     def solves_per_sweep(self):
-        return 2 + self.Nt + 1
+        return 2 + self.Nt + 1 + self.measure_nrv

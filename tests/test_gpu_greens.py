@@ -127,3 +127,31 @@ def test_pair_estimator_needs_two_vectors():
     ge = sq.GreensEstimator(fdm, (n, Ls), Nrv=1, rng=np.random.default_rng(4), maxiter=5000, tol=1e-8)
     with pytest.raises(L.SmoqyError):
         sq.measure_GΔΔ_G00(np.zeros(Ls + (ge.Lτ + 1,), dtype=complex), ge, (1, 1, 1, 1), (0,), (0,), (0,), (0,), 1.0)
+
+
+def test_walker_batch_measurement():
+    """WalkerBatch.measure_greens: nwalkers x Nrv right-hand sides in one batched solve on a follower handle, G(Δ,0) per walker
+    against the oracle contraction of the same GR, R."""
+    from smoqyelphqmc_amd.walkers import WalkerBatch
+
+    b = WalkerBatch("holstein_honeycomb_L4_Ltau40", nwalkers=2)
+    Nrv = 3
+    G, iters = b.measure_greens(Nrv, orbitals=(1, 2), tol=1e-11)
+    assert G.shape == (2, 41, 4, 4) and np.all(iters > 0)
+    hg, _, (r, gr, mtr), R = b._ge
+    GRd = hg.vec_download(gr)
+    Lt, N = b.Lt, b.N
+    for w, m in enumerate(b.models):
+        expV, ch, sh = orc.update_fields(m.fpi.V, m.fpi.t, b.perm, m.fpi.dtau, True)
+        M, _ = dense.dense_M(b.nt, expV, ch, sh, True)
+        Rw = np.asarray(R[:, :, w * Nrv : (w + 1) * Nrv])
+        want = np.linalg.solve(M, Rw.reshape(Lt * N, Nrv, order="F"))
+        got = GRd[:, :, w * Nrv : (w + 1) * Nrv].reshape(Lt * N, Nrv, order="F")
+        assert np.abs(got - want).max() < 1e-8 * np.abs(want).max()
+        shape = (Lt, 2, 4, 4, Nrv)
+        ref = greens.measure_GD0(got.reshape(shape, order="F"), np.conj(Rw).reshape(shape, order="F"), 1, 2)
+        assert np.abs(G[w] - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+    # a sweep with the measurement included counts 27 + Nrv solves per walker
+    b2 = WalkerBatch("holstein_honeycomb_L4_Ltau40", nwalkers=2, measure_nrv=2)
+    b2.sweep()
+    assert b2.solves_per_sweep == 29 and b2.stats.solves == 2 * 29
