@@ -186,3 +186,30 @@ def test_bitwise_reproducible_solves_and_force():
         b.h.close()
     for x, y in zip(*outs):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("Lt", [13, 22, 34])
+@pytest.mark.parametrize("is_sym", [True, False])
+def test_time_extents_with_large_prime_factors_fall_back_to_rocfft(Lt, is_sym):
+    """Lτ with a prime factor above 7 has no Stockham plan: the preconditioner and the FourierTransformer go through the rocFFT
+    plans and the unfused CG kernels automatically."""
+    N = 24
+    h, o, nt, colors = make(lat.chain_neighbor_table(N), Lt, N, is_sym, seed=3, nrhs=2, vscale=0.5)
+    v = rand(Lt, N, 2, 4)
+    w = v.copy(order="F")
+    h.call("smoqy_fft_forward", L.ptr(w), 0, 2)
+    ft = orc.OracleFT(Lt, N)
+    assert relerr(w[:, :, 1], ft.forward(v[:, :, 1])) < 1e-13
+    h.call("smoqy_fft_inverse", L.ptr(w), 0, 2)
+    assert relerr(w, v) < 1e-13
+    rv = np.random.default_rng(5).standard_normal(N)
+    P = orc.OracleKPM(o[0])
+    P.update(rv)
+    h.call("smoqy_precond_update", 0, L.ptr(rv))
+    out = np.zeros_like(v)
+    h.call("smoqy_precond_apply", L.ptr(out), L.ptr(v), 0, 2)
+    assert relerr(out[:, :, 0], P.apply(v[:, :, 0])) < 1e-10
+    x, it, eps = solve(h, v, 1e-10, 5000, 1)
+    xo, ito, _ = o[0].cg_solve(v[:, :, 0], precond=P, tol=1e-10, maxiter=5000)
+    assert abs(int(it[0]) - ito) <= 2 and eps.max() < 1e-10
+    assert relerr(x[:, :, 0], xo) < 1e-8
