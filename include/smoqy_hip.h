@@ -179,6 +179,11 @@ int smoqy_cg_config(smoqy_ctx *ctx, int check_every);
 /* replay one captured CG iteration as a hipGraph instead of launching its kernels one by one (off by
  * default: not faster on MI355X at the sizes measured) */
 int smoqy_cg_use_graph(smoqy_ctx *ctx, int on);
+/* a failed capture is not silent: the solve continues with eager launches, the switch is cleared, and the reason is what
+ * smoqy_last_error returns after this call.  *enabled = the switch now, *captured = cached graphs that are still valid (the
+ * cache is dropped whenever something baked into the captured kernel arguments changes: the coefficient table growing in
+ * smoqy_precond_update/_set, smoqy_fft_use_rocfft, smoqy_set_tau_chunk, smoqy_set_stream, the *_force_generic switches). */
+int smoqy_cg_graph_status(smoqy_ctx *ctx, int *enabled, int *captured);
 
 /* ---- force terms of the pseudofermion action (handles with nrhs = 1) ------ */
 

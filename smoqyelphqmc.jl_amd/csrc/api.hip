@@ -60,9 +60,14 @@ struct smoqy_ctx {
     // trajectory converge in nearly the same number of iterations, so the first burst runs that far
     // before the host polls the device for the first time
     // captured CG iteration (hipGraph), keyed by everything baked into its kernel arguments
-    struct IterGraph { const void *x = nullptr; int pre = 0, Tc = 0, ffast = 0, kfast = 0; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
+    // (x, preconditioning, kernel configuration) plus `epoch`: the kernel arguments captured in a graph hold d_coefs / maxorder /
+    // nslot, the own-vs-rocFFT choice, Tc and the stream's rocFFT info BY VALUE, so every entry point that changes one of them
+    // bumps graph_epoch (drop_graphs) and a stale graph is never replayed.
+    struct IterGraph { const void *x = nullptr; int pre = 0, Tc = 0, ffast = 0, kfast = 0; unsigned epoch = 0; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
     IterGraph graphs[4];
     int graph_next = 0;
+    unsigned graph_epoch = 1;
+    std::string graph_note;  // why the last capture failed (also appended to smoqy_last_error)
     // off by default: measured on MI355X the replay (≈10-16 µs per graph launch) does not beat six eager
     // launches per iteration (76.5 vs 80 ms per single-walker sweep); reset to 0 after a failed capture
     int use_graph = 0;
@@ -161,6 +166,16 @@ struct smoqy_ctx {
 #define CHECK_CTX(ctx)            \
     if (!(ctx)) return 1;         \
     (void)hipSetDevice((ctx)->device)
+
+// destroy every captured CG iteration: called whenever something baked into the captured kernel arguments changes
+static void drop_graphs(smoqy_ctx *c)
+{
+    c->graph_epoch++;
+    for (auto &gph : c->graphs) {
+        if (gph.exec) { (void)hipGraphExecDestroy(gph.exec); gph.exec = nullptr; }
+        if (gph.graph) { (void)hipGraphDestroy(gph.graph); gph.graph = nullptr; }
+    }
+}
 
 static int check_vec(smoqy_ctx *c, int id)
 {
@@ -309,7 +324,17 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) FAIL(c, 4, "this library is built for gfx950 (MI355X) only; device %d is %s", c->device, prop.gcnArchName);
     static std::once_flag cfg_once;
-    std::call_once(cfg_once, [] { configure_fdm_kernels(); configure_kpm_kernels(); configure_tfft_kernels(); configure_force_kernels(); });
+    static hipError_t cfg_err = hipSuccess;
+    static const char *cfg_what = "";
+    std::call_once(cfg_once, [] {
+        hipError_t (*cfgs[])(const char **) = {configure_fdm_kernels, configure_kpm_kernels, configure_tfft_kernels, configure_force_kernels};
+        for (auto f : cfgs) {
+            const char *w = "";
+            const hipError_t e = f(&w);
+            if (e != hipSuccess && cfg_err == hipSuccess) { cfg_err = e; cfg_what = w; }
+        }
+    });
+    if (cfg_err != hipSuccess) FAIL(c, 2, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for %s: %s", cfg_what, hipGetErrorString(cfg_err));
     HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIPCHK(c, hipEventCreate(&c->ev0));
@@ -576,6 +601,7 @@ int smoqy_set_stream(smoqy_ctx *c, void *s)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = s ? (hipStream_t)s : c->own_stream;
     FFTCHK(c, rocfft_execution_info_set_stream(c->fft_info, c->stream));
+    drop_graphs(c);
     return 0;
 }
 
@@ -613,6 +639,7 @@ int smoqy_dims(const smoqy_ctx *c, int d[6])
 int smoqy_set_tau_chunk(smoqy_ctx *c, int Tc)
 {
     CHECK_CTX(c);
+    drop_graphs(c);
     if (Tc <= 0) { c->user_Tc = false; choose_chunking(c); return 0; }
     if (c->d_big) {
         if (Tc != 1) FAIL(c, 1, "lattices beyond the LDS limit run with one time slice per workgroup");
@@ -1011,6 +1038,7 @@ int smoqy_fft_use_rocfft(smoqy_ctx *c, int on)
 {
     CHECK_CTX(c);
     c->use_tfft = on ? 0 : 1;
+    drop_graphs(c);
     return 0;
 }
 
@@ -1110,6 +1138,7 @@ static int upload_precond(smoqy_ctx *c, int w)
         int cap = c->maxorder;
         while (cap < need) cap *= 2;
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        drop_graphs(c);  // captured Chebyshev launches hold the old table pointer and stride
         HIPCHK(c, hipFree(c->d_coefs));
         c->d_coefs = nullptr;
         HIPCHK(c, hipMalloc(&c->d_coefs, (size_t)c->g.nw * c->nslot * cap * sizeof(double2)));
@@ -1216,6 +1245,7 @@ int smoqy_matvec_force_generic(smoqy_ctx *c, int on)
     CHECK_CTX(c);
     const Geometry &g = c->g;
     c->ff.enabled = (!on && g.is_sym && g.ncol >= 1 && g.ncol <= kFdmColours && c->ff.threads <= 1024) ? 1 : 0;
+    drop_graphs(c);
     choose_chunking(c);
     return 0;
 }
@@ -1228,6 +1258,7 @@ int smoqy_precond_force_generic(smoqy_ctx *c, int on)
     (void)g;
     maxp = c->kg.threads;
     c->kg.fast = (!on && g.ncol >= 1 && g.ncol <= kMaxColours && maxp <= 1024) ? 1 : 0;
+    drop_graphs(c);
     return 0;
 }
 
@@ -1355,6 +1386,19 @@ int smoqy_cg_use_graph(smoqy_ctx *c, int on)
     return 0;
 }
 
+// state of the graph replay: *enabled = the switch as it stands (a failed capture clears it), *captured = live cached graphs;
+// returns 0; smoqy_last_error holds the reason of the last failed capture
+int smoqy_cg_graph_status(smoqy_ctx *c, int *enabled, int *captured)
+{
+    CHECK_CTX(c);
+    int n = 0;
+    for (auto &gph : c->graphs) n += (gph.exec && gph.epoch == c->graph_epoch) ? 1 : 0;
+    if (enabled) *enabled = c->use_graph;
+    if (captured) *captured = n;
+    if (!c->graph_note.empty()) c->err = c->graph_note;
+    return 0;
+}
+
 int smoqy_cg_config(smoqy_ctx *c, int check_every)
 {
     CHECK_CTX(c);
@@ -1448,23 +1492,33 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
             // kGraphIters CG iterations captured once per (x, preconditioning, kernel configuration) and replayed:
             // the inner loop is launch bound at small batch (4 short dependent kernels per iteration)
             for (auto &gph : c->graphs)
-                if (gph.exec && gph.x == (const void *)x && gph.pre == (int)any_pre && gph.Tc == c->Tc && gph.ffast == c->ff.enabled && gph.kfast == c->kg.fast) gexec = gph.exec;
+                if (gph.exec && gph.epoch == c->graph_epoch && gph.x == (const void *)x && gph.pre == (int)any_pre && gph.Tc == c->Tc && gph.ffast == c->ff.enabled && gph.kfast == c->kg.fast) gexec = gph.exec;
             if (!gexec) {
                 smoqy_ctx::IterGraph &slot = c->graphs[c->graph_next];
                 c->graph_next = (c->graph_next + 1) % 4;
                 if (slot.exec) { (void)hipGraphExecDestroy(slot.exec); slot.exec = nullptr; }
                 if (slot.graph) { (void)hipGraphDestroy(slot.graph); slot.graph = nullptr; }
-                bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                hipError_t ge = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+                const char *stage = "hipStreamBeginCapture";
+                bool ok = ge == hipSuccess;
                 int rc = 0;
                 if (ok) {
                     for (int q = 0; q < kGraphIters && rc == 0; ++q) rc = cg_iteration(c, a, any_pre);
-                    ok = (hipStreamEndCapture(c->stream, &slot.graph) == hipSuccess) && rc == 0 && slot.graph;
+                    ge = hipStreamEndCapture(c->stream, &slot.graph);
+                    stage = rc ? "kernel launch during capture" : "hipStreamEndCapture";
+                    ok = ge == hipSuccess && rc == 0 && slot.graph;
                 }
-                if (ok) ok = hipGraphInstantiate(&slot.exec, slot.graph, nullptr, nullptr, 0) == hipSuccess;
+                if (ok) { ge = hipGraphInstantiate(&slot.exec, slot.graph, nullptr, nullptr, 0); stage = "hipGraphInstantiate"; ok = ge == hipSuccess; }
                 if (ok) {
-                    slot.x = x; slot.pre = any_pre; slot.Tc = c->Tc; slot.ffast = c->ff.enabled; slot.kfast = c->kg.fast;
+                    slot.x = x; slot.pre = any_pre; slot.Tc = c->Tc; slot.ffast = c->ff.enabled; slot.kfast = c->kg.fast; slot.epoch = c->graph_epoch;
                     gexec = slot.exec;
                 } else {
+                    // not silent: the solve goes on with eager launches, graph replay is switched off, and the reason is kept where
+                    // smoqy_cg_graph_status / smoqy_last_error can show it
+                    char note[256];
+                    snprintf(note, sizeof(note), "hipGraph capture of the CG iteration failed at %s (%s); falling back to eager launches", stage, hipGetErrorString(ge));
+                    c->graph_note = note;
+                    c->err = note;
                     (void)hipGetLastError();
                     if (slot.graph) { (void)hipGraphDestroy(slot.graph); slot.graph = nullptr; }
                     slot.exec = nullptr;

@@ -275,12 +275,14 @@ static void launch_one(hipStream_t st, const FdmArgs &a, size_t lds)
 
 // raise the dynamic-LDS limit of every instantiation once, outside any stream capture
 template <bool SYM, int OP>
-static void configure_one() { (void)hipFuncSetAttribute((const void *)fdm_kernel<SYM, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); }
-void configure_fdm_kernels()
+static void configure_one(hipError_t &first, const char **what) { SMOQY_SET_LDS((fdm_kernel<SYM, OP>), 160 * 1024 - 256); }
+hipError_t configure_fdm_kernels(const char **what)
 {
-    (void)hipFuncSetAttribute((const void *)checkerboard_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    configure_one<true, 0>(); configure_one<true, 1>(); configure_one<true, 2>(); configure_one<true, 3>();
-    configure_one<false, 0>(); configure_one<false, 1>(); configure_one<false, 2>(); configure_one<false, 3>();
+    hipError_t first = hipSuccess;
+    SMOQY_SET_LDS(checkerboard_kernel, 160 * 1024 - 256);
+    configure_one<true, 0>(first, what); configure_one<true, 1>(first, what); configure_one<true, 2>(first, what); configure_one<true, 3>(first, what);
+    configure_one<false, 0>(first, what); configure_one<false, 1>(first, what); configure_one<false, 2>(first, what); configure_one<false, 3>(first, what);
+    return first;
 }
 
 void launch_fdm(hipStream_t st, int op, bool sym, const FdmArgs &a, size_t lds)

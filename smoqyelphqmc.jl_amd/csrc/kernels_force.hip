@@ -225,10 +225,12 @@ __global__ void phonon_fields_kernel(ForceArgs a, const double *__restrict__ V0,
 
 }  // namespace
 
-void configure_force_kernels()
+hipError_t configure_force_kernels(const char **what)
 {
-    (void)hipFuncSetAttribute((const void *)dmdx_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    (void)hipFuncSetAttribute((const void *)dmdx_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    hipError_t first = hipSuccess;
+    SMOQY_SET_LDS(dmdx_kernel<true>, 160 * 1024 - 256);
+    SMOQY_SET_LDS(dmdx_kernel<false>, 160 * 1024 - 256);
+    return first;
 }
 
 void launch_dmdx(hipStream_t st, const ForceArgs &a, bool sym)

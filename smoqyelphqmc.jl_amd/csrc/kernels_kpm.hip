@@ -814,11 +814,13 @@ __global__ void __launch_bounds__(1024) lanczos_kernel(KpmArgs k, KpmGeom kg, in
 }
 
 // raise the dynamic-LDS limit of the generic kernels once, outside any stream capture
-void configure_kpm_kernels()
+hipError_t configure_kpm_kernels(const char **what)
 {
-    (void)hipFuncSetAttribute((const void *)cheb_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    (void)hipFuncSetAttribute((const void *)lanczos_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    (void)hipFuncSetAttribute((const void *)lanczos_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    hipError_t first = hipSuccess;
+    SMOQY_SET_LDS(cheb_generic_kernel, 160 * 1024 - 256);
+    SMOQY_SET_LDS((lanczos_kernel<0, false>), 160 * 1024 - 256);
+    SMOQY_SET_LDS((lanczos_kernel<2, false>), 160 * 1024 - 256);
+    return first;
 }
 
 void launch_lanczos(hipStream_t st, const KpmArgs &k, const KpmGeom &kg, int w0, int nw, const double *randvec, int nsteps, double *alpha, double *beta, bool use_BtB)

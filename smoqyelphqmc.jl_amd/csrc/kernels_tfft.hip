@@ -194,8 +194,16 @@ __global__ void __launch_bounds__(256) tfft_kernel(TfftArgs a)
     const int Lt = a.Lt, SB = a.SB, N = a.N;
     double2 *A = lds, *B = A + (size_t)Lt * SB, *WT = B + (size_t)Lt * SB;
     const int tile = blockIdx.x % a.ntile, sys = blockIdx.x / a.ntile;
-    constexpr bool CG = (MODE == MODE_FWD_CG || MODE == MODE_INV_CG);
-    if (CG && a.st[sys].done) return;
+    if (MODE == MODE_FWD_CG) {
+        // `done` was written by an earlier launch (inverse kernel of the previous iteration or cg_start): safe to gate on.
+        // Latch it into `stop` for the inverse kernel of THIS iteration, which must not look at `done` (it writes it).
+        const int done = a.st[sys].done;
+        if (done) {
+            if (tile == 0 && threadIdx.x == 0) a.st[sys].stop = done;
+            return;
+        }
+    }
+    if (MODE == MODE_INV_CG && a.st[sys].stop) return;
     const int i0 = tile * SB, ns = min(SB, N - i0);
     const size_t sstride = (size_t)a.nsys * N;
     const size_t base = (size_t)sys * N + i0;
@@ -338,18 +346,15 @@ bool tfft_plan(int Lt, int N, TfftArgs &a)
     return true;
 }
 
-static void configure_tfft()
+hipError_t configure_tfft_kernels(const char **what)
 {
-    static bool done = false;
-    if (done) return;
-    done = true;
-    (void)hipFuncSetAttribute((const void *)tfft_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-    (void)hipFuncSetAttribute((const void *)tfft_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-    (void)hipFuncSetAttribute((const void *)tfft_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-    (void)hipFuncSetAttribute((const void *)tfft_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    hipError_t first = hipSuccess;
+    SMOQY_SET_LDS(tfft_kernel<0>, 160 * 1024 - 512);
+    SMOQY_SET_LDS(tfft_kernel<1>, 160 * 1024 - 512);
+    SMOQY_SET_LDS(tfft_kernel<2>, 160 * 1024 - 512);
+    SMOQY_SET_LDS(tfft_kernel<3>, 160 * 1024 - 512);
+    return first;
 }
-
-void configure_tfft_kernels() { configure_tfft(); }
 
 void launch_tfft(hipStream_t st, int mode, const TfftArgs &a)
 {

@@ -382,6 +382,7 @@ __global__ void __launch_bounds__(kThreads) cg_start_kernel(CgArgs a)
             s.eps = eps;
             s.iters = 0;
             s.done = bad ? 2 : (conv ? 1 : 0);
+            s.stop = s.done;
         }
     }
 }
@@ -390,7 +391,13 @@ __global__ void __launch_bounds__(kThreads) cg_start_kernel(CgArgs a)
 __global__ void __launch_bounds__(kThreads) cg_update_xr_kernel(CgArgs a)
 {
     CG_PROLOGUE
-    if (a.st[sys].done) return;
+    {   // latch `done` (written by an earlier launch) into `stop` for this iteration's cg_update_p, see CgState::stop
+        const int done = a.st[sys].done;
+        if (done) {
+            if (chunk == 0 && threadIdx.x == 0) a.st[sys].stop = done;
+            return;
+        }
+    }
     const double2 rz = reduce_partials(a.part_rz + (size_t)sys * a.rz_stride, a.nrz, red);
     const double2 pz = reduce_partials(a.part_pz + (size_t)sys * a.nchunk, a.nchunk, red);
     const double2 alpha = cdiv(rz, pz);
@@ -419,7 +426,7 @@ __global__ void __launch_bounds__(kThreads) cg_update_xr_kernel(CgArgs a)
 __global__ void __launch_bounds__(kThreads) cg_update_p_kernel(CgArgs a)
 {
     CG_PROLOGUE
-    if (a.st[sys].done) return;
+    if (a.st[sys].stop) return;  // not `done`: chunk 0 of this very launch writes it
     const double rr = reduce_partials(a.part_rr + (size_t)sys * a.nchunk, a.nchunk, red);
     const double eps = sqrt(rr) / sqrt(a.st[sys].normb2);
     const bool conv = eps < a.st[sys].tol;

@@ -36,7 +36,12 @@ struct CgState {
     double alpha_re, alpha_im;  // α of the current iteration (the x update happens one kernel later than the r update)
     double eps;         // last relative residual
     int iters;          // completed iterations
-    int done;           // 0 running, 1 converged, 2 maxiter reached
+    int done;           // 0 running, 1 converged, 2 maxiter reached; written by the LAST kernel of an iteration only
+    int stop;           // `done` as it stood when the iteration began: latched by the FIRST update kernel of the next iteration
+                        // (forward tau-FFT / cg_update_xr) and by cg_start.  The closing kernel of an iteration (inverse tau-FFT /
+                        // cg_update_p) gates on `stop`, never on `done`, because one of its own workgroups writes `done` and a
+                        // launch carries no co-residency guarantee: a workgroup dispatched after that write must still apply the
+                        // final x += αp.
     int precond_on;     // this system's walker has an active preconditioner
     int maxiter;        // stop criteria live here (not in kernel arguments) so a captured iteration can be replayed
     double tol;
@@ -120,8 +125,15 @@ struct FdmFast {
 void launch_fdm(hipStream_t st, int op, bool sym, const FdmArgs &a, size_t lds_bytes);
 size_t fdm_lds_bytes(int op, int N, int Tc);
 void launch_checkerboard(hipStream_t st, const FdmArgs &a, int inverse, int transposed, int col0, int ncols);
-void configure_fdm_kernels();
-void configure_kpm_kernels();
+// each configure_* raises the dynamic-LDS limit of its kernels (once, outside any stream capture) and returns the first HIP
+// error with the kernel's name in *what; smoqy_create fails on it instead of running kernels with a silently smaller limit
+hipError_t configure_fdm_kernels(const char **what);
+hipError_t configure_kpm_kernels(const char **what);
+#define SMOQY_SET_LDS(fn, bytes)                                                                                                       \
+    do {                                                                                                                               \
+        hipError_t _e = hipFuncSetAttribute((const void *)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));                   \
+        if (_e != hipSuccess && first == hipSuccess) { first = _e; *what = #fn; }                                                       \
+    } while (0)
 bool fdm_fast_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
 void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff);
 bool fdm_own_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
@@ -186,7 +198,7 @@ struct ForceArgs {
     double2 *scratch;                   // see FdmArgs::scratch
     size_t scratch_stride;
 };
-void configure_force_kernels();
+hipError_t configure_force_kernels(const char **what);
 void launch_dmdx(hipStream_t st, const ForceArgs &a, bool sym);
 void launch_dldx(hipStream_t st, const ForceArgs &a);
 void launch_force_reduce(hipStream_t st, const ForceArgs &a, double *out);
@@ -223,7 +235,7 @@ struct TfftArgs {
     CgState *st;
 };
 bool tfft_plan(int Lt, int N, TfftArgs &a);
-void configure_tfft_kernels();
+hipError_t configure_tfft_kernels(const char **what);
 void launch_tfft(hipStream_t st, int mode, const TfftArgs &a);
 
 }  // namespace smoqy

@@ -1,0 +1,161 @@
+"""Oracle parity of the EXACT launch shapes ``bench.py`` times ("next" #1).
+
+``bench.py`` drives ``WalkerBatch(workload, nwalkers=16)`` handles: 16 systems per launch at full lattice size.  That shape selects
+kernels no small-lattice test reaches — the 4-wavefront ``fdm_fast_kernel<NCOL, ·>`` with its inter-wave LDS hand-over
+(kernels_fdm_fast.hip), ``cheb_own_kernel<NCOL>`` at 256 lanes (kernels_kpm.hip) and the fused τ-FFT CG kernels at 64 site tiles
+per system (kernels_tfft.hip) — so here they are compared with the CPU oracle directly:
+
+  (a) mul_M!, mul_Mt!, mul_MtM!, mul_MMt!        src/FermionDetMatrix.jl:329-340, 385-427, 484-525      <= 1e-13
+  (b) ldiv!(u', P, u) of the KPM preconditioner  src/KPMPreconditioner.jl:355-414                       <= 1e-11
+  (c) preconditioned cg_solve!, x and iterations src/IterativeSolvers/ConjugateGradient.jl:169-249      x: 1e-9 vs the oracle's
+      iterate at the same tol (both within κ·tol of the exact solution), iteration count within ±1 of the oracle (a different
+      summation order may move the stop test by one step; the device's own exact counts are pinned in tests/golden/)
+
+on systems 0, 7 and 15 of the batch, for the headline lattice and for the other two lattice families of BASELINE.json (4 colours with
+τ-dependent hoppings; 2 colours at Lτ = 200).  The ≤ 8-system shape (owner-computes kernels by default) is covered by the 8-walker
+cases, and a child process re-runs this file with the owner-computes kernels switched off (SMOQY_FDM_OWN=0, SMOQY_CHEB_OWN=0) so the
+LDS-resident twins see the same shapes.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from smoqyelphqmc_amd import _lib as L
+from smoqyelphqmc_amd.walkers import WalkerBatch
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+OP_TOL = 1e-13
+KPM_TOL = 1e-11
+
+SHAPES = [
+    ("holstein_honeycomb_L16_Ltau128", 16),  # what bench.py launches
+    ("holstein_honeycomb_L16_Ltau128", 8),   # the <= 8-system dispatch (owner-computes MᵀM)
+    ("ossh_square_L12_Ltau100", 16),
+    ("bssh_chain_L256_Ltau200", 16),
+]
+
+
+def relerr(got, want):
+    return np.abs(got - want).max() / np.abs(want).max()
+
+
+class Shape:
+    """One WalkerBatch exactly as bench.py builds it, plus the oracle of the walkers that are checked."""
+
+    def __init__(self, name, nw):
+        self.batch = WalkerBatch(name, nwalkers=nw)
+        self.h = self.batch.h
+        self.nw, self.Lt, self.N = nw, self.batch.Lt, self.batch.N
+        self.check = sorted({0, nw // 2 - 1, nw - 1})
+        self.oracles = {}
+        for w in self.check:
+            m = self.batch.models[w]
+            expV, ch, sh = orc.update_fields(m.fpi.V, m.fpi.t, self.batch.perm, m.fpi.dtau, True)
+            self.oracles[w] = orc.OracleFDM(self.batch.nt, expV, ch, sh, True)
+
+    def rand(self, seed):
+        g = np.random.default_rng(seed)
+        shape = (self.Lt, self.N, self.nw)
+        return np.asfortranarray(g.standard_normal(shape) + 1j * g.standard_normal(shape))
+
+    def precond(self, seed):
+        rv = np.ascontiguousarray(np.random.default_rng(seed).standard_normal((self.nw, self.N)))
+        self.h.call("smoqy_precond_update_all", L.ptr(rv))
+        Ps = {}
+        for w in self.check:
+            Ps[w] = orc.OracleKPM(self.oracles[w])
+            Ps[w].update(rv[w])
+            assert Ps[w].active
+        return Ps
+
+
+@pytest.fixture(scope="module", params=SHAPES, ids=lambda p: f"{p[0]}-{p[1]}sys")
+def shape(request):
+    s = Shape(*request.param)
+    yield s
+    s.h.close()
+
+
+def test_device_fields_match_the_oracle_fields(shape):
+    """The batch formed its fields on the device from x (smoqy_update_from_phonons_all); the oracle from V, t on the host."""
+    for w in shape.check:
+        m = shape.batch.models[w]
+        expV, ch, sh = orc.update_fields(m.fpi.V, m.fpi.t, shape.batch.perm, m.fpi.dtau, True)
+        g_e, g_c, g_s = np.zeros_like(expV), np.zeros_like(ch), np.zeros_like(sh)
+        shape.h.call("smoqy_get_fields", w, L.ptr(g_e), L.ptr(g_c), L.ptr(g_s))
+        np.testing.assert_allclose(g_e, expV, rtol=1e-14)
+        np.testing.assert_allclose(g_c, ch, rtol=1e-14)
+        np.testing.assert_allclose(g_s, sh, rtol=1e-13, atol=1e-16)
+
+
+def test_matvec_all_ops_at_the_benchmarked_shape(shape):
+    v = shape.rand(21)
+    a, b = shape.h.vec_alloc(), shape.h.vec_alloc()
+    shape.h.vec_upload(a, v)
+    for op, name in ((L.OP_M, "mul_M"), (L.OP_MT, "mul_Mt"), (L.OP_MTM, "mul_MtM"), (L.OP_MMT, "mul_MMt")):
+        shape.h.call("smoqy_matvec_v", op, b, a)
+        got = shape.h.vec_download(b)
+        for w in shape.check:
+            assert relerr(got[:, :, w], getattr(shape.oracles[w], name)(v[:, :, w])) < OP_TOL, (name, w)
+    # in place (lmul_M!, src/FermionDetMatrix.jl:372)
+    shape.h.call("smoqy_matvec_v", L.OP_MTM, a, a)
+    got = shape.h.vec_download(a)
+    for w in shape.check:
+        assert relerr(got[:, :, w], shape.oracles[w].mul_MtM(v[:, :, w])) < OP_TOL
+    shape.h.call("smoqy_vec_free", a)
+    shape.h.call("smoqy_vec_free", b)
+
+
+def test_kpm_apply_at_the_benchmarked_shape(shape):
+    Ps = shape.precond(31)
+    v = shape.rand(32)
+    a, b = shape.h.vec_alloc(), shape.h.vec_alloc()
+    shape.h.vec_upload(a, v)
+    shape.h.call("smoqy_precond_apply_v", b, a)
+    got = shape.h.vec_download(b)
+    for w in shape.check:
+        assert relerr(got[:, :, w], Ps[w].apply(v[:, :, w])) < KPM_TOL, w
+    shape.h.call("smoqy_vec_free", a)
+    shape.h.call("smoqy_vec_free", b)
+
+
+@pytest.mark.parametrize("tol", [1e-10, 1e-5])  # tol_action and tol_force = sqrt(tol) of the sweep
+def test_pcg_at_the_benchmarked_shape(shape, tol):
+    Ps = shape.precond(41)
+    bv = shape.rand(42)
+    xb, bb = shape.h.vec_alloc(), shape.h.vec_alloc()
+    shape.h.vec_upload(bb, bv)
+    shape.h.vec_upload(xb, bv)
+    iters = np.zeros(shape.nw, dtype=np.int32)
+    eps = np.zeros(shape.nw)
+    shape.h.call("smoqy_cg_solve_v", xb, xb, C.c_double(tol), 10000, 1, L.ptr(iters), L.ptr(eps))  # x === b: zero initial guess
+    x = shape.h.vec_download(xb)
+    assert np.all(eps < tol) and np.all(iters > 0) and np.all(iters < 10000)
+    for w in (shape.check[0], shape.check[-1]):
+        o = shape.oracles[w]
+        xo, ito, epo = o.cg_solve(bv[:, :, w], precond=Ps[w], tol=tol, maxiter=10000)
+        assert abs(int(iters[w]) - ito) <= 1, (w, iters[w], ito)
+        # identical algorithm on identical data: the iterates agree far below the solve tolerance when the counts agree
+        if int(iters[w]) == ito:
+            assert relerr(x[:, :, w], xo) < 1e-9 * max(1.0, tol / 1e-10), w
+        # true residual of the returned x equals the reported eps (the recurrence residual) to a few percent
+        res = np.linalg.norm(o.mul_MtM(x[:, :, w]) - bv[:, :, w]) / np.linalg.norm(bv[:, :, w])
+        assert res < tol and abs(res - eps[w]) < 0.05 * eps[w] + 1e-13, (w, res, eps[w])
+    shape.h.call("smoqy_vec_free", xb)
+    shape.h.call("smoqy_vec_free", bb)
+
+
+@pytest.mark.skipif(os.environ.get("SMOQY_FDM_OWN") == "0", reason="already the child run")
+def test_same_shapes_with_the_owner_computes_kernels_switched_off():
+    env = dict(os.environ, SMOQY_CHEB_OWN="0", SMOQY_FDM_OWN="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "honeycomb or ossh"], capture_output=True, text=True, env=env, cwd=ROOT,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

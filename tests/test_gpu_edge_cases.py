@@ -213,3 +213,108 @@ def test_time_extents_with_large_prime_factors_fall_back_to_rocfft(Lt, is_sym):
     xo, ito, _ = o[0].cg_solve(v[:, :, 0], precond=P, tol=1e-10, maxiter=5000)
     assert abs(int(it[0]) - ito) <= 2 and eps.max() < 1e-10
     assert relerr(x[:, :, 0], xo) < 1e-8
+
+
+def _oversubscribed_solve(concurrent):
+    """16 walkers x 10 right-hand sides at L = 16, Lτ = 128: 160 systems x 64 site tiles = 10 240 workgroups per τ-FFT launch, far
+    beyond what is co-resident (256 CUs), optionally with a long-running kernel queue on a second stream competing for the CUs."""
+    import threading
+
+    name = "holstein_honeycomb_L16_Ltau128"
+    nw, nrhs = 16, 10
+    models = [lat.CONFIGS[name](walker=w) for w in range(nw)]
+    nt, perm, colors = lat.checkerboard_decomposition(models[0].fpi.neighbor_table)
+    Lt, N = models[0].fpi.Ltau, models[0].fpi.N
+    h = L.Handle(Lt, N, nt, colors, True, nw, nrhs)
+    for w, m in enumerate(models):
+        h.call("smoqy_update_from_path_integral", w, L.ptr(m.fpi.V), L.ptr(m.fpi.t), L.ptr(perm), C.c_double(m.fpi.dtau))
+    rv = np.ascontiguousarray(np.random.default_rng(77).standard_normal((nw, N)))
+    h.call("smoqy_precond_update_all", L.ptr(rv))
+    g = np.random.default_rng(78)
+    ph = g.uniform(0, 2 * np.pi, (Lt, N, nw * nrhs))
+    b = np.asfortranarray(np.exp(1j * ph))  # unit-modulus random-phase vectors (src/Measurements/GreensEstimator.jl:141-142)
+    b[:, :, 5::7] *= 1e-3  # spread the convergence times so systems retire in different iterations
+    bid, xid, aid = h.vec_alloc(), h.vec_alloc(), h.vec_alloc()
+    h.vec_upload(bid, b)
+    h.vec_upload(xid, b)
+    other = None
+    if concurrent:
+        h2 = L.Handle(Lt, N, nt, colors, True, 64, 1)
+        for w in range(64):
+            m = models[w % nw]
+            h2.call("smoqy_update_from_path_integral", w, L.ptr(m.fpi.V), L.ptr(m.fpi.t), L.ptr(perm), C.c_double(m.fpi.dtau))
+        u, v = h2.vec_alloc(), h2.vec_alloc()
+        other = threading.Thread(target=lambda: h2.bench_matvec(L.OP_MTM, v, u, 4000))  # ~0.2 s of back-to-back full-chip launches
+        other.start()
+    it = np.zeros(nw * nrhs, dtype=np.int32)
+    eps = np.zeros(nw * nrhs)
+    h.call("smoqy_cg_solve_v", xid, xid, C.c_double(1e-10), 10000, 1, L.ptr(it), L.ptr(eps))
+    if other:
+        other.join()
+        h2.close()
+    h.call("smoqy_matvec_v", L.OP_MTM, aid, xid)
+    x, ax = h.vec_download(xid), h.vec_download(aid)
+    res = np.array([np.linalg.norm(ax[:, :, s] - b[:, :, s]) / np.linalg.norm(b[:, :, s]) for s in range(nw * nrhs)])
+    h.close()
+    return x, it, eps, res
+
+
+def test_cg_stop_latch_on_an_oversubscribed_grid():
+    """CgState::stop (kernels_tfft.hip / kernels_vec.hip): the closing kernel of a CG iteration must not gate on the `done` flag one
+    of its own workgroups writes.  With 10 240 workgroups per launch a late workgroup of a system certainly starts after that
+    system's tile 0 has finished; had it skipped the final x += αp the true residual would exceed the reported one by up to κ.
+    Checks: true residual ‖b − MᵀMx‖/‖b‖ of every system agrees with the returned ϵ; two runs — one alone, one with a second
+    stream saturating the chip — agree bit for bit."""
+    x0, it0, eps0, res0 = _oversubscribed_solve(False)
+    assert np.all(eps0 < 1e-10) and len(set(it0.tolist())) > 1  # systems did retire at different iterations
+    assert np.all(res0 < 1e-10)
+    np.testing.assert_allclose(res0, eps0, rtol=0.01, atol=2e-13)
+    x1, it1, eps1, res1 = _oversubscribed_solve(True)
+    assert np.array_equal(it0, it1) and np.array_equal(eps0, eps1)
+    assert np.array_equal(x0, x1)
+
+
+def test_graph_replay_survives_a_coefficient_table_reallocation():
+    """A captured CG iteration bakes KpmArgs (d_coefs, maxorder) and the FFT choice into its kernel arguments; growing the table
+    (order > maxorder through smoqy_precond_set) or flipping smoqy_fft_use_rocfft must drop the cached graphs instead of replaying
+    them with a freed pointer."""
+    m = lat.holstein_honeycomb(4, 40)
+    nt, perm, colors = lat.checkerboard_decomposition(m.fpi.neighbor_table)
+    Lt, N = 40, 32
+
+    def mk():
+        h = L.Handle(Lt, N, nt, colors, True, 1, 2)
+        h.call("smoqy_update_from_path_integral", 0, L.ptr(m.fpi.V), L.ptr(m.fpi.t), L.ptr(perm), C.c_double(m.fpi.dtau))
+        h.call("smoqy_precond_update", 0, L.ptr(np.random.default_rng(10).standard_normal(N)))
+        return h
+
+    def state(h):
+        act, norder = C.c_int(0), C.c_int(0)
+        bounds, order = np.zeros(2), np.zeros(Lt, dtype=np.int32)
+        h.call("smoqy_precond_get", 0, C.byref(act), bounds.ctypes.data_as(C.POINTER(C.c_double)), order.ctypes.data_as(C.POINTER(C.c_int)), C.byref(norder), None, None)
+        return bounds, order[: norder.value].copy()
+
+    b = rand(Lt, N, 2, 12)
+    outs = {}
+    for graph in (0, 1):
+        h = mk()
+        h.call("smoqy_cg_use_graph", graph)
+        x_a, it_a, _ = solve(h, b, 1e-10, 10000, 1)  # captures with the initial table (maxorder = 64)
+        bounds, order = state(h)
+        # a host-supplied expansion whose slot-0 order exceeds the table's stride: constant polynomials (coefficient 1, rest 0)
+        big = order.copy()
+        big[0] = 150
+        coefs = np.zeros(int(big.sum()), dtype=complex)
+        coefs[np.concatenate(([0], np.cumsum(big)[:-1]))] = 1.0
+        h.call("smoqy_precond_set", 0, 1, L.ptr(bounds), L.ptr(big), L.ptr(coefs))
+        x_b, it_b, eps_b = solve(h, b, 1e-10, 10000, 1)
+        h.call("smoqy_fft_use_rocfft", 1)
+        x_c, it_c, eps_c = solve(h, b, 1e-10, 10000, 1)
+        en, cap = C.c_int(-1), C.c_int(-1)
+        h.call("smoqy_cg_graph_status", C.byref(en), C.byref(cap))
+        assert en.value == graph and (cap.value >= 1) == bool(graph)
+        outs[graph] = (x_a, it_a, x_b, it_b, x_c, it_c)
+        assert eps_b.max() < 1e-10 and eps_c.max() < 1e-10
+        h.close()
+    for eager, replay in zip(outs[0], outs[1]):
+        assert np.array_equal(eager, replay)
