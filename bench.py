@@ -94,25 +94,37 @@ def cpu_baseline(workload, tol, Nt):
     single = cpu_sample(workload, tol, Nt, walker=0)
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(w), "--workload", workload, "--cpu-tol", repr(tol), "--cpu-nt", str(Nt)],
-                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for w in range(cores)]
-    rates = []
-    for pr in procs:
-        out, _ = pr.communicate(timeout=600)
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True) for w in range(cores)]
+    rates, failures = [], []
+    for w, pr in enumerate(procs):
         try:
+            out, err = pr.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            out, err = pr.communicate()
+            failures.append({"worker": w, "returncode": "timeout", "stderr_tail": (err or "")[-300:]})
+            continue
+        try:
+            if pr.returncode != 0:
+                raise ValueError(f"exit code {pr.returncode}")
             rates.append(float(json.loads(out.strip().splitlines()[-1])["value"]))
-        except (ValueError, IndexError, KeyError):
-            pass
-    if len(rates) != cores:  # a worker failed: fall back to the single-core measurement, labelled as such
-        return single
+        except (ValueError, IndexError, KeyError) as e:
+            failures.append({"worker": w, "returncode": pr.returncode, "error": str(e), "stderr_tail": (err or "")[-300:]})
     agg = dict(single)
-    agg.update({
-        "value": sum(rates),
-        "cores": cores,
-        "sample": f"{cores} walkers, one per core and all at once, each: " + single["sample"].split(": ", 1)[1],
-        "single_core_value": single["value"],
-        "per_core_min": min(rates),
-        "per_core_max": max(rates),
-    })
+    agg["single_core_value"] = single["value"]
+    agg["workers_failed"] = len(failures)
+    if failures:
+        # never substituted silently: the aggregate covers the workers that DID finish, the record says how many did not and why
+        agg["degraded"] = True
+        agg["worker_failures"] = failures[:4]
+    if rates:
+        agg.update({
+            "value": sum(rates),
+            "cores": len(rates),
+            "sample": f"{len(rates)} walkers, one per core and all at once, each: " + single["sample"].split(": ", 1)[1],
+            "per_core_min": min(rates),
+            "per_core_max": max(rates),
+        })
     return agg
 
 
@@ -170,6 +182,131 @@ def cpu_sample(workload, tol, Nt, walker=0):
         "host_cores_available": available_cores(),
         "host_cores_visible": os.cpu_count(),
     }
+
+
+def measure_copy_ceiling(h, L, gib=1.0, reps=10):
+    """Device stream-copy ceiling measured on THIS box: a plain 16-byte-per-lane copy kernel over 2 x `gib` GiB
+    (far beyond the 256 MiB Infinity Cache), HIP events on the handle's stream.  Moved bytes = read + write."""
+    nbytes = int(gib * (1 << 30))
+    ms = L.C.c_double(0.0)
+    h.call("smoqy_bench_copy", L.C.c_size_t(nbytes), reps, L.C.byref(ms))
+    gbs = 2.0 * nbytes * reps / (ms.value * 1e-3) / 1e9
+    return {"GBs": gbs, "bytes_per_copy": 2 * nbytes, "reps": reps, "frac_of_spec": gbs / HBM_PEAK_GBS,
+            "note": "hand-written 16-byte-per-lane nontemporal copy kernel (shape from tools/copy_probe.hip), src and dst 1 GiB each; MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy"}
+
+
+def committed_traffic(workload, systems):
+    """HBM-side bytes per fused-MᵀM launch from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, collected in
+    separate --pmc runs per MI355X_MICROARCH.md; counters cannot be read from inside bench.py).  Newest round first; only quoted
+    when the profile was taken at this workload and batch size."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_fdm_mtm*.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        recs = pmc if isinstance(pmc, list) else [pmc]
+        for r in recs:
+            if r.get("workload") == workload and r.get("systems_per_launch") == systems and "traffic_bytes_per_launch" in r:
+                return r["traffic_bytes_per_launch"], "profiles/" + os.path.basename(path)
+    return None, None
+
+
+def roofline_record(args, batch, per, S, dev, insitu, extra, L, np):
+    """The `roofline` object of the JSON line.  Dominant kernel: the fused MᵀM apply.
+
+    achieved / frac          ALGORITHMIC bytes per launch (2(2S+F) per system, F once per walker) over the average
+                             duration of the launches sampled INSIDE the timed region by the device clock (agrees with rocprofv3's
+                             per-dispatch duration of the same command, profiles/).
+    traffic / frac_traffic   bytes the kernel really moves beyond L2 (committed PMC passes; the fused kernel moves each array once,
+                             ~0.41 of the two-pass algorithmic count) over the same duration.
+    isolated                 the same kernel alone on the GPU (back-to-back launches, HIP events; `--roofline-only` repeats this leg).
+    copy_ceiling             device stream-copy rate measured in this run; every fraction is also quoted against it.
+    batch_scan               1..64 systems per launch; the 64-system point is the HBM-resident one (working set > Infinity Cache).
+    """
+    h = batch.h
+    a, b = h.vec_alloc(), h.vec_alloc()
+    g = np.random.default_rng(3)
+    h.vec_upload(a, np.asfortranarray(g.standard_normal((batch.Lt, batch.N, per)) + 1j * g.standard_normal((batch.Lt, batch.N, per))))
+    h.bench_matvec(L.OP_MTM, b, a, 50)
+    ms = h.bench_matvec(L.OP_MTM, b, a, args.matvec_reps)
+    iso_s = ms * 1e-3 / args.matvec_reps
+    alg = h.algorithmic_bytes(L.OP_MTM)
+    tc = L.C.c_int(0)
+    h.call("smoqy_get_tau_chunk", L.C.byref(tc))
+    traffic, traffic_src = committed_traffic(args.workload, per)
+    copy = measure_copy_ceiling(h, L)
+
+    def fr(bytes_, sec):
+        gbs = bytes_ / sec / 1e9
+        return {"GBs": gbs, "frac": gbs / HBM_PEAK_GBS, "frac_of_copy_ceiling": gbs / copy["GBs"]}
+
+    isolated = {"avg_launch_us": iso_s * 1e6, "launches": args.matvec_reps, "algorithmic": fr(alg, iso_s), "traffic": fr(traffic, iso_s) if traffic else None,
+                "note": "back-to-back launches of the kernel alone on the handle's stream, HIP events around all of them; 16 systems (64 MiB in + out + fields) sit in the Infinity Cache"}
+    timed_s = insitu["device_us"] * 1e-6 if insitu["device_us"] else None
+    prim_s, prim_src = (timed_s, "timed region, device clock") if timed_s else (iso_s, "isolated leg (no timed region in this run)")
+    roofline = {
+        "bound": "hbm",
+        "kernel": "fdm_fast_kernel<NCOL, MtM> (fused MᵀM apply; fdm_own_kernel at <= 8 systems)",
+        "achieved": alg / prim_s / 1e9,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": alg / prim_s / 1e9 / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "traffic_source": traffic_src,
+        "traffic_measured_live": False,
+        "frac_traffic": (traffic / prim_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+        "frac_of_copy_ceiling": alg / prim_s / 1e9 / copy["GBs"],
+        "frac_traffic_of_copy_ceiling": (traffic / prim_s / 1e9 / copy["GBs"]) if traffic else None,
+        "avg_launch_us": prim_s * 1e6,
+        "duration_source": prim_src,
+        "launches_sampled": insitu["device_n"] if timed_s else args.matvec_reps,
+        "algorithmic_bytes_per_launch": alg,
+        "systems_per_launch": per,
+        "tau_chunk": tc.value,
+        "concurrent_streams": S,
+        "in_timed_region": None if not timed_s else {
+            "device_clock_avg_us": insitu["device_us"], "event_pair_avg_us": insitu["event_us"], "launches_sampled": insitu["device_n"],
+            "note": "every 16th full-batch MtM launch of the CG loops while all streams run; the device clock spans first workgroup start -> last workgroup end "
+                    "(rocprofv3's dispatch duration), the event pair also holds the dependency gap to the previous launch on the stream",
+        },
+        "isolated": isolated,
+        "copy_ceiling": copy,
+        "note": "frac = algorithmic bytes (two passes counted for the fused kernel) over the in-run duration; frac_traffic = bytes really moved beyond L2 over the same duration; "
+                "at 16 systems per launch the working set is Infinity-Cache resident, the HBM-resident figure is batch_scan's 64-system point",
+    }
+    # GB/s versus batch size (SURVEY.md §8(d) latency caveat), always reported: heuristic tau chunk, 200 launches per point
+    scan = []
+    for nb in (1, 2, 4, 8, 16, 32, 64, 128):
+        hb = L.Handle(batch.Lt, batch.N, batch.nt, batch.colors, True, nb, 1, dev)
+        for w in range(nb):
+            m = batch.models[w % per]
+            hb.call("smoqy_update_from_path_integral", w, L.ptr(m.fpi.V), L.ptr(m.fpi.t), L.ptr(batch.perm), L.C.c_double(m.fpi.dtau))
+        va, vb = hb.vec_alloc(), hb.vec_alloc()
+        hb.vec_upload(va, np.asfortranarray(g.standard_normal((batch.Lt, batch.N, nb)) + 1j * g.standard_normal((batch.Lt, batch.N, nb))))
+        best = None
+        for tcand in ((1, 2, 3, 4) if args.batch_scan else (0,)):
+            hb.call("smoqy_set_tau_chunk", tcand)
+            hb.bench_matvec(L.OP_MTM, vb, va, 20)
+            t_s = hb.bench_matvec(L.OP_MTM, vb, va, 200) / 200 * 1e-3
+            algb = hb.algorithmic_bytes(L.OP_MTM)
+            tcv = L.C.c_int(0)
+            hb.call("smoqy_get_tau_chunk", L.C.byref(tcv))
+            tr, _ = committed_traffic(args.workload, nb)
+            rec = {"batch": nb, "tau_chunk": tcv.value, "us": t_s * 1e6, "GBs": algb / t_s / 1e9, "frac": algb / t_s / 1e9 / HBM_PEAK_GBS,
+                   "working_set_MiB": (2 * 16.0 * batch.Lt * batch.N * nb + nb * (8.0 * batch.Lt * batch.N + 16.0 * batch.Lt * batch.Nh)) / 2**20,
+                   "traffic_GBs": (tr / t_s / 1e9) if tr else None, "frac_traffic": (tr / t_s / 1e9 / HBM_PEAK_GBS) if tr else None}
+            rec["hbm_resident"] = rec["working_set_MiB"] > 256.0  # beyond the 256 MiB Infinity Cache
+            if best is None or rec["GBs"] > best["GBs"]:
+                best = rec
+        scan.append(best)
+        hb.close()
+    roofline["batch_scan"] = scan
+    roofline["batch_at_40pct"] = next((r["batch"] for r in scan if r["frac"] >= 0.4), None)
+    roofline["hbm_resident_point"] = next((r for r in scan if r["hbm_resident"]), None)
+    h.call("smoqy_vec_free", a)
+    h.call("smoqy_vec_free", b)
+    return roofline
 
 
 def main():
@@ -237,105 +374,47 @@ def main():
     for b in batches:
         b.stats.solves = b.stats.iters_sum = 0
         # roofline: the dominant kernel's launches inside the timed region are sampled with HIP events on the stream
-        # they run on (every 8th full-batch fused MᵀM launch of the CG loop)
-        b.h.call("smoqy_matvec_timing", 8, 4096)
+        # they run on (every 16th full-batch fused MᵀM launch of the CG loop)
+        b.h.call("smoqy_matvec_timing", 16, 1024)
     fence()
     t0 = time.perf_counter()
     run(args.steps)
     fence()
     elapsed = reduce_max_time(time.perf_counter() - t0, device="cpu" if args.rehearse_one_gpu else "cuda")
     value = aggregate_throughput(wpg * args.steps, world, elapsed) if args.steps else 0.0
-    insitu_us, insitu_n = 0.0, 0
+    # sampled fused-MᵀM launches of the timed region: by the device's own clock (first workgroup's start -> last workgroup's end,
+    # what rocprofv3 reports per dispatch) and by the HIP event pairs around them (which also hold the gap to the previous launch)
+    ev_us = ev_n = dv_us = dv_n = 0.0
     for b in batches:
         us, n = L.C.c_double(0.0), L.C.c_int(0)
+        b.h.call("smoqy_matvec_timing_read_device", L.C.byref(us), L.C.byref(n))
+        dv_us += us.value * n.value
+        dv_n += n.value
         b.h.call("smoqy_matvec_timing_read", L.C.byref(us), L.C.byref(n))
-        insitu_us += us.value * n.value
-        insitu_n += n.value
-    insitu_us = insitu_us / insitu_n if insitu_n else None
+        ev_us += us.value * n.value
+        ev_n += n.value
+    insitu = {"device_us": dv_us / dv_n if dv_n else None, "device_n": int(dv_n), "event_us": ev_us / ev_n if ev_n else None, "event_n": int(ev_n)}
 
     if rank == 0:
-        # --- roofline of the dominant kernel: fused MᵀM apply ------------------------------------
-        h = batch.h
-        a, b = h.vec_alloc(), h.vec_alloc()
-        g = np.random.default_rng(3)
-        h.vec_upload(a, np.asfortranarray(g.standard_normal((batch.Lt, batch.N, per)) + 1j * g.standard_normal((batch.Lt, batch.N, per))))
-        h.bench_matvec(L.OP_MTM, b, a, 50)
-        ms = h.bench_matvec(L.OP_MTM, b, a, args.matvec_reps)
-        per_launch_s = ms * 1e-3 / args.matvec_reps
-        alg = h.algorithmic_bytes(L.OP_MTM)
-        achieved = alg / per_launch_s / 1e9
-        tc = L.C.c_int(0)
-        h.call("smoqy_get_tau_chunk", L.C.byref(tc))
-        # HBM-side traffic of the same kernel comes from the committed PMC passes (FETCH_SIZE / WRITE_SIZE
-        # collected in separate rocprofv3 runs and corrected per MI355X_MICROARCH.md); it is only quoted
-        # when that profile was taken at this workload and batch size
-        traffic, traffic_src = None, None
-        try:
-            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_fdm_mtm.json")
-            pmc = json.load(open(pmc_path))
-            if pmc.get("workload") == args.workload and pmc.get("systems_per_launch") == per:
-                traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/r01_pmc_traffic_fdm_mtm.json"
-        except (OSError, ValueError, KeyError):
-            pass
-        # `achieved` is the kernel with the GPU to itself (back-to-back launches on the handle's stream, HIP events on that
-        # stream; `python bench.py --roofline-only` repeats exactly this leg for rocprofv3).  `in_timed_region` is the same
-        # kernel sampled with event pairs while S streams share the GPU: those brackets contain the dependency gap to the
-        # neighbouring launches and the time slices of the other streams' kernels, so they describe the mix, not the kernel.
-        roofline = {
-            "bound": "hbm",
-            "kernel": "fdm_fast_kernel<3, MtM> (fused MᵀM apply)",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": alg,
-            "avg_launch_us": per_launch_s * 1e6,
-            "launches": args.matvec_reps,
-            "systems_per_launch": per,
-            "tau_chunk": tc.value,
-            "in_timed_region": None if not insitu_us else {
-                "avg_launch_us": insitu_us, "achieved": alg / (insitu_us * 1e-6) / 1e9, "frac": alg / (insitu_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "launches_sampled": insitu_n, "concurrent_streams": S,
-                "note": "event pairs around every 8th MtM launch of the CG loops while all streams run; includes inter-launch gaps and the other streams' time slices",
-            },
-            "note": "working set is L2/Infinity-Cache resident at this size; fraction is algorithmic bytes over launch duration, see DESIGN.md",
-        }
         extra = {}
-        if args.batch_scan:
-            scan = []
-            for nb in (1, 2, 4, 8, 16, 32, 64):
-                hb = L.Handle(batch.Lt, batch.N, batch.nt, batch.colors, True, nb, 1, dev)
-                for w in range(nb):
-                    m = batch.models[w % per]
-                    hb.call("smoqy_update_from_path_integral", w, L.ptr(m.fpi.V), L.ptr(m.fpi.t), L.ptr(batch.perm), L.C.c_double(m.fpi.dtau))
-                va, vb = hb.vec_alloc(), hb.vec_alloc()
-                hb.vec_upload(va, np.asfortranarray(g.standard_normal((batch.Lt, batch.N, nb)) + 1j * g.standard_normal((batch.Lt, batch.N, nb))))
-                best = None
-                for tcand in (1, 2, 3, 4):
-                    hb.call("smoqy_set_tau_chunk", tcand)
-                    hb.bench_matvec(L.OP_MTM, vb, va, 20)
-                    t_ms = hb.bench_matvec(L.OP_MTM, vb, va, 200) / 200
-                    gbs = hb.algorithmic_bytes(L.OP_MTM) / (t_ms * 1e-3) / 1e9
-                    if best is None or gbs > best["GBs"]:
-                        best = {"batch": nb, "tau_chunk": tcand, "us": t_ms * 1e3, "GBs": gbs, "frac": gbs / HBM_PEAK_GBS}
-                scan.append(best)
-                hb.close()
-            extra["matvec_batch_scan"] = scan
-        # the literal BASELINE.json configuration — ONE walker per GPU — next to the batched headline figure (outside the timed region)
+        roofline = roofline_record(args, batch, per, S, dev, insitu, extra, L, np)
+        # the literal BASELINE.json configuration — ONE walker per GPU — and the 8- / 16-walker one-stream figures next to the
+        # batched headline (outside the timed region): what a user who keeps the reference's rank-per-walker model gets
         if world == 1 and not args.roofline_only:
-            one = WalkerBatch(args.workload, nwalkers=1, walker0=mine.start, device=dev)
-            one.sweep()
-            one.h.call("smoqy_sync")
-            t1 = time.perf_counter()
-            for _ in range(2):
-                one.sweep()
-            one.h.call("smoqy_sync")
-            ms_one = (time.perf_counter() - t1) / 2 * 1e3
-            one.h.close()
-            extra["single_walker"] = {"walkers_per_gpu": 1, "sweeps_per_s": 1e3 / ms_one, "ms_per_sweep": ms_one,
-                                      "note": "one walker on one stream: the launch-latency regime (4 dependent launches per CG iteration)"}
+            one_stream = []
+            for nw1 in (1, 8, 16):
+                ob = WalkerBatch(args.workload, nwalkers=nw1, walker0=mine.start, device=dev)
+                ob.sweep()
+                ob.h.call("smoqy_sync")
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    ob.sweep()
+                ob.h.call("smoqy_sync")
+                ms_one = (time.perf_counter() - t1) / 2 * 1e3
+                ob.h.close()
+                one_stream.append({"walkers_per_gpu": nw1, "streams": 1, "sweeps_per_s": nw1 * 1e3 / ms_one, "ms_per_sweep": ms_one})
+            extra["single_walker"] = dict(one_stream[0], note="one walker on one stream: the launch-latency regime (4 dependent launches per CG iteration)")
+            extra["one_stream"] = one_stream
         # the CPU baseline is a rank-0, N = 1 measurement (it would only hold the other ranks at the final barrier)
         cpu = None if (args.no_cpu_baseline or args.roofline_only or world > 1) else cpu_baseline(args.workload, batch.tol, batch.Nt)
         # the whole sweep against the roofline: algorithmic bytes of one preconditioned CG iteration per walker as SURVEY.md §8(d)

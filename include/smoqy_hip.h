@@ -287,6 +287,13 @@ int smoqy_timer_stop(smoqy_ctx *ctx, double *ms);
  * by an event pair on the handle's stream (at most max_samples); _read synchronises, returns the mean and stops sampling */
 int smoqy_matvec_timing(smoqy_ctx *ctx, int sample_every, int max_samples);
 int smoqy_matvec_timing_read(smoqy_ctx *ctx, double *avg_us, int *samples);
+/* the same sampled launches by the device's constant 100 MHz clock: mean of (last workgroup's end - first workgroup's start), the
+ * interval rocprofv3 --kernel-trace reports for a dispatch (an event pair on a busy stream also holds the gap to the previous
+ * launch).  Call before smoqy_matvec_timing_read, which ends the sampling. */
+int smoqy_matvec_timing_read_device(smoqy_ctx *ctx, double *avg_us, int *samples);
+/* device stream-copy ceiling: `reps` device-to-device copies of `bytes` bytes by a plain 16-byte-per-lane copy
+ * kernel between two HIP events; each copy moves 2 * bytes.  Buffers are allocated and freed inside the call. */
+int smoqy_bench_copy(smoqy_ctx *ctx, size_t bytes, int reps, double *ms);
 int smoqy_bench_matvec(smoqy_ctx *ctx, int op, int out, int in, int reps, double *ms);
 /* algorithmic bytes of one launch of `op` over all systems ((2S+F) per M / Mᵀ,
  * 2(2S+F) per MᵀM / MMᵀ, F counted once per walker) */

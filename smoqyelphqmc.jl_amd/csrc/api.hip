@@ -138,6 +138,8 @@ struct smoqy_ctx {
     struct MvTiming {
         int every = 0, seen = 0, used = 0;
         std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+        unsigned long long *d_stamp = nullptr;  // [cap][wgs][2] start / end of every workgroup of each sampled launch (FdmArgs::stamp)
+        int stamp_cap = 0, stamp_wgs = 0;
     } mvt;
 
     size_t vec_elems() const { return (size_t)g.nsys * g.Lt * g.N; }
@@ -309,6 +311,7 @@ int smoqy_destroy(smoqy_ctx *c)
     for (void *q : {c->force.blob, (void *)c->force.d_x, (void *)c->force.d_contrib, (void *)c->force.d_out, (void *)c->force.d_bare})
         if (q) (void)hipFree(q);
     for (auto &e : c->mvt.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (c->mvt.d_stamp) (void)hipFree(c->mvt.d_stamp);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -856,7 +859,10 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
     }
     auto &T = c->mvt;
     const bool sample = T.every > 0 && op == SMOQY_OP_MTM && count == c->g.nsys && T.used < (int)T.ev.size() && (T.seen++ % T.every) == 0;
-    if (sample) HIPCHK(c, hipEventRecord(T.ev[T.used].first, c->stream));
+    if (sample) {
+        HIPCHK(c, hipEventRecord(T.ev[T.used].first, c->stream));
+        if (T.d_stamp && T.used < T.stamp_cap && a.nchunk * a.sys_count <= T.stamp_wgs) a.stamp = T.d_stamp + 2 * (size_t)T.stamp_wgs * T.used;  // register-resident kernels only
+    }
     if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_own(c->stream, op, a, c->ff);
     else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_fast(c->stream, op, a, c->ff);
     else launch_fdm(c->stream, op, c->g.is_sym != 0, a, c->d_big ? 0 : fdm_lds_bytes(op, c->g.N, c->Tc));
@@ -2105,8 +2111,49 @@ int smoqy_matvec_timing(smoqy_ctx *c, int sample_every, int max_samples)
         HIPCHK(c, hipEventCreate(&b));
         T.ev.push_back({a, b});
     }
+    {   // one (start, end) slot per workgroup per sampled launch, at most 1024 launches (16 MiB at 1024 workgroups)
+        const int cap = std::min(max_samples, 1024), wgs = c->g.Lt * c->g.nsys;  // nchunk <= Lt
+        if (cap > T.stamp_cap || wgs != T.stamp_wgs) {
+            if (T.d_stamp) (void)hipFree(T.d_stamp);
+            T.d_stamp = nullptr;
+            T.stamp_cap = T.stamp_wgs = 0;
+            if (cap > 0) {
+                HIPCHK(c, hipMalloc(&T.d_stamp, 2 * (size_t)cap * wgs * sizeof(unsigned long long)));
+                T.stamp_cap = cap;
+                T.stamp_wgs = wgs;
+            }
+        }
+        if (T.d_stamp) HIPCHK(c, hipMemset(T.d_stamp, 0, 2 * (size_t)T.stamp_cap * T.stamp_wgs * sizeof(unsigned long long)));
+    }
     T.every = sample_every;
     T.seen = T.used = 0;
+    return 0;
+}
+
+// the same sampled launches by the device's own clock: mean of (last workgroup's end - first workgroup's start), the interval
+// rocprofv3 --kernel-trace reports for a dispatch.  Call BEFORE smoqy_matvec_timing_read (which ends the sampling).
+int smoqy_matvec_timing_read_device(smoqy_ctx *c, double *avg_us, int *samples)
+{
+    CHECK_CTX(c);
+    auto &T = c->mvt;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int n = std::min(T.used, T.stamp_cap);
+    const size_t per = 2 * (size_t)T.stamp_wgs;
+    std::vector<unsigned long long> st(per * (size_t)std::max(n, 1));
+    if (n) HIPCHK(c, hipMemcpy(st.data(), T.d_stamp, per * n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double sum = 0.0;
+    int cnt = 0;
+    for (int k = 0; k < n; ++k) {
+        unsigned long long t0 = ~0ull, t1 = 0ull;
+        for (int b = 0; b < T.stamp_wgs; ++b) {
+            const unsigned long long s0 = st[per * k + 2 * b], s1 = st[per * k + 2 * b + 1];
+            if (s0) t0 = std::min(t0, s0);   // slots of workgroups that never ran (smaller grid) stay 0
+            t1 = std::max(t1, std::max(s0, s1));  // a workgroup that retired at entry (converged system) only has a start
+        }
+        if (t0 != ~0ull && t1 > t0) { sum += (double)(t1 - t0) * 0.01; ++cnt; }  // 100 MHz ticks -> µs
+    }
+    if (avg_us) *avg_us = cnt ? sum / cnt : 0.0;
+    if (samples) *samples = cnt;
     return 0;
 }
 
@@ -2144,6 +2191,33 @@ int smoqy_bench_matvec(smoqy_ctx *c, int op, int out, int in, int reps, double *
     HIPCHK(c, hipEventElapsedTime(&f, c->ev0, c->ev1));
     *ms = f;
     return check_launch(c, "bench_matvec");
+}
+
+// device stream-copy ceiling: `reps` copies of `bytes` bytes (src -> dst, both allocated here, far larger than the 256 MiB
+// Infinity Cache when bytes >= 1 GiB) between two HIP events on the handle's stream; moved bytes = 2 * bytes per copy
+int smoqy_bench_copy(smoqy_ctx *c, size_t bytes, int reps, double *ms)
+{
+    CHECK_CTX(c);
+    if (bytes < 16 || reps < 1) FAIL(c, 1, "invalid copy benchmark parameters");
+    const size_t n = bytes / sizeof(double2);
+    double2 *src = nullptr, *dst = nullptr;
+    HIPCHK(c, hipMalloc(&src, n * sizeof(double2)));
+    if (hipMalloc(&dst, n * sizeof(double2)) != hipSuccess) { (void)hipFree(src); FAIL(c, 2, "out of device memory for the copy benchmark"); }
+    int rc = 0;
+    float f = 0;
+    do {
+        if (hipMemsetAsync(src, 1, n * sizeof(double2), c->stream) != hipSuccess) { rc = 2; break; }
+        launch_stream_copy(c->stream, dst, src, n);  // warm-up (page faults, clocks)
+        if (hipEventRecord(c->ev0, c->stream) != hipSuccess) { rc = 2; break; }
+        for (int r = 0; r < reps; ++r) launch_stream_copy(c->stream, dst, src, n);
+        if (hipEventRecord(c->ev1, c->stream) != hipSuccess || hipEventSynchronize(c->ev1) != hipSuccess) { rc = 2; break; }
+        if (hipEventElapsedTime(&f, c->ev0, c->ev1) != hipSuccess) { rc = 2; break; }
+    } while (0);
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    if (rc) FAIL(c, rc, "HIP error in the copy benchmark: %s", hipGetErrorString(hipGetLastError()));
+    *ms = f;
+    return check_launch(c, "bench_copy");
 }
 
 int smoqy_algorithmic_bytes(const smoqy_ctx *c, int op, double *bytes)

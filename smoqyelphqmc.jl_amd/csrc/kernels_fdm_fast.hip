@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
     int bid = blockIdx.x;
     if ((nblk & 7) == 0) bid = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
     const int chunk = bid % a.nchunk, sys = a.sys_first + bid / a.nchunk;
+    stamp_begin(a.stamp);
     if (a.cg && a.cg[sys].done) return;
     const int w = sys / a.nrhs;
     const int Lt = a.Lt, N = a.N;
@@ -306,6 +307,7 @@ __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
             a.partial[(size_t)sys * a.nchunk + chunk] = t;
         }
     }
+    stamp_end(a.stamp);
 }
 
 template <int NCOL>

@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(TMAX) fdm_own_kernel(FdmArgs a, FdmFast ff)
     int bid = blockIdx.x;
     if ((nblk & 7) == 0) bid = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
     const int chunk = bid % a.nchunk, sys = a.sys_first + bid / a.nchunk;
+    stamp_begin(a.stamp);
     if (a.cg && a.cg[sys].done) return;
     const int w = sys / a.nrhs;
     const int Lt = a.Lt, N = a.N, T = blockDim.x, T2 = 2 * T, j = threadIdx.x;
@@ -304,6 +305,7 @@ __global__ void __launch_bounds__(TMAX) fdm_own_kernel(FdmArgs a, FdmFast ff)
             a.partial[(size_t)sys * a.nchunk + chunk] = t;
         }
     }
+    stamp_end(a.stamp);
 }
 
 template <int NCOL, int KM>

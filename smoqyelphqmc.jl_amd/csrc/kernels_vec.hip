@@ -233,6 +233,33 @@ void launch_lambda_apply(hipStream_t st, int op, double2 *out, const double2 *in
 }
 
 // ---------------------------------------------------------------------------------------------
+// device stream copy: the measured HBM ceiling bench.py quotes next to the 8 TB/s specification.
+// Shape chosen by tools/copy_probe.hip on MI355X (1 GiB -> 1 GiB): a workgroup owns contiguous 16 KiB tiles, four independent
+// 16-byte nontemporal loads in flight per lane, 16384 workgroups: 6.31 TB/s; a grid-stride loop whose four loads sit 16 MiB apart
+// (same channel) reaches 4.3-4.9 TB/s, hipMemcpyDtoD 5.05 TB/s.
+// ---------------------------------------------------------------------------------------------
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) stream_copy_kernel(v2d_t *__restrict__ dst, const v2d_t *__restrict__ src, size_t n)
+{
+    constexpr int U = 4;
+    const size_t tile = (size_t)U * 256, ntile = n / tile;
+    for (size_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const size_t base = t * tile + threadIdx.x;
+        v2d_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(&src[base + u * 256]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(v[u], &dst[base + u * 256]);
+    }
+    for (size_t i = ntile * tile + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+void launch_stream_copy(hipStream_t st, double2 *dst, const double2 *src, size_t n)
+{
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(16384), dim3(256), 0, st, reinterpret_cast<v2d_t *>(dst), reinterpret_cast<const v2d_t *>(src), n);
+}
+
+// ---------------------------------------------------------------------------------------------
 // dot(a, b) per system (LinearAlgebra.dot: conjugate-linear in a)
 // ---------------------------------------------------------------------------------------------
 __global__ void dot_partial_kernel(const double2 *__restrict__ a, const double2 *__restrict__ b, double2 *__restrict__ partial, int Lt, int N, int nsys, int Tc, int nchunk)

@@ -63,7 +63,22 @@ struct FdmArgs {
     // (scratch_stride elements per workgroup, L2-resident; same code, same barriers)
     double2 *scratch;
     size_t scratch_stride;
+    // measurement aid (smoqy_matvec_timing): when non-null, workgroup b of the launch stores the device's constant 100 MHz clock
+    // into stamp[2b] at entry and stamp[2b + 1] at exit (plain stores to its own slot — a shared atomic counter would serialise
+    // the 1024 workgroups at ~12 ns each and lengthen the launch it measures); the host takes min(start) / max(end): first start
+    // -> last end of the launch, the interval rocprofv3 reports, free of the inter-launch gap an event pair includes
+    unsigned long long *stamp;
 };
+
+// stamps for FdmArgs::stamp
+__device__ __forceinline__ void stamp_begin(unsigned long long *st)
+{
+    if (st && threadIdx.x == 0) st[2 * (size_t)blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+}
+__device__ __forceinline__ void stamp_end(unsigned long long *st)
+{
+    if (st && threadIdx.x == 0) st[2 * (size_t)blockIdx.x + 1] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+}
 
 struct KpmArgs {
     int Lt, N, Nh, ncol, nsys, nrhs, is_sym;
@@ -140,6 +155,8 @@ bool fdm_own_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
 void launch_fdm_own(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff);
 void launch_pack_csf(hipStream_t st, const double *ch, const double *sh, const int *psrc, double2 *csf, int *cs_varies, int Lt, int Lt1, int Nh, int ptotal);
 
+// device stream-copy ceiling (kernels_vec.hip): dst[i] = src[i], 16 bytes per lane, grid-stride
+void launch_stream_copy(hipStream_t st, double2 *dst, const double2 *src, size_t n);
 void launch_transpose_in(hipStream_t st, const double2 *host_layout, double2 *dev_layout, int Lt, int N, int nsys, int sys0, int count);
 void launch_transpose_out(hipStream_t st, const double2 *dev_layout, double2 *host_layout, int Lt, int N, int nsys, int sys0, int count);
 void launch_transpose_real_in(hipStream_t st, const double *src, double *dst, int Lt, int n);   // (Lt x n col-major) -> [l][n]

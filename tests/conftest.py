@@ -21,8 +21,9 @@ def pytest_sessionstart(session):
             import __graft_entry__
 
             __graft_entry__.build()
-        except Exception as e:  # noqa: BLE001 - report and let the dependent tests fail on their own
-            print(f"[conftest] build() failed: {e}", file=sys.stderr)
+        except Exception as e:  # noqa: BLE001
+            # a failed build is THE failure: stop here instead of letting dependent tests fail later with unrelated errors
+            pytest.exit(f"[conftest] __graft_entry__.build() failed, nothing to test: {e}", returncode=3)
 
 
 @pytest.fixture(scope="session")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM-side traffic of the fused MᵀM kernel: FETCH_SIZE and WRITE_SIZE in two separate rocprofv3 --pmc passes
-# (no trace domains other than --kernel-trace).  usage: tools/pmc_traffic.sh [batch]   -> gpurun_out/pmc_traffic.json
+# (no trace domains other than --kernel-trace).  usage: tools/pmc_traffic.sh [batch]   -> gpurun_out/pmc_traffic_fdm_mtm_b<batch>.json
 nb=${1:-16}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
@@ -26,7 +26,7 @@ res.update({
     "traffic_bytes_per_launch": (2 * res["FETCH_SIZE"]["mean_KB"] + res["WRITE_SIZE"]["mean_KB"]) * 1024,
     "algorithmic_bytes_per_launch": 2 * (2 * 16 * 128 * 512 + 8 * 128 * 512 + 16 * 128 * 768) * nb,
 })
-json.dump(res, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
+json.dump(res, open(f"gpurun_out/pmc_traffic_fdm_mtm_b{nb}.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
 rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
