@@ -163,6 +163,9 @@ int smoqy_precond_set(smoqy_ctx *ctx, int walker, int active, const double *boun
 /* ldiv!(u', P, u) complex method (Sym :355-414, Asym :488-550); identity while inactive */
 int smoqy_precond_apply_v(smoqy_ctx *ctx, int out, int in);
 int smoqy_precond_apply(smoqy_ctx *ctx, void *out, const void *in, int sys0, int count);
+/* ldiv!(u', P, u) real-vector methods (Sym :288-352, Asym :417-485): out / in are Ltau x N x count float64.  Half the frequencies are
+ * evaluated, the rest is their complex conjugate (:334 / :468), the real part of the back-transform is returned (:344 / :475). */
+int smoqy_precond_apply_real(smoqy_ctx *ctx, double *out, const double *in, int sys0, int count);
 
 /* ---- conjugate gradient (ldiv!(v', fdm, v), src/FermionDetMatrix.jl:248-288) ----------- */
 

@@ -199,6 +199,14 @@ class OracleKPM:
         lib().orc_kpm_apply(self._h, _p(out), _p(v))
         return out
 
+    def apply_real(self, v):
+        """ldiv!(u', P, u), real-vector method (:288-352 / :417-485): half the frequencies, conjugate mirror, real part."""
+        f = self.fdm
+        v = np.asfortranarray(np.asarray(v, dtype=np.float64).reshape(f.Lt, f.N, order="F"))
+        out = np.zeros_like(v, order="F")
+        lib().orc_kpm_apply_real(self._h, _p(out), _p(v))
+        return out
+
     @property
     def active(self):
         return bool(lib().orc_kpm_active(self._h))

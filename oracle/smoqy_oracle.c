@@ -229,6 +229,9 @@ typedef struct {
     int n;
     cplx *w;      /* w[k] = exp(-2 pi i k / n) */
     cplx *work;   /* n scratch */
+    cplx *theta;  /* theta[l] = exp(-i pi l / n): the FourierTransformer's twiddle, precomputed once as the reference does
+                     (src/FourierTransformer.jl:15) */
+    cplx *buf;    /* n scratch of the column transform (the reference's plans are in place and allocation free) */
     int nfac, fac[64];
 } orc_fft;
 
@@ -268,6 +271,9 @@ orc_fft *orc_fft_create(int n)
     p->w = (cplx *)malloc(sizeof(cplx) * (size_t)n);
     p->work = (cplx *)malloc(sizeof(cplx) * (size_t)(n > 64 ? n : 64));
     for (int k = 0; k < n; ++k) p->w[k] = cexp(-2.0 * M_PI * I * (double)k / (double)n);
+    p->theta = (cplx *)malloc(sizeof(cplx) * (size_t)n);
+    p->buf = (cplx *)malloc(sizeof(cplx) * (size_t)n);
+    for (int l = 0; l < n; ++l) p->theta[l] = cexp(-I * M_PI * (double)l / (double)n);
     int m = n;
     for (int f = 2; m > 1;) {
         if (m % f == 0) { p->fac[p->nfac++] = f; m /= f; }
@@ -279,7 +285,7 @@ orc_fft *orc_fft_create(int n)
 void orc_fft_destroy(orc_fft *p)
 {
     if (!p) return;
-    free(p->w); free(p->work); free(p);
+    free(p->w); free(p->work); free(p->theta); free(p->buf); free(p);
 }
 
 /* in-place transform of one contiguous column; sign<0 forward, >0 backward (unnormalised) */
@@ -292,26 +298,22 @@ static void fft_col(const orc_fft *p, cplx *x, cplx *buf, int sign)
 /* FourierTransformer — src/FourierTransformer.jl:12-21 (theta), :39-50 (lmul!), :53-64 (ldiv!) */
 void orc_ft_forward(const orc_fft *p, cplx *u, int Lt, int N)
 {
-    cplx *buf = (cplx *)malloc(sizeof(cplx) * (size_t)Lt);
     double isq = 1.0 / sqrt((double)Lt);
     for (int i = 0; i < N; ++i) {
         cplx *c = u + IDX(0, i, Lt);
-        for (int l = 0; l < Lt; ++l) c[l] *= cexp(-I * M_PI * (double)l / (double)Lt) * isq; /* :46 */
-        fft_col(p, c, buf, -1);                                                               /* :47 */
+        for (int l = 0; l < Lt; ++l) c[l] *= p->theta[l] * isq; /* :46, theta from :15 */
+        fft_col(p, c, p->buf, -1);                              /* :47 */
     }
-    free(buf);
 }
 
 void orc_ft_inverse(const orc_fft *p, cplx *u, int Lt, int N)
 {
-    cplx *buf = (cplx *)malloc(sizeof(cplx) * (size_t)Lt);
-    double sq = sqrt((double)Lt);
+    double sq = sqrt((double)Lt) / (double)Lt; /* FFTW's ifft carries the 1/n (:60), then * sqrt(Lt) / theta (:61) */
     for (int i = 0; i < N; ++i) {
         cplx *c = u + IDX(0, i, Lt);
-        fft_col(p, c, buf, +1); /* :60, FFTW ifft carries the 1/n */
-        for (int l = 0; l < Lt; ++l) c[l] = c[l] / (double)Lt * sq / cexp(-I * M_PI * (double)l / (double)Lt); /* :61 */
+        fft_col(p, c, p->buf, +1);                                      /* :60 */
+        for (int l = 0; l < Lt; ++l) c[l] = c[l] * sq * conj(p->theta[l]); /* :61, 1/theta = conj(theta) since |theta| = 1 */
     }
-    free(buf);
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -599,6 +601,39 @@ void orc_kpm_apply(orc_kpm *P, cplx *out, const cplx *in)
     }
     for (int i = 0; i < N; ++i) for (int l = 0; l < Lt; ++l) out[IDX(l, i, Lt)] = P->vt[(size_t)i + (size_t)N * l]; /* :403 */
     orc_ft_inverse(P->fft, out, Lt, N);                                    /* :406 */
+}
+
+/* ldiv!(u', P, u) REAL-vector methods — Sym: src/KPMPreconditioner.jl:288-352; Asym: :417-485.  Half the frequencies
+ * (n = 1..cld(Lt,2)) are evaluated and the other half is filled in as the complex conjugate (:334 / :465), the result is the real
+ * part of the back-transform (:344 / :475).  Never reached by CG (its vectors are always complex); restated so that the mirror's
+ * real-vector method has an oracle. */
+void orc_kpm_apply_real(orc_kpm *P, double *out, const double *in)
+{
+    int Lt = P->Lt, N = P->N, Lo2 = (Lt + 1) / 2;
+    size_t V = (size_t)Lt * N;
+    if (!P->active) { if (out != in) memcpy(out, in, V * sizeof(double)); return; } /* :349 / :480 */
+    for (size_t k = 0; k < V; ++k) P->v[k] = in[k];                                  /* mul!(v, U, u) :306 / :438 */
+    orc_ft_forward(P->fft, P->v, Lt, N);
+    for (int i = 0; i < N; ++i) for (int l = 0; l < Lt; ++l) P->vt[(size_t)i + (size_t)N * l] = P->v[IDX(l, i, Lt)]; /* :309 */
+    for (int n = 0; n < Lo2; ++n) {                                                  /* :312 / :444 */
+        cplx *vn = P->vt + (size_t)N * n, *vm = P->vt + (size_t)N * (Lt - n - 1);
+        if (P->is_sym) {
+            if (P->order[n] > 1) kpm_lmul(&P->B, P->coefs[n], P->order[n], vn, P->emin, P->emax, P->tmp); /* :324 */
+            else for (int i = 0; i < N; ++i) vn[i] *= P->coefs[n][0];                                       /* :328 */
+        } else {
+            if (P->order[n] > 1) { /* :450-460 */
+                kpm_lmul(&P->B, P->coefs[Lt - n - 1], P->order[Lt - n - 1], vn, P->emin, P->emax, P->tmp);
+                kpm_lmul(&P->B, P->coefs[n], P->order[n], vn, P->emin, P->emax, P->tmp);
+            } else {
+                double a = creal(P->coefs[n][0]) * creal(P->coefs[n][0]) + cimag(P->coefs[n][0]) * cimag(P->coefs[n][0]);
+                for (int i = 0; i < N; ++i) vn[i] *= a; /* :464 */
+            }
+        }
+        for (int i = 0; i < N; ++i) vm[i] = conj(vn[i]); /* :334 / :468 (for odd Lt the middle column conjugates itself, as in the reference) */
+    }
+    for (int i = 0; i < N; ++i) for (int l = 0; l < Lt; ++l) P->v[IDX(l, i, Lt)] = P->vt[(size_t)i + (size_t)N * l]; /* :338 */
+    orc_ft_inverse(P->fft, P->v, Lt, N);                                             /* :341 */
+    for (size_t k = 0; k < V; ++k) out[k] = creal(P->v[k]);                          /* :344 */
 }
 
 int orc_kpm_active(const orc_kpm *P) { return P->active; }

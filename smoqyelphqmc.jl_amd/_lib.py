@@ -89,6 +89,7 @@ SIGNATURES = {
     "smoqy_precond_set": [_p, _i, _i, _p, _p, _p],
     "smoqy_precond_apply_v": [_p, _i, _i],
     "smoqy_precond_apply": [_p, _p, _p, _i, _i],
+    "smoqy_precond_apply_real": [_p, _p, _p, _i, _i],
     "smoqy_cg_solve_v": [_p, _i, _i, _d, _i, _i, _p, _p],
     "smoqy_cg_solve": [_p, _p, _p, _i, _i, _i, _d, _i, _i, _p, _p],
     "smoqy_cg_config": [_p, _i],

@@ -356,12 +356,12 @@ def ldiv(*args, preconditioner=I, rng=None, maxiter=None, tol=None):
         up, P, u = args
         h = P.handle
         if isinstance(up, np.ndarray) and up.dtype == np.float64:
-            # the real-vector methods (KPMPreconditioner.jl:288-352, 417-485): P⁻¹ applied to a real vector through the same
-            # device path (the reference exploits the conjugate symmetry of the real input to visit half the frequencies; the
-            # result is the real part of the complex apply)
-            tmp = np.zeros((h.Lt, h.N, 1), dtype=np.complex128, order="F")
-            h.call("smoqy_precond_apply", L.ptr(tmp), L.ptr(L.as_state(np.asarray(u, dtype=np.complex128), h.Lt, h.N)), 0, 1)
-            up[...] = tmp[:, :, 0].real.reshape(up.shape, order="F")
+            # the real-vector methods (KPMPreconditioner.jl:288-352, 417-485): the device evaluates the frequencies ω < cld(Lτ, 2),
+            # mirrors them as complex conjugates (:334) and returns the real part of the back-transform (:344)
+            if not (up.flags.f_contiguous or up.ndim == 1) or up.size != h.Lt * h.N:
+                raise ValueError("output vector must be a float64 Fortran-contiguous (tau-fastest) array of Ltau*N elements")
+            uin = np.asfortranarray(np.asarray(u, dtype=np.float64))
+            h.call("smoqy_precond_apply_real", L.ptr(up), L.ptr(uin), 0, 1)
             return None
         uin = L.as_state(u, h.Lt, h.N)
         uout = L.writable_state(up, h.Lt, h.N)

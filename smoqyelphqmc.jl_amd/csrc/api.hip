@@ -1331,7 +1331,7 @@ int smoqy_precond_set(smoqy_ctx *c, int w, int active, const double *bounds, con
 // frequency-space part of ldiv!(u', P, u): v = FFT⁻¹ · (per-ω Chebyshev / Lτ) · FFT src, in the
 // twiddled basis (the θ phases are the caller's business).  part_rz, when given, receives the
 // Parseval partials of src·v per (system, ω).
-static int precond_core(smoqy_ctx *c, const double2 *src, double2 *v, const CgState *cg, double2 *part_rz)
+static int precond_core(smoqy_ctx *c, const double2 *src, double2 *v, const CgState *cg, double2 *part_rz, bool half = false)
 {
     const bool own = c->tf_ok && c->use_tfft;
     void *in[1] = {(void *)src}, *out[1] = {v};
@@ -1343,7 +1343,9 @@ static int precond_core(smoqy_ctx *c, const double2 *src, double2 *v, const CgSt
     else FFTCHK(c, rocfft_execute(c->plan_f_oop, in, out, c->fft_info));
     KpmArgs k = kpm_args(c, v, cg);
     k.part_rz = part_rz;
+    k.half = half ? 1 : 0;
     launch_cheb(c->stream, k, c->kg);                                                   // :381-400 (no transposes needed in this layout)
+    if (half) launch_conj_mirror(c->stream, v, c->g.Lt, c->g.N, c->g.nsys);             // :334 / :468
     if (own) {
         TfftArgs t = c->tf;
         t.src = v; t.dst = v; t.pre_tw = nullptr; t.post_tw = nullptr;
@@ -1352,14 +1354,14 @@ static int precond_core(smoqy_ctx *c, const double2 *src, double2 *v, const CgSt
     return check_launch(c, "precond_core");
 }
 
-static int precond_apply_dev(smoqy_ctx *c, double2 *out, const double2 *in)
+static int precond_apply_dev(smoqy_ctx *c, double2 *out, const double2 *in, bool half = false)
 {
     const Geometry &g = c->g;
     // walkers with an inactive preconditioner come out as the identity (:410) — the Chebyshev
     // kernel reduces to the 1/Lτ scale for them
     HIPCHK(c, hipMemcpyAsync(c->cg_v, in, c->vec_elems() * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
     launch_fft_twiddle(c->stream, c->cg_v, c->d_th, g.Lt, g.N, g.nsys, 0);   // θ  (FourierTransformer.jl:46; the 1/√Lτ pair is in the kernel's scale)
-    if (int rc = precond_core(c, c->cg_v, c->cg_v, nullptr, nullptr)) return rc;
+    if (int rc = precond_core(c, c->cg_v, c->cg_v, nullptr, nullptr, half)) return rc;
     launch_fft_twiddle(c->stream, c->cg_v, c->d_th, g.Lt, g.N, g.nsys, 1);   // θ⁻¹ (:61)
     HIPCHK(c, hipMemcpyAsync(out, c->cg_v, c->vec_elems() * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
     return check_launch(c, "precond_apply");
@@ -1381,6 +1383,28 @@ int smoqy_precond_apply(smoqy_ctx *c, void *out, const void *in, int sys0, int c
     if (int rc = upload_into(c, c->scr[1], in, sys0, count)) return rc;
     if (int rc = precond_apply_dev(c, c->scr[2], c->scr[1])) return rc;
     return download_from(c, c->scr[2], out, sys0, count);
+}
+
+// ldiv!(u′, P, u) for REAL vectors (Sym KPMPreconditioner.jl:288-352, Asym :417-485): u is promoted to complex (:306), only the
+// frequencies ω < cld(Lτ, 2) go through the Chebyshev kernels, the other half is filled in as their complex conjugate (:334) and
+// the real part of the back-transform is returned (:344).  Inactive preconditioner: copy (:349).
+int smoqy_precond_apply_real(smoqy_ctx *c, double *out, const double *in, int sys0, int count)
+{
+    CHECK_CTX(c);
+    CHECK_RANGE(c, sys0, count);
+    HIPCHK(c, hipSetDevice(c->device));
+    const Geometry &g = c->g;
+    const size_t n = (size_t)count * g.Lt * g.N;
+    if (int rc = ensure_stage_real(c, n)) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_stage_real, in, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_real_to_complex(c->stream, c->d_stage_real, c->d_stage, n);
+    launch_transpose_in(c->stream, c->d_stage, c->scr[1], g.Lt, g.N, g.nsys, sys0, count);
+    if (int rc = precond_apply_dev(c, c->scr[2], c->scr[1], true)) return rc;
+    launch_transpose_out(c->stream, c->scr[2], c->d_stage, g.Lt, g.N, g.nsys, sys0, count);
+    launch_complex_to_real(c->stream, c->d_stage, c->d_stage_real, n);
+    HIPCHK(c, hipMemcpyAsync(out, c->d_stage_real, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_launch(c, "precond_apply_real");
 }
 
 // ---- conjugate gradient ---------------------------------------------------------------------------

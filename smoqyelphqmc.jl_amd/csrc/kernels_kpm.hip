@@ -319,6 +319,7 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
     double2 *vo = (k.vout ? k.vout : k.v) + ((size_t)om * k.nsys + sys) * N;
     double2 *prz = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride + om : nullptr;
     const int Lo2 = (Lt + 1) / 2;
+    if (k.half && om >= Lo2) return;
     const int slot = SYM ? (om >= Lo2 ? Lt - om - 1 : om) : om;  // :387
     const bool act = k.active[w] != 0;                           // inactive preconditioner = identity (:410)
     const int n = act ? k.order[(size_t)w * k.nslot + slot] : 1;
@@ -407,39 +408,56 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
 // or 1 (L = 2) exchanges per step — two instead of four on the honeycomb lattice.  The fused C₁D̄C₁ stage
 // recomputes the mate's intermediate value (same bond, mate's d̄) instead of fetching it.  Exchanges ping-pong
 // between two LDS images, so each costs a single barrier.  Arithmetic per site is identical to cheb_fast_kernel.
-template <int NCOL>
-__global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
+// P = 2 ("paired"): one workgroup carries BOTH frequencies ω and Lτ-1-ω of a system.  They share the expansion slot
+// (n′ = Lτ-ω+1 at KPMPreconditioner.jl:387), i.e. order, coefficients, bounds and B̄, so a lane runs two independent
+// recurrences against the same barriers: twice the instruction-level parallelism per exchange, half the workgroups.
+template <int NCOL, int P>
+__global__ void __launch_bounds__(P == 2 ? 512 : 1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
 {
     static_assert(NCOL >= 2, "single-colour decompositions use cheb_fast_kernel");
     constexpr int Q = NCOL >= 3 ? 1 : 0, CL = NCOL - 1;
     extern __shared__ double2 lds[];
     __shared__ double red[17];
     const int N = k.N, Lt = k.Lt, T = blockDim.x, j = threadIdx.x;
-    double2 *Wb[2] = {lds, lds + 2 * T};
-    double2 *CF = lds + 4 * T;
+    double2 *Wb[2] = {lds, lds + 2 * P * T};
+    double2 *CF = lds + 4 * P * T;
     const int sys = blockIdx.x % k.nsys, rank = blockIdx.x / k.nsys;
-    const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);  // heaviest orders first, rank-major
+    const int Lo2 = (Lt + 1) / 2;
+    // heaviest orders first, rank-major (slot 0 carries the longest chain)
+    int om[P];
+    if (P == 1) om[0] = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);
+    else { om[0] = rank; om[P - 1] = Lt - 1 - rank; }
+    const bool two = (P == 2) && om[P - 1] != om[0];  // odd Lτ: the middle frequency is its own mirror
     const int w = sys / k.nrhs;
     if (k.cg && k.cg[sys].done) return;
-    const double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
-    double2 *vo = (k.vout ? k.vout : k.v) + ((size_t)om * k.nsys + sys) * N;
-    double2 *prz = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride + om : nullptr;
-    const int Lo2 = (Lt + 1) / 2;
-    const int slot = om >= Lo2 ? Lt - om - 1 : om;  // :387
+    if (k.half && om[0] >= Lo2) return;  // only launched with P = 1 in this mode
+    const double2 *v[P];
+    double2 *vo[P], *prz[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        v[p] = k.v + ((size_t)om[p] * k.nsys + sys) * N;
+        vo[p] = (k.vout ? k.vout : k.v) + ((size_t)om[p] * k.nsys + sys) * N;
+        prz[p] = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride + om[p] : nullptr;
+    }
+    const int slot = om[0] >= Lo2 ? Lt - om[0] - 1 : om[0];  // :387
     const bool act = k.active[w] != 0;
     const int n = act ? k.order[(size_t)w * k.nslot + slot] : 1;
     const double2 *coefs = k.coefs + ((size_t)w * k.nslot + slot) * k.maxorder;
     if (n <= 1) {  // single-term expansion: scalar multiply (:398)
         const double f = k.scale * (act ? coefs[0].x : 1.0);
-        double acc = 0.0;
-        for (int i = j; i < N; i += T) {
-            const double2 x = v[i];
-            vo[i] = make_double2(f * x.x, f * x.y);
-            acc += f * (x.x * x.x + x.y * x.y);
-        }
-        if (prz) {
-            const double t = block_sum_real(acc, red);
-            if (j == 0) *prz = make_double2(t, 0.0);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (p == 1 && !two) break;
+            double acc = 0.0;
+            for (int i = j; i < N; i += T) {
+                const double2 x = v[p][i];
+                vo[p][i] = make_double2(f * x.x, f * x.y);
+                acc += f * (x.x * x.x + x.y * x.y);
+            }
+            if (prz[p]) {
+                const double t = block_sum_real(acc, red);
+                if (j == 0) *prz[p] = make_double2(t, 0.0);
+            }
         }
         return;
     }
@@ -456,7 +474,9 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
     const double2 *pcs = kg.pcs + (size_t)w * kg.ptotal;
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) { px[c] = py[c] = j; cx[c] = cy[c] = make_double2(1.0, 0.0); }
-    double2 ax = make_double2(0.0, 0.0), ay = ax;
+    double2 ax[P], ay[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) ax[p] = ay[p] = make_double2(0.0, 0.0);
     if (on) {
         sx = own[j]; sy = own[T + j];
         oy = (sy != sx) ? T + j : j;
@@ -469,124 +489,179 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
             cx[c] = pcs[own[(4 + 4 * c + 2) * T + j]];
             cy[c] = pcs[own[(4 + 4 * c + 3) * T + j]];
         }
-        ax = v[sx]; ay = v[sy];
+#pragma unroll
+        for (int p = 0; p < P; ++p) { ax[p] = v[p][sx]; ay[p] = v[p][sy]; }
     }
-    const double2 v0x = ax, v0y = ay;
+    double2 v0x[P], v0y[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { v0x[p] = ax[p]; v0y[p] = ay[p]; }
     for (int i = j; i < n; i += T) CF[i] = coefs[i];  // coefficients in LDS: no global load inside the chain
     int buf = 0;
-    // own values -> LDS image, barrier, the two mates of colour c_ come back in (mx_, my_)
-#define OWN_EXCHANGE(c_, mx_, my_)                       \
-    {                                                    \
-        double2 *Wc = Wb[buf];                           \
-        buf ^= 1;                                        \
-        if (on) { Wc[ox] = ax; Wc[oy] = ay; }            \
-        __syncthreads();                                 \
-        mx_ = Wc[px[c_]];                                \
-        my_ = Wc[py[c_]];                                \
+    // own values -> LDS image (one per frequency), ONE barrier, the two mates of colour c_ come back in (mx_, my_)
+#define OWN_EXCHANGE(c_, mx_, my_)                                            \
+    {                                                                         \
+        double2 *Wc = Wb[buf];                                                \
+        buf ^= 1;                                                             \
+        if (on) {                                                             \
+            _Pragma("unroll") for (int p = 0; p < P; ++p) {                   \
+                Wc[2 * T * p + ox] = ax[p];                                   \
+                Wc[2 * T * p + oy] = ay[p];                                   \
+            }                                                                 \
+        }                                                                     \
+        __syncthreads();                                                      \
+        _Pragma("unroll") for (int p = 0; p < P; ++p) {                       \
+            mx_[p] = Wc[2 * T * p + px[c_]];                                  \
+            my_[p] = Wc[2 * T * p + py[c_]];                                  \
+        }                                                                     \
     }
-#define OWN_STAGE(c_)                                                        \
-    {                                                                        \
-        if (c_ == Q) {                                                       \
-            const double2 t_ = lin2(cx[Q].x, ax, cx[Q].y, ay);               \
-            ay = lin2(cx[Q].x, ay, cx[Q].y, ax);                             \
-            ax = t_;                                                         \
-        } else {                                                             \
-            double2 mx_, my_;                                                \
-            OWN_EXCHANGE(c_, mx_, my_)                                       \
-            ax = lin2(cx[c_].x, ax, cx[c_].y, mx_);                          \
-            ay = lin2(cy[c_].x, ay, cy[c_].y, my_);                          \
-        }                                                                    \
+#define OWN_STAGE(c_)                                                            \
+    {                                                                            \
+        if (c_ == Q) {                                                           \
+            _Pragma("unroll") for (int p = 0; p < P; ++p) {                      \
+                const double2 t_ = lin2(cx[Q].x, ax[p], cx[Q].y, ay[p]);         \
+                ay[p] = lin2(cx[Q].x, ay[p], cx[Q].y, ax[p]);                    \
+                ax[p] = t_;                                                      \
+            }                                                                    \
+        } else {                                                                 \
+            double2 mx_[P], my_[P];                                              \
+            OWN_EXCHANGE(c_, mx_, my_)                                           \
+            _Pragma("unroll") for (int p = 0; p < P; ++p) {                      \
+                ax[p] = lin2(cx[c_].x, ax[p], cx[c_].y, mx_[p]);                 \
+                ay[p] = lin2(cy[c_].x, ay[p], cy[c_].y, my_[p]);                 \
+            }                                                                    \
+        }                                                                        \
     }
     // into the basis α̃ = C_L α (see cheb_fast_kernel)
     {
-        double2 mx, my;
+        double2 mx[P], my[P];
         OWN_EXCHANGE(CL, mx, my)
-        ax = lin2(cx[CL].x, ax, cx[CL].y, mx);
-        ay = lin2(cy[CL].x, ay, cy[CL].y, my);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            ax[p] = lin2(cx[CL].x, ax[p], cx[CL].y, mx[p]);
+            ay[p] = lin2(cy[CL].x, ay[p], cy[CL].y, my[p]);
+        }
     }
     const double qcx = cx[CL].x * cx[CL].x + cx[CL].y * cx[CL].y, qsx = 2.0 * cx[CL].x * cx[CL].y;  // C_L²
     const double qcy = cy[CL].x * cy[CL].x + cy[CL].y * cy[CL].y, qsy = 2.0 * cy[CL].x * cy[CL].y;
-    double2 a1x = ax, a1y = ay, a2x = make_double2(0, 0), a2y = a2x, accx = a2x, accy = a2x;
+    double2 a1x[P], a1y[P], a2x[P], a2y[P], accx[P], accy[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        a1x[p] = ax[p]; a1y[p] = ay[p];
+        a2x[p] = a2y[p] = accx[p] = accy[p] = make_double2(0.0, 0.0);
+    }
     __syncthreads();  // CF visible
     for (int kk = 1; kk < n; ++kk) {
         const double2 ck = CF[kk];
 #pragma unroll
         for (int c = NCOL - 2; c >= 1; --c) OWN_STAGE(c)
         if (Q == 0) {  // C₁ D̄ C₁ in registers
-            double2 x = lin2(cx[0].x, ax, cx[0].y, ay), y = lin2(cx[0].x, ay, cx[0].y, ax);
-            x = make_double2(dx * x.x, dx * x.y);
-            y = make_double2(dy * y.x, dy * y.y);
-            ax = lin2(cx[0].x, x, cx[0].y, y);
-            ay = lin2(cx[0].x, y, cx[0].y, x);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                double2 x = lin2(cx[0].x, ax[p], cx[0].y, ay[p]), y = lin2(cx[0].x, ay[p], cx[0].y, ax[p]);
+                x = make_double2(dx * x.x, dx * x.y);
+                y = make_double2(dy * y.x, dy * y.y);
+                ax[p] = lin2(cx[0].x, x, cx[0].y, y);
+                ay[p] = lin2(cx[0].x, y, cx[0].y, x);
+            }
         } else {       // one exchange; the mate's value after C₁ and D̄ is recomputed here (same bond, its own d̄)
-            double2 mx, my;
+            double2 mx[P], my[P];
             OWN_EXCHANGE(0, mx, my)
-            double2 x = lin2(cx[0].x, ax, cx[0].y, mx), xm = lin2(cx[0].x, mx, cx[0].y, ax);
-            double2 y = lin2(cy[0].x, ay, cy[0].y, my), ym = lin2(cy[0].x, my, cy[0].y, ay);
-            x = make_double2(dx * x.x, dx * x.y);
-            xm = make_double2(dmx * xm.x, dmx * xm.y);
-            y = make_double2(dy * y.x, dy * y.y);
-            ym = make_double2(dmy * ym.x, dmy * ym.y);
-            ax = lin2(cx[0].x, x, cx[0].y, xm);
-            ay = lin2(cy[0].x, y, cy[0].y, ym);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                double2 x = lin2(cx[0].x, ax[p], cx[0].y, mx[p]), xm = lin2(cx[0].x, mx[p], cx[0].y, ax[p]);
+                double2 y = lin2(cy[0].x, ay[p], cy[0].y, my[p]), ym = lin2(cy[0].x, my[p], cy[0].y, ay[p]);
+                x = make_double2(dx * x.x, dx * x.y);
+                xm = make_double2(dmx * xm.x, dmx * xm.y);
+                y = make_double2(dy * y.x, dy * y.y);
+                ym = make_double2(dmy * ym.x, dmy * ym.y);
+                ax[p] = lin2(cx[0].x, x, cx[0].y, xm);
+                ay[p] = lin2(cy[0].x, y, cy[0].y, ym);
+            }
         }
 #pragma unroll
         for (int c = 1; c <= NCOL - 2; ++c) OWN_STAGE(c)
-        double2 xi, xj;
+        double2 xi[P], xj[P];
         {
-            double2 mx, my;
+            double2 mx[P], my[P];
             OWN_EXCHANGE(CL, mx, my)
-            xi = lin2(qcx, ax, qsx, mx);
-            xj = lin2(qcy, ay, qsy, my);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                xi[p] = lin2(qcx, ax[p], qsx, mx[p]);
+                xj[p] = lin2(qcy, ay[p], qsy, my[p]);
+            }
         }
         // three-term recurrence on the lane's own sites (kpm_lmul!)
-        double2 a3x, a3y;
-        if (kk == 1) {
-            a3x = make_double2((xi.x - avg * a1x.x) * imag_, (xi.y - avg * a1x.y) * imag_);
-            a3y = make_double2((xj.x - avg * a1y.x) * imag_, (xj.y - avg * a1y.y) * imag_);
-            const double2 c0 = CF[0];
-            const double2 t0x = cmulk(c0, a1x), t0y = cmulk(c0, a1y), t1x = cmulk(ck, a3x), t1y = cmulk(ck, a3y);
-            accx = make_double2(t0x.x + t1x.x, t0x.y + t1x.y);
-            accy = make_double2(t0y.x + t1y.x, t0y.y + t1y.y);
-        } else {
-            a3x = make_double2(2.0 * (xi.x - avg * a2x.x) * imag_ - a1x.x, 2.0 * (xi.y - avg * a2x.y) * imag_ - a1x.y);
-            a3y = make_double2(2.0 * (xj.x - avg * a2y.x) * imag_ - a1y.x, 2.0 * (xj.y - avg * a2y.y) * imag_ - a1y.y);
-            const double2 tx = cmulk(ck, a3x), ty = cmulk(ck, a3y);
-            accx = make_double2(accx.x + tx.x, accx.y + tx.y);
-            accy = make_double2(accy.x + ty.x, accy.y + ty.y);
-            a1x = a2x; a1y = a2y;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            double2 a3x, a3y;
+            if (kk == 1) {
+                a3x = make_double2((xi[p].x - avg * a1x[p].x) * imag_, (xi[p].y - avg * a1x[p].y) * imag_);
+                a3y = make_double2((xj[p].x - avg * a1y[p].x) * imag_, (xj[p].y - avg * a1y[p].y) * imag_);
+                const double2 c0 = CF[0];
+                const double2 t0x = cmulk(c0, a1x[p]), t0y = cmulk(c0, a1y[p]), t1x = cmulk(ck, a3x), t1y = cmulk(ck, a3y);
+                accx[p] = make_double2(t0x.x + t1x.x, t0x.y + t1x.y);
+                accy[p] = make_double2(t0y.x + t1y.x, t0y.y + t1y.y);
+            } else {
+                a3x = make_double2(2.0 * (xi[p].x - avg * a2x[p].x) * imag_ - a1x[p].x, 2.0 * (xi[p].y - avg * a2x[p].y) * imag_ - a1x[p].y);
+                a3y = make_double2(2.0 * (xj[p].x - avg * a2y[p].x) * imag_ - a1y[p].x, 2.0 * (xj[p].y - avg * a2y[p].y) * imag_ - a1y[p].y);
+                const double2 tx = cmulk(ck, a3x), ty = cmulk(ck, a3y);
+                accx[p] = make_double2(accx[p].x + tx.x, accx[p].y + tx.y);
+                accy[p] = make_double2(accy[p].x + ty.x, accy[p].y + ty.y);
+                a1x[p] = a2x[p]; a1y[p] = a2y[p];
+            }
+            a2x[p] = a3x; a2y[p] = a3y;
+            ax[p] = a3x; ay[p] = a3y;
         }
-        a2x = a3x; a2y = a3y;
-        ax = a3x; ay = a3y;
     }
     // back to the original basis: C_L⁻¹ on the accumulated sum
     {
-        ax = accx; ay = accy;
-        double2 mx, my;
+#pragma unroll
+        for (int p = 0; p < P; ++p) { ax[p] = accx[p]; ay[p] = accy[p]; }
+        double2 mx[P], my[P];
         OWN_EXCHANGE(CL, mx, my)
         const double idx_ = 1.0 / (cx[CL].x * cx[CL].x - cx[CL].y * cx[CL].y), idy_ = 1.0 / (cy[CL].x * cy[CL].x - cy[CL].y * cy[CL].y);
-        ax = make_double2((cx[CL].x * accx.x - cx[CL].y * mx.x) * idx_, (cx[CL].x * accx.y - cx[CL].y * mx.y) * idx_);
-        ay = make_double2((cy[CL].x * accy.x - cy[CL].y * my.x) * idy_, (cy[CL].x * accy.y - cy[CL].y * my.y) * idy_);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            ax[p] = make_double2((cx[CL].x * accx[p].x - cx[CL].y * mx[p].x) * idx_, (cx[CL].x * accx[p].y - cx[CL].y * mx[p].y) * idx_);
+            ay[p] = make_double2((cy[CL].x * accy[p].x - cy[CL].y * my[p].x) * idy_, (cy[CL].x * accy[p].y - cy[CL].y * my[p].y) * idy_);
+        }
     }
 #undef OWN_STAGE
 #undef OWN_EXCHANGE
-    double2 acc = make_double2(0.0, 0.0);
-    if (on) {
-        ax = make_double2(k.scale * ax.x, k.scale * ax.y);
-        ay = make_double2(k.scale * ay.x, k.scale * ay.y);
-        vo[sx] = ax;
-        acc.x += v0x.x * ax.x + v0x.y * ax.y;
-        acc.y += v0x.x * ax.y - v0x.y * ax.x;
-        if (sy != sx) {
-            vo[sy] = ay;
-            acc.x += v0y.x * ay.x + v0y.y * ay.y;
-            acc.y += v0y.x * ay.y - v0y.y * ay.x;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (p == 1 && !two) break;
+        double2 acc = make_double2(0.0, 0.0);
+        if (on) {
+            const double2 bx = make_double2(k.scale * ax[p].x, k.scale * ax[p].y), by = make_double2(k.scale * ay[p].x, k.scale * ay[p].y);
+            vo[p][sx] = bx;
+            acc.x += v0x[p].x * bx.x + v0x[p].y * bx.y;
+            acc.y += v0x[p].x * bx.y - v0x[p].y * bx.x;
+            if (sy != sx) {
+                vo[p][sy] = by;
+                acc.x += v0y[p].x * by.x + v0y[p].y * by.y;
+                acc.y += v0y[p].x * by.y - v0y[p].y * by.x;
+            }
+        }
+        if (prz[p]) {
+            const double2 t = block_sum_cplx(acc, red);
+            if (j == 0) *prz[p] = t;
         }
     }
-    if (prz) {
-        const double2 t = block_sum_cplx(acc, red);
-        if (j == 0) *prz = t;
+}
+
+// A/B switch for measurements.  OFF by default: measured on MI355X (honeycomb L = 16, Lτ = 128) the paired kernel takes 33.5 µs
+// against 23.7 µs at 16 systems and 31.0 against 21.7 µs at one system — the two longest chains (ω = 0 and Lτ-1, order 41 each)
+// land in the same workgroup and a step with twice the arithmetic costs 1.42x, i.e. a step is 58 % synchronisation latency and
+// 42 % instruction issue; the kernel's duration IS its longest chain, so halving the workgroups buys nothing.
+static int cheb_pair_enabled()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("SMOQY_CHEB_PAIR");
+        v = (e && e[0] == '1') ? 1 : 0;
     }
+    return v;
 }
 
 static int cheb_own_enabled()
@@ -676,6 +751,7 @@ __global__ void __launch_bounds__(kThreads) cheb_generic_kernel(KpmArgs k)
     const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);
     const int w = sys / k.nrhs;
     if (k.cg && k.cg[sys].done) return;
+    if (k.half && om >= (Lt + 1) / 2) return;
     const double *dbar = k.dbar + (size_t)w * N, *cbar = k.cbar + (size_t)w * k.Nh, *sbar = k.sbar + (size_t)w * k.Nh;
     const double emin = k.bounds[2 * w], emax = k.bounds[2 * w + 1];
     const double avg = 0.5 * (emax + emin), mag = 0.5 * (emax - emin);
@@ -727,8 +803,14 @@ void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
         const dim3 grid((unsigned)(k.Lt * k.nsys)), block((unsigned)kg.threads);
 #define CHEB_LAUNCH(S_, C_) hipLaunchKernelGGL((cheb_fast_kernel<S_, C_>), grid, block, lds, st, k, kg)
         if (k.is_sym && k.ncol >= 2 && k.ncol <= 6 && kg.own && cheb_own_enabled()) {
-            const size_t olds = sizeof(double2) * (4 * (size_t)kg.threads + (size_t)k.maxorder);
-#define OWN_LAUNCH(C_) hipLaunchKernelGGL((cheb_own_kernel<C_>), grid, block, olds, st, k, kg)
+            const bool pair = cheb_pair_enabled() && kg.threads <= 512 && !k.half;
+            const size_t olds = sizeof(double2) * (4 * (size_t)kg.threads * (pair ? 2 : 1) + (size_t)k.maxorder);
+            const dim3 pgrid((unsigned)(((k.Lt + 1) / 2) * k.nsys));
+#define OWN_LAUNCH(C_)                                                                          \
+    {                                                                                           \
+        if (pair) hipLaunchKernelGGL((cheb_own_kernel<C_, 2>), pgrid, block, olds, st, k, kg);  \
+        else hipLaunchKernelGGL((cheb_own_kernel<C_, 1>), grid, block, olds, st, k, kg);        \
+    }
             switch (k.ncol) {
                 case 2: OWN_LAUNCH(2); break;
                 case 3: OWN_LAUNCH(3); break;
@@ -759,6 +841,26 @@ void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
         const size_t lds = k.scratch ? 0 : sizeof(double2) * 4 * (size_t)k.N;
         hipLaunchKernelGGL(cheb_generic_kernel, dim3((unsigned)(k.Lt * k.nsys)), dim3(kThreads), lds, st, k);
     }
+}
+
+__global__ void conj_mirror_kernel(double2 *v, int Lt, int N, int nsys)
+{
+    const size_t per = (size_t)nsys * N;
+    const int Lo2 = (Lt + 1) / 2;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per * Lo2; idx += (size_t)gridDim.x * blockDim.x) {
+        const int om = (int)(idx / per);
+        const size_t r = idx - (size_t)om * per;
+        const double2 x = v[(size_t)om * per + r];
+        v[(size_t)(Lt - 1 - om) * per + r] = make_double2(x.x, -x.y);
+    }
+}
+
+void launch_conj_mirror(hipStream_t st, double2 *v, int Lt, int N, int nsys)
+{
+    const size_t tot = (size_t)nsys * N * ((Lt + 1) / 2);
+    int blocks = (int)((tot + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(conj_mirror_kernel, dim3(blocks), dim3(256), 0, st, v, Lt, N, nsys);
 }
 
 // ---------------------------------------------------------------------------------------------

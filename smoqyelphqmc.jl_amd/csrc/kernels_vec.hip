@@ -6,6 +6,8 @@
 // workgroup re-reduces in the same order, so no atomics and no run-to-run jitter.
 #include "smoqy_internal.h"
 
+#include <algorithm>
+
 namespace smoqy {
 
 __device__ __forceinline__ double wsum(double v)
@@ -230,6 +232,24 @@ void launch_lambda_apply(hipStream_t st, int op, double2 *out, const double2 *in
     int blocks = (int)((tot + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(lambda_apply_kernel, dim3(blocks), dim3(256), 0, st, op, out, in, Lam, Lt, N, nsys, nrhs, wfixed);
+}
+
+// real <-> complex staging of the real-vector entry points (KPMPreconditioner.jl:306 `mul!(v, U, u)` with real u, :344 `real(v)`)
+__global__ void real_to_complex_kernel(const double *__restrict__ re, double2 *__restrict__ z, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) z[i] = make_double2(re[i], 0.0);
+}
+__global__ void complex_to_real_kernel(const double2 *__restrict__ z, double *__restrict__ re, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) re[i] = z[i].x;
+}
+void launch_real_to_complex(hipStream_t st, const double *re, double2 *z, size_t n)
+{
+    hipLaunchKernelGGL(real_to_complex_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, re, z, n);
+}
+void launch_complex_to_real(hipStream_t st, const double2 *z, double *re, size_t n)
+{
+    hipLaunchKernelGGL(complex_to_real_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, z, re, n);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -98,6 +98,8 @@ struct KpmArgs {
     double2 *part_rz;                   // optional [nsys][rz_stride]: Parseval partial of r·z per (system, ω)
     int rz_stride;
     double scale;                       // output scale (1/Lτ: rocFFT's inverse is unnormalised)
+    int half;                           // real-vector ldiv! (KPMPreconditioner.jl:312 / :444): only ω < cld(Lτ, 2) are evaluated,
+                                        // launch_conj_mirror fills in the rest
 };
 
 // geometry of the KPM fast path: per-colour bond lists padded with identity self bonds (i, i) so
@@ -171,6 +173,11 @@ void launch_tau_means(hipStream_t st, const KpmGeom &kg, const double *expV, con
 // alpha/beta: [nw][1024] each; randvec: [nw][N]
 void launch_lanczos(hipStream_t st, const KpmArgs &k, const KpmGeom &kg, int w0, int nw, const double *randvec, int nsteps, double *alpha, double *beta, bool use_BtB);
 void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg);
+// v[Lτ-1-ω] = conj(v[ω]) for ω < cld(Lτ, 2) (KPMPreconditioner.jl:334 / :468; the middle frequency of an odd Lτ conjugates itself)
+void launch_conj_mirror(hipStream_t st, double2 *v, int Lt, int N, int nsys);
+// boundary conversion of real vectors: host layout (Lτ x N x count doubles) <-> complex host-layout staging
+void launch_real_to_complex(hipStream_t st, const double *re, double2 *z, size_t n);
+void launch_complex_to_real(hipStream_t st, const double2 *z, double *re, size_t n);
 
 // CG kernels (kernels_vec.hip): the loop runs in the twiddled basis, see there
 struct CgArgs {

@@ -248,7 +248,9 @@ def test_checkerboard_entry_points(setup):
 
 @pytest.mark.parametrize("is_sym", [True, False])
 def test_kpm_ldiv_on_a_real_vector(is_sym):
-    """The real-vector ldiv! methods (src/KPMPreconditioner.jl:288-352, 417-485): same operator applied to a real vector."""
+    """The real-vector ldiv! methods (src/KPMPreconditioner.jl:288-352, 417-485) through the mirror: the device evaluates half the
+    frequencies and mirrors the rest; compared with the complex method on the same (promoted) vector.  Oracle parity of the
+    device method itself: tests/test_gpu_parity.py::test_kpm_real_vector_apply."""
     m = lat.holstein_honeycomb(4, 10)  # N = 32 > 20 Lanczos steps
     fdm = (sq.SymFermionDetMatrix if is_sym else sq.AsymFermionDetMatrix)(m.fpi, maxiter=5000, tol=1e-10)
     P = sq.KPMPreconditioner(fdm, rng=np.random.default_rng(5))
@@ -260,6 +262,5 @@ def test_kpm_ldiv_on_a_real_vector(is_sym):
     uc = np.asfortranarray(u.astype(complex))
     upc = np.zeros_like(uc)
     sq.ldiv(upc, P, uc)
-    assert np.abs(up - upc.real).max() < 1e-15 * np.abs(upc).max()
-    if is_sym:  # P⁻¹ is a real symmetric operator for real fields: nothing is lost in the real part
-        assert np.abs(upc.imag).max() < 1e-12 * np.abs(upc.real).max()
+    assert np.abs(up - upc.real).max() < 1e-13 * np.abs(upc).max()
+    assert np.abs(upc.imag).max() < 1e-12 * np.abs(upc.real).max()  # the complex method keeps a real vector real (Sym and Asym)

@@ -33,6 +33,8 @@ def model_of(kind, walker=0):
         return lat.ossh_square(6, 12, walker=walker)
     if kind == "chain_L24":
         return lat.bssh_chain(24, 16, walker=walker)
+    if kind == "chain_odd":
+        return lat.bssh_chain(24, 9, walker=walker)
     raise KeyError(kind)
 
 
@@ -265,6 +267,31 @@ def test_kpm_preconditioner_state_and_apply(kind, is_sym, generic):
     p.h.call("smoqy_precond_apply", L.ptr(out), L.ptr(v), 0, 2)
     for s in range(2):
         assert relerr(out[:, :, s], P.apply(v[:, :, s])) < 1e-11
+
+
+@pytest.mark.parametrize("kind", ["honeycomb_L4", "square_L6", "chain_odd"])  # Ltau = 40, 12, 9 (odd: the middle frequency mirrors itself)
+@pytest.mark.parametrize("is_sym", [True, False])
+@pytest.mark.parametrize("generic", [False, True])
+def test_kpm_real_vector_apply(kind, is_sym, generic):
+    """smoqy_precond_apply_real against the oracle's restatement of the real-vector ldiv! methods
+    (src/KPMPreconditioner.jl:288-352 Sym, :417-485 Asym): half the frequencies, conjugate mirror, real part."""
+    p = Problem(kind, is_sym, nwalkers=1, nrhs=2)
+    p.h.call("smoqy_precond_force_generic", int(generic))
+    rv = np.random.default_rng(8).standard_normal(p.N)
+    P = orc.OracleKPM(p.oracles[0])
+    P.update(rv)
+    p.h.call("smoqy_precond_update", 0, L.ptr(rv))
+    assert P.active
+    u = np.asfortranarray(np.random.default_rng(19).standard_normal((p.Lt, p.N, 2)))
+    out = np.zeros_like(u)
+    p.h.call("smoqy_precond_apply_real", L.ptr(out), L.ptr(u), 0, 2)
+    for s in range(2):
+        want = P.apply_real(u[:, :, s])
+        assert np.abs(out[:, :, s] - want).max() < 1e-11 * np.abs(want).max()
+    # a sub-range call touches only its own system
+    one = np.zeros((p.Lt, p.N, 1), order="F")
+    p.h.call("smoqy_precond_apply_real", L.ptr(one), L.ptr(np.asfortranarray(u[:, :, 1:2])), 1, 1)
+    assert np.abs(one[:, :, 0] - out[:, :, 1]).max() < 1e-13 * np.abs(out).max()
 
 
 @pytest.mark.parametrize("is_sym", [True, False])

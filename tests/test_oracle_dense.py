@@ -274,3 +274,43 @@ def test_preconditioned_cg_same_solution_fewer_iterations(is_sym):
     herm_tol = 1e-10 if is_sym else 5e-2
     assert abs(np.vdot(u, P.apply(v)) - np.vdot(P.apply(u), v)) < herm_tol * abs(np.vdot(u, P.apply(v)))
     assert np.vdot(u, P.apply(u)).real > 0
+
+
+@pytest.mark.parametrize("is_sym", [True, False])
+@pytest.mark.parametrize("kind", ["honeycomb", "chain_odd"])
+def test_kpm_real_vector_method(kind, is_sym):
+    """ldiv!(u′, P, u) for REAL vectors (src/KPMPreconditioner.jl:288-352 Sym, :417-485 Asym): half the frequencies are evaluated,
+    the other half is their complex conjugate, the result is the real part of the back-transform.
+    (i) For a real input the antiperiodic transform obeys v[Lτ-1-ω] = conj(v[ω]) and the per-frequency operator of ω and Lτ-1-ω
+        is the same real matrix (Sym: real coefficients in real B̄; Asym: p_c(B̄)·p_c̄(B̄) = |p_c(B̄)|²), so the real method must
+        equal the complex method applied to (u + 0i), whose imaginary part must vanish — checked, not assumed, for both types.
+    (ii) Known answer: for τ-independent fields P⁻¹ is the exact inverse of MᵀM up to the Chebyshev truncation, also on real vectors.
+    Odd Lτ exercises the middle frequency, which the reference conjugates onto itself (:334)."""
+    if kind == "honeycomb":
+        m = lat.holstein_honeycomb(2, 12)
+    else:
+        m = lat.bssh_chain(6, 9)  # Lτ = 9: odd
+    nt, perm, colors = lat.checkerboard_decomposition(m.fpi.neighbor_table)
+    # τ-independent fields so that (ii) holds
+    m.fpi.V[:, :] = m.fpi.V[:, :1]
+    m.fpi.t[:, :] = m.fpi.t[:, :1]
+    expV, ch, sh = orc.update_fields(m.fpi.V, m.fpi.t, perm, m.fpi.dtau, is_sym)
+    Lt, N = expV.shape
+    f = orc.OracleFDM(nt, expV, ch, sh, is_sym)
+    P = orc.OracleKPM(f, a1=8.0, a2=8.0)
+    P.update(np.random.default_rng(21).standard_normal(N))
+    assert P.active
+    u = np.asfortranarray(np.random.default_rng(22).standard_normal((Lt, N)))
+    got = P.apply_real(u)
+    full = P.apply(u.astype(complex))
+    scale = np.abs(full).max()
+    assert np.abs(full.imag).max() < 1e-13 * scale          # (i) the complex method keeps a real vector real
+    np.testing.assert_allclose(got, full.real, atol=1e-13 * scale)
+    M, _ = dense.dense_M(nt, expV, ch, sh, is_sym)
+    A = (M.conj().T @ M).real
+    want = np.linalg.solve(A, dense.vec(u.astype(complex)).real)
+    tol = 5e-6 if is_sym else 5e-2  # Asym: conj(coefs) as a polynomial in B̄ instead of B̄ᵀ, see the complex test above
+    np.testing.assert_allclose(dense.vec(got.astype(complex)).real, want, atol=tol * np.abs(want).max())
+    # inactive preconditioner: plain copy (:349 / :480)
+    Q = orc.OracleKPM(f)
+    np.testing.assert_array_equal(Q.apply_real(u), u)
