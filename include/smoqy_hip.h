@@ -15,7 +15,12 @@
  *     fields are Ltau x N / Ltau x Nh float64.  Indices are Int64 and 1-based.
  *   - the library never keeps a host pointer after a call returns.
  *   - one in-flight call per handle; a handle owns one HIP stream.
- *   - only real matrix-element type T = Float64 is implemented (is_complex_T must be 0).
+ *   - matrix-element type T: Float64 (is_complex_T = 0) or ComplexF64 (is_complex_T = 1, complex hoppings).  With complex T
+ *     the hopping-derived arrays cross the boundary as complex128 (interleaved re, im) exactly where the reference holds a
+ *     Matrix{T}: cosh_dtt / sinh_dtt of smoqy_update_fields / smoqy_get_fields (Ltau x Nh), t of
+ *     smoqy_update_from_path_integral[_all] (Nh x Ltau), and the Lanczos start vectors of smoqy_precond_update[_all] (N complex
+ *     deviates per walker: randn! on a Vector{ComplexF64}).  V, expV and Λ stay real.  Complex handles run on the generic kernels;
+ *     the force terms and the device-side update! from phonon fields are real-T only and return an error for them.
  *
  * A handle carries `nwalkers` independent field sets (one FermionDetMatrix + Λ + KPM
  * preconditioner each) times `nrhs` right-hand sides per walker; system s belongs to walker
@@ -50,8 +55,9 @@ enum { SMOQY_OP_M = 0, SMOQY_OP_MT = 1, SMOQY_OP_MTM = 2, SMOQY_OP_MMT = 3 };
  * checkerboard decomposition, which is an INPUT: neighbor_table is 2 x Nh (1-based, colour
  * sorted), color_ranges is 2 x ncolors (1-based inclusive first/last bond of each colour).
  * Bonds of one colour must touch disjoint sites (checked).  device_id < 0 = current device. */
-/* Limits: real hoppings only (is_complex_T must be 0).  Lattices of more than 2556 sites run on generic kernels that stage
- * their time slices in global memory instead of LDS (functional, not tuned). */
+/* Lattices of more than 2556 sites run on generic kernels that stage their time slices in global memory instead of LDS
+ * (functional, not tuned).  is_complex_T != 0 selects T = ComplexF64: bond factor [[c, s], [conj(s), c]]
+ * (src/checkerboard_matrix_multiply.jl:60-68), s = sign(conj t) sinh(Δτ'|t|) (src/FermionDetMatrix.jl:224-231). */
 int smoqy_create(smoqy_ctx **out, int Ltau, int N, int Nh, int ncolors, const int64_t *neighbor_table,
                  const int64_t *color_ranges, int is_sym, int is_complex_T, int nwalkers, int nrhs, int device_id);
 int smoqy_destroy(smoqy_ctx *ctx);

@@ -22,7 +22,7 @@ def bond_factor(N, i, j, c, s):
 
 def gamma(N, nt, c, s):
     """Γ = F_Nh ⋯ F_2 F_1: ``checkerboard_lmul!`` with ``transposed=false`` applies bond 1 first."""
-    G = np.eye(N)
+    G = np.eye(N, dtype=np.result_type(np.asarray(s).dtype, np.float64))
     for h in range(nt.shape[1]):
         G = bond_factor(N, int(nt[0, h]) - 1, int(nt[1, h]) - 1, c[h], s[h]) @ G
     return G
@@ -45,7 +45,7 @@ def dense_M(nt, expV, cosh, sinh, is_sym=True):
     vector layout (element (l, i) of an Ltau x N column-major array is index l + Ltau*i)."""
     Lt, N = expV.shape
     Bs = propagators(nt, expV, cosh, sinh, is_sym)
-    M = np.zeros((Lt, N, Lt, N))
+    M = np.zeros((Lt, N, Lt, N), dtype=Bs[0].dtype)
     for l in range(Lt):
         M[l, :, l, :] += np.eye(N)
         if l == 0:

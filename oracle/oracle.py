@@ -13,12 +13,15 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libsmoqy_oracle.so")
+# SMOQY_ORACLE_LIB selects another build of the same source (the sanitizer build of tests/test_oracle_sanitizers.py)
+_LIB_PATH = os.environ.get("SMOQY_ORACLE_LIB") or os.path.join(_HERE, "libsmoqy_oracle.so")
 
 
 def build(force: bool = False) -> str:
     """Compile the C restatement with gcc (a few seconds)."""
     src = os.path.join(_HERE, "smoqy_oracle.c")
+    if os.environ.get("SMOQY_ORACLE_LIB"):
+        return _LIB_PATH  # built by whoever set the variable
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.run(["make", "-C", _HERE, "-B", "libsmoqy_oracle.so"], check=True, capture_output=True)
     return _LIB_PATH
@@ -33,6 +36,7 @@ def lib():
         build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.orc_fdm_create.restype = C.c_void_p
+        _lib.orc_fdm_create_c.restype = C.c_void_p
         _lib.orc_kpm_create.restype = C.c_void_p
         _lib.orc_fft_create.restype = C.c_void_p
         _lib.orc_cg_solve.restype = C.c_int
@@ -56,13 +60,17 @@ class OracleFDM:
     def __init__(self, neighbor_table, expV, cosh, sinh, is_sym=True):
         self.nt = np.asfortranarray(neighbor_table, dtype=np.int64)
         self.expV = np.asfortranarray(expV, dtype=np.float64)
-        self.cosh = np.asfortranarray(cosh, dtype=np.float64)
-        self.sinh = np.asfortranarray(sinh, dtype=np.float64)
+        self.cosh = np.asfortranarray(np.real(cosh), dtype=np.float64)
+        # T = ComplexF64 (complex hoppings): sinhΔτt carries the phase sign(conj t); kept as separate real / imaginary arrays
+        self.is_complex = bool(np.iscomplexobj(sinh))
+        self.sinh = np.asfortranarray(np.real(sinh), dtype=np.float64)
+        self.sinh_im = np.asfortranarray(np.imag(sinh), dtype=np.float64) if self.is_complex else None
         self.Lt, self.N = self.expV.shape
         self.Nh = self.nt.shape[1]
         self.is_sym = bool(is_sym)
         assert self.cosh.shape == (self.Lt, self.Nh) and self.sinh.shape == (self.Lt, self.Nh)
-        self._h = C.c_void_p(lib().orc_fdm_create(self.Lt, self.N, self.Nh, int(self.is_sym), _p(self.nt), _p(self.expV), _p(self.cosh), _p(self.sinh)))
+        self._h = C.c_void_p(lib().orc_fdm_create_c(self.Lt, self.N, self.Nh, int(self.is_sym), _p(self.nt), _p(self.expV), _p(self.cosh), _p(self.sinh),
+                                                    _p(self.sinh_im) if self.is_complex else None))
 
     def __del__(self):
         try:
@@ -91,8 +99,8 @@ class OracleFDM:
     def checkerboard(self, v, transposed=False, inverse=False, interval=None):
         v = fvec(v).reshape(self.Lt, self.N, order="F")
         h0, h1 = (0, self.Nh) if interval is None else interval
-        fn = lib().orc_checkerboard_ldiv if inverse else lib().orc_checkerboard_lmul
-        fn(_p(v), self.Lt, self.N, _p(self.nt), _p(self.cosh), _p(self.sinh), int(transposed), int(h0), int(h1))
+        fn = lib().orc_checkerboard_ldiv_c if inverse else lib().orc_checkerboard_lmul_c
+        fn(_p(v), self.Lt, self.N, _p(self.nt), _p(self.cosh), _p(self.sinh), _p(self.sinh_im) if self.is_complex else None, int(transposed), int(h0), int(h1))
         return v
 
     def cg_solve(self, b, x0=None, precond=None, tol=1e-10, maxiter=10000):
@@ -110,13 +118,18 @@ def update_fields(V, t, perm, dtau, is_sym=True):
     """update!(fdm, fpi) (src/FermionDetMatrix.jl:208-236).  V is (N, Ltau), t is (Nh, Ltau),
     perm is the 1-based checkerboard permutation.  Returns (expV, cosh, sinh)."""
     V = np.asfortranarray(V, dtype=np.float64)
-    t = np.asfortranarray(t, dtype=np.float64)
     perm = np.ascontiguousarray(perm, dtype=np.int64)
     N, Lt = V.shape
-    Nh = t.shape[0]
+    Nh = np.shape(t)[0]
     expV = np.zeros((Lt, N), order="F")
     ch = np.zeros((Lt, Nh), order="F")
     sh = np.zeros((Lt, Nh), order="F")
+    if np.iscomplexobj(t):  # T = ComplexF64: returns a complex sinh array
+        tr, ti = np.asfortranarray(np.real(t), dtype=np.float64), np.asfortranarray(np.imag(t), dtype=np.float64)
+        shi = np.zeros((Lt, Nh), order="F")
+        lib().orc_update_fields_c(_p(expV), _p(ch), _p(sh), _p(shi), Lt, N, Nh, _p(V), _p(tr), _p(ti), _p(perm), C.c_double(dtau), int(is_sym))
+        return expV, ch, np.asfortranarray(sh + 1j * shi)
+    t = np.asfortranarray(t, dtype=np.float64)
     lib().orc_update_fields(_p(expV), _p(ch), _p(sh), Lt, N, Nh, _p(V), _p(t), _p(perm), C.c_double(dtau), int(is_sym))
     return expV, ch, sh
 
@@ -187,9 +200,16 @@ class OracleKPM:
 
     def update(self, randvec):
         """update_preconditioner! (:554-597); ``randvec`` = the N normal deviates drawn at :634."""
+        f = self.fdm
+        if f.is_complex:  # randn!(rng, v) on a Vector{ComplexF64}: N complex deviates
+            rv = np.ascontiguousarray(randvec, dtype=np.complex128)
+            assert rv.shape == (f.N,)
+            rr, ri = np.ascontiguousarray(rv.real), np.ascontiguousarray(rv.imag)
+            lib().orc_kpm_update_c(self._h, _p(f.expV), _p(f.cosh), _p(f.sinh), _p(f.sinh_im), _p(rr), _p(ri))
+            return
         rv = np.ascontiguousarray(randvec, dtype=np.float64)
-        assert rv.shape == (self.fdm.N,)
-        lib().orc_kpm_update(self._h, _p(self.fdm.expV), _p(self.fdm.cosh), _p(self.fdm.sinh), _p(rv))
+        assert rv.shape == (f.N,)
+        lib().orc_kpm_update(self._h, _p(f.expV), _p(f.cosh), _p(f.sinh), _p(rv))
 
     def apply(self, v):
         """ldiv!(u', P, u), complex method (:355-414 / :488-550)."""

@@ -25,8 +25,9 @@
  * expV (Ltau x N), cosh/sinh (Ltau x Nh) are column-major doubles.  The neighbour table is
  * 2 x Nh column-major int64, 1-based, already colour sorted (src/FermionDetMatrix.jl:96).
  *
- * Only real matrix-element type T = Float64 is restated (every shipped reference script
- * uses real hoppings).
+ * Matrix-element type T: Float64 everywhere by default; the *_c entry points restate T = ComplexF64 (complex hoppings:
+ * sinh carries the phase sign(conj t), the bond factor is [[c, s], [conj(s), c]], src/checkerboard_matrix_multiply.jl:60-68,
+ * src/FermionDetMatrix.jl:224-231) for the operator, the CG and the KPM preconditioner.  The force terms stay real-T only.
  */
 #include <complex.h>
 #include <math.h>
@@ -42,41 +43,51 @@ typedef double complex cplx;
 /* checkerboard_lmul!  — src/checkerboard_matrix_multiply.jl:26-72                       */
 /* bonds [h0, h1) (0-based half open), reversed when transposed (lines 45-47)            */
 /* ------------------------------------------------------------------------------------ */
-void orc_checkerboard_lmul(cplx *u, int Lt, int N, const int64_t *nt, const double *ch,
-                           const double *sh, int transposed, int h0, int h1)
+/* shi = imaginary part of sinhΔτt (NULL for real T) */
+static void chk_apply(cplx *u, int Lt, const int64_t *nt, const double *ch, const double *sh, const double *shi, int reversed, int inverse, int h0, int h1)
 {
-    (void)N;
     int nb = h1 - h0;
     for (int k = 0; k < nb; ++k) {
-        int h = transposed ? (h1 - 1 - k) : (h0 + k);
+        int h = reversed ? (h1 - 1 - k) : (h0 + k);
         int i = (int)nt[2 * h] - 1, j = (int)nt[2 * h + 1] - 1;
         cplx *ui = u + IDX(0, i, Lt), *uj = u + IDX(0, j, Lt);
-        const double *c = ch + IDX(0, h, Lt), *s = sh + IDX(0, h, Lt);
-        for (int l = 0; l < Lt; ++l) { /* lines 60-68 */
+        const double *c = ch + IDX(0, h, Lt), *s = sh + IDX(0, h, Lt), *si = shi ? shi + IDX(0, h, Lt) : NULL;
+        for (int l = 0; l < Lt; ++l) { /* lmul :60-68, ldiv :133-141 */
             cplx a = ui[l], b = uj[l];
-            ui[l] = c[l] * a + s[l] * b;
-            uj[l] = c[l] * b + s[l] * a; /* conj(s) == s for real T */
+            cplx sij = si ? s[l] + I * si[l] : s[l];
+            if (inverse) sij = -sij;
+            ui[l] = c[l] * a + sij * b;
+            uj[l] = c[l] * b + conj(sij) * a;
         }
     }
 }
 
-/* checkerboard_ldiv! — src/checkerboard_matrix_multiply.jl:98-145 (reversed when NOT transposed) */
+void orc_checkerboard_lmul_c(cplx *u, int Lt, int N, const int64_t *nt, const double *ch, const double *sh, const double *shi, int transposed, int h0, int h1)
+{
+    (void)N;
+    chk_apply(u, Lt, nt, ch, sh, shi, transposed, 0, h0, h1); /* reversed when transposed (:45-47) */
+}
+
+void orc_checkerboard_lmul(cplx *u, int Lt, int N, const int64_t *nt, const double *ch,
+                           const double *sh, int transposed, int h0, int h1)
+{
+    orc_checkerboard_lmul_c(u, Lt, N, nt, ch, sh, NULL, transposed, h0, h1);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* checkerboard_ldiv!  — src/checkerboard_matrix_multiply.jl:98-145                      */
+/* inverse factor [[c,-s],[-conj(s),c]] (c^2-|s|^2 = 1), order reversed when NOT transposed (:118-120) */
+/* ------------------------------------------------------------------------------------ */
+void orc_checkerboard_ldiv_c(cplx *u, int Lt, int N, const int64_t *nt, const double *ch, const double *sh, const double *shi, int transposed, int h0, int h1)
+{
+    (void)N;
+    chk_apply(u, Lt, nt, ch, sh, shi, !transposed, 1, h0, h1);
+}
+
 void orc_checkerboard_ldiv(cplx *u, int Lt, int N, const int64_t *nt, const double *ch,
                            const double *sh, int transposed, int h0, int h1)
 {
-    (void)N;
-    int nb = h1 - h0;
-    for (int k = 0; k < nb; ++k) {
-        int h = (!transposed) ? (h1 - 1 - k) : (h0 + k);
-        int i = (int)nt[2 * h] - 1, j = (int)nt[2 * h + 1] - 1;
-        cplx *ui = u + IDX(0, i, Lt), *uj = u + IDX(0, j, Lt);
-        const double *c = ch + IDX(0, h, Lt), *s = sh + IDX(0, h, Lt);
-        for (int l = 0; l < Lt; ++l) {
-            cplx a = ui[l], b = uj[l];
-            ui[l] = c[l] * a - s[l] * b;
-            uj[l] = c[l] * b - s[l] * a;
-        }
-    }
+    orc_checkerboard_ldiv_c(u, Lt, N, nt, ch, sh, NULL, transposed, h0, h1);
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -102,6 +113,26 @@ void orc_update_fields(double *expV, double *ch, double *sh, int Lt, int N, int 
     }
 }
 
+/* T = ComplexF64: t = t_re + i t_im; sinh carries sign(conj(t)) = conj(t)/|t| (:231) */
+void orc_update_fields_c(double *expV, double *ch, double *sh, double *shi, int Lt, int N, int Nh, const double *V, const double *t_re, const double *t_im,
+                         const int64_t *perm, double dtau, int is_sym)
+{
+    for (int i = 0; i < N; ++i)
+        for (int l = 0; l < Lt; ++l) expV[IDX(l, i, Lt)] = exp(-dtau * V[i + (size_t)N * l]); /* :217 */
+    double dt2 = is_sym ? dtau / 2 : dtau; /* :220 */
+    for (int h = 0; h < Nh; ++h) {
+        int hp = (int)perm[h] - 1; /* :224 */
+        for (int l = 0; l < Lt; ++l) {
+            cplx tt = t_re[hp + (size_t)Nh * l] + I * t_im[hp + (size_t)Nh * l];
+            double ab = cabs(tt), a = dt2 * ab;
+            cplx sg = ab > 0 ? conj(tt) / ab : 0.0; /* sign(conj(t′)); Julia's sign(0) = 0 */
+            ch[IDX(l, h, Lt)] = cosh(a);               /* :230 */
+            sh[IDX(l, h, Lt)] = creal(sg) * sinh(a);   /* :231 */
+            shi[IDX(l, h, Lt)] = cimag(sg) * sinh(a);
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* the fermion determinant matrix                                                        */
 /* ------------------------------------------------------------------------------------ */
@@ -109,6 +140,7 @@ typedef struct {
     int Lt, N, Nh, is_sym;
     const int64_t *nt;
     const double *expV, *ch, *sh;
+    const double *shi; /* imaginary part of sinhΔτt, NULL for T = Float64 */
     cplx *tmp1, *tmp2; /* src/FermionDetMatrix.jl:53-54 */
 } orc_fdm;
 
@@ -122,11 +154,11 @@ void orc_mul_M(const orc_fdm *f, cplx *out, const cplx *in)
         for (int l = 1; l < Lt; ++l) out[IDX(l, i, Lt)] = in[IDX(l - 1, i, Lt)];
     }
     if (f->is_sym) {
-        orc_checkerboard_lmul(out, Lt, N, f->nt, f->ch, f->sh, 1, 0, f->Nh); /* :401 */
+        orc_checkerboard_lmul_c(out, Lt, N, f->nt, f->ch, f->sh, f->shi, 1, 0, f->Nh); /* :401 */
         for (size_t k = 0; k < (size_t)Lt * N; ++k) out[k] *= f->expV[k];    /* :407 */
-        orc_checkerboard_lmul(out, Lt, N, f->nt, f->ch, f->sh, 0, 0, f->Nh); /* :410 */
+        orc_checkerboard_lmul_c(out, Lt, N, f->nt, f->ch, f->sh, f->shi, 0, 0, f->Nh); /* :410 */
     } else {
-        orc_checkerboard_lmul(out, Lt, N, f->nt, f->ch, f->sh, 0, 0, f->Nh); /* :446 */
+        orc_checkerboard_lmul_c(out, Lt, N, f->nt, f->ch, f->sh, f->shi, 0, 0, f->Nh); /* :446 */
         for (size_t k = 0; k < (size_t)Lt * N; ++k) out[k] *= f->expV[k];    /* :452 */
     }
     for (int i = 0; i < N; ++i) { /* :416-424 / :455-463 */
@@ -142,12 +174,12 @@ void orc_mul_Mt(const orc_fdm *f, cplx *out, const cplx *in)
     size_t V = (size_t)Lt * N;
     if (f->is_sym) {
         memcpy(out, in, V * sizeof(cplx));                                   /* checkerboard_mul! :497 */
-        orc_checkerboard_lmul(out, Lt, N, f->nt, f->ch, f->sh, 1, 0, f->Nh);
+        orc_checkerboard_lmul_c(out, Lt, N, f->nt, f->ch, f->sh, f->shi, 1, 0, f->Nh);
         for (size_t k = 0; k < V; ++k) out[k] *= f->expV[k];                 /* :503 */
-        orc_checkerboard_lmul(out, Lt, N, f->nt, f->ch, f->sh, 0, 0, f->Nh); /* :506 */
+        orc_checkerboard_lmul_c(out, Lt, N, f->nt, f->ch, f->sh, f->shi, 0, 0, f->Nh); /* :506 */
     } else {
         for (size_t k = 0; k < V; ++k) out[k] = f->expV[k] * in[k];          /* :541 */
-        orc_checkerboard_lmul(out, Lt, N, f->nt, f->ch, f->sh, 1, 0, f->Nh); /* :544 */
+        orc_checkerboard_lmul_c(out, Lt, N, f->nt, f->ch, f->sh, f->shi, 1, 0, f->Nh); /* :544 */
     }
     for (int i = 0; i < N; ++i) { /* :512-522 / :550-560 */
         cplx last = in[IDX(Lt - 1, i, Lt)] + out[IDX(0, i, Lt)];
@@ -325,6 +357,7 @@ typedef struct {
     int N, Nh, is_sym;
     const int64_t *nt;
     double *d, *c, *s; /* means over tau */
+    double *si;        /* mean of Im sinhΔτt (all zero for T = Float64) */
 } orc_bbar;
 
 static void bbar_chk(const orc_bbar *B, cplx *v, int transposed)
@@ -333,8 +366,9 @@ static void bbar_chk(const orc_bbar *B, cplx *v, int transposed)
         int h = transposed ? B->Nh - 1 - k : k;
         int i = (int)B->nt[2 * h] - 1, j = (int)B->nt[2 * h + 1] - 1;
         cplx a = v[i], b = v[j];
-        v[i] = B->c[h] * a + B->s[h] * b;
-        v[j] = B->c[h] * b + B->s[h] * a;
+        cplx sij = B->s[h] + I * B->si[h];
+        v[i] = B->c[h] * a + sij * b;
+        v[j] = B->c[h] * b + conj(sij) * a;
     }
 }
 
@@ -463,6 +497,7 @@ orc_kpm *orc_kpm_create(int Lt, int N, int Nh, int is_sym, const int64_t *nt, do
     P->B.d = (double *)calloc((size_t)N, sizeof(double));
     P->B.c = (double *)calloc((size_t)(Nh > 0 ? Nh : 1), sizeof(double));
     P->B.s = (double *)calloc((size_t)(Nh > 0 ? Nh : 1), sizeof(double));
+    P->B.si = (double *)calloc((size_t)(Nh > 0 ? Nh : 1), sizeof(double));
     P->fft = orc_fft_create(Lt);
     P->ncoef_slots = is_sym ? (Lt + 1) / 2 : Lt; /* :254-257, :268-271 */
     P->order = (int *)calloc((size_t)P->ncoef_slots, sizeof(int));
@@ -478,7 +513,7 @@ orc_kpm *orc_kpm_create(int Lt, int N, int Nh, int is_sym, const int64_t *nt, do
 void orc_kpm_destroy(orc_kpm *P)
 {
     if (!P) return;
-    free(P->B.d); free(P->B.c); free(P->B.s);
+    free(P->B.d); free(P->B.c); free(P->B.s); free(P->B.si);
     orc_fft_destroy(P->fft);
     for (int i = 0; i < P->ncoef_slots; ++i) free(P->coefs[i]);
     free(P->order); free(P->coefs); free(P->v); free(P->vt); free(P->tmp); free(P->lan_a); free(P->lan_b);
@@ -517,24 +552,26 @@ static void kpm_update_expansions(orc_kpm *P)
     }
 }
 
-/* lanczos! (SmoQyKPMCore, restated): plain n-step Lanczos from the start vector v0 (real) */
-static void lanczos(orc_kpm *P, const double *v0, int use_BtB)
+/* lanczos! (SmoQyKPMCore, restated): plain n-step Lanczos from the start vector v0 (+ i v0i when the matrix element type is
+ * complex: randn!(rng, v) on a Vector{ComplexF64} draws complex deviates, src/KPMPreconditioner.jl:634).  The operator is Hermitian,
+ * so alpha = Re<v_k, A v_k> and beta = |w| are real. */
+static void lanczos(orc_kpm *P, const double *v0, const double *v0i, int use_BtB)
 {
     int N = P->N, n = P->nlanczos;
     cplx *vk = (cplx *)calloc((size_t)N, sizeof(cplx)), *vkm = (cplx *)calloc((size_t)N, sizeof(cplx)), *w = (cplx *)calloc((size_t)N, sizeof(cplx));
     double nrm = 0;
-    for (int i = 0; i < N; ++i) nrm += v0[i] * v0[i];
+    for (int i = 0; i < N; ++i) nrm += v0[i] * v0[i] + (v0i ? v0i[i] * v0i[i] : 0.0);
     nrm = sqrt(nrm);
-    for (int i = 0; i < N; ++i) vk[i] = v0[i] / nrm;
+    for (int i = 0; i < N; ++i) vk[i] = (v0[i] + (v0i ? I * v0i[i] : 0.0)) / nrm;
     double beta = 0;
     for (int k = 0; k < n; ++k) {
         memcpy(w, vk, sizeof(cplx) * (size_t)N);
         if (use_BtB) bbar_mul_BtB(&P->B, w); else bbar_mul(&P->B, w);
         double alpha = 0;
-        for (int i = 0; i < N; ++i) alpha += creal(vk[i]) * creal(w[i]);
+        for (int i = 0; i < N; ++i) alpha += creal(vk[i]) * creal(w[i]) + cimag(vk[i]) * cimag(w[i]);
         P->lan_a[k] = alpha;
         double nb = 0;
-        for (int i = 0; i < N; ++i) { w[i] = w[i] - alpha * vk[i] - beta * vkm[i]; nb += creal(w[i]) * creal(w[i]); }
+        for (int i = 0; i < N; ++i) { w[i] = w[i] - alpha * vk[i] - beta * vkm[i]; nb += creal(w[i]) * creal(w[i]) + cimag(w[i]) * cimag(w[i]); }
         nb = sqrt(nb);
         if (k < n - 1) P->lan_b[k] = nb;
         beta = nb;
@@ -546,19 +583,20 @@ static void lanczos(orc_kpm *P, const double *v0, int use_BtB)
 
 /* update_preconditioner! — src/KPMPreconditioner.jl:554-597.
  * randvec: the N normal deviates the caller's rng would have produced at :634 / :652. */
-void orc_kpm_update(orc_kpm *P, const double *expV, const double *ch, const double *sh, const double *randvec)
+void orc_kpm_update_c(orc_kpm *P, const double *expV, const double *ch, const double *sh, const double *shi, const double *randvec, const double *randvec_im)
 {
     int Lt = P->Lt, N = P->N, Nh = P->Nh;
     /* update_B̄! :604-621: means over tau */
     for (int i = 0; i < N; ++i) { double a = 0; for (int l = 0; l < Lt; ++l) a += expV[IDX(l, i, Lt)]; P->B.d[i] = a / Lt; }
     for (int h = 0; h < Nh; ++h) {
         double a = 0, b = 0;
-        for (int l = 0; l < Lt; ++l) { a += ch[IDX(l, h, Lt)]; b += sh[IDX(l, h, Lt)]; }
-        P->B.c[h] = a / Lt; P->B.s[h] = b / Lt;
+        double bi = 0;
+        for (int l = 0; l < Lt; ++l) { a += ch[IDX(l, h, Lt)]; b += sh[IDX(l, h, Lt)]; if (shi) bi += shi[IDX(l, h, Lt)]; }
+        P->B.c[h] = a / Lt; P->B.s[h] = b / Lt; P->B.si[h] = bi / Lt;
     }
     /* calculate_bounds! :625-658 */
     double emin, emax;
-    lanczos(P, randvec, !P->is_sym);
+    lanczos(P, randvec, randvec_im, !P->is_sym);
     orc_tridiag_extremes(P->lan_a, P->lan_b, P->nlanczos, &emin, &emax);
     if (!P->is_sym) { emin = sqrt(emin); emax = sqrt(emax); } /* :655 */
     emin *= (1 - P->rbuf); /* :569-570 */
@@ -572,6 +610,11 @@ void orc_kpm_update(orc_kpm *P, const double *expV, const double *ch, const doub
     } else {
         P->active = 0; /* :593 */
     }
+}
+
+void orc_kpm_update(orc_kpm *P, const double *expV, const double *ch, const double *sh, const double *randvec)
+{
+    orc_kpm_update_c(P, expV, ch, sh, NULL, randvec, NULL);
 }
 
 /* ldiv!(u', P, u) complex methods — Sym: src/KPMPreconditioner.jl:355-414; Asym: :488-550 */
@@ -689,13 +732,18 @@ done:
 }
 
 /* convenience constructor used from Python */
-orc_fdm *orc_fdm_create(int Lt, int N, int Nh, int is_sym, const int64_t *nt, const double *expV, const double *ch, const double *sh)
+orc_fdm *orc_fdm_create_c(int Lt, int N, int Nh, int is_sym, const int64_t *nt, const double *expV, const double *ch, const double *sh, const double *shi)
 {
     orc_fdm *f = (orc_fdm *)calloc(1, sizeof(orc_fdm));
-    f->Lt = Lt; f->N = N; f->Nh = Nh; f->is_sym = is_sym; f->nt = nt; f->expV = expV; f->ch = ch; f->sh = sh;
+    f->Lt = Lt; f->N = N; f->Nh = Nh; f->is_sym = is_sym; f->nt = nt; f->expV = expV; f->ch = ch; f->sh = sh; f->shi = shi;
     f->tmp1 = (cplx *)calloc((size_t)Lt * N, sizeof(cplx));
     f->tmp2 = (cplx *)calloc((size_t)Lt * N, sizeof(cplx));
     return f;
+}
+
+orc_fdm *orc_fdm_create(int Lt, int N, int Nh, int is_sym, const int64_t *nt, const double *expV, const double *ch, const double *sh)
+{
+    return orc_fdm_create_c(Lt, N, Nh, is_sym, nt, expV, ch, sh, NULL);
 }
 
 void orc_fdm_destroy(orc_fdm *f)

@@ -198,16 +198,17 @@ class GeSlot(C.Structure):
 class Handle:
     """Owns one ``smoqy_ctx`` (one FermionDetMatrix worth of device state per walker)."""
 
-    def __init__(self, Lt, N, neighbor_table, color_ranges, is_sym=True, nwalkers=1, nrhs=1, device=-1):
+    def __init__(self, Lt, N, neighbor_table, color_ranges, is_sym=True, nwalkers=1, nrhs=1, device=-1, is_complex=False):
         self.lib = load()
         nt = np.asfortranarray(neighbor_table, dtype=np.int64)
         cr = np.asfortranarray(color_ranges, dtype=np.int64)
         self.Lt, self.N, self.Nh, self.ncol = int(Lt), int(N), int(nt.shape[1]) if nt.ndim == 2 else 0, int(cr.shape[1]) if cr.ndim == 2 else 0
         self.is_sym, self.nw, self.nrhs = bool(is_sym), int(nwalkers), int(nrhs)
+        self.is_complex = bool(is_complex)  # matrix-element type T = ComplexF64 (complex hoppings)
         self.nsys = self.nw * self.nrhs
         self.device = int(device)
         h = _p()
-        rc = self.lib.smoqy_create(C.byref(h), self.Lt, self.N, self.Nh, self.ncol, ptr(nt), ptr(cr), int(self.is_sym), 0, self.nw, self.nrhs, int(device))
+        rc = self.lib.smoqy_create(C.byref(h), self.Lt, self.N, self.Nh, self.ncol, ptr(nt), ptr(cr), int(self.is_sym), int(self.is_complex), self.nw, self.nrhs, int(device))
         if rc != 0:
             raise SmoqyError(f"smoqy_create failed ({rc}): " + (self.lib.smoqy_last_error(None) or b"").decode())
         self._h = h

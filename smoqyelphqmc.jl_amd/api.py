@@ -72,15 +72,17 @@ class FermionDetMatrix:
         self._colors = colors
         self.checkerboard_colors = [range(int(colors[0, c]), int(colors[1, c]) + 1) for c in range(colors.shape[1])]
         self.cgs = ConjugateGradientSolver(np.empty(self.Lt * self.N), maxiter=maxiter, tol=tol)
-        self.handle = L.Handle(self.Lt, self.N, self.checkerboard_neighbor_table, colors, self.is_sym, 1, nrhs, device)
+        # matrix-element type T of FermionDetMatrix{T, E} (:19): complex when the path integral carries complex hoppings
+        self.T = np.complex128 if np.iscomplexobj(fpi.t) else np.float64
+        self.handle = L.Handle(self.Lt, self.N, self.checkerboard_neighbor_table, colors, self.is_sym, 1, nrhs, device, is_complex=self.T is np.complex128)
         self.nrhs = nrhs
         update(self, fpi)
 
     # field access used by KPMPreconditioner (:208-209) and the force code
     def _fields(self):
         e = np.zeros((self.Lt, self.N), order="F")
-        c = np.zeros((self.Lt, self.Nh), order="F")
-        s = np.zeros((self.Lt, self.Nh), order="F")
+        c = np.zeros((self.Lt, self.Nh), order="F", dtype=self.T)  # Matrix{T}, :47-48
+        s = np.zeros((self.Lt, self.Nh), order="F", dtype=self.T)
         self.handle.call("smoqy_get_fields", 0, L.ptr(e), L.ptr(c), L.ptr(s))
         return e, c, s
 
@@ -113,7 +115,9 @@ def update(fermion_det_matrix: FermionDetMatrix, fermion_path_integral: FermionP
     """update!(fdm, fpi), src/FermionDetMatrix.jl:208-236, computed on the device."""
     fpi = fermion_path_integral
     V = np.asfortranarray(fpi.V, dtype=np.float64)
-    t = np.asfortranarray(fpi.t, dtype=np.float64)
+    if np.iscomplexobj(fpi.t) and fermion_det_matrix.T is not np.complex128:
+        raise TypeError("complex hoppings need a FermionDetMatrix constructed with matrix-element type T = ComplexF64")
+    t = np.asfortranarray(fpi.t, dtype=fermion_det_matrix.T)
     if V.shape != (fermion_det_matrix.N, fermion_det_matrix.Lt) or t.shape != (fermion_det_matrix.Nh, fermion_det_matrix.Lt):
         raise ValueError("FermionPathIntegral arrays do not match the FermionDetMatrix")
     fermion_det_matrix.handle.call("smoqy_update_from_path_integral", 0, L.ptr(V), L.ptr(t), L.ptr(fermion_det_matrix.checkerboard_perm), C.c_double(fpi.dtau))
@@ -125,7 +129,7 @@ def size(fermion_det_matrix: FermionDetMatrix, dim=None):
 
 
 def eltype(fermion_det_matrix: FermionDetMatrix):
-    return np.float64
+    return fermion_det_matrix.T
 
 
 # ---- matrix-vector products --------------------------------------------------------------------
@@ -283,7 +287,11 @@ def update_preconditioner(P, fermion_det_matrix=None, rng=None, *ignore):
     if not isinstance(P, KPMPreconditioner):
         return None
     rng = rng if rng is not None else np.random.default_rng()
-    rv = np.ascontiguousarray(rng.standard_normal(P.fdm.N))  # randn!(rng, v), :634
+    if P.fdm.T is np.complex128:
+        # randn!(rng, v) on a Vector{ComplexF64}: (re, im) pairs of variance 1/2 each, :634
+        rv = np.ascontiguousarray((rng.standard_normal(2 * P.fdm.N) * np.sqrt(0.5)).view(np.complex128))
+    else:
+        rv = np.ascontiguousarray(rng.standard_normal(P.fdm.N))  # randn!(rng, v), :634
     P.handle.call("smoqy_precond_update", 0, L.ptr(rv))
     return None
 

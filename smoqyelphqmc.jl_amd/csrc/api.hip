@@ -37,6 +37,7 @@ struct smoqy_ctx {
     int *d_col_off = nullptr;
     // fields [nw][Lt][*]
     double *d_expV = nullptr, *d_ch = nullptr, *d_sh = nullptr, *d_lam = nullptr;
+    double *d_shi = nullptr, *d_sbari = nullptr;  // T = ComplexF64 only: Im sinhΔτt [nw][Lt][Nh] and its tau-mean [nw][Nh]
     // user vectors
     std::vector<double2 *> vecs;
     // scratch
@@ -222,7 +223,7 @@ static FdmArgs fdm_args(smoqy_ctx *c, const double2 *in, double2 *out, double2 *
     a.Lt = g.Lt; a.N = g.N; a.Nh = g.Nh; a.ncol = g.ncol; a.nsys = g.nsys; a.nrhs = g.nrhs;
     a.Tc = c->Tc; a.nchunk = c->nchunk;
     a.bonds = c->d_bonds; a.col_off = c->d_col_off;
-    a.expV = c->d_expV; a.ch = c->d_ch; a.sh = c->d_sh;
+    a.expV = c->d_expV; a.ch = c->d_ch; a.sh = c->d_sh; a.shi = c->d_shi;
     a.in = in; a.out = out; a.partial = partial; a.cg = cg;
     a.sys_first = sys0; a.sys_count = count;
     a.hop_re = 1.0; a.hop_im = 0.0; a.antiperiodic = 1;  // the reference operator
@@ -236,7 +237,7 @@ static KpmArgs kpm_args(smoqy_ctx *c, double2 *v, const CgState *cg)
     const Geometry &g = c->g;
     k.Lt = g.Lt; k.N = g.N; k.Nh = g.Nh; k.ncol = g.ncol; k.nsys = g.nsys; k.nrhs = g.nrhs; k.is_sym = g.is_sym;
     k.bonds = c->d_bonds; k.col_off = c->d_col_off;
-    k.dbar = c->d_dbar; k.cbar = c->d_cbar; k.sbar = c->d_sbar;
+    k.dbar = c->d_dbar; k.cbar = c->d_cbar; k.sbar = c->d_sbar; k.sbari = c->d_sbari;
     k.order = c->d_order; k.coefs = c->d_coefs; k.bounds = c->d_bounds; k.active = c->d_active;
     k.nslot = c->nslot; k.maxorder = c->maxorder;
     k.v = v; k.cg = cg;
@@ -299,7 +300,7 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->fft_info) rocfft_execution_info_destroy(c->fft_info);
     void *ptrs[] = {c->d_bonds, c->d_col_off, c->d_expV, c->d_ch, c->d_sh, c->d_lam, c->d_stage, c->d_stage_real, c->d_stage_int, c->scr[0], c->scr[1], c->scr[2], c->cg_r, c->cg_p,
                     c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->fft_work, c->d_tw, c->d_th, c->d_wtab, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
-                    c->d_rand, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_big};
+                    c->d_rand, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_big, c->d_shi, c->d_sbari};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (double2 *v : c->vecs)
@@ -379,6 +380,12 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     HIPCHK(c, hipMemset(c->d_ch, 0, g.nw * VH * sizeof(double)));
     HIPCHK(c, hipMemset(c->d_sh, 0, g.nw * VH * sizeof(double)));
     HIPCHK(c, hipMemset(c->d_lam, 0, g.nw * V * sizeof(double)));
+    if (g.is_cplx) {
+        HIPCHK(c, hipMalloc(&c->d_shi, g.nw * VH * sizeof(double)));
+        HIPCHK(c, hipMemset(c->d_shi, 0, g.nw * VH * sizeof(double)));
+        HIPCHK(c, hipMalloc(&c->d_sbari, (size_t)g.nw * std::max(g.Nh, 1) * sizeof(double)));
+        HIPCHK(c, hipMemset(c->d_sbari, 0, (size_t)g.nw * std::max(g.Nh, 1) * sizeof(double)));
+    }
 
     const size_t ve = c->vec_elems();
     HIPCHK(c, hipMalloc(&c->d_stage, ve * sizeof(double2)));
@@ -455,7 +462,7 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     HIPCHK(c, hipMalloc(&c->d_cbar, (size_t)g.nw * std::max(g.Nh, 1) * sizeof(double)));
     HIPCHK(c, hipMalloc(&c->d_sbar, (size_t)g.nw * std::max(g.Nh, 1) * sizeof(double)));
     HIPCHK(c, hipMalloc(&c->d_bounds, (size_t)g.nw * 2 * sizeof(double)));
-    HIPCHK(c, hipMalloc(&c->d_rand, (size_t)g.nw * g.N * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_rand, (size_t)g.nw * g.N * (g.is_cplx ? 2 : 1) * sizeof(double)));
     HIPCHK(c, hipMalloc(&c->d_lan, (size_t)g.nw * 2 * 1024 * sizeof(double)));
     HIPCHK(c, hipHostMalloc(&c->h_lan, (size_t)g.nw * 2 * 1024 * sizeof(double)));
     {
@@ -478,7 +485,7 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
         }
         c->kg.ptotal = (int)pb.size();
         c->kg.threads = std::max(64, ((maxp + 63) / 64) * 64);
-        c->kg.fast = (g.ncol >= 1 && g.ncol <= kMaxColours && maxp <= 1024) ? 1 : 0;
+        c->kg.fast = (!g.is_cplx && g.ncol >= 1 && g.ncol <= kMaxColours && maxp <= 1024) ? 1 : 0;  // complex hoppings: generic kernels
         // LDS positions: the first colour's x sites in list order, then its y sites
         std::vector<int> pos((size_t)g.N);
         for (int i = 0; i < g.N; ++i) pos[i] = i;
@@ -555,7 +562,7 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
         c->ff.cs_varies = c->d_cs_varies;
         c->ff.psites = c->d_psites; c->ff.pos = c->d_pos;
         c->ff.pbonds = c->d_pbonds; c->ff.poff = c->d_poff; c->ff.csf = c->d_csf; c->ff.ptotal = c->kg.ptotal; c->ff.threads = c->kg.threads;
-        c->ff.enabled = (g.is_sym && g.ncol >= 1 && g.ncol <= kFdmColours && maxp <= 1024) ? 1 : 0;
+        c->ff.enabled = (!g.is_cplx && g.is_sym && g.ncol >= 1 && g.ncol <= kFdmColours && maxp <= 1024) ? 1 : 0;
         choose_chunking(c);
     }
     HIPCHK(c, hipMalloc(&c->d_order, (size_t)g.nw * c->nslot * sizeof(int)));
@@ -575,17 +582,13 @@ int smoqy_create(smoqy_ctx **out, int Ltau, int N, int Nh, int ncolors, const in
         g_create_error = "smoqy_create: invalid dimensions or null tables";
         return 1;
     }
-    if (is_complex_T) {
-        g_create_error = "smoqy_create: complex matrix-element type T is not implemented (real hoppings only)";
-        return 6;
-    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         g_create_error = "smoqy_create: no HIP device visible — this library has no CPU path";
         return 4;
     }
     smoqy_ctx *c = new smoqy_ctx();
-    c->g = Geometry{Ltau, N, Nh, ncolors, nwalkers, nrhs, nwalkers * nrhs, is_sym ? 1 : 0};
+    c->g = Geometry{Ltau, N, Nh, ncolors, nwalkers, nrhs, nwalkers * nrhs, is_sym ? 1 : 0, is_complex_T ? 1 : 0};
     if (device_id < 0) { if (hipGetDevice(&c->device) != hipSuccess) c->device = 0; }
     else c->device = device_id;
     int rc = create_impl(c, neighbor_table, color_ranges);
@@ -696,6 +699,18 @@ int smoqy_update_fields(smoqy_ctx *c, int w, const double *expV, const double *c
     const Geometry &g = c->g;
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = upload_real_field(c, expV, c->d_expV + (size_t)w * g.Lt * g.N, g.N)) return rc;
+    if (g.is_cplx) {
+        // T = ComplexF64: coshΔτt and sinhΔτt arrive as complex128 arrays (the reference stores both as Matrix{T}); the device keeps
+        // Re cosh, Re sinh and Im sinh as separate real arrays
+        const size_t cnt = (size_t)g.Lt * g.Nh;
+        std::vector<double> re(cnt), im(cnt);
+        for (size_t k = 0; k < cnt; ++k) re[k] = ch[2 * k];
+        if (int rc = upload_real_field(c, re.data(), c->d_ch + (size_t)w * cnt, g.Nh)) return rc;
+        for (size_t k = 0; k < cnt; ++k) { re[k] = sh[2 * k]; im[k] = sh[2 * k + 1]; }
+        if (int rc = upload_real_field(c, re.data(), c->d_sh + (size_t)w * cnt, g.Nh)) return rc;
+        if (int rc = upload_real_field(c, im.data(), c->d_shi + (size_t)w * cnt, g.Nh)) return rc;
+        return check_launch(c, "update_fields");
+    }
     if (int rc = upload_real_field(c, ch, c->d_ch + (size_t)w * g.Lt * g.Nh, g.Nh)) return rc;
     if (int rc = upload_real_field(c, sh, c->d_sh + (size_t)w * g.Lt * g.Nh, g.Nh)) return rc;
     launch_pack_csf(c->stream, c->d_ch + (size_t)w * g.Lt * g.Nh, c->d_sh + (size_t)w * g.Lt * g.Nh, c->d_psrc, c->d_csf + (size_t)w * g.Lt * c->kg.ptotal, c->d_cs_varies + w, g.Lt, g.Lt, g.Nh, c->kg.ptotal);
@@ -708,9 +723,10 @@ static int update_pi_range(smoqy_ctx *c, int w0, int nw, const double *V, const 
 {
     const Geometry &g = c->g;
     const size_t nV = (size_t)g.Lt * g.N, nT = (size_t)g.Lt * g.Nh;
-    if (int rc = ensure_stage_real(c, (size_t)nw * (nV + nT) + 1)) return rc;
+    const size_t tw = g.is_cplx ? 2 : 1;  // T = ComplexF64: t is complex128
+    if (int rc = ensure_stage_real(c, (size_t)nw * (nV + tw * nT) + 2)) return rc;
     if (int rc = ensure_stage_int(c, (size_t)std::max(g.Nh, 1))) return rc;
-    double *dV = c->d_stage_real, *dT = c->d_stage_real + (size_t)nw * nV;
+    double *dV = c->d_stage_real, *dT = c->d_stage_real + (size_t)nw * nV + ((size_t)nw * nV & 1);  // 16-byte aligned for double2
     if (V) HIPCHK(c, hipMemcpyAsync(dV, V, (size_t)nw * nV * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (t && nT) {
         if (!perm) FAIL(c, 1, "perm must be given with t");
@@ -719,11 +735,17 @@ static int update_pi_range(smoqy_ctx *c, int w0, int nw, const double *V, const 
             if (perm[h] < 1 || perm[h] > g.Nh) FAIL(c, 1, "perm[%d] = %lld out of range", h + 1, (long long)perm[h]);
             p0[h] = (int)perm[h] - 1;
         }
-        HIPCHK(c, hipMemcpyAsync(dT, t, (size_t)nw * nT * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dT, t, (size_t)nw * nT * tw * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_stage_int, p0.data(), p0.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));  // p0 is a temporary
     }
     const bool do_t = t && nT;
+    if (g.is_cplx) {
+        launch_fields_from_path_integral_c(c->stream, V ? dV : nullptr, do_t ? (const double2 *)dT : nullptr, c->d_stage_int, c->d_expV + (size_t)w0 * nV, c->d_ch + (size_t)w0 * nT, c->d_sh + (size_t)w0 * nT,
+                                           c->d_shi + (size_t)w0 * nT, nw * g.Lt, g.N, g.Nh, dtau, g.is_sym ? dtau / 2 : dtau);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return check_launch(c, "update_from_path_integral");
+    }
     launch_fields_from_path_integral(c->stream, V ? dV : nullptr, do_t ? dT : nullptr, c->d_stage_int, c->d_expV + (size_t)w0 * nV, c->d_ch + (size_t)w0 * nT, c->d_sh + (size_t)w0 * nT, nw * g.Lt, g.N, g.Nh,
                                      dtau, g.is_sym ? dtau / 2 : dtau);  // FermionDetMatrix.jl:220
     if (do_t) launch_pack_csf(c->stream, c->d_ch + (size_t)w0 * nT, c->d_sh + (size_t)w0 * nT, c->d_psrc, c->d_csf + (size_t)w0 * g.Lt * c->kg.ptotal, c->d_cs_varies + w0, nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal);
@@ -753,6 +775,20 @@ int smoqy_get_fields(smoqy_ctx *c, int w, double *expV, double *ch, double *sh)
     const Geometry &g = c->g;
     HIPCHK(c, hipSetDevice(c->device));
     if (expV) if (int rc = download_real_field(c, c->d_expV + (size_t)w * g.Lt * g.N, expV, g.N)) return rc;
+    if (g.is_cplx) {  // complex128 out, as the reference's Matrix{T} fields
+        const size_t cnt = (size_t)g.Lt * g.Nh;
+        std::vector<double> re(cnt), im(cnt);
+        if (ch) {
+            if (int rc = download_real_field(c, c->d_ch + (size_t)w * cnt, re.data(), g.Nh)) return rc;
+            for (size_t k = 0; k < cnt; ++k) { ch[2 * k] = re[k]; ch[2 * k + 1] = 0.0; }
+        }
+        if (sh) {
+            if (int rc = download_real_field(c, c->d_sh + (size_t)w * cnt, re.data(), g.Nh)) return rc;
+            if (int rc = download_real_field(c, c->d_shi + (size_t)w * cnt, im.data(), g.Nh)) return rc;
+            for (size_t k = 0; k < cnt; ++k) { sh[2 * k] = re[k]; sh[2 * k + 1] = im[k]; }
+        }
+        return check_launch(c, "get_fields");
+    }
     if (ch) if (int rc = download_real_field(c, c->d_ch + (size_t)w * g.Lt * g.Nh, ch, g.Nh)) return rc;
     if (sh) if (int rc = download_real_field(c, c->d_sh + (size_t)w * g.Lt * g.Nh, sh, g.Nh)) return rc;
     return check_launch(c, "get_fields");
@@ -1204,9 +1240,9 @@ static int precond_update_range(smoqy_ctx *c, int w0, int nw, const double *rand
     const Geometry &g = c->g;
     const int n = c->nlanczos;
     // update_B̄! :604-621
-    launch_tau_means(c->stream, c->kg, c->d_expV, c->d_ch, c->d_sh, c->d_dbar, c->d_cbar, c->d_sbar, g.Lt, g.N, g.Nh, w0, nw);
+    launch_tau_means(c->stream, c->kg, c->d_expV, c->d_ch, c->d_sh, c->d_dbar, c->d_cbar, c->d_sbar, g.Lt, g.N, g.Nh, w0, nw, c->d_shi, c->d_sbari);
     // calculate_bounds! :625-658 (start vectors drawn by the caller's rng at :634 / :652)
-    HIPCHK(c, hipMemcpyAsync(c->d_rand, randvecs, (size_t)nw * g.N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_rand, randvecs, (size_t)nw * g.N * (g.is_cplx ? 2 : 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));  // complex T: N complex deviates per walker (:634)
     KpmArgs k = kpm_args(c, nullptr, nullptr);
     launch_lanczos(c->stream, k, c->kg, w0, nw, c->d_rand, n, c->d_lan, c->d_lan + (size_t)g.nw * 1024, !g.is_sym);
     HIPCHK(c, hipMemcpy2DAsync(c->h_lan, 1024 * sizeof(double), c->d_lan, 1024 * sizeof(double), (size_t)n * sizeof(double), (size_t)nw, hipMemcpyDeviceToHost, c->stream));
@@ -1250,7 +1286,7 @@ int smoqy_matvec_force_generic(smoqy_ctx *c, int on)
 {
     CHECK_CTX(c);
     const Geometry &g = c->g;
-    c->ff.enabled = (!on && g.is_sym && g.ncol >= 1 && g.ncol <= kFdmColours && c->ff.threads <= 1024) ? 1 : 0;
+    c->ff.enabled = (!on && !g.is_cplx && g.is_sym && g.ncol >= 1 && g.ncol <= kFdmColours && c->ff.threads <= 1024) ? 1 : 0;
     drop_graphs(c);
     choose_chunking(c);
     return 0;
@@ -1263,7 +1299,7 @@ int smoqy_precond_force_generic(smoqy_ctx *c, int on)
     int maxp = 0;
     (void)g;
     maxp = c->kg.threads;
-    c->kg.fast = (!on && g.ncol >= 1 && g.ncol <= kMaxColours && maxp <= 1024) ? 1 : 0;
+    c->kg.fast = (!on && !g.is_cplx && g.ncol >= 1 && g.ncol <= kMaxColours && maxp <= 1024) ? 1 : 0;
     drop_graphs(c);
     return 0;
 }
@@ -1324,7 +1360,7 @@ int smoqy_precond_set(smoqy_ctx *c, int w, int active, const double *bounds, con
         p.coefs[s].assign(src, src + order[s]);
         src += order[s];
     }
-    launch_tau_means(c->stream, c->kg, c->d_expV, c->d_ch, c->d_sh, c->d_dbar, c->d_cbar, c->d_sbar, g.Lt, g.N, g.Nh, w, 1);
+    launch_tau_means(c->stream, c->kg, c->d_expV, c->d_ch, c->d_sh, c->d_dbar, c->d_cbar, c->d_sbar, g.Lt, g.N, g.Nh, w, 1, c->d_shi, c->d_sbari);
     return upload_precond(c, w);
 }
 
@@ -1642,6 +1678,7 @@ int smoqy_force_set_couplings(smoqy_ctx *c, const smoqy_couplings *cp)
     CHECK_CTX(c);
     const Geometry &g = c->g;
     if (g.nrhs != 1) FAIL(c, 1, "the force entry points need a handle with nrhs = 1");
+    if (g.is_cplx) FAIL(c, 6, "the force terms and the device-side update! from phonon fields are implemented for real hoppings only (T = Float64)");
     if (!cp || cp->Nph < 0 || cp->Nholstein < 0 || cp->Nssh < 0) FAIL(c, 1, "invalid couplings");
     auto &F = c->force;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1921,7 +1958,7 @@ int smoqy_copy_fields(smoqy_ctx *dst, int dst_walker, smoqy_ctx *src, int src_wa
     CHECK_WALKER(dst, dst_walker);
     if (src_walker < 0 || src_walker >= src->g.nw) FAIL(dst, 1, "source walker %d out of range", src_walker);
     const Geometry &a = dst->g, &b = src->g;
-    if (a.Lt != b.Lt || a.N != b.N || a.Nh != b.Nh || a.ncol != b.ncol || a.is_sym != b.is_sym || dst->kg.ptotal != src->kg.ptotal || dst->device != src->device)
+    if (a.Lt != b.Lt || a.N != b.N || a.Nh != b.Nh || a.ncol != b.ncol || a.is_sym != b.is_sym || a.is_cplx != b.is_cplx || dst->kg.ptotal != src->kg.ptotal || dst->device != src->device)
         FAIL(dst, 1, "smoqy_copy_fields needs two handles of the same lattice, propagator form and device");
     HIPCHK(dst, hipStreamSynchronize(src->stream));  // the source's fields are final
     const size_t nV = (size_t)a.Lt * a.N, nT = (size_t)a.Lt * a.Nh, nP = (size_t)a.Lt * dst->kg.ptotal;
@@ -1930,6 +1967,7 @@ int smoqy_copy_fields(smoqy_ctx *dst, int dst_walker, smoqy_ctx *src, int src_wa
     if (nT) {
         HIPCHK(dst, hipMemcpyAsync(dst->d_ch + dst_walker * nT, src->d_ch + src_walker * nT, nT * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
         HIPCHK(dst, hipMemcpyAsync(dst->d_sh + dst_walker * nT, src->d_sh + src_walker * nT, nT * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+        if (a.is_cplx) HIPCHK(dst, hipMemcpyAsync(dst->d_shi + dst_walker * nT, src->d_shi + src_walker * nT, nT * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
     }
     if (nP) HIPCHK(dst, hipMemcpyAsync(dst->d_csf + dst_walker * nP, src->d_csf + src_walker * nP, nP * sizeof(double2), hipMemcpyDeviceToDevice, dst->stream));
     HIPCHK(dst, hipMemcpyAsync(dst->d_cs_varies + dst_walker, src->d_cs_varies + src_walker, sizeof(int), hipMemcpyDeviceToDevice, dst->stream));

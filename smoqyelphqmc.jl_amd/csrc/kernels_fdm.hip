@@ -27,8 +27,9 @@ __device__ __forceinline__ double2 hopcomb_g(double2 v, double2 u, bool wrapped,
 __device__ __forceinline__ int wrap(int l, int Lt) { return l >= Lt ? l - Lt : (l < 0 ? l + Lt : l); }
 
 // One checkerboard colour on nk LDS-resident slices: lane = bond.
+// shi != nullptr: complex hopping, factor [[c, s], [conj(s), c]] with s = sh + i shi (checkerboard_matrix_multiply.jl:60-68)
 __device__ __forceinline__ void colour_stage(double2 *U, int nk, int N, int lbase, int Lt, int Nh, const int2 *__restrict__ bonds, const double *__restrict__ ch,
-                                             const double *__restrict__ sh, int cb, int ce)
+                                             const double *__restrict__ sh, const double *__restrict__ shi, int cb, int ce)
 {
     for (int h = cb + (int)threadIdx.x; h < ce; h += (int)blockDim.x) {
         const int2 b = bonds[h];
@@ -37,8 +38,14 @@ __device__ __forceinline__ void colour_stage(double2 *U, int nk, int N, int lbas
             const double c = ch[(size_t)l * Nh + h], s = sh[(size_t)l * Nh + h];
             double2 *row = U + (size_t)k * N;
             const double2 a = row[b.x], d = row[b.y];
-            row[b.x] = make_double2(c * a.x + s * d.x, c * a.y + s * d.y);
-            row[b.y] = make_double2(c * d.x + s * a.x, c * d.y + s * a.y);
+            if (shi) {
+                const double t = shi[(size_t)l * Nh + h];
+                row[b.x] = make_double2(c * a.x + (s * d.x - t * d.y), c * a.y + (s * d.y + t * d.x));  // c a + s d
+                row[b.y] = make_double2(c * d.x + (s * a.x + t * a.y), c * d.y + (s * a.y - t * a.x));  // c d + conj(s) a
+            } else {
+                row[b.x] = make_double2(c * a.x + s * d.x, c * a.y + s * d.y);
+                row[b.y] = make_double2(c * d.x + s * a.x, c * d.y + s * a.y);
+            }
         }
     }
     __syncthreads();
@@ -58,18 +65,18 @@ __device__ __forceinline__ void diag_stage(double2 *U, int nk, int N, int lbase,
 // U[k] <- B_l U[k] (DAGGER = false) or B_lᴴ U[k] (true), l = (lbase + k) mod Lt.
 // Sym:  B = Γ D Γᴴ (Hermitian);  Asym:  B = D Γ,  Bᴴ = Γᴴ D.   Γ = colours applied first-to-last.
 template <bool SYM, bool DAGGER>
-__device__ __forceinline__ void propagate(double2 *U, int nk, int lbase, const FdmArgs &a, const double *expV, const double *ch, const double *sh)
+__device__ __forceinline__ void propagate(double2 *U, int nk, int lbase, const FdmArgs &a, const double *expV, const double *ch, const double *sh, const double *shi)
 {
     if (SYM) {
-        for (int c = a.ncol - 1; c >= 0; --c) colour_stage(U, nk, a.N, lbase, a.Lt, a.Nh, a.bonds, ch, sh, a.col_off[c], a.col_off[c + 1]);
+        for (int c = a.ncol - 1; c >= 0; --c) colour_stage(U, nk, a.N, lbase, a.Lt, a.Nh, a.bonds, ch, sh, shi, a.col_off[c], a.col_off[c + 1]);
         diag_stage(U, nk, a.N, lbase, a.Lt, expV);
-        for (int c = 0; c < a.ncol; ++c) colour_stage(U, nk, a.N, lbase, a.Lt, a.Nh, a.bonds, ch, sh, a.col_off[c], a.col_off[c + 1]);
+        for (int c = 0; c < a.ncol; ++c) colour_stage(U, nk, a.N, lbase, a.Lt, a.Nh, a.bonds, ch, sh, shi, a.col_off[c], a.col_off[c + 1]);
     } else if (!DAGGER) {
-        for (int c = 0; c < a.ncol; ++c) colour_stage(U, nk, a.N, lbase, a.Lt, a.Nh, a.bonds, ch, sh, a.col_off[c], a.col_off[c + 1]);
+        for (int c = 0; c < a.ncol; ++c) colour_stage(U, nk, a.N, lbase, a.Lt, a.Nh, a.bonds, ch, sh, shi, a.col_off[c], a.col_off[c + 1]);
         diag_stage(U, nk, a.N, lbase, a.Lt, expV);
     } else {
         diag_stage(U, nk, a.N, lbase, a.Lt, expV);
-        for (int c = a.ncol - 1; c >= 0; --c) colour_stage(U, nk, a.N, lbase, a.Lt, a.Nh, a.bonds, ch, sh, a.col_off[c], a.col_off[c + 1]);
+        for (int c = a.ncol - 1; c >= 0; --c) colour_stage(U, nk, a.N, lbase, a.Lt, a.Nh, a.bonds, ch, sh, shi, a.col_off[c], a.col_off[c + 1]);
     }
 }
 
@@ -107,6 +114,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
     const int nk = min(a.Tc, Lt - l0);
     const double *expV = a.expV + (size_t)w * Lt * N;
     const double *ch = a.ch + (size_t)w * Lt * a.Nh, *sh = a.sh + (size_t)w * Lt * a.Nh;
+    const double *shi = a.shi ? a.shi + (size_t)w * Lt * a.Nh : nullptr;
     const size_t sstride = (size_t)a.nsys * N;  // distance between time slices
     const double2 *in = a.in + (size_t)sys * N;
     double2 *out = a.out + (size_t)sys * N;
@@ -120,7 +128,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
             U[idx] = in[(size_t)wrap(l0 + k - 1, Lt) * sstride + i];
         }
         __syncthreads();
-        propagate<SYM, false>(U, nk, l0, a, expV, ch, sh);
+        propagate<SYM, false>(U, nk, l0, a, expV, ch, sh, shi);
         for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {
             const int k = idx / N, i = idx - k * N, l = l0 + k;
             const double2 v = in[(size_t)l * sstride + i], u = U[idx];
@@ -135,7 +143,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
             U[idx] = in[(size_t)wrap(l0 + k + 1, Lt) * sstride + i];
         }
         __syncthreads();
-        propagate<SYM, true>(U, nk, wrap(l0 + 1, Lt), a, expV, ch, sh);
+        propagate<SYM, true>(U, nk, wrap(l0 + 1, Lt), a, expV, ch, sh, shi);
         for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {
             const int k = idx / N, i = idx - k * N, l = l0 + k;
             const double2 v = in[(size_t)l * sstride + i], u = U[idx];
@@ -152,7 +160,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
             U[idx] = in[(size_t)wrap(l0 + k - 1, Lt) * sstride + i];
         }
         __syncthreads();
-        propagate<SYM, false>(U, nk1, l0, a, expV, ch, sh);
+        propagate<SYM, false>(U, nk1, l0, a, expV, ch, sh, shi);
         for (int idx = threadIdx.x; idx < nk1 * N; idx += blockDim.x) {
             const int k = idx / N, i = idx - k * N, l = wrap(l0 + k, Lt);
             const double2 v = in[(size_t)l * sstride + i], u = U[idx];
@@ -161,7 +169,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
         __syncthreads();
         for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) U[idx] = Y[idx + N];
         __syncthreads();
-        propagate<SYM, true>(U, nk, wrap(l0 + 1, Lt), a, expV, ch, sh);
+        propagate<SYM, true>(U, nk, wrap(l0 + 1, Lt), a, expV, ch, sh, shi);
         for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {
             const int k = idx / N, i = idx - k * N, l = l0 + k;
             const double2 y = Y[idx], u = U[idx];
@@ -182,7 +190,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
             U[idx] = in[(size_t)wrap(l0 + k, Lt) * sstride + i];
         }
         __syncthreads();
-        propagate<SYM, true>(U, nk1, l0, a, expV, ch, sh);
+        propagate<SYM, true>(U, nk1, l0, a, expV, ch, sh, shi);
         for (int idx = threadIdx.x; idx < nk1 * N; idx += blockDim.x) {
             const int k = idx / N, i = idx - k * N, l = wrap(l0 + k - 1, Lt);
             const double2 v = in[(size_t)l * sstride + i], u = U[idx];
@@ -191,7 +199,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
         __syncthreads();
         for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) U[idx] = Y[idx];
         __syncthreads();
-        propagate<SYM, false>(U, nk, l0, a, expV, ch, sh);
+        propagate<SYM, false>(U, nk, l0, a, expV, ch, sh, shi);
         for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {
             const int k = idx / N, i = idx - k * N, l = l0 + k;
             const double2 y = Y[idx + N], u = U[idx];
@@ -225,6 +233,7 @@ __global__ void __launch_bounds__(kThreads) checkerboard_kernel(FdmArgs a, int i
     const int w = sys / a.nrhs, Lt = a.Lt, N = a.N;
     const int l0 = chunk * a.Tc, nk = min(a.Tc, Lt - l0);
     const double *ch = a.ch + (size_t)w * Lt * a.Nh, *sh = a.sh + (size_t)w * Lt * a.Nh;
+    const double *shi = a.shi ? a.shi + (size_t)w * Lt * a.Nh : nullptr;
     const size_t sstride = (size_t)a.nsys * N;
     double2 *v = a.out + (size_t)sys * N;
     for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {
@@ -243,6 +252,12 @@ __global__ void __launch_bounds__(kThreads) checkerboard_kernel(FdmArgs a, int i
                 const double ss = inverse ? -sh[(size_t)(l0 + k) * a.Nh + h] : sh[(size_t)(l0 + k) * a.Nh + h];
                 double2 *row = U + (size_t)k * N;
                 const double2 x = row[b.x], y = row[b.y];
+                if (shi) {  // complex hopping: [[c, s], [conj(s), c]], inverse [[c, -s], [-conj(s), c]] (:133-141)
+                    const double tt = inverse ? -shi[(size_t)(l0 + k) * a.Nh + h] : shi[(size_t)(l0 + k) * a.Nh + h];
+                    row[b.x] = make_double2(cc * x.x + (ss * y.x - tt * y.y), cc * x.y + (ss * y.y + tt * y.x));
+                    row[b.y] = make_double2(cc * y.x + (ss * x.x + tt * x.y), cc * y.y + (ss * x.y - tt * x.x));
+                    continue;
+                }
                 row[b.x] = make_double2(cc * x.x + ss * y.x, cc * x.y + ss * y.y);
                 row[b.y] = make_double2(cc * y.x + ss * x.x, cc * y.y + ss * x.y);
             }

@@ -58,15 +58,17 @@ __device__ __forceinline__ double2 lin2(double a, double2 x, double b, double2 y
 // update_B̄! (:604-621) for every walker in one launch, plus the padded (c̄, s̄) table
 // ---------------------------------------------------------------------------------------------
 __global__ void tau_means_kernel(const double *__restrict__ expV, const double *__restrict__ ch, const double *__restrict__ sh, double *dbar, double *cbar, double *sbar, double2 *pcs,
-                                 const int *__restrict__ psrc, int ptotal, int Lt, int N, int Nh)
+                                 const int *__restrict__ psrc, int ptotal, int Lt, int N, int Nh, const double *__restrict__ shi, double *sbari)
 {
     // 64 outputs x 4 tau-groups per workgroup: lanes run over sites/bonds (coalesced), each
     // thread sums every 4th slice with 8 loads in flight, then one LDS hop across the groups
     __shared__ double2 part[4][64];
+    __shared__ double parti[4][64];
     const int w = blockIdx.y;
     const int j = blockIdx.x * 64 + threadIdx.x, ty = threadIdx.y;
     expV += (size_t)w * Lt * N; ch += (size_t)w * Lt * Nh; sh += (size_t)w * Lt * Nh;
-    double a = 0, b = 0;
+    if (shi) shi += (size_t)w * Lt * Nh;
+    double a = 0, b = 0, bi = 0;
     int h = -1;
     if (j < N) {
 #pragma unroll 8
@@ -76,11 +78,15 @@ __global__ void tau_means_kernel(const double *__restrict__ expV, const double *
         if (h >= 0) {
 #pragma unroll 8
             for (int l = ty; l < Lt; l += 4) { a += ch[(size_t)l * Nh + h]; b += sh[(size_t)l * Nh + h]; }
+            if (shi)
+                for (int l = ty; l < Lt; l += 4) bi += shi[(size_t)l * Nh + h];
         }
     }
     part[ty][threadIdx.x] = make_double2(a, b);
+    parti[ty][threadIdx.x] = bi;
     __syncthreads();
     if (ty != 0) return;
+    bi = (parti[0][threadIdx.x] + parti[1][threadIdx.x]) + (parti[2][threadIdx.x] + parti[3][threadIdx.x]);
     a = (part[0][threadIdx.x].x + part[1][threadIdx.x].x) + (part[2][threadIdx.x].x + part[3][threadIdx.x].x);
     b = (part[0][threadIdx.x].y + part[1][threadIdx.x].y) + (part[2][threadIdx.x].y + part[3][threadIdx.x].y);
     if (j < N) {
@@ -90,6 +96,7 @@ __global__ void tau_means_kernel(const double *__restrict__ expV, const double *
             a /= Lt; b /= Lt;
             cbar[(size_t)w * Nh + h] = a;
             sbar[(size_t)w * Nh + h] = b;
+            if (sbari) sbari[(size_t)w * Nh + h] = bi / Lt;
         } else {
             a = 1.0; b = 0.0;  // identity self bond
         }
@@ -97,11 +104,12 @@ __global__ void tau_means_kernel(const double *__restrict__ expV, const double *
     }
 }
 
-void launch_tau_means(hipStream_t st, const KpmGeom &kg, const double *expV, const double *ch, const double *sh, double *dbar, double *cbar, double *sbar, int Lt, int N, int Nh, int w0, int nw)
+void launch_tau_means(hipStream_t st, const KpmGeom &kg, const double *expV, const double *ch, const double *sh, double *dbar, double *cbar, double *sbar, int Lt, int N, int Nh, int w0, int nw, const double *shi,
+                      double *sbari)
 {
     dim3 grid((N + kg.ptotal + 63) / 64, nw);
     hipLaunchKernelGGL(tau_means_kernel, grid, dim3(64, 4), 0, st, expV + (size_t)w0 * Lt * N, ch + (size_t)w0 * Lt * Nh, sh + (size_t)w0 * Lt * Nh, dbar + (size_t)w0 * N, cbar + (size_t)w0 * Nh,
-                       sbar + (size_t)w0 * Nh, kg.pcs + (size_t)w0 * kg.ptotal, kg.psrc, kg.ptotal, Lt, N, Nh);
+                       sbar + (size_t)w0 * Nh, kg.pcs + (size_t)w0 * kg.ptotal, kg.psrc, kg.ptotal, Lt, N, Nh, shi ? shi + (size_t)w0 * Lt * Nh : nullptr, sbari ? sbari + (size_t)w0 * Nh : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -677,44 +685,51 @@ static int cheb_own_enabled()
 // ---------------------------------------------------------------------------------------------
 // generic fallback (any number of colours / sites): bond tables read from memory each stage
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bbar_colour(double2 *W, const int2 *__restrict__ bonds, const double *__restrict__ cbar, const double *__restrict__ sbar, int cb, int ce)
+// sbari != nullptr: complex hopping means, factor [[c̄, s̄], [conj(s̄), c̄]]
+__device__ __forceinline__ void bbar_colour(double2 *W, const int2 *__restrict__ bonds, const double *__restrict__ cbar, const double *__restrict__ sbar, const double *__restrict__ sbari, int cb, int ce)
 {
     for (int h = cb + (int)threadIdx.x; h < ce; h += (int)blockDim.x) {
         const int2 b = bonds[h];
         const double c = cbar[h], s = sbar[h];
         const double2 a = W[b.x], d = W[b.y];
-        W[b.x] = make_double2(c * a.x + s * d.x, c * a.y + s * d.y);
-        W[b.y] = make_double2(c * d.x + s * a.x, c * d.y + s * a.y);
+        if (sbari) {
+            const double t = sbari[h];
+            W[b.x] = make_double2(c * a.x + (s * d.x - t * d.y), c * a.y + (s * d.y + t * d.x));
+            W[b.y] = make_double2(c * d.x + (s * a.x + t * a.y), c * d.y + (s * a.y - t * a.x));
+        } else {
+            W[b.x] = make_double2(c * a.x + s * d.x, c * a.y + s * d.y);
+            W[b.y] = make_double2(c * d.x + s * a.x, c * d.y + s * a.y);
+        }
     }
     __syncthreads();
 }
 
 template <int MODE>
-__device__ __forceinline__ void bbar_apply(double2 *W, int N, int ncol, const int2 *bonds, const int *col_off, const double *dbar, const double *cbar, const double *sbar)
+__device__ __forceinline__ void bbar_apply(double2 *W, int N, int ncol, const int2 *bonds, const int *col_off, const double *dbar, const double *cbar, const double *sbar, const double *sbari = nullptr)
 {
     if (MODE == 0)
-        for (int c = ncol - 1; c >= 0; --c) bbar_colour(W, bonds, cbar, sbar, col_off[c], col_off[c + 1]);
+        for (int c = ncol - 1; c >= 0; --c) bbar_colour(W, bonds, cbar, sbar, sbari, col_off[c], col_off[c + 1]);
     else
-        for (int c = 0; c < ncol; ++c) bbar_colour(W, bonds, cbar, sbar, col_off[c], col_off[c + 1]);
+        for (int c = 0; c < ncol; ++c) bbar_colour(W, bonds, cbar, sbar, sbari, col_off[c], col_off[c + 1]);
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
         const double d = (MODE == 2) ? dbar[i] * dbar[i] : dbar[i];
         W[i] = make_double2(d * W[i].x, d * W[i].y);
     }
     __syncthreads();
     if (MODE == 0)
-        for (int c = 0; c < ncol; ++c) bbar_colour(W, bonds, cbar, sbar, col_off[c], col_off[c + 1]);
+        for (int c = 0; c < ncol; ++c) bbar_colour(W, bonds, cbar, sbar, sbari, col_off[c], col_off[c + 1]);
     else if (MODE == 2)
-        for (int c = ncol - 1; c >= 0; --c) bbar_colour(W, bonds, cbar, sbar, col_off[c], col_off[c + 1]);
+        for (int c = ncol - 1; c >= 0; --c) bbar_colour(W, bonds, cbar, sbar, sbari, col_off[c], col_off[c + 1]);
 }
 
 template <int MODE>
 __device__ __forceinline__ void kpm_poly(double2 *W, double2 *A1, double2 *A2, double2 *ACC, const double2 *__restrict__ coefs, int n, double avg, double mag, const KpmArgs &k, const double *dbar,
-                                         const double *cbar, const double *sbar)
+                                         const double *cbar, const double *sbar, const double *sbari)
 {
     const int N = k.N;
     for (int i = threadIdx.x; i < N; i += blockDim.x) { A1[i] = ACC[i]; W[i] = ACC[i]; }
     __syncthreads();
-    bbar_apply<MODE>(W, N, k.ncol, k.bonds, k.col_off, dbar, cbar, sbar);
+    bbar_apply<MODE>(W, N, k.ncol, k.bonds, k.col_off, dbar, cbar, sbar, sbari);
     const double2 c0 = coefs[0], c1 = n > 1 ? coefs[1] : make_double2(0.0, 0.0);
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
         const double2 a1 = A1[i];
@@ -726,7 +741,7 @@ __device__ __forceinline__ void kpm_poly(double2 *W, double2 *A1, double2 *A2, d
     }
     __syncthreads();
     for (int kk = 2; kk < n; ++kk) {
-        bbar_apply<MODE>(W, N, k.ncol, k.bonds, k.col_off, dbar, cbar, sbar);
+        bbar_apply<MODE>(W, N, k.ncol, k.bonds, k.col_off, dbar, cbar, sbar, sbari);
         const double2 ck = coefs[kk];
         for (int i = threadIdx.x; i < N; i += blockDim.x) {
             const double2 a1 = A1[i], a2 = A2[i];
@@ -753,6 +768,7 @@ __global__ void __launch_bounds__(kThreads) cheb_generic_kernel(KpmArgs k)
     if (k.cg && k.cg[sys].done) return;
     if (k.half && om >= (Lt + 1) / 2) return;
     const double *dbar = k.dbar + (size_t)w * N, *cbar = k.cbar + (size_t)w * k.Nh, *sbar = k.sbar + (size_t)w * k.Nh;
+    const double *sbari = k.sbari ? k.sbari + (size_t)w * k.Nh : nullptr;
     const double emin = k.bounds[2 * w], emax = k.bounds[2 * w + 1];
     const double avg = 0.5 * (emax + emin), mag = 0.5 * (emax - emin);
     const double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
@@ -768,12 +784,12 @@ __global__ void __launch_bounds__(kThreads) cheb_generic_kernel(KpmArgs k)
         for (int i = threadIdx.x; i < N; i += blockDim.x) ACC[i] = v[i];
         __syncthreads();
         if (k.is_sym) {
-            kpm_poly<0>(W, A1, A2, ACC, coefs, n, avg, mag, k, dbar, cbar, sbar);
+            kpm_poly<0>(W, A1, A2, ACC, coefs, n, avg, mag, k, dbar, cbar, sbar, sbari);
         } else {
             const int omc = Lt - om - 1;
             const double2 *coefs_c = k.coefs + ((size_t)w * k.nslot + omc) * k.maxorder;
-            kpm_poly<1>(W, A1, A2, ACC, coefs_c, k.order[(size_t)w * k.nslot + omc], avg, mag, k, dbar, cbar, sbar);
-            kpm_poly<1>(W, A1, A2, ACC, coefs, n, avg, mag, k, dbar, cbar, sbar);
+            kpm_poly<1>(W, A1, A2, ACC, coefs_c, k.order[(size_t)w * k.nslot + omc], avg, mag, k, dbar, cbar, sbar, sbari);
+            kpm_poly<1>(W, A1, A2, ACC, coefs, n, avg, mag, k, dbar, cbar, sbar, sbari);
         }
         for (int i = threadIdx.x; i < N; i += blockDim.x) {
             const double2 x = v[i], o = make_double2(k.scale * ACC[i].x, k.scale * ACC[i].y);
@@ -875,31 +891,40 @@ __global__ void __launch_bounds__(1024) lanczos_kernel(KpmArgs k, KpmGeom kg, in
     const int N = k.N, w = w0 + blockIdx.x;
     double2 *W = (!FAST && k.scratch) ? k.scratch + (size_t)blockIdx.x * k.scratch_stride : lds, *VK = W + N, *VKM = VK + N;
     const double *dbar = k.dbar + (size_t)w * N, *cbar = k.cbar + (size_t)w * k.Nh, *sbar = k.sbar + (size_t)w * k.Nh;
-    randvec += (size_t)blockIdx.x * N;
+    // T = ComplexF64 (generic path only): the start vector is N complex deviates (randn! on a Vector{ComplexF64},
+    // KPMPreconditioner.jl:634) and B̄ is complex Hermitian; the Lanczos vectors are then genuinely complex.  For real hoppings every
+    // imaginary part below is an exact zero and the arithmetic reduces bit for bit to the real recurrence.
+    const double *sbari = (!FAST && k.sbari) ? k.sbari + (size_t)w * k.Nh : nullptr;
+    const bool cplx = sbari != nullptr;
+    randvec += (size_t)blockIdx.x * N * (cplx ? 2 : 1);
     alpha += (size_t)blockIdx.x * 1024;
     beta += (size_t)blockIdx.x * 1024;
     LaneBonds lb;
     if (FAST) load_lane_bonds(lb, kg, w, k.ncol);
     double acc = 0;
-    for (int i = threadIdx.x; i < N; i += blockDim.x) acc += randvec[i] * randvec[i];
+    for (int i = threadIdx.x; i < N; i += blockDim.x) acc += cplx ? randvec[2 * i] * randvec[2 * i] + randvec[2 * i + 1] * randvec[2 * i + 1] : randvec[i] * randvec[i];
     const double nrm = sqrt(block_sum_real(acc, red));
     // the fast path works in LDS-position order (a permutation: dot products are unaffected)
-    for (int i = threadIdx.x; i < N; i += blockDim.x) { VK[FAST ? kg.pos[i] : i] = make_double2(randvec[i] / nrm, 0.0); VKM[i] = make_double2(0.0, 0.0); }
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        VK[FAST ? kg.pos[i] : i] = cplx ? make_double2(randvec[2 * i] / nrm, randvec[2 * i + 1] / nrm) : make_double2(randvec[i] / nrm, 0.0);
+        VKM[i] = make_double2(0.0, 0.0);
+    }
     __syncthreads();
     double bprev = 0.0;
     for (int s = 0; s < nsteps; ++s) {
         for (int i = threadIdx.x; i < N; i += blockDim.x) W[i] = VK[i];
         __syncthreads();
         if (FAST) bbar_apply_regs<MODE>(W, lb, k.ncol, N, dbar, kg.pos);
-        else bbar_apply<MODE>(W, N, k.ncol, k.bonds, k.col_off, dbar, cbar, sbar);
+        else bbar_apply<MODE>(W, N, k.ncol, k.bonds, k.col_off, dbar, cbar, sbar, sbari);
         acc = 0;
-        for (int i = threadIdx.x; i < N; i += blockDim.x) acc += VK[i].x * W[i].x;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) acc += FAST ? VK[i].x * W[i].x : VK[i].x * W[i].x + VK[i].y * W[i].y;
         const double al = block_sum_real(acc, red);
         acc = 0;
         for (int i = threadIdx.x; i < N; i += blockDim.x) {
             const double wv = W[i].x - al * VK[i].x - bprev * VKM[i].x;
-            W[i].x = wv;
-            acc += wv * wv;
+            const double wi = FAST ? 0.0 : W[i].y - al * VK[i].y - bprev * VKM[i].y;
+            W[i] = make_double2(wv, wi);
+            acc += FAST ? wv * wv : wv * wv + wi * wi;
         }
         const double nb = sqrt(block_sum_real(acc, red));
         if (threadIdx.x == 0) {
@@ -908,7 +933,7 @@ __global__ void __launch_bounds__(1024) lanczos_kernel(KpmArgs k, KpmGeom kg, in
         }
         for (int i = threadIdx.x; i < N; i += blockDim.x) {
             VKM[i] = VK[i];
-            VK[i] = make_double2(W[i].x / nb, 0.0);
+            VK[i] = make_double2(W[i].x / nb, FAST ? 0.0 : W[i].y / nb);
         }
         bprev = nb;
         __syncthreads();

@@ -139,6 +139,35 @@ __global__ void fields_kernel(const double *__restrict__ V, const double *__rest
     }
 }
 
+// T = ComplexF64: the hopping is complex128, sinh = sign(conj t) sinh(Δτ′|t|) = conj(t)/|t| · sinh (Julia's sign(0) = 0)
+__global__ void fields_kernel_c(const double *__restrict__ V, const double2 *__restrict__ t, const int *__restrict__ perm0, double *__restrict__ expV, double *__restrict__ ch,
+                                double *__restrict__ sh, double *__restrict__ shi, int Lt, int N, int Nh, double dtau, double dtau_k)
+{
+    const size_t nV = V ? (size_t)Lt * N : 0, nT = t ? (size_t)Lt * Nh : 0;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nV + nT; idx += (size_t)gridDim.x * blockDim.x) {
+        if (idx < nV) {
+            expV[idx] = exp(-dtau * V[idx]);  // :217
+        } else {
+            const size_t j = idx - nV;
+            const int l = (int)(j / Nh), h = (int)(j - (size_t)l * Nh);
+            const double2 tt = t[(size_t)l * Nh + perm0[h]];  // :224-228
+            const double ab = hypot(tt.x, tt.y), a = dtau_k * ab, sn = sinh(a);
+            ch[j] = cosh(a);                                   // :230
+            sh[j] = ab > 0.0 ? tt.x / ab * sn : 0.0;           // :231, Re sign(conj t)
+            shi[j] = ab > 0.0 ? -tt.y / ab * sn : 0.0;         //        Im sign(conj t)
+        }
+    }
+}
+
+void launch_fields_from_path_integral_c(hipStream_t st, const double *V, const double2 *t, const int *perm0, double *expV, double *ch, double *sh, double *shi, int Lt, int N, int Nh, double dtau, double dtau_k)
+{
+    const size_t tot = (V ? (size_t)Lt * N : 0) + (t ? (size_t)Lt * Nh : 0);
+    if (tot == 0) return;
+    int blocks = (int)((tot + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fields_kernel_c, dim3(blocks), dim3(256), 0, st, V, t, perm0, expV, ch, sh, shi, Lt, N, Nh, dtau, dtau_k);
+}
+
 void launch_fields_from_path_integral(hipStream_t st, const double *V, const double *t, const int *perm0, double *expV, double *ch, double *sh, int Lt, int N, int Nh, double dtau, double dtau_k)
 {
     const size_t tot = (V ? (size_t)Lt * N : 0) + (t ? (size_t)Lt * Nh : 0);

@@ -27,6 +27,7 @@ constexpr int kFdmColours = 4;      // colours held in registers by the fast Fer
 struct Geometry {
     int Lt, N, Nh, ncol, nw, nrhs, nsys;
     int is_sym;
+    int is_cplx;  // matrix-element type T = ComplexF64 (complex hoppings): generic kernels only
 };
 
 // per-system CG state living on the device
@@ -52,6 +53,8 @@ struct FdmArgs {
     const int2 *bonds;      // [Nh] 0-based site pairs, colour sorted
     const int *col_off;     // [ncol+1] bond offsets of the colours
     const double *expV, *ch, *sh;
+    const double *shi;      // imaginary part of sinhΔτt for T = ComplexF64 (same layout as sh), nullptr for real hoppings: the bond
+                            // factor is [[c, s], [conj(s), c]] (src/checkerboard_matrix_multiply.jl:60-68); generic kernels only
     const double2 *in;
     double2 *out;
     double2 *partial;       // [nsys][nchunk] dot(in, out) partials, or nullptr
@@ -85,6 +88,7 @@ struct KpmArgs {
     const int2 *bonds;
     const int *col_off;
     const double *dbar, *cbar, *sbar;   // [w][N], [w][Nh], [w][Nh] tau-means
+    const double *sbari;                // [w][Nh] tau-mean of Im sinhΔτt (T = ComplexF64), nullptr for real hoppings
     const int *order;                   // [w][nslot]
     const double2 *coefs;               // [w][nslot][maxorder]
     const double *bounds;               // [w][2]
@@ -164,13 +168,16 @@ void launch_transpose_out(hipStream_t st, const double2 *dev_layout, double2 *ho
 void launch_transpose_real_in(hipStream_t st, const double *src, double *dst, int Lt, int n);   // (Lt x n col-major) -> [l][n]
 void launch_transpose_real_out(hipStream_t st, const double *src, double *dst, int Lt, int n);  // [l][n] -> (Lt x n col-major)
 void launch_fields_from_path_integral(hipStream_t st, const double *V, const double *t, const int *perm0, double *expV, double *ch, double *sh, int Lt, int N, int Nh, double dtau, double dtau_k);
+// T = ComplexF64: t is complex128 [l][h]; sinh carries sign(conj t) (src/FermionDetMatrix.jl:231)
+void launch_fields_from_path_integral_c(hipStream_t st, const double *V, const double2 *t, const int *perm0, double *expV, double *ch, double *sh, double *shi, int Lt, int N, int Nh, double dtau, double dtau_k);
 void launch_lambda_update(hipStream_t st, double *Lam, int Lt, int N, const double *x, int Nph, double dtau, int ncoup, const int *c2p, const int *c2s, const double *alpha, const double *alpha3, const int *phsym, const int *site_first, const int *site_next, int Lt1);
 void launch_lambda_apply(hipStream_t st, int op, double2 *out, const double2 *in, const double *Lam, int Lt, int N, int nsys, int nrhs, int wslot_override);
 void launch_dot(hipStream_t st, const double2 *a, const double2 *b, double2 *partial, double2 *out, int Lt, int N, int nsys, int Tc, int nchunk);
 void launch_fft_twiddle(hipStream_t st, double2 *v, const double2 *tw, int Lt, int N, int nsys, int inverse);
 void launch_make_twiddle(hipStream_t st, double2 *tw, int Lt, double scale);
-void launch_tau_means(hipStream_t st, const KpmGeom &kg, const double *expV, const double *ch, const double *sh, double *dbar, double *cbar, double *sbar, int Lt, int N, int Nh, int w0, int nw);
-// alpha/beta: [nw][1024] each; randvec: [nw][N]
+void launch_tau_means(hipStream_t st, const KpmGeom &kg, const double *expV, const double *ch, const double *sh, double *dbar, double *cbar, double *sbar, int Lt, int N, int Nh, int w0, int nw, const double *shi = nullptr,
+                      double *sbari = nullptr);
+// alpha/beta: [nw][1024] each; randvec: [nw][N] doubles, or [nw][N] complex128 when k.sbari != nullptr (T = ComplexF64)
 void launch_lanczos(hipStream_t st, const KpmArgs &k, const KpmGeom &kg, int w0, int nw, const double *randvec, int nsteps, double *alpha, double *beta, bool use_BtB);
 void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg);
 // v[Lτ-1-ω] = conj(v[ω]) for ω < cld(Lτ, 2) (KPMPreconditioner.jl:334 / :468; the middle frequency of an odd Lτ conjugates itself)

@@ -1,0 +1,201 @@
+"""Matrix-element type T = ComplexF64 (complex hoppings) on the GPU against the CPU oracle, whose complex-T restatement is pinned by
+dense matrices in tests/test_oracle_complex_T.py.  Reference: the bond factor [[c, s], [conj(s), c]] with
+s = sign(conj t)·sinh(Δτ′|t|) (src/checkerboard_matrix_multiply.jl:60-68, src/FermionDetMatrix.jl:224-231); the operator type is
+FermionDetMatrix{T<:Number} (:19).  Complex handles run on the generic kernels (kernels_fdm.hip, cheb_generic_kernel, generic Lanczos)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import smoqyelphqmc_amd as sq
+from smoqyelphqmc_amd import _lib as L
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+lat = sq.lattice
+OP_TOL = 1e-13
+
+
+def relerr(got, want):
+    return np.abs(got - want).max() / np.abs(want).max()
+
+
+def complex_problem(kind, is_sym, nwalkers=1, nrhs=1):
+    models, ts = [], []
+    for w in range(nwalkers):
+        if kind == "honeycomb":
+            m = lat.holstein_honeycomb(4, 40, walker=w)
+        elif kind == "square":
+            m = lat.ossh_square(6, 12, walker=w)
+        else:
+            m = lat.bssh_chain(24, 9, walker=w)
+        g = np.random.default_rng(300 + w)
+        Nh, Lt = m.fpi.t.shape
+        ts.append(np.asfortranarray(m.fpi.t * np.exp(1j * g.uniform(0, 2 * np.pi, Nh))[:, None]))
+        models.append(m)
+    m0 = models[0]
+    nt, perm, colors = lat.checkerboard_decomposition(m0.fpi.neighbor_table)
+    Lt, N = m0.fpi.Ltau, m0.fpi.N
+    h = L.Handle(Lt, N, nt, colors, is_sym, nwalkers, nrhs, is_complex=True)
+    oracles = []
+    for w, (m, t) in enumerate(zip(models, ts)):
+        expV, ch, sh = orc.update_fields(m.fpi.V, t, perm, m.fpi.dtau, is_sym)
+        h.call("smoqy_update_from_path_integral", w, L.ptr(m.fpi.V), L.ptr(t), L.ptr(perm), C.c_double(m.fpi.dtau))
+        oracles.append(orc.OracleFDM(nt, expV, ch, sh, is_sym))
+    return h, oracles, (Lt, N, nt, perm, colors), models, ts
+
+
+def rand(Lt, N, count, seed):
+    g = np.random.default_rng(seed)
+    return np.asfortranarray(g.standard_normal((Lt, N, count)) + 1j * g.standard_normal((Lt, N, count)))
+
+
+@pytest.mark.parametrize("is_sym", [True, False])
+def test_fields_complex_T(is_sym):
+    h, o, (Lt, N, nt, perm, colors), models, ts = complex_problem("square", is_sym)
+    Nh = nt.shape[1]
+    e = np.zeros((Lt, N), order="F")
+    c = np.zeros((Lt, Nh), order="F", dtype=complex)
+    s = np.zeros((Lt, Nh), order="F", dtype=complex)
+    h.call("smoqy_get_fields", 0, L.ptr(e), L.ptr(c), L.ptr(s))
+    np.testing.assert_allclose(e, o[0].expV, rtol=1e-15)
+    np.testing.assert_allclose(c.real, o[0].cosh, rtol=1e-15)
+    assert np.all(c.imag == 0)
+    np.testing.assert_allclose(s, o[0].sinh + 1j * o[0].sinh_im, rtol=1e-13, atol=1e-17)
+    # smoqy_update_fields takes the complex arrays back (round trip through the other entry point)
+    h2 = L.Handle(Lt, N, nt, colors, is_sym, 1, 1, is_complex=True)
+    h2.call("smoqy_update_fields", 0, L.ptr(e), L.ptr(c), L.ptr(s))
+    v = rand(Lt, N, 1, 2)
+    a, b = np.zeros_like(v), np.zeros_like(v)
+    h.call("smoqy_matvec", L.OP_MTM, L.ptr(a), L.ptr(v), 0, 1)
+    h2.call("smoqy_matvec", L.OP_MTM, L.ptr(b), L.ptr(v), 0, 1)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("kind", ["honeycomb", "square", "chain"])
+@pytest.mark.parametrize("is_sym", [True, False])
+@pytest.mark.parametrize("Tc", [1, 2, 3])
+def test_matvec_complex_T(kind, is_sym, Tc):
+    h, o, (Lt, N, *_), *_ = complex_problem(kind, is_sym, nwalkers=2, nrhs=2)
+    h.call("smoqy_set_tau_chunk", Tc)
+    v = rand(Lt, N, 4, 3)
+    a, b = h.vec_alloc(), h.vec_alloc()
+    h.vec_upload(a, v)
+    for op, name in ((L.OP_M, "mul_M"), (L.OP_MT, "mul_Mt"), (L.OP_MTM, "mul_MtM"), (L.OP_MMT, "mul_MMt")):
+        h.call("smoqy_matvec_v", op, b, a)
+        got = h.vec_download(b)
+        for s in range(4):
+            assert relerr(got[:, :, s], getattr(o[s // 2], name)(v[:, :, s])) < OP_TOL, (kind, is_sym, Tc, name, s)
+    # adjoint identity across separate launches
+    h.call("smoqy_matvec_v", L.OP_M, b, a)
+    Mv = h.vec_download(b)
+    h.call("smoqy_matvec_v", L.OP_MT, b, a)
+    Mtv = h.vec_download(b)
+    lhs, rhs = np.vdot(v[:, :, 1], Mv[:, :, 0] * 0 + Mv[:, :, 1]), np.vdot(Mtv[:, :, 1], v[:, :, 1])
+    assert abs(lhs - rhs) < 1e-12 * abs(lhs)
+
+
+@pytest.mark.parametrize("is_sym", [True, False])
+def test_checkerboard_complex_T(is_sym):
+    h, o, (Lt, N, nt, perm, colors), *_ = complex_problem("square", is_sym)
+    v = rand(Lt, N, 1, 4)
+    ncol = colors.shape[1]
+    for tr in (False, True):
+        for inv in (False, True):
+            w = v.copy(order="F")
+            h.call("smoqy_checkerboard", L.ptr(w), int(inv), int(tr), 0, ncol, 0, 1)
+            assert relerr(w[:, :, 0], o[0].checkerboard(v[:, :, 0], transposed=tr, inverse=inv)) < 1e-14
+        for col in range(ncol):  # one colour at a time, as the force code walks them
+            w = v.copy(order="F")
+            h.call("smoqy_checkerboard", L.ptr(w), 0, int(tr), col, 1, 0, 1)
+            want = o[0].checkerboard(v[:, :, 0], transposed=tr, interval=(int(colors[0, col]) - 1, int(colors[1, col])))
+            assert relerr(w[:, :, 0], want) < 1e-14
+
+
+@pytest.mark.parametrize("kind", ["honeycomb", "chain"])
+@pytest.mark.parametrize("is_sym", [True, False])
+def test_cg_unpreconditioned_complex_T(kind, is_sym):
+    h, o, (Lt, N, *_), *_ = complex_problem(kind, is_sym, nwalkers=1, nrhs=2)
+    b = rand(Lt, N, 2, 7)
+    x = np.zeros_like(b)
+    iters = np.zeros(2, dtype=np.int32)
+    eps = np.zeros(2)
+    h.call("smoqy_cg_solve", L.ptr(x), L.ptr(b), 1, 0, 2, C.c_double(1e-12), 5000, 0, L.ptr(iters), L.ptr(eps))
+    for s in range(2):
+        xo, ito, epo = o[0].cg_solve(b[:, :, s], tol=1e-12, maxiter=5000)
+        assert relerr(x[:, :, s], xo) < 1e-10
+        assert abs(int(iters[s]) - ito) <= 2 and eps[s] < 1e-12
+        assert relerr(o[0].mul_MtM(x[:, :, s]), b[:, :, s]) < 1e-11
+
+
+def _precond_state(h, Lt):
+    act, norder = C.c_int(0), C.c_int(0)
+    bounds, order = np.zeros(2), np.zeros(Lt, dtype=np.int32)
+    la, lb = np.zeros(20), np.zeros(19)
+    h.call("smoqy_precond_get", 0, C.byref(act), bounds.ctypes.data_as(C.POINTER(C.c_double)), order.ctypes.data_as(C.POINTER(C.c_int)), C.byref(norder),
+           la.ctypes.data_as(C.POINTER(C.c_double)), lb.ctypes.data_as(C.POINTER(C.c_double)))
+    return bool(act.value), bounds, order[: norder.value], la, lb
+
+
+@pytest.mark.parametrize("kind", ["honeycomb", "square", "chain"])
+@pytest.mark.parametrize("is_sym", [True, False])
+def test_kpm_preconditioner_and_pcg_complex_T(kind, is_sym):
+    h, o, (Lt, N, *_), *_ = complex_problem(kind, is_sym, nwalkers=1, nrhs=2)
+    g = np.random.default_rng(8)
+    rv = np.ascontiguousarray((g.standard_normal(N) + 1j * g.standard_normal(N)) * np.sqrt(0.5))  # randn! on a Vector{ComplexF64}
+    P = orc.OracleKPM(o[0])
+    P.update(rv)
+    h.call("smoqy_precond_update", 0, L.ptr(rv))
+    act, bounds, order, la, lb = _precond_state(h, Lt)
+    oa, ob = P.lanczos()
+    assert act == P.active and P.active
+    np.testing.assert_allclose(la[:8], oa[:8], rtol=1e-10)
+    np.testing.assert_allclose(lb[:8], ob[:8], rtol=1e-9)
+    np.testing.assert_allclose(bounds, P.bounds, rtol=1e-9)
+    assert np.array_equal(order, P.order)
+    v = rand(Lt, N, 2, 9)
+    out = np.zeros_like(v)
+    h.call("smoqy_precond_apply", L.ptr(out), L.ptr(v), 0, 2)
+    for s in range(2):
+        assert relerr(out[:, :, s], P.apply(v[:, :, s])) < 1e-11
+    for rocfft in (0, 1):  # fused tau-FFT iteration and the rocFFT + BLAS-1 form
+        h.call("smoqy_fft_use_rocfft", rocfft)
+        x = np.zeros_like(v)
+        iters = np.zeros(2, dtype=np.int32)
+        eps = np.zeros(2)
+        h.call("smoqy_cg_solve", L.ptr(x), L.ptr(v), 1, 0, 2, C.c_double(1e-10), 10000, 1, L.ptr(iters), L.ptr(eps))
+        for s in range(2):
+            xo, ito, epo = o[0].cg_solve(v[:, :, s], precond=P, tol=1e-10, maxiter=10000)
+            assert abs(int(iters[s]) - ito) <= 2 and eps[s] < 1e-10, (iters, ito)
+            assert relerr(x[:, :, s], xo) < 1e-9
+            assert relerr(o[0].mul_MtM(x[:, :, s]), v[:, :, s]) < 1e-9
+
+
+def test_mirror_with_complex_hoppings():
+    """The reference-shaped mirror: a FermionPathIntegral with complex t makes a FermionDetMatrix{ComplexF64}."""
+    m = lat.holstein_honeycomb(4, 10)
+    g = np.random.default_rng(1)
+    m.fpi.t = np.asfortranarray(m.fpi.t * np.exp(1j * g.uniform(0, 2 * np.pi, m.fpi.t.shape[0]))[:, None])
+    fdm = sq.SymFermionDetMatrix(m.fpi, maxiter=5000, tol=1e-10)
+    assert sq.eltype(fdm) is np.complex128 and np.iscomplexobj(fdm.sinhΔτt)
+    nt, perm, colors = lat.checkerboard_decomposition(m.fpi.neighbor_table)
+    expV, ch, sh = orc.update_fields(m.fpi.V, m.fpi.t, perm, m.fpi.dtau, True)
+    o = orc.OracleFDM(nt, expV, ch, sh, True)
+    v = rand(10, 32, 1, 5)[:, :, 0].copy(order="F")
+    out = np.zeros_like(v)
+    sq.mul_MtM(out, fdm, v)
+    assert relerr(out, o.mul_MtM(v)) < OP_TOL
+    P = sq.KPMPreconditioner(fdm, rng=np.random.default_rng(5))
+    assert P.active
+    x = np.zeros_like(v)
+    iters, eps = sq.ldiv(x, fdm, v, preconditioner=P, rng=np.random.default_rng(6))
+    assert eps < 1e-10 and relerr(o.mul_MtM(x), v) < 1e-9
+
+
+def test_force_entry_points_reject_complex_T():
+    h, *_ = complex_problem("chain", True)
+    m = lat.bssh_chain(24, 9)
+    nt, perm, colors = lat.checkerboard_decomposition(m.fpi.neighbor_table)
+    cs, keep = L.couplings_struct(m.force_couplings(perm))
+    with pytest.raises(L.SmoqyError, match="real hoppings only"):
+        h.call("smoqy_force_set_couplings", C.byref(cs))
