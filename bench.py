@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=6, help="concurrent lock-step batches per GPU (one HIP stream + host thread each)")
     ap.add_argument("--solve-concurrency", type=int, default=3, help="at most this many batches inside the CG at once (0 = no limit)")
     ap.add_argument("--measure-nrv", type=int, default=0, help="add update_greens_estimator! + measure_GΔ0! with this many random vectors to every sweep (27 + Nrv solves)")
+    ap.add_argument("--hmc", choices=["device", "host"], default="device",
+                    help="device: the EFA leapfrog of the HMC trajectory runs on the GPU (x, p and the force never leave it; smoqy_hmc_trajectory_v); "
+                         "host: round-1 form, a synthetic drift on the host with x uploaded and the force downloaded every step")
     ap.add_argument("--tau-chunk", type=int, default=0)
     ap.add_argument("--check-every", type=int, default=0)
     ap.add_argument("--matvec-reps", type=int, default=400)
@@ -347,7 +350,7 @@ def main():
     mine = walker_range(rank, world, wpg)  # walkers [rank*wpg, (rank+1)*wpg): no overlap between ranks, no exchange
     per = wpg // S
     batches = [WalkerBatch(args.workload, nwalkers=per, walker0=mine.start + s * per, device=dev, check_every=args.check_every or None, tau_chunk=args.tau_chunk or None,
-                           host_threads=max(2, 16 // S), measure_nrv=args.measure_nrv) for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
+                           host_threads=max(2, 16 // S), measure_nrv=args.measure_nrv, device_efa=args.hmc == "device") for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
     batch = batches[0]
     if args.solve_concurrency > 0:
         import threading
@@ -403,7 +406,7 @@ def main():
         if world == 1 and not args.roofline_only:
             one_stream = []
             for nw1 in (1, 8, 16):
-                ob = WalkerBatch(args.workload, nwalkers=nw1, walker0=mine.start, device=dev)
+                ob = WalkerBatch(args.workload, nwalkers=nw1, walker0=mine.start, device=dev, device_efa=args.hmc == "device")
                 ob.sweep()
                 ob.h.call("smoqy_sync")
                 t1 = time.perf_counter()
@@ -450,6 +453,8 @@ def main():
                 "cg_tol": batch.tol,
                 "avg_cg_iters": sum(b.stats.iters_sum for b in batches) / max(sum(b.stats.solves for b in batches), 1),
                 "preconditioner": "KPM (Sym)",
+                "hmc": ("EFA leapfrog on the device, Nt = %d steps of dt = pi/(2 Nt), trajectory always rejected (x restored) so the field distribution stays the one SURVEY.md 8(d) defines" % batch.Nt)
+                if args.hmc == "device" else "synthetic host-side drift (round-1 form)",
                 "parallelism": f"walker-parallel, {world} rank(s) x {wpg} walkers ({S} lock-step batches of {per}), no collective",
             },
             "roofline": roofline,

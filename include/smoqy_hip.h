@@ -238,6 +238,40 @@ int smoqy_force_store_v(smoqy_ctx *ctx, int psi, double *out);
 int smoqy_pff_step_v(smoqy_ctx *ctx, int phi, int psi, const double *x_all, const double *randvec_all, double tol, int maxiter, int use_precond,
                      double *Sf, int *iters, double *eps, double *dSdx);
 
+/* ---- EFA leapfrog on the device ------------------------------------ */
+
+/* SmoQyDQMC's ExactFourierAccelerator is NOT part of the reference tree: these entry points implement what its call sites in
+ * src/EFAPFFHMCUpdater.jl fix — initialize_momentum! (:142), evolve_eom! (:150, :202), kinetic_energy (:244), the momentum kick
+ * `p -= Δt ∂S∂x` (:196) — as exact harmonic evolution of every τ-Fourier mode of the phonon fields, with the accelerator's tables as
+ * INPUTS.  Parity unpinned (no source to compare with); oracle: oracle/efa.py, pinned by energy conservation / reversibility / a dense
+ * matrix exponential.  x, p and the force stay on the device across a whole trajectory.  Needs smoqy_force_set_couplings and
+ * smoqy_set_bare_model, a handle with nrhs = 1 and Ltau = 2^a 3^b 5^c 7^d.
+ *
+ * q, m: Nph x Ltau (column-major, like x).  q[p, ω] = eigenvalue of the harmonic bosonic action of phonon p at the periodic τ-frequency ω
+ * (S_b = 1/2 Σ q |x̃|², unitary transform), e.g. Δτ M [Ω² + 4/Δτ² sin²(πω/Lτ)]; m[p, ω] = dynamical mass of the fictitious momentum
+ * (K = 1/2 Σ |p̃|²/m; m = q is "exact" acceleration: every mode turns with unit frequency).  Both must be symmetric under ω → Lτ-ω.
+ * Phonons flagged infinite-mass in smoqy_couplings.finite_mass are left untouched. */
+int smoqy_efa_config(smoqy_ctx *ctx, const double *q, const double *m);
+/* x_all / p_all: Nph x Ltau x nwalkers; NULL leaves that array as it is.  Setting x also refreshes the fields (update!). */
+int smoqy_efa_set_state(smoqy_ctx *ctx, const double *x_all, const double *p_all);
+int smoqy_efa_get_state(smoqy_ctx *ctx, double *x_all, double *p_all);
+/* initialize_momentum!(p, efa, rng): R_all holds Nph x Ltau x nwalkers unit normal deviates from the caller's rng; p = F⁻¹ √m F R;
+ * K[w] = kinetic energy (src/EFAPFFHMCUpdater.jl:142) */
+int smoqy_efa_initialize_momentum(smoqy_ctx *ctx, const double *R_all, double *K);
+/* kinetic_energy(p, efa) (:244) and the harmonic bosonic action 1/2 Σ q |x̃|² of the current state, per walker (either may be NULL) */
+int smoqy_efa_energies(smoqy_ctx *ctx, double *K, double *Sb);
+/* [p -= kick_dt * ∂S/∂x with the force the last force evaluation left on the device (:196)]; evolve_eom!(x, p, dt, efa) (:150, :202);
+ * [refresh_fields != 0: update!(fermion_path_integral), update!(fdm), update_Λ! from the new x (:203-205)] */
+int smoqy_efa_evolve(smoqy_ctx *ctx, double dt, double kick_dt, int refresh_fields);
+/* restore = 0: copyto!(x0, x) (:130);  restore = 1: the reject branch — copyto!(x, x0) and update! (:263-275) */
+int smoqy_efa_checkpoint(smoqy_ctx *ctx, int restore);
+/* the trajectory of hmc_update! between the momentum refresh and the final action (src/EFAPFFHMCUpdater.jl:148-206) in ONE call:
+ * evolve(Δt/2), update!; Nt times { calculate_derivative_fermionic_action! at tol_force; p -= Δt ∂S_f/∂x; evolve(Δt, last step Δt/2);
+ * update! }.  Φ in vector phi, Ψ left in psi.  randvecs: N x nwalkers x Nt Lanczos start vectors (the rng stays on the host); Sf, iters,
+ * eps: nwalkers x Nt (any may be NULL).  Only the fermionic force is applied: anharmonic / dispersive phonon terms (:190-193) are the
+ * caller's to add through smoqy_efa_evolve step by step. */
+int smoqy_hmc_trajectory_v(smoqy_ctx *ctx, int phi, int psi, int Nt, double dt, double tol_force, int maxiter, int use_precond, const double *randvecs, double *Sf, int *iters, double *eps);
+
 /* ---- device-side update! from the phonon fields ------------------- */
 
 /* bare on-site energies V⁰ (N) and hoppings t⁰ (Nh, FermionPathIntegral order) — what

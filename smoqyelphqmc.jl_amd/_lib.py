@@ -104,6 +104,14 @@ SIGNATURES = {
     "smoqy_pff_step_v": [_p, _i, _i, _p, _p, _d, _i, _i, _p, _p, _p, _p],
     "smoqy_set_bare_model": [_p, _p, _p, _p],
     "smoqy_update_from_phonons_all": [_p, _p],
+    "smoqy_efa_config": [_p, _p, _p],
+    "smoqy_efa_set_state": [_p, _p, _p],
+    "smoqy_efa_get_state": [_p, _p, _p],
+    "smoqy_efa_initialize_momentum": [_p, _p, _p],
+    "smoqy_efa_energies": [_p, _p, _p],
+    "smoqy_efa_evolve": [_p, _d, _d, _i],
+    "smoqy_efa_checkpoint": [_p, _i],
+    "smoqy_hmc_trajectory_v": [_p, _i, _i, _i, _d, _d, _i, _i, _p, _p, _p, _p],
     "smoqy_copy_fields": [_p, _i, _p, _i],
     "smoqy_ge_config": [_p, _i, _i, _p],
     "smoqy_ge_measure_GD0": [_p, _i, _i, _i, _i, _p],

@@ -111,6 +111,12 @@ struct smoqy_ctx {
         double *d_bare = nullptr;  // [V⁰ (N) | t⁰ in checkerboard order (Nh)]
         bool bare_set = false, t_done = false;
         ForceArgs tmpl{};
+        // EFA leapfrog: momenta, saved positions, per-(ω, mode) action eigenvalues and masses
+        std::vector<int> finite_mass;
+        bool efa_set = false;
+        double *d_p = nullptr, *d_x0 = nullptr, *d_q = nullptr, *d_m = nullptr, *d_part = nullptr, *h_part = nullptr;
+        int *d_fm = nullptr;
+        int efa_SB = 8, efa_ntile = 0;
     } force;
     // GreensEstimator contractions
     struct GeState {
@@ -309,7 +315,9 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->h_poll_dot) (void)hipHostFree(c->h_poll_dot);
     if (c->h_lan) (void)hipHostFree(c->h_lan);
     if (c->force.h_out) (void)hipHostFree(c->force.h_out);
-    for (void *q : {c->force.blob, (void *)c->force.d_x, (void *)c->force.d_contrib, (void *)c->force.d_out, (void *)c->force.d_bare})
+    if (c->force.h_part) (void)hipHostFree(c->force.h_part);
+    for (void *q : {c->force.blob, (void *)c->force.d_x, (void *)c->force.d_contrib, (void *)c->force.d_out, (void *)c->force.d_bare, (void *)c->force.d_p, (void *)c->force.d_x0, (void *)c->force.d_q,
+                    (void *)c->force.d_m, (void *)c->force.d_part, (void *)c->force.d_fm})
         if (q) (void)hipFree(q);
     for (auto &e : c->mvt.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->mvt.d_stamp) (void)hipFree(c->mvt.d_stamp);
@@ -1682,9 +1690,10 @@ int smoqy_force_set_couplings(smoqy_ctx *c, const smoqy_couplings *cp)
     if (!cp || cp->Nph < 0 || cp->Nholstein < 0 || cp->Nssh < 0) FAIL(c, 1, "invalid couplings");
     auto &F = c->force;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (void *q : {F.blob, (void *)F.d_x, (void *)F.d_contrib, (void *)F.d_out, (void *)F.d_bare})
+    for (void *q : {F.blob, (void *)F.d_x, (void *)F.d_contrib, (void *)F.d_out, (void *)F.d_bare, (void *)F.d_p, (void *)F.d_x0, (void *)F.d_q, (void *)F.d_m, (void *)F.d_part, (void *)F.d_fm})
         if (q) (void)hipFree(q);
     if (F.h_out) (void)hipHostFree(F.h_out);
+    if (F.h_part) (void)hipHostFree(F.h_part);
     F = smoqy_ctx::ForceState{};
     const int Nph = cp->Nph, Nhol = cp->Nholstein, Nssh = cp->Nssh;
     const int Q = 2 * Nhol + 2 * Nssh;
@@ -1762,6 +1771,8 @@ int smoqy_force_set_couplings(smoqy_ctx *c, const smoqy_couplings *cp)
     HIPCHK(c, hipMalloc(&F.d_contrib, (size_t)g.nw * g.Lt * std::max(Q, 1) * sizeof(double)));
     HIPCHK(c, hipMalloc(&F.d_bare, ((size_t)g.N + g.Nh + 1) * sizeof(double)));
     F.Nph = Nph; F.Nhol = Nhol; F.Nssh = Nssh; F.Q = Q; F.dtau = cp->dtau; F.set = true;
+    F.finite_mass.assign((size_t)std::max(Nph, 1), 1);
+    for (int p = 0; p < Nph; ++p) F.finite_mass[p] = cp->finite_mass[p] ? 1 : 0;
     return 0;
 }
 
@@ -1918,6 +1929,23 @@ int smoqy_force_store_v(smoqy_ctx *c, int psi, double *out)
 
 // ---- calculate_derivative_fermionic_action! in one call ---------------------------------------------------
 
+// calculate_derivative_fermionic_action! (src/PFFCalculator.jl:119-157) on the fields as they stand: [update_preconditioner!], Ψ = Λ⁻ᵀΦ,
+// Ψ = (MᵀM)⁻¹Ψ, Ψ = Λ⁻¹Ψ, S_f = Φ·Ψ (left in d_dot_out), and with want_force the force in force.d_out.  No phonon-field upload, no
+// force download: the callers decide what crosses the boundary.
+static int pff_core(smoqy_ctx *c, int phi, int psi, const double *randvec_all, double tol, int maxiter, int use_precond, bool want_force, int *iters, double *eps)
+{
+    const Geometry &g = c->g;
+    if (randvec_all && use_precond) if (int rc = precond_update_range(c, 0, g.nw, randvec_all)) return rc;  // FermionDetMatrix.jl:259
+    launch_lambda_apply(c->stream, SMOQY_LAMBDA_LDIVT, c->vecs[psi], c->vecs[phi], c->d_lam, g.Lt, g.N, g.nsys, g.nrhs, -1);  // Ψ = Λ⁻ᵀΦ  PFFCalculator.jl:97
+    HIPCHK(c, hipMemcpyAsync(c->scr[0], c->vecs[psi], c->vec_elems() * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    if (int rc = cg_dev(c, c->vecs[psi], c->scr[0], true, tol, maxiter, use_precond, iters, eps)) return rc;                   // ldiv!(Ψ, fdm, Ψ)  :99
+    launch_lambda_apply(c->stream, SMOQY_LAMBDA_LDIV, c->scr[0], c->vecs[psi], c->d_lam, g.Lt, g.N, g.nsys, g.nrhs, -1);       // Ψ = Λ⁻¹Ψ  :107
+    std::swap(c->scr[0], c->vecs[psi]);
+    launch_dot(c->stream, c->vecs[phi], c->vecs[psi], c->part_c, c->d_dot_out, g.Lt, g.N, g.nsys, c->Tc, c->nchunk);           // S_f = Φ·Ψ  :109
+    if (want_force) if (int rc = force_device(c, psi)) return rc;                                                               // :146-155
+    return 0;
+}
+
 int smoqy_pff_step_v(smoqy_ctx *c, int phi, int psi, const double *x_all, const double *randvec_all, double tol, int maxiter, int use_precond, double *Sf, int *iters, double *eps, double *dSdx)
 {
     CHECK_CTX(c);
@@ -1928,15 +1956,8 @@ int smoqy_pff_step_v(smoqy_ctx *c, int phi, int psi, const double *x_all, const 
     if (g.nrhs != 1) FAIL(c, 1, "smoqy_pff_step_v needs a handle with nrhs = 1");
     if (dSdx && !c->force.set) FAIL(c, 1, "call smoqy_force_set_couplings first");
     if (x_all) if (int rc = smoqy_update_from_phonons_all(c, x_all)) return rc;                          // EFAPFFHMCUpdater.jl:200-205
-    if (randvec_all && use_precond) if (int rc = precond_update_range(c, 0, g.nw, randvec_all)) return rc;  // FermionDetMatrix.jl:259
-    launch_lambda_apply(c->stream, SMOQY_LAMBDA_LDIVT, c->vecs[psi], c->vecs[phi], c->d_lam, g.Lt, g.N, g.nsys, g.nrhs, -1);  // Ψ = Λ⁻ᵀΦ  PFFCalculator.jl:97
-    HIPCHK(c, hipMemcpyAsync(c->scr[0], c->vecs[psi], c->vec_elems() * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
-    if (int rc = cg_dev(c, c->vecs[psi], c->scr[0], true, tol, maxiter, use_precond, iters, eps)) return rc;                   // ldiv!(Ψ, fdm, Ψ)  :99
-    launch_lambda_apply(c->stream, SMOQY_LAMBDA_LDIV, c->scr[0], c->vecs[psi], c->d_lam, g.Lt, g.N, g.nsys, g.nrhs, -1);       // Ψ = Λ⁻¹Ψ  :107
-    std::swap(c->scr[0], c->vecs[psi]);
-    launch_dot(c->stream, c->vecs[phi], c->vecs[psi], c->part_c, c->d_dot_out, g.Lt, g.N, g.nsys, c->Tc, c->nchunk);           // S_f = Φ·Ψ  :109
+    if (int rc = pff_core(c, phi, psi, randvec_all, tol, maxiter, use_precond, dSdx != nullptr, iters, eps)) return rc;
     if (dSdx) {
-        if (int rc = force_device(c, psi)) return rc;                                                                           // :146-155
         const size_t nx = (size_t)g.nw * g.Lt * c->force.Nph;
         if (nx) HIPCHK(c, hipMemcpyAsync(dSdx, c->force.d_out, nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
@@ -1947,6 +1968,201 @@ int smoqy_pff_step_v(smoqy_ctx *c, int phi, int psi, const double *x_all, const 
     if (Sf)
         for (int w = 0; w < g.nw; ++w) Sf[w] = hdot[w].x;
     return 0;
+}
+
+// ---- EFA leapfrog on the device -----------------------------------------------------------
+// SmoQyDQMC's ExactFourierAccelerator (initialize_momentum!, evolve_eom!, kinetic_energy; call sites src/EFAPFFHMCUpdater.jl:142, 150,
+// 202, 244) is NOT under /root/reference: what is built here is fixed by those call sites and by the published algorithm — exact
+// harmonic evolution of every τ-Fourier mode of the phonon fields under the quadratic bosonic action, with a per-mode dynamical mass —
+// and takes the per-(ω, mode) action eigenvalues q and masses m as INPUTS, so the shim passes whatever its accelerator holds.
+// Parity unpinned.
+
+static int efa_launch(smoqy_ctx *c, int mode, double dt, double kick, bool with_force)
+{
+    auto &F = c->force;
+    const Geometry &g = c->g;
+    EfaArgs e{};
+    e.Lt = g.Lt; e.Nph = F.Nph; e.nw = g.nw; e.SB = F.efa_SB; e.ntile = F.efa_ntile; e.nfac = c->tf.nfac;
+    for (int f = 0; f < 16; ++f) e.fac[f] = c->tf.fac[f];
+    e.wtab = c->d_wtab;
+    e.x = F.d_x; e.p = F.d_p; e.force = with_force ? F.d_out : nullptr; e.kick = kick;
+    e.q = F.d_q; e.m = F.d_m; e.finite_mass = F.d_fm; e.dt = dt; e.mode = mode; e.part = F.d_part;
+    launch_efa(c->stream, e);
+    return check_launch(c, "efa");
+}
+
+// (K, S_b) of the state the last efa_launch left, summed over the tiles in fixed order
+static int efa_read_energies(smoqy_ctx *c, double *K, double *Sb)
+{
+    auto &F = c->force;
+    const size_t n = 2 * (size_t)c->g.nw * F.efa_ntile;
+    HIPCHK(c, hipMemcpyAsync(F.h_part, F.d_part, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int w = 0; w < c->g.nw; ++w) {
+        double k = 0.0, s = 0.0;
+        for (int t = 0; t < F.efa_ntile; ++t) { k += F.h_part[2 * ((size_t)w * F.efa_ntile + t)]; s += F.h_part[2 * ((size_t)w * F.efa_ntile + t) + 1]; }
+        if (K) K[w] = k;
+        if (Sb) Sb[w] = s;
+    }
+    return 0;
+}
+
+#define CHECK_EFA(c)                                                                                                  \
+    if (!(c)->force.set || !(c)->force.bare_set) FAIL(c, 1, "call smoqy_force_set_couplings and smoqy_set_bare_model first"); \
+    if (!(c)->force.efa_set) FAIL(c, 1, "call smoqy_efa_config first")
+
+int smoqy_efa_config(smoqy_ctx *c, const double *q, const double *m)
+{
+    CHECK_CTX(c);
+    auto &F = c->force;
+    if (!F.set) FAIL(c, 1, "call smoqy_force_set_couplings first");
+    if (!q || !m) FAIL(c, 1, "q and m must be given");
+    if (!c->tf_ok) FAIL(c, 5, "the EFA kernels need a time extent that factors into 2, 3, 5, 7 (Ltau = %d)", c->g.Lt);
+    const Geometry &g = c->g;
+    const size_t nqm = (size_t)g.Lt * std::max(F.Nph, 1), nx = (size_t)g.nw * nqm;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (void *z : {(void *)F.d_p, (void *)F.d_x0, (void *)F.d_q, (void *)F.d_m, (void *)F.d_part, (void *)F.d_fm})
+        if (z) (void)hipFree(z);
+    if (F.h_part) (void)hipHostFree(F.h_part);
+    F.d_p = F.d_x0 = F.d_q = F.d_m = F.d_part = F.h_part = nullptr; F.d_fm = nullptr; F.efa_set = false;
+    F.efa_SB = 8;
+    while (F.efa_SB > 1 && (2 * (size_t)g.Lt * F.efa_SB + g.Lt) * sizeof(double2) > 150 * 1024) F.efa_SB /= 2;
+    F.efa_ntile = (std::max(F.Nph, 1) + F.efa_SB - 1) / F.efa_SB;
+    HIPCHK(c, hipMalloc(&F.d_p, nx * sizeof(double)));
+    HIPCHK(c, hipMemset(F.d_p, 0, nx * sizeof(double)));
+    HIPCHK(c, hipMalloc(&F.d_x0, nx * sizeof(double)));
+    HIPCHK(c, hipMalloc(&F.d_q, nqm * sizeof(double)));
+    HIPCHK(c, hipMalloc(&F.d_m, nqm * sizeof(double)));
+    HIPCHK(c, hipMalloc(&F.d_fm, F.finite_mass.size() * sizeof(int)));
+    HIPCHK(c, hipMalloc(&F.d_part, 2 * (size_t)g.nw * F.efa_ntile * sizeof(double)));
+    HIPCHK(c, hipHostMalloc(&F.h_part, 2 * (size_t)g.nw * F.efa_ntile * sizeof(double)));
+    // the ω ↔ −ω symmetry of q and m is what keeps the evolved fields real: check instead of assuming
+    for (int p = 0; p < F.Nph; ++p)
+        for (int om = 1; om < g.Lt; ++om) {
+            const double a = q[p + (size_t)F.Nph * om], b = q[p + (size_t)F.Nph * (g.Lt - om)], ma = m[p + (size_t)F.Nph * om], mb = m[p + (size_t)F.Nph * (g.Lt - om)];
+            if (std::fabs(a - b) > 1e-12 * (std::fabs(a) + std::fabs(b)) || (std::isfinite(ma) && std::fabs(ma - mb) > 1e-12 * (std::fabs(ma) + std::fabs(mb))))
+                FAIL(c, 1, "q / m of phonon %d are not symmetric under omega -> Ltau - omega (omega = %d)", p + 1, om);
+        }
+    HIPCHK(c, hipMemcpy(F.d_q, q, nqm * sizeof(double), hipMemcpyHostToDevice));  // Nph x Ltau column-major == [ω][p]
+    HIPCHK(c, hipMemcpy(F.d_m, m, nqm * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(F.d_fm, F.finite_mass.data(), F.finite_mass.size() * sizeof(int), hipMemcpyHostToDevice));
+    F.efa_set = true;
+    return 0;
+}
+
+int smoqy_efa_set_state(smoqy_ctx *c, const double *x_all, const double *p_all)
+{
+    CHECK_CTX(c);
+    CHECK_EFA(c);
+    const size_t nx = (size_t)c->g.nw * c->g.Lt * c->force.Nph;
+    if (p_all && nx) {
+        HIPCHK(c, hipMemcpyAsync(c->force.d_p, p_all, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (x_all) return smoqy_update_from_phonons_all(c, x_all);  // x and the fields that follow from it
+    return 0;
+}
+
+int smoqy_efa_get_state(smoqy_ctx *c, double *x_all, double *p_all)
+{
+    CHECK_CTX(c);
+    CHECK_EFA(c);
+    const size_t nx = (size_t)c->g.nw * c->g.Lt * c->force.Nph;
+    if (x_all && nx) HIPCHK(c, hipMemcpyAsync(x_all, c->force.d_x, nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (p_all && nx) HIPCHK(c, hipMemcpyAsync(p_all, c->force.d_p, nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// fields (exp(-ΔτV), cosh/sinh, Λ) from the device-resident x: the tail of smoqy_update_from_phonons_all without the upload
+static int refresh_from_device_x(smoqy_ctx *c)
+{
+    auto &F = c->force;
+    const Geometry &g = c->g;
+    ForceArgs a = force_args(c, 0.0, nullptr, nullptr);
+    const bool do_t = g.Nh > 0 && (F.Nssh > 0 || !F.t_done);
+    launch_phonon_fields(c->stream, a, F.d_bare, F.d_bare + g.N, c->d_expV, c->d_ch, c->d_sh, c->d_lam, g.is_sym ? F.dtau / 2 : F.dtau, do_t);
+    if (do_t) launch_pack_csf(c->stream, c->d_ch, c->d_sh, c->d_psrc, c->d_csf, c->d_cs_varies, g.nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal);
+    F.t_done = true;
+    return check_launch(c, "refresh_from_device_x");
+}
+
+int smoqy_efa_initialize_momentum(smoqy_ctx *c, const double *R_all, double *K)
+{
+    CHECK_CTX(c);
+    CHECK_EFA(c);
+    if (!R_all) FAIL(c, 1, "R_all is NULL");
+    const size_t nx = (size_t)c->g.nw * c->g.Lt * c->force.Nph;
+    if (nx) HIPCHK(c, hipMemcpyAsync(c->force.d_p, R_all, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (int rc = efa_launch(c, 1, 0.0, 0.0, false)) return rc;
+    return efa_read_energies(c, K, nullptr);
+}
+
+int smoqy_efa_energies(smoqy_ctx *c, double *K, double *Sb)
+{
+    CHECK_CTX(c);
+    CHECK_EFA(c);
+    if (int rc = efa_launch(c, 2, 0.0, 0.0, false)) return rc;
+    return efa_read_energies(c, K, Sb);
+}
+
+int smoqy_efa_evolve(smoqy_ctx *c, double dt, double kick_dt, int refresh_fields)
+{
+    CHECK_CTX(c);
+    CHECK_EFA(c);
+    if (int rc = efa_launch(c, 0, dt, kick_dt, kick_dt != 0.0)) return rc;
+    if (refresh_fields) if (int rc = refresh_from_device_x(c)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smoqy_efa_checkpoint(smoqy_ctx *c, int restore)
+{
+    CHECK_CTX(c);
+    CHECK_EFA(c);
+    const size_t nx = (size_t)c->g.nw * c->g.Lt * c->force.Nph;
+    if (!restore) {
+        if (nx) HIPCHK(c, hipMemcpyAsync(c->force.d_x0, c->force.d_x, nx * sizeof(double), hipMemcpyDeviceToDevice, c->stream));  // copyto!(x0, x), :130
+    } else {
+        if (nx) HIPCHK(c, hipMemcpyAsync(c->force.d_x, c->force.d_x0, nx * sizeof(double), hipMemcpyDeviceToDevice, c->stream));  // copyto!(x, x0) + update!, :266-275
+        if (int rc = refresh_from_device_x(c)) return rc;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smoqy_hmc_trajectory_v(smoqy_ctx *c, int phi, int psi, int Nt, double dt, double tol_force, int maxiter, int use_precond, const double *randvecs, double *Sf, int *iters, double *eps)
+{
+    CHECK_CTX(c);
+    CHECK_EFA(c);
+    if (int rc = check_vec(c, phi)) return rc;
+    if (int rc = check_vec(c, psi)) return rc;
+    if (phi == psi) FAIL(c, 1, "phi and psi must be different vectors");
+    const Geometry &g = c->g;
+    if (g.nrhs != 1) FAIL(c, 1, "smoqy_hmc_trajectory_v needs a handle with nrhs = 1");
+    if (Nt < 1) FAIL(c, 1, "Nt < 1");
+    if (use_precond && !randvecs) FAIL(c, 1, "randvecs is NULL");
+    std::vector<int> it((size_t)g.nw);
+    std::vector<double> ep((size_t)g.nw);
+    double2 *hdot = reinterpret_cast<double2 *>(c->h_poll_dot);
+    // evolve_eom!(x, p, Δt/2); update!(fdm)                                                            EFAPFFHMCUpdater.jl:148-152
+    if (int rc = efa_launch(c, 0, 0.5 * dt, 0.0, false)) return rc;
+    if (int rc = refresh_from_device_x(c)) return rc;
+    for (int t = 0; t < Nt; ++t) {                                                                   // :162
+        const double *rv = use_precond ? randvecs + (size_t)t * g.nw * g.N : nullptr;
+        if (int rc = pff_core(c, phi, psi, rv, tol_force, maxiter, use_precond, true, it.data(), ep.data())) return rc;  // :172 (force stays in force.d_out)
+        HIPCHK(c, hipMemcpyAsync(hdot, c->d_dot_out, (size_t)g.nsys * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+        // p -= Δt ∂S/∂x (:196) fused into evolve_eom!(x, p, Δt′) (:201-202); update!(fdm) (:204-205)
+        if (int rc = efa_launch(c, 0, (t == Nt - 1) ? 0.5 * dt : dt, dt, true)) return rc;
+        if (int rc = refresh_from_device_x(c)) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int w = 0; w < g.nw; ++w) {
+            if (Sf) Sf[(size_t)t * g.nw + w] = hdot[w].x;
+            if (iters) iters[(size_t)t * g.nw + w] = it[w];
+            if (eps) eps[(size_t)t * g.nw + w] = ep[w];
+        }
+    }
+    return check_launch(c, "hmc_trajectory");
 }
 
 // ---- GreensEstimator -----------------------------------------------------------

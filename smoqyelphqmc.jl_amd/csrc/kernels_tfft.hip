@@ -321,6 +321,93 @@ __global__ void __launch_bounds__(256) tfft_kernel(TfftArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// EFA leapfrog kernel.  Workgroup = (tile of SB phonon modes, walker), every τ of the tile in LDS, z = x + i p transformed with the
+// same Stockham passes as the state vectors (one complex transform carries both real fields: x̃_ω = (z̃_ω + conj z̃_{-ω})/2,
+// p̃_ω = (z̃_ω − conj z̃_{-ω})/(2i)).  Per mode the harmonic flow of H = |p̃|²/(2m) + q|x̃|²/2 is exact:
+//   x̃(t) = cos(wt) x̃ + sin(wt)/(m w) p̃,   p̃(t) = cos(wt) p̃ − m w sin(wt) x̃,   w = √(q/m)
+// (w = 1 for every mode when m = q: "exact Fourier acceleration").  Energies use the unitary normalisation |·|²/Lτ.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) efa_kernel(EfaArgs a, TfftArgs plan)
+{
+    extern __shared__ double2 lds[];
+    __shared__ double red[18];
+    const int Lt = a.Lt, SB = a.SB, Nph = a.Nph;
+    double2 *A = lds, *B = A + (size_t)Lt * SB, *WT = B + (size_t)Lt * SB;
+    const int tile = blockIdx.x % a.ntile, w = blockIdx.x / a.ntile;
+    const int i0 = tile * SB, ns = min(SB, Nph - i0);
+    const size_t wbase = (size_t)w * Lt * Nph;
+    for (int q = threadIdx.x; q < Lt; q += blockDim.x) WT[q] = a.wtab[q];
+    for (int idx = threadIdx.x; idx < Lt * SB; idx += blockDim.x) {
+        const int l = idx / SB, sb = idx - l * SB;
+        double2 z = make_double2(0.0, 0.0);
+        if (sb < ns) {
+            const size_t off = wbase + (size_t)l * Nph + i0 + sb;
+            z = make_double2(a.mode == 1 ? 0.0 : a.x[off], a.p[off]);
+            if (a.force) z.y -= a.kick * a.force[off];
+            if (a.mode == 1) z = make_double2(z.y, 0.0);  // transform the noise as a real field
+        }
+        A[idx] = z;
+    }
+    __syncthreads();
+    double2 *res = stockham(A, B, WT, plan, false);
+    double2 *oth = (res == A) ? B : A;
+    double accK = 0.0, accS = 0.0;
+    const double iLt = 1.0 / (double)Lt;
+    for (int idx = threadIdx.x; idx < Lt * SB; idx += blockDim.x) {
+        const int om = idx / SB, sb = idx - om * SB;
+        double2 out = make_double2(0.0, 0.0);
+        if (sb < ns) {
+            const int omm = om == 0 ? 0 : Lt - om;
+            const double2 zp = res[idx], zm = res[omm * SB + sb];
+            double2 X = make_double2(0.5 * (zp.x + zm.x), 0.5 * (zp.y - zm.y));   // x̃_ω
+            double2 P = make_double2(0.5 * (zp.y + zm.y), -0.5 * (zp.x - zm.x));  // p̃_ω = (z̃_ω − conj z̃_{-ω})/(2i)
+            const double q = a.q[(size_t)om * Nph + i0 + sb], m = a.m[(size_t)om * Nph + i0 + sb];
+            const bool live = a.finite_mass[i0 + sb] != 0 && m > 0.0 && isfinite(m);
+            if (a.mode == 1) {
+                // p̃ = √m R̃ (covariance F⁻¹ diag(m) F); a frozen mode gets no momentum
+                const double f = live ? sqrt(m) : 0.0;
+                out = make_double2(f * zp.x, f * zp.y);
+                P = out; X = make_double2(0.0, 0.0);
+            } else if (a.mode == 0 && live) {
+                const double wq = sqrt(q / m);
+                double sn, cs;
+                sincos(wq * a.dt, &sn, &cs);
+                const double f1 = wq > 0.0 ? sn / (m * wq) : a.dt / m, f2 = m * wq * sn;
+                const double2 Xn = make_double2(cs * X.x + f1 * P.x, cs * X.y + f1 * P.y);
+                const double2 Pn = make_double2(cs * P.x - f2 * X.x, cs * P.y - f2 * X.y);
+                X = Xn; P = Pn;
+                out = make_double2(X.x - P.y, X.y + P.x);  // z̃' = x̃' + i p̃'
+            } else {
+                out = zp;
+            }
+            if (live) {
+                accK += 0.5 * (P.x * P.x + P.y * P.y) / m * iLt;
+                accS += 0.5 * q * (X.x * X.x + X.y * X.y) * iLt;
+            }
+        }
+        oth[idx] = out;
+    }
+    __syncthreads();
+    if (a.mode != 2) {
+        res = stockham(oth, res, WT, plan, true);
+        for (int idx = threadIdx.x; idx < Lt * SB; idx += blockDim.x) {
+            const int l = idx / SB, sb = idx - l * SB;
+            if (sb < ns && (a.mode == 1 || a.finite_mass[i0 + sb] != 0)) {  // an infinite-mass mode is not touched at all (its momentum is set to zero when sampled)
+                const size_t off = wbase + (size_t)l * Nph + i0 + sb;
+                const double2 z = res[idx];
+                if (a.mode == 0) { a.x[off] = z.x * iLt; a.p[off] = z.y * iLt; }
+                else a.p[off] = z.x * iLt;  // real by the ω ↔ −ω symmetry of m
+            }
+        }
+    }
+    if (a.part) {
+        const double2 t = bsum(make_double2(accK, accS), red);
+        if (threadIdx.x == 0) { a.part[2 * (size_t)blockIdx.x] = t.x; a.part[2 * (size_t)blockIdx.x + 1] = t.y; }
+    }
+}
+
 }  // namespace
 
 bool tfft_plan(int Lt, int N, TfftArgs &a)
@@ -353,6 +440,7 @@ hipError_t configure_tfft_kernels(const char **what)
     SMOQY_SET_LDS(tfft_kernel<1>, 160 * 1024 - 512);
     SMOQY_SET_LDS(tfft_kernel<2>, 160 * 1024 - 512);
     SMOQY_SET_LDS(tfft_kernel<3>, 160 * 1024 - 512);
+    SMOQY_SET_LDS(efa_kernel, 160 * 1024 - 512);
     return first;
 }
 
@@ -366,6 +454,16 @@ void launch_tfft(hipStream_t st, int mode, const TfftArgs &a)
         case 2: hipLaunchKernelGGL((tfft_kernel<2>), grid, block, lds, st, a); break;
         default: hipLaunchKernelGGL((tfft_kernel<3>), grid, block, lds, st, a); break;
     }
+}
+
+void launch_efa(hipStream_t st, const EfaArgs &a)
+{
+    TfftArgs plan{};
+    plan.Lt = a.Lt; plan.N = a.Nph; plan.nsys = a.nw; plan.SB = a.SB; plan.ntile = a.ntile; plan.nfac = a.nfac;
+    for (int f = 0; f < 16; ++f) plan.fac[f] = a.fac[f];
+    plan.wtab = a.wtab;
+    const size_t lds = (2 * (size_t)a.Lt * a.SB + a.Lt) * sizeof(double2);
+    hipLaunchKernelGGL(efa_kernel, dim3((unsigned)(a.ntile * a.nw)), dim3(256), lds, st, a, plan);
 }
 
 }  // namespace smoqy

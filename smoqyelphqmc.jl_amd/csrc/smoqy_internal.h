@@ -266,6 +266,25 @@ struct TfftArgs {
     CgState *st;
 };
 bool tfft_plan(int Lt, int N, TfftArgs &a);
+
+// Exact-Fourier-acceleration leapfrog on the phonon fields (call sites src/EFAPFFHMCUpdater.jl:142, 150, 202,
+// 244 — SmoQyDQMC's ExactFourierAccelerator itself is not under /root/reference: parity unpinned).  x and p live as
+// [nw][Lτ][Nph] doubles; per (frequency ω of the periodic τ transform, phonon mode) q is the eigenvalue of the harmonic bosonic action
+// S_b = ½ Σ q |x̃|² and m the dynamical mass of the fictitious momenta, K = ½ Σ |p̃|²/m (unitary transform).
+struct EfaArgs {
+    int Lt, Nph, nw, SB, ntile, nfac;
+    int fac[16];
+    const double2 *wtab;
+    double *x, *p;             // [nw][Lt][Nph]
+    const double *force;       // optional [nw][Lt][Nph]: p -= kick * force before anything else (EFAPFFHMCUpdater.jl:196)
+    double kick;
+    const double *q, *m;       // [Lt][Nph]
+    const int *finite_mass;    // [Nph] 0: infinite-mass mode, left untouched
+    double dt;                 // evolve_eom! time (mode 0)
+    int mode;                  // 0: kick + exact harmonic evolution by dt; 1: p <- F⁻¹ √m F p (momenta from unit normal deviates); 2: energies only
+    double *part;              // [nw][ntile][2] partial (K, S_b) of the state on exit
+};
+void launch_efa(hipStream_t st, const EfaArgs &a);
 hipError_t configure_tfft_kernels(const char **what);
 void launch_tfft(hipStream_t st, int mode, const TfftArgs &a);
 

@@ -47,7 +47,8 @@ class WalkerBatch:
     solve_gate = None
 
     def __init__(self, workload: str, nwalkers: int = 1, walker0: int = 0, is_sym: bool = True, device: int = -1, tol: float = 1e-10, maxiter: int = 10_000, Nt: int = 24,
-                 drift: float = 0.02, check_every: int | None = None, tau_chunk: int | None = None, smooth: bool = False, host_threads: int = 8, device_update: bool = True, measure_nrv: int = 0):
+                 drift: float = 0.02, check_every: int | None = None, tau_chunk: int | None = None, smooth: bool = False, host_threads: int = 8, device_update: bool = True, measure_nrv: int = 0,
+                 device_efa: bool = False, omega: float = 1.0, mass: float = 1.0):
         self.models = [lat.CONFIGS[workload](walker=walker0 + w, smooth=smooth) for w in range(nwalkers)]
         m0 = self.models[0]
         self.workload = workload
@@ -97,6 +98,14 @@ class WalkerBatch:
             self.h.call("smoqy_set_bare_model", L.ptr(V0), L.ptr(t0), L.ptr(self.perm))
         self.stats = SweepStats()
         self.refresh_fields(first=True)
+        # EFA leapfrog on the device (parity unpinned — SmoQyDQMC's accelerator is not part of the reference tree):
+        # x, p and the force stay on the GPU for the whole trajectory.  Off by default: the host-side drift stays the tested default.
+        self.device_efa = bool(device_efa)
+        self.dH = None
+        if self.device_efa:
+            if not device_update:
+                raise ValueError("device_efa needs device_update=True")
+            self.efa_setup(omega, mass)
 
     # ---- field plumbing -------------------------------------------------------------------------
     def refresh_fields(self, first: bool = False):
@@ -247,6 +256,58 @@ class WalkerBatch:
         self.stats.iters_sum += int(iters.sum())
         return np.transpose(out, (0,) + tuple(range(out.ndim - 1, 0, -1))), iters
 
+    # ---- EFA-PFF-HMC trajectory on the device (src/EFAPFFHMCUpdater.jl:102-276) ------------------------------
+    def efa_setup(self, omega=1.0, mass=1.0):
+        """ExactFourierAccelerator(Ω, M, β, Δτ, η = 0) tables (src/EFAPFFHMCUpdater.jl:92): q = m = Δτ M [Ω² + 4/Δτ² sin²(πω/Lτ)] per phonon
+        mode; infinite-mass partner modes (bond SSH) are frozen."""
+        fm = np.asarray(self.force_couplings.finite_mass, dtype=bool)
+        om = np.arange(self.Lt)
+        row = self.dtau * mass * (omega**2 + 4.0 / self.dtau**2 * np.sin(np.pi * om / self.Lt) ** 2)
+        q = np.asfortranarray(np.where(fm[:, None], row[None, :], np.inf))
+        self.efa_q, self.efa_m = q, q.copy(order="F")
+        self.h.call("smoqy_efa_config", L.ptr(self.efa_q), L.ptr(self.efa_m))
+        self._efa_R = self.h.pinned_empty((self.nw, self.Lt, self.Nph_force))
+        self._efa_rv = self.h.pinned_empty((self.Nt, self.nw, self.N))
+
+    def efa_energies(self):
+        K, Sb = np.zeros(self.nw), np.zeros(self.nw)
+        self.h.call("smoqy_efa_energies", L.ptr(K), L.ptr(Sb))
+        return K, Sb
+
+    def hmc_trajectory_device(self, dt=None):
+        """hmc_update! (src/EFAPFFHMCUpdater.jl:102-276) with the whole trajectory on the device: Φ sampled (:133), momenta refreshed
+        (:142), evolve(Δt/2) + Nt × {force solve, kick, evolve, update!} in ONE library call (:148-206), final action at tol_action (:217),
+        ΔH (:234-250).  Returns (ΔH per walker, last action tuple); the caller accepts or rejects (smoqy_efa_checkpoint)."""
+        dt = np.pi / (2 * self.Nt) if dt is None else float(dt)          # tutorials/holstein_honeycomb.jl:542
+        sf0 = self.sample_pseudofermion_fields()                          # :133
+        self.h.call("smoqy_efa_checkpoint", 0)                            # copyto!(x0, x), :130
+        R = self._efa_R
+        list(self.pool.map(lambda w: self.rng[w].standard_normal(out=R[w].reshape(-1)), range(self.nw)))
+        K0 = np.zeros(self.nw)
+        self.h.call("smoqy_efa_initialize_momentum", L.ptr(R), L.ptr(K0))  # :142
+        _, Sb0 = self.efa_energies()                                      # bosonic action, :136
+        rv = self._efa_rv
+        for t in range(self.Nt):
+            for w in range(self.nw):
+                self.rng[w].standard_normal(out=rv[t, w])                 # randn!(rng, v) of each update_preconditioner!, KPMPreconditioner.jl:634
+        sf = np.zeros((self.Nt, self.nw))
+        iters = np.zeros((self.Nt, self.nw), dtype=np.int32)
+        eps = np.zeros((self.Nt, self.nw))
+        gate = WalkerBatch.solve_gate
+        if gate is not None:
+            gate.acquire()
+        try:
+            self.h.call("smoqy_hmc_trajectory_v", self.phi, self.u, int(self.Nt), C.c_double(dt), C.c_double(self.tol_force), int(self.maxiter), 1, L.ptr(rv), L.ptr(sf), L.ptr(iters), L.ptr(eps))
+        finally:
+            if gate is not None:
+                gate.release()
+        self.stats.solves += self.nw * self.Nt
+        self.stats.iters_sum += int(iters.sum())
+        last = self.pff_step(self.tol, moved=False, want_force=False)      # final action, :217
+        K1, Sb1 = self.efa_energies()                                      # :238-244
+        self.dH = (last[0] + Sb1 + K1) - (sf0 + Sb0 + K0)                   # :247-250
+        return self.dH, last
+
     def drift_fields(self, pis, step):
         np.multiply(pis, step, out=self._tmp)
         np.add(self.xs, self._tmp, out=self.xs)
@@ -272,6 +333,15 @@ class WalkerBatch:
             last = self.calculate_fermionic_action(self.tol)
             self.drift_fields(pis, -self.drift)  # "rejected": restore x, update! (src/reflection_update.jl)
         # HMC trajectory (src/EFAPFFHMCUpdater.jl:102-276)
+        if self.device_efa:
+            # the real EFA leapfrog, device resident; the move is then ALWAYS rejected (x restored from x0, :263-275) so that the
+            # benchmark keeps solving on the field distribution SURVEY.md §8(d) defines instead of thermalising away from it
+            _, last = self.hmc_trajectory_device()
+            self.h.call("smoqy_efa_checkpoint", 1)
+            self.stats.action = float(np.sum(last[0]))
+            if self.measure_nrv:
+                self.measure_greens(self.measure_nrv)
+            return last
         self.sample_pseudofermion_fields()
         pis = self._momentum()
         dx = pis * (self.drift / self.Nt)
