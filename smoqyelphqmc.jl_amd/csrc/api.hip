@@ -247,7 +247,7 @@ static KpmArgs kpm_args(smoqy_ctx *c, double2 *v, const CgState *cg)
     k.order = c->d_order; k.coefs = c->d_coefs; k.bounds = c->d_bounds; k.active = c->d_active;
     k.nslot = c->nslot; k.maxorder = c->maxorder;
     k.v = v; k.cg = cg;
-    k.part_rz = nullptr; k.rz_stride = g.Lt; k.scale = 1.0 / (double)g.Lt;
+    k.part_rz = nullptr; k.rz_stride = 2 * g.Lt; k.scale = 1.0 / (double)g.Lt;  // two r·z slots per frequency: the component-split Chebyshev kernel fills both
     k.scratch = c->d_big; k.scratch_stride = c->big_stride;
     return k;
 }
@@ -400,7 +400,7 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     for (auto &s : c->scr) { HIPCHK(c, hipMalloc(&s, ve * sizeof(double2))); HIPCHK(c, hipMemset(s, 0, ve * sizeof(double2))); }
     double2 **cgv[] = {&c->cg_r, &c->cg_p, &c->cg_z, &c->cg_v};
     for (auto p : cgv) { HIPCHK(c, hipMalloc(p, ve * sizeof(double2))); HIPCHK(c, hipMemset(*p, 0, ve * sizeof(double2))); }
-    c->pstride = std::max(g.Lt, (g.N + 3) / 4);  // room for Lt (per-frequency), nchunk and per-site-tile partials
+    c->pstride = std::max(2 * g.Lt, (g.N + 3) / 4);  // room for 2 Lt (per-frequency, per-component), nchunk and per-site-tile partials
     const size_t np = (size_t)g.nsys * c->pstride;
     HIPCHK(c, hipMalloc(&c->part_pz, np * sizeof(double2)));
     HIPCHK(c, hipMalloc(&c->part_rz, np * sizeof(double2)));
@@ -1532,7 +1532,8 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
     a.v = c->cg_z;  // z = P⁻¹ r shares the buffer of A p: their lifetimes do not overlap
     a.part_pz = c->part_pz; a.part_rz = c->part_rz; a.part_rr = c->part_rr; a.part_bb = c->part_bb;
     a.st = c->d_st; a.tol = tol; a.maxiter = maxiter; a.use_precond = any_pre ? 1 : 0;
-    a.rz_stride = g.Lt; a.nrz = any_pre ? g.Lt : c->nchunk;
+    a.rz_stride = 2 * g.Lt;
+    a.nrz = any_pre ? (cheb_split_active(kpm_args(c, nullptr, nullptr), c->kg) ? 2 * g.Lt : g.Lt) : c->nchunk;
 
     if (!x_is_b) {  // r0 = b - A x0  (ConjugateGradient.jl:119-120), in the twiddled basis
         launch_fft_twiddle(c->stream, x, c->d_th, g.Lt, g.N, g.nsys, 0);

@@ -416,56 +416,74 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
 // or 1 (L = 2) exchanges per step — two instead of four on the honeycomb lattice.  The fused C₁D̄C₁ stage
 // recomputes the mate's intermediate value (same bond, mate's d̄) instead of fetching it.  Exchanges ping-pong
 // between two LDS images, so each costs a single barrier.  Arithmetic per site is identical to cheb_fast_kernel.
-// P = 2 ("paired"): one workgroup carries BOTH frequencies ω and Lτ-1-ω of a system.  They share the expansion slot
-// (n′ = Lτ-ω+1 at KPMPreconditioner.jl:387), i.e. order, coefficients, bounds and B̄, so a lane runs two independent
-// recurrences against the same barriers: twice the instruction-level parallelism per exchange, half the workgroups.
-template <int NCOL, int P>
-__global__ void __launch_bounds__(P == 2 ? 512 : 1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
+// SPLIT = true ("component split"): B̄, the bounds and the Sym coefficients are all REAL, so the real and the imaginary part of a frequency
+// vector are two independent real recurrences.  Each gets its own workgroup: a lane then carries half the arithmetic per exchange
+// (a step costs 0.58 synchronisation + 0.42 instruction issue, measured through the paired-frequency experiment), the
+// LDS images shrink to doubles, and the longest chain — which IS the kernel's duration — gets shorter.  Per component the arithmetic
+// is exactly that of the complex kernel (products with an exact zero imaginary part drop out), so the output is bit-identical; only
+// the Parseval partial of r·z is accumulated in two slots per frequency instead of one, and its imaginary part (rounding noise around
+// the exact zero of a real symmetric P⁻¹) is not formed.
+namespace ownk {
+template <bool SPLIT> struct Scalar { using type = double2; };
+template <> struct Scalar<true> { using type = double; };
+__device__ __forceinline__ double2 zero(double2) { return make_double2(0.0, 0.0); }
+__device__ __forceinline__ double zero(double) { return 0.0; }
+__device__ __forceinline__ double lin(double a, double x, double b, double y) { return a * x + b * y; }
+__device__ __forceinline__ double2 lin(double a, double2 x, double b, double2 y) { return lin2(a, x, b, y); }
+__device__ __forceinline__ double scl(double a, double x) { return a * x; }
+__device__ __forceinline__ double2 scl(double a, double2 x) { return make_double2(a * x.x, a * x.y); }
+__device__ __forceinline__ double add(double x, double y) { return x + y; }
+__device__ __forceinline__ double2 add(double2 x, double2 y) { return make_double2(x.x + y.x, x.y + y.y); }
+__device__ __forceinline__ double sub(double x, double y) { return x - y; }
+__device__ __forceinline__ double2 sub(double2 x, double2 y) { return make_double2(x.x - y.x, x.y - y.y); }
+// coefficient times vector: the complex kernel keeps the general complex product (Sym coefficients have an exact zero imaginary part)
+__device__ __forceinline__ double cmul(double2 c, double x) { return c.x * x; }
+__device__ __forceinline__ double2 cmul(double2 c, double2 x) { return cmulk(c, x); }
+__device__ __forceinline__ double ld(const double2 *v, int i, int comp, double) { return comp ? v[i].y : v[i].x; }
+__device__ __forceinline__ double2 ld(const double2 *v, int i, int, double2) { return v[i]; }
+__device__ __forceinline__ void st(double2 *v, int i, int comp, double x) { if (comp) v[i].y = x; else v[i].x = x; }
+__device__ __forceinline__ void st(double2 *v, int i, int, double2 x) { v[i] = x; }
+}  // namespace ownk
+
+template <int NCOL, bool SPLIT>
+__global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
 {
     static_assert(NCOL >= 2, "single-colour decompositions use cheb_fast_kernel");
+    using namespace ownk;
+    using T = typename Scalar<SPLIT>::type;
     constexpr int Q = NCOL >= 3 ? 1 : 0, CL = NCOL - 1;
     extern __shared__ double2 lds[];
     __shared__ double red[17];
-    const int N = k.N, Lt = k.Lt, T = blockDim.x, j = threadIdx.x;
-    double2 *Wb[2] = {lds, lds + 2 * P * T};
-    double2 *CF = lds + 4 * P * T;
-    const int sys = blockIdx.x % k.nsys, rank = blockIdx.x / k.nsys;
-    const int Lo2 = (Lt + 1) / 2;
-    // heaviest orders first, rank-major (slot 0 carries the longest chain)
-    int om[P];
-    if (P == 1) om[0] = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);
-    else { om[0] = rank; om[P - 1] = Lt - 1 - rank; }
-    const bool two = (P == 2) && om[P - 1] != om[0];  // odd Lτ: the middle frequency is its own mirror
+    const int N = k.N, Lt = k.Lt, Tn = blockDim.x, j = threadIdx.x;
+    T *Wb[2] = {reinterpret_cast<T *>(lds), reinterpret_cast<T *>(lds) + 2 * Tn};
+    double2 *CF = reinterpret_cast<double2 *>(reinterpret_cast<T *>(lds) + 4 * Tn);
+    // heaviest orders first, rank-major; with SPLIT the two components of a frequency are neighbours in the dispatch order
+    const int sys = blockIdx.x % k.nsys, slotid = blockIdx.x / k.nsys;
+    const int comp = SPLIT ? (slotid & 1) : 0, rank = SPLIT ? (slotid >> 1) : slotid;
+    const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);
     const int w = sys / k.nrhs;
     if (k.cg && k.cg[sys].done) return;
-    if (k.half && om[0] >= Lo2) return;  // only launched with P = 1 in this mode
-    const double2 *v[P];
-    double2 *vo[P], *prz[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        v[p] = k.v + ((size_t)om[p] * k.nsys + sys) * N;
-        vo[p] = (k.vout ? k.vout : k.v) + ((size_t)om[p] * k.nsys + sys) * N;
-        prz[p] = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride + om[p] : nullptr;
-    }
-    const int slot = om[0] >= Lo2 ? Lt - om[0] - 1 : om[0];  // :387
+    const int Lo2 = (Lt + 1) / 2;
+    if (k.half && om >= Lo2) return;
+    const double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
+    double2 *vo = (k.vout ? k.vout : k.v) + ((size_t)om * k.nsys + sys) * N;
+    double2 *prz = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride + (SPLIT ? 2 * om + comp : om) : nullptr;
+    const int slot = om >= Lo2 ? Lt - om - 1 : om;  // :387
     const bool act = k.active[w] != 0;
     const int n = act ? k.order[(size_t)w * k.nslot + slot] : 1;
     const double2 *coefs = k.coefs + ((size_t)w * k.nslot + slot) * k.maxorder;
     if (n <= 1) {  // single-term expansion: scalar multiply (:398)
         const double f = k.scale * (act ? coefs[0].x : 1.0);
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            if (p == 1 && !two) break;
-            double acc = 0.0;
-            for (int i = j; i < N; i += T) {
-                const double2 x = v[p][i];
-                vo[p][i] = make_double2(f * x.x, f * x.y);
-                acc += f * (x.x * x.x + x.y * x.y);
-            }
-            if (prz[p]) {
-                const double t = block_sum_real(acc, red);
-                if (j == 0) *prz[p] = make_double2(t, 0.0);
-            }
+        double acc = 0.0;
+        for (int i = j; i < N; i += Tn) {
+            const T x = ld(v, i, comp, T{});
+            st(vo, i, comp, scl(f, x));
+            if constexpr (SPLIT) acc += f * (x * x);
+            else acc += f * (x.x * x.x + x.y * x.y);
+        }
+        if (prz) {
+            const double t = block_sum_real(acc, red);
+            if (j == 0) *prz = make_double2(t, 0.0);
         }
         return;
     }
@@ -482,192 +500,152 @@ __global__ void __launch_bounds__(P == 2 ? 512 : 1024) cheb_own_kernel(KpmArgs k
     const double2 *pcs = kg.pcs + (size_t)w * kg.ptotal;
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) { px[c] = py[c] = j; cx[c] = cy[c] = make_double2(1.0, 0.0); }
-    double2 ax[P], ay[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) ax[p] = ay[p] = make_double2(0.0, 0.0);
+    T ax = zero(T{}), ay = zero(T{});
     if (on) {
-        sx = own[j]; sy = own[T + j];
-        oy = (sy != sx) ? T + j : j;
+        sx = own[j]; sy = own[Tn + j];
+        oy = (sy != sx) ? Tn + j : j;
         dx = dbar[sx]; dy = dbar[sy];
-        dmx = dbar[own[2 * T + j]]; dmy = dbar[own[3 * T + j]];
+        dmx = dbar[own[2 * Tn + j]]; dmy = dbar[own[3 * Tn + j]];
 #pragma unroll
         for (int c = 0; c < NCOL; ++c) {
-            px[c] = own[(4 + 4 * c + 0) * T + j];
-            py[c] = own[(4 + 4 * c + 1) * T + j];
-            cx[c] = pcs[own[(4 + 4 * c + 2) * T + j]];
-            cy[c] = pcs[own[(4 + 4 * c + 3) * T + j]];
+            px[c] = own[(4 + 4 * c + 0) * Tn + j];
+            py[c] = own[(4 + 4 * c + 1) * Tn + j];
+            cx[c] = pcs[own[(4 + 4 * c + 2) * Tn + j]];
+            cy[c] = pcs[own[(4 + 4 * c + 3) * Tn + j]];
         }
-#pragma unroll
-        for (int p = 0; p < P; ++p) { ax[p] = v[p][sx]; ay[p] = v[p][sy]; }
+        ax = ld(v, sx, comp, T{}); ay = ld(v, sy, comp, T{});
     }
-    double2 v0x[P], v0y[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) { v0x[p] = ax[p]; v0y[p] = ay[p]; }
-    for (int i = j; i < n; i += T) CF[i] = coefs[i];  // coefficients in LDS: no global load inside the chain
+    const T v0x = ax, v0y = ay;
+    for (int i = j; i < n; i += Tn) CF[i] = coefs[i];  // coefficients in LDS: no global load inside the chain
     int buf = 0;
-    // own values -> LDS image (one per frequency), ONE barrier, the two mates of colour c_ come back in (mx_, my_)
-#define OWN_EXCHANGE(c_, mx_, my_)                                            \
-    {                                                                         \
-        double2 *Wc = Wb[buf];                                                \
-        buf ^= 1;                                                             \
-        if (on) {                                                             \
-            _Pragma("unroll") for (int p = 0; p < P; ++p) {                   \
-                Wc[2 * T * p + ox] = ax[p];                                   \
-                Wc[2 * T * p + oy] = ay[p];                                   \
-            }                                                                 \
-        }                                                                     \
-        __syncthreads();                                                      \
-        _Pragma("unroll") for (int p = 0; p < P; ++p) {                       \
-            mx_[p] = Wc[2 * T * p + px[c_]];                                  \
-            my_[p] = Wc[2 * T * p + py[c_]];                                  \
-        }                                                                     \
+    // own values -> LDS image, barrier, the two mates of colour c_ come back in (mx_, my_)
+#define OWN_EXCHANGE(c_, mx_, my_)                       \
+    {                                                    \
+        T *Wc = Wb[buf];                                 \
+        buf ^= 1;                                        \
+        if (on) { Wc[ox] = ax; Wc[oy] = ay; }            \
+        __syncthreads();                                 \
+        mx_ = Wc[px[c_]];                                \
+        my_ = Wc[py[c_]];                                \
     }
-#define OWN_STAGE(c_)                                                            \
-    {                                                                            \
-        if (c_ == Q) {                                                           \
-            _Pragma("unroll") for (int p = 0; p < P; ++p) {                      \
-                const double2 t_ = lin2(cx[Q].x, ax[p], cx[Q].y, ay[p]);         \
-                ay[p] = lin2(cx[Q].x, ay[p], cx[Q].y, ax[p]);                    \
-                ax[p] = t_;                                                      \
-            }                                                                    \
-        } else {                                                                 \
-            double2 mx_[P], my_[P];                                              \
-            OWN_EXCHANGE(c_, mx_, my_)                                           \
-            _Pragma("unroll") for (int p = 0; p < P; ++p) {                      \
-                ax[p] = lin2(cx[c_].x, ax[p], cx[c_].y, mx_[p]);                 \
-                ay[p] = lin2(cy[c_].x, ay[p], cy[c_].y, my_[p]);                 \
-            }                                                                    \
-        }                                                                        \
+#define OWN_STAGE(c_)                                                        \
+    {                                                                        \
+        if (c_ == Q) {                                                       \
+            const T t_ = lin(cx[Q].x, ax, cx[Q].y, ay);                      \
+            ay = lin(cx[Q].x, ay, cx[Q].y, ax);                              \
+            ax = t_;                                                         \
+        } else {                                                             \
+            T mx_, my_;                                                      \
+            OWN_EXCHANGE(c_, mx_, my_)                                       \
+            ax = lin(cx[c_].x, ax, cx[c_].y, mx_);                           \
+            ay = lin(cy[c_].x, ay, cy[c_].y, my_);                           \
+        }                                                                    \
     }
     // into the basis α̃ = C_L α (see cheb_fast_kernel)
     {
-        double2 mx[P], my[P];
+        T mx, my;
         OWN_EXCHANGE(CL, mx, my)
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            ax[p] = lin2(cx[CL].x, ax[p], cx[CL].y, mx[p]);
-            ay[p] = lin2(cy[CL].x, ay[p], cy[CL].y, my[p]);
-        }
+        ax = lin(cx[CL].x, ax, cx[CL].y, mx);
+        ay = lin(cy[CL].x, ay, cy[CL].y, my);
     }
     const double qcx = cx[CL].x * cx[CL].x + cx[CL].y * cx[CL].y, qsx = 2.0 * cx[CL].x * cx[CL].y;  // C_L²
     const double qcy = cy[CL].x * cy[CL].x + cy[CL].y * cy[CL].y, qsy = 2.0 * cy[CL].x * cy[CL].y;
-    double2 a1x[P], a1y[P], a2x[P], a2y[P], accx[P], accy[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        a1x[p] = ax[p]; a1y[p] = ay[p];
-        a2x[p] = a2y[p] = accx[p] = accy[p] = make_double2(0.0, 0.0);
-    }
+    T a1x = ax, a1y = ay, a2x = zero(T{}), a2y = zero(T{}), accx = zero(T{}), accy = zero(T{});
     __syncthreads();  // CF visible
     for (int kk = 1; kk < n; ++kk) {
         const double2 ck = CF[kk];
 #pragma unroll
         for (int c = NCOL - 2; c >= 1; --c) OWN_STAGE(c)
         if (Q == 0) {  // C₁ D̄ C₁ in registers
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                double2 x = lin2(cx[0].x, ax[p], cx[0].y, ay[p]), y = lin2(cx[0].x, ay[p], cx[0].y, ax[p]);
-                x = make_double2(dx * x.x, dx * x.y);
-                y = make_double2(dy * y.x, dy * y.y);
-                ax[p] = lin2(cx[0].x, x, cx[0].y, y);
-                ay[p] = lin2(cx[0].x, y, cx[0].y, x);
-            }
+            T x = lin(cx[0].x, ax, cx[0].y, ay), y = lin(cx[0].x, ay, cx[0].y, ax);
+            x = scl(dx, x);
+            y = scl(dy, y);
+            ax = lin(cx[0].x, x, cx[0].y, y);
+            ay = lin(cx[0].x, y, cx[0].y, x);
         } else {       // one exchange; the mate's value after C₁ and D̄ is recomputed here (same bond, its own d̄)
-            double2 mx[P], my[P];
+            T mx, my;
             OWN_EXCHANGE(0, mx, my)
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                double2 x = lin2(cx[0].x, ax[p], cx[0].y, mx[p]), xm = lin2(cx[0].x, mx[p], cx[0].y, ax[p]);
-                double2 y = lin2(cy[0].x, ay[p], cy[0].y, my[p]), ym = lin2(cy[0].x, my[p], cy[0].y, ay[p]);
-                x = make_double2(dx * x.x, dx * x.y);
-                xm = make_double2(dmx * xm.x, dmx * xm.y);
-                y = make_double2(dy * y.x, dy * y.y);
-                ym = make_double2(dmy * ym.x, dmy * ym.y);
-                ax[p] = lin2(cx[0].x, x, cx[0].y, xm);
-                ay[p] = lin2(cy[0].x, y, cy[0].y, ym);
-            }
+            T x = lin(cx[0].x, ax, cx[0].y, mx), xm = lin(cx[0].x, mx, cx[0].y, ax);
+            T y = lin(cy[0].x, ay, cy[0].y, my), ym = lin(cy[0].x, my, cy[0].y, ay);
+            x = scl(dx, x);
+            xm = scl(dmx, xm);
+            y = scl(dy, y);
+            ym = scl(dmy, ym);
+            ax = lin(cx[0].x, x, cx[0].y, xm);
+            ay = lin(cy[0].x, y, cy[0].y, ym);
         }
 #pragma unroll
         for (int c = 1; c <= NCOL - 2; ++c) OWN_STAGE(c)
-        double2 xi[P], xj[P];
+        T xi, xj;
         {
-            double2 mx[P], my[P];
+            T mx, my;
             OWN_EXCHANGE(CL, mx, my)
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                xi[p] = lin2(qcx, ax[p], qsx, mx[p]);
-                xj[p] = lin2(qcy, ay[p], qsy, my[p]);
-            }
+            xi = lin(qcx, ax, qsx, mx);
+            xj = lin(qcy, ay, qsy, my);
         }
         // three-term recurrence on the lane's own sites (kpm_lmul!)
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            double2 a3x, a3y;
-            if (kk == 1) {
-                a3x = make_double2((xi[p].x - avg * a1x[p].x) * imag_, (xi[p].y - avg * a1x[p].y) * imag_);
-                a3y = make_double2((xj[p].x - avg * a1y[p].x) * imag_, (xj[p].y - avg * a1y[p].y) * imag_);
-                const double2 c0 = CF[0];
-                const double2 t0x = cmulk(c0, a1x[p]), t0y = cmulk(c0, a1y[p]), t1x = cmulk(ck, a3x), t1y = cmulk(ck, a3y);
-                accx[p] = make_double2(t0x.x + t1x.x, t0x.y + t1x.y);
-                accy[p] = make_double2(t0y.x + t1y.x, t0y.y + t1y.y);
-            } else {
-                a3x = make_double2(2.0 * (xi[p].x - avg * a2x[p].x) * imag_ - a1x[p].x, 2.0 * (xi[p].y - avg * a2x[p].y) * imag_ - a1x[p].y);
-                a3y = make_double2(2.0 * (xj[p].x - avg * a2y[p].x) * imag_ - a1y[p].x, 2.0 * (xj[p].y - avg * a2y[p].y) * imag_ - a1y[p].y);
-                const double2 tx = cmulk(ck, a3x), ty = cmulk(ck, a3y);
-                accx[p] = make_double2(accx[p].x + tx.x, accx[p].y + tx.y);
-                accy[p] = make_double2(accy[p].x + ty.x, accy[p].y + ty.y);
-                a1x[p] = a2x[p]; a1y[p] = a2y[p];
-            }
-            a2x[p] = a3x; a2y[p] = a3y;
-            ax[p] = a3x; ay[p] = a3y;
+        T a3x, a3y;
+        if (kk == 1) {
+            a3x = scl(imag_, sub(xi, scl(avg, a1x)));
+            a3y = scl(imag_, sub(xj, scl(avg, a1y)));
+            const double2 c0 = CF[0];
+            accx = add(cmul(c0, a1x), cmul(ck, a3x));
+            accy = add(cmul(c0, a1y), cmul(ck, a3y));
+        } else {
+            a3x = sub(scl(imag_, scl(2.0, sub(xi, scl(avg, a2x)))), a1x);
+            a3y = sub(scl(imag_, scl(2.0, sub(xj, scl(avg, a2y)))), a1y);
+            accx = add(accx, cmul(ck, a3x));
+            accy = add(accy, cmul(ck, a3y));
+            a1x = a2x; a1y = a2y;
         }
+        a2x = a3x; a2y = a3y;
+        ax = a3x; ay = a3y;
     }
     // back to the original basis: C_L⁻¹ on the accumulated sum
     {
-#pragma unroll
-        for (int p = 0; p < P; ++p) { ax[p] = accx[p]; ay[p] = accy[p]; }
-        double2 mx[P], my[P];
+        ax = accx; ay = accy;
+        T mx, my;
         OWN_EXCHANGE(CL, mx, my)
         const double idx_ = 1.0 / (cx[CL].x * cx[CL].x - cx[CL].y * cx[CL].y), idy_ = 1.0 / (cy[CL].x * cy[CL].x - cy[CL].y * cy[CL].y);
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            ax[p] = make_double2((cx[CL].x * accx[p].x - cx[CL].y * mx[p].x) * idx_, (cx[CL].x * accx[p].y - cx[CL].y * mx[p].y) * idx_);
-            ay[p] = make_double2((cy[CL].x * accy[p].x - cy[CL].y * my[p].x) * idy_, (cy[CL].x * accy[p].y - cy[CL].y * my[p].y) * idy_);
-        }
+        ax = scl(idx_, sub(scl(cx[CL].x, accx), scl(cx[CL].y, mx)));
+        ay = scl(idy_, sub(scl(cy[CL].x, accy), scl(cy[CL].y, my)));
     }
 #undef OWN_STAGE
 #undef OWN_EXCHANGE
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        if (p == 1 && !two) break;
-        double2 acc = make_double2(0.0, 0.0);
-        if (on) {
-            const double2 bx = make_double2(k.scale * ax[p].x, k.scale * ax[p].y), by = make_double2(k.scale * ay[p].x, k.scale * ay[p].y);
-            vo[p][sx] = bx;
-            acc.x += v0x[p].x * bx.x + v0x[p].y * bx.y;
-            acc.y += v0x[p].x * bx.y - v0x[p].y * bx.x;
+    double2 acc = make_double2(0.0, 0.0);
+    if (on) {
+        ax = scl(k.scale, ax);
+        ay = scl(k.scale, ay);
+        st(vo, sx, comp, ax);
+        if (sy != sx) st(vo, sy, comp, ay);
+        if constexpr (SPLIT) {
+            // Re conj(r)·z = r_re z_re + r_im z_im: this workgroup adds the term of its component.  The imaginary part
+            // r_re z_im − r_im z_re couples the two workgroups of a frequency (and, in place, races with the other one's stores); for the
+            // real symmetric P⁻¹ of the Sym form it is rounding noise around an exact zero and is left at zero.
+            acc.x += v0x * ax;
+            if (sy != sx) acc.x += v0y * ay;
+        } else {
+            acc.x += v0x.x * ax.x + v0x.y * ax.y;
+            acc.y += v0x.x * ax.y - v0x.y * ax.x;
             if (sy != sx) {
-                vo[p][sy] = by;
-                acc.x += v0y[p].x * by.x + v0y[p].y * by.y;
-                acc.y += v0y[p].x * by.y - v0y[p].y * by.x;
+                acc.x += v0y.x * ay.x + v0y.y * ay.y;
+                acc.y += v0y.x * ay.y - v0y.y * ay.x;
             }
         }
-        if (prz[p]) {
-            const double2 t = block_sum_cplx(acc, red);
-            if (j == 0) *prz[p] = t;
-        }
+    }
+    if (prz) {
+        const double2 t = block_sum_cplx(acc, red);
+        if (j == 0) *prz = t;
     }
 }
 
-// A/B switch for measurements.  OFF by default: measured on MI355X (honeycomb L = 16, Lτ = 128) the paired kernel takes 33.5 µs
-// against 23.7 µs at 16 systems and 31.0 against 21.7 µs at one system — the two longest chains (ω = 0 and Lτ-1, order 41 each)
-// land in the same workgroup and a step with twice the arithmetic costs 1.42x, i.e. a step is 58 % synchronisation latency and
-// 42 % instruction issue; the kernel's duration IS its longest chain, so halving the workgroups buys nothing.
-static int cheb_pair_enabled()
+// A/B switch for measurements (default on)
+static int cheb_split_enabled()
 {
     static int v = -1;
     if (v < 0) {
-        const char *e = getenv("SMOQY_CHEB_PAIR");
-        v = (e && e[0] == '1') ? 1 : 0;
+        const char *e = getenv("SMOQY_CHEB_SPLIT");
+        v = (e && e[0] == '0') ? 0 : 1;
     }
     return v;
 }
@@ -812,6 +790,12 @@ __global__ void __launch_bounds__(kThreads) cheb_generic_kernel(KpmArgs k)
     }
 }
 
+// the component-split owner-computes kernel writes TWO r·z partials per frequency (2·Lτ slots): the CG driver asks before it sizes its reductions
+bool cheb_split_active(const KpmArgs &k, const KpmGeom &kg)
+{
+    return kg.fast && k.is_sym && k.ncol >= 2 && k.ncol <= 6 && kg.own && cheb_own_enabled() && cheb_split_enabled() && !k.half && k.sbari == nullptr;
+}
+
 void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
 {
     if (kg.fast) {
@@ -819,13 +803,13 @@ void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
         const dim3 grid((unsigned)(k.Lt * k.nsys)), block((unsigned)kg.threads);
 #define CHEB_LAUNCH(S_, C_) hipLaunchKernelGGL((cheb_fast_kernel<S_, C_>), grid, block, lds, st, k, kg)
         if (k.is_sym && k.ncol >= 2 && k.ncol <= 6 && kg.own && cheb_own_enabled()) {
-            const bool pair = cheb_pair_enabled() && kg.threads <= 512 && !k.half;
-            const size_t olds = sizeof(double2) * (4 * (size_t)kg.threads * (pair ? 2 : 1) + (size_t)k.maxorder);
-            const dim3 pgrid((unsigned)(((k.Lt + 1) / 2) * k.nsys));
-#define OWN_LAUNCH(C_)                                                                          \
-    {                                                                                           \
-        if (pair) hipLaunchKernelGGL((cheb_own_kernel<C_, 2>), pgrid, block, olds, st, k, kg);  \
-        else hipLaunchKernelGGL((cheb_own_kernel<C_, 1>), grid, block, olds, st, k, kg);        \
+            const bool split = cheb_split_active(k, kg);
+            const size_t olds = (split ? sizeof(double) : sizeof(double2)) * 4 * (size_t)kg.threads + sizeof(double2) * (size_t)k.maxorder;
+            const dim3 sgrid((unsigned)(2 * k.Lt * k.nsys));
+#define OWN_LAUNCH(C_)                                                                            \
+    {                                                                                             \
+        if (split) hipLaunchKernelGGL((cheb_own_kernel<C_, true>), sgrid, block, olds, st, k, kg); \
+        else hipLaunchKernelGGL((cheb_own_kernel<C_, false>), grid, block, olds, st, k, kg);       \
     }
             switch (k.ncol) {
                 case 2: OWN_LAUNCH(2); break;

@@ -180,6 +180,7 @@ void launch_tau_means(hipStream_t st, const KpmGeom &kg, const double *expV, con
 // alpha/beta: [nw][1024] each; randvec: [nw][N] doubles, or [nw][N] complex128 when k.sbari != nullptr (T = ComplexF64)
 void launch_lanczos(hipStream_t st, const KpmArgs &k, const KpmGeom &kg, int w0, int nw, const double *randvec, int nsteps, double *alpha, double *beta, bool use_BtB);
 void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg);
+bool cheb_split_active(const KpmArgs &k, const KpmGeom &kg);  // true: the Chebyshev kernel writes 2·Lτ r·z partials per system instead of Lτ
 // v[Lτ-1-ω] = conj(v[ω]) for ω < cld(Lτ, 2) (KPMPreconditioner.jl:334 / :468; the middle frequency of an odd Lτ conjugates itself)
 void launch_conj_mirror(hipStream_t st, double2 *v, int Lt, int N, int nsys);
 // boundary conversion of real vectors: host layout (Lτ x N x count doubles) <-> complex host-layout staging
