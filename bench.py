@@ -56,7 +56,9 @@ def parse():
     ap.add_argument("--cpu-tol", type=float, default=1e-10, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-nt", type=int, default=24, help=argparse.SUPPRESS)
     ap.add_argument("--roofline-only", action="store_true", help="run only the isolated roofline leg (for a rocprofv3 pass whose kernel average must match roofline.avg_launch_us)")
-    ap.add_argument("--batch-scan", action="store_true", help="also report matvec GB/s vs batch size")
+    ap.add_argument("--batch-scan", action="store_true", help="try tau chunks 1..4 at every point of the batch scan (the default scan uses the heuristic chunk)")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="only warm-up + timed region: no isolated leg, batch scan, copy ceiling, one-stream or CPU legs (for a rocprofv3 pass whose per-kernel averages must agree with roofline.avg_launch_us)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="rehearsal of the N>1 control flow on a one-GPU box: every rank uses cuda:0 and the barrier / MAX reduction run over gloo")
     return ap.parse_args()
@@ -228,13 +230,20 @@ def roofline_record(args, batch, per, S, dev, insitu, extra, L, np):
     batch_scan               1..64 systems per launch; the 64-system point is the HBM-resident one (working set > Infinity Cache).
     """
     h = batch.h
+    alg = h.algorithmic_bytes(L.OP_MTM)
+    if args.timed_only:  # nothing but the timed region's own launches (rocprofv3 cross-check)
+        t_s = insitu["device_us"] * 1e-6
+        traffic, traffic_src = committed_traffic(args.workload, per)
+        return {"bound": "hbm", "kernel": "fdm_fast_kernel<NCOL, MtM>", "achieved": alg / t_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t_s / 1e9 / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_live": False, "frac_traffic": (traffic / t_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "avg_launch_us": insitu["device_us"], "duration_source": "timed region, device clock", "launches_sampled": insitu["device_n"], "event_pair_avg_us": insitu["event_us"],
+                "algorithmic_bytes_per_launch": alg, "systems_per_launch": per, "concurrent_streams": S}
     a, b = h.vec_alloc(), h.vec_alloc()
     g = np.random.default_rng(3)
     h.vec_upload(a, np.asfortranarray(g.standard_normal((batch.Lt, batch.N, per)) + 1j * g.standard_normal((batch.Lt, batch.N, per))))
     h.bench_matvec(L.OP_MTM, b, a, 50)
     ms = h.bench_matvec(L.OP_MTM, b, a, args.matvec_reps)
     iso_s = ms * 1e-3 / args.matvec_reps
-    alg = h.algorithmic_bytes(L.OP_MTM)
     tc = L.C.c_int(0)
     h.call("smoqy_get_tau_chunk", L.C.byref(tc))
     traffic, traffic_src = committed_traffic(args.workload, per)
@@ -280,7 +289,7 @@ def roofline_record(args, batch, per, S, dev, insitu, extra, L, np):
     }
     # GB/s versus batch size (SURVEY.md §8(d) latency caveat), always reported: heuristic tau chunk, 200 launches per point
     scan = []
-    for nb in (1, 2, 4, 8, 16, 32, 64, 128):
+    for nb in (() if args.roofline_only else (1, 2, 4, 8, 16, 32, 64, 128)):  # --roofline-only: the isolated leg alone, for its rocprofv3 cross-check
         hb = L.Handle(batch.Lt, batch.N, batch.nt, batch.colors, True, nb, 1, dev)
         for w in range(nb):
             m = batch.models[w % per]
@@ -403,7 +412,7 @@ def main():
         roofline = roofline_record(args, batch, per, S, dev, insitu, extra, L, np)
         # the literal BASELINE.json configuration — ONE walker per GPU — and the 8- / 16-walker one-stream figures next to the
         # batched headline (outside the timed region): what a user who keeps the reference's rank-per-walker model gets
-        if world == 1 and not args.roofline_only:
+        if world == 1 and not args.roofline_only and not args.timed_only:
             one_stream = []
             for nw1 in (1, 8, 16):
                 ob = WalkerBatch(args.workload, nwalkers=nw1, walker0=mine.start, device=dev, device_efa=args.hmc == "device")
@@ -419,7 +428,7 @@ def main():
             extra["single_walker"] = dict(one_stream[0], note="one walker on one stream: the launch-latency regime (4 dependent launches per CG iteration)")
             extra["one_stream"] = one_stream
         # the CPU baseline is a rank-0, N = 1 measurement (it would only hold the other ranks at the final barrier)
-        cpu = None if (args.no_cpu_baseline or args.roofline_only or world > 1) else cpu_baseline(args.workload, batch.tol, batch.Nt)
+        cpu = None if (args.no_cpu_baseline or args.roofline_only or args.timed_only or world > 1) else cpu_baseline(args.workload, batch.tol, batch.Nt)
         # the whole sweep against the roofline: algorithmic bytes of one preconditioned CG iteration per walker as SURVEY.md §8(d)
         # counts them for the reference's pass structure — MᵀM 2(2S+F), forward and inverse FourierTransformer 2S each, the
         # per-frequency Chebyshev apply 2S, the BLAS-1 lines 10S — times the iterations all walkers ran per second

@@ -4,6 +4,7 @@ import torch
 from smoqyelphqmc_amd.walkers import WalkerBatch
 nw = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 wl = sys.argv[2] if len(sys.argv) > 2 else "holstein_honeycomb_L16_Ltau128"
-b = WalkerBatch(wl, nwalkers=nw)
+form = sys.argv[3] if len(sys.argv) > 3 else "sym"   # "asym": AsymFermionDetMatrix (generic kernels)
+b = WalkerBatch(wl, nwalkers=nw, is_sym=form != "asym")
 b.sweep(); b.sweep()
 t0 = time.perf_counter(); b.sweep(); b.h.call("smoqy_sync"); print("sweep ms", 1e3 * (time.perf_counter() - t0))
