@@ -15,12 +15,15 @@ generated before the timed region; random vectors are drawn on the host inside i
 reference does.
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      dominant kernel = the fused MᵀM apply (fdm_kernel<…, MTM>): algorithmic bytes per
-                launch (2·(2S+F) per system, F once per walker) divided by the
-                average launch duration measured with HIP events on the kernel's own stream.
-  cpu_baseline  the CPU oracle (a single-threaded restatement of the reference algorithm, NOT the
-                Julia reference, which cannot run here) timed on a bounded sample of the same
-                workload on the host cores.
+  roofline      dominant kernel = the fused MᵀM apply.  `achieved` / `frac`: ALGORITHMIC bytes per launch (2·(2S+F) per
+                system, F once per walker) over the average duration of the launches sampled INSIDE the timed region by the device clock
+                (first workgroup start -> last workgroup end, the interval rocprofv3 reports; the HIP event pairs around the same launches
+                are reported next to it).  `traffic` / `frac_traffic`: bytes really moved beyond L2 (committed PMC passes) over the same
+                duration.  `isolated`: the kernel alone on the GPU.  `copy_ceiling`: a device stream copy measured in this run.
+                `batch_scan`: 1..128 systems per launch; `hbm_resident_point`: the 128-system launch (working set > Infinity Cache).
+  one_stream    sweeps/s of 1, 8, 16 walkers on one stream (single_walker = BASELINE.json's literal configuration)
+  cpu_baseline  the CPU oracle (a single-threaded restatement of the reference algorithm, NOT the Julia reference, which cannot run
+                here) timed on a bounded sample of the same workload, one walker per host core, all at once.
 """
 import argparse
 import json
