@@ -570,7 +570,7 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
         c->ff.cs_varies = c->d_cs_varies;
         c->ff.psites = c->d_psites; c->ff.pos = c->d_pos;
         c->ff.pbonds = c->d_pbonds; c->ff.poff = c->d_poff; c->ff.csf = c->d_csf; c->ff.ptotal = c->kg.ptotal; c->ff.threads = c->kg.threads;
-        c->ff.enabled = (!g.is_cplx && g.is_sym && g.ncol >= 1 && g.ncol <= kFdmColours && maxp <= 1024) ? 1 : 0;
+        c->ff.enabled = (!g.is_cplx && g.ncol >= 1 && g.ncol <= kFdmColours && maxp <= 1024) ? 1 : 0;  // Sym: fdm_fast/own kernels; Asym: fdm_fast_asym_kernel
         choose_chunking(c);
     }
     HIPCHK(c, hipMalloc(&c->d_order, (size_t)g.nw * c->nslot * sizeof(int)));
@@ -908,7 +908,7 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
         if (T.d_stamp && T.used < T.stamp_cap && a.nchunk * a.sys_count <= T.stamp_wgs) a.stamp = T.d_stamp + 2 * (size_t)T.stamp_wgs * T.used;  // register-resident kernels only
     }
     if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_own(c->stream, op, a, c->ff);
-    else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_fast(c->stream, op, a, c->ff);
+    else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_fast(c->stream, op, a, c->ff, c->g.is_sym != 0);
     else launch_fdm(c->stream, op, c->g.is_sym != 0, a, c->d_big ? 0 : fdm_lds_bytes(op, c->g.N, c->Tc));
     if (sample) HIPCHK(c, hipEventRecord(T.ev[T.used++].second, c->stream));
     return check_launch(c, "matvec");
@@ -1294,7 +1294,7 @@ int smoqy_matvec_force_generic(smoqy_ctx *c, int on)
 {
     CHECK_CTX(c);
     const Geometry &g = c->g;
-    c->ff.enabled = (!on && !g.is_cplx && g.is_sym && g.ncol >= 1 && g.ncol <= kFdmColours && c->ff.threads <= 1024) ? 1 : 0;
+    c->ff.enabled = (!on && !g.is_cplx && g.ncol >= 1 && g.ncol <= kFdmColours && c->ff.threads <= 1024) ? 1 : 0;
     drop_graphs(c);
     choose_chunking(c);
     return 0;

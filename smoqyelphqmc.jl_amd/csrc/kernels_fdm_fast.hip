@@ -310,6 +310,276 @@ __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
     stamp_end(a.stamp);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Asym form (round 2): B_l = D_l Γ_l, B_lᴴ = Γ_lᴴ D_l with Γ = C_{L-1} … C_1 C_0 (colour 0 first), src/FermionDetMatrix.jl:430-466, 528-563.
+// Same machinery as the Sym kernel — padded per-colour bond lists, the (cosh, sinh) pairs of a lane's bonds in registers, slices in LDS,
+// the last stage of a propagate left in registers — with two differences: there is no folded middle stage (L stages per B instead of 2L-1),
+// and the two operators end on DIFFERENT colours: M leaves its result with the owner of the last colour's bond (where D is applied), Mᴴ
+// with the owner of the first colour's bond.  The fused products therefore hand y = Mv (or Mᴴv) over through a second LDS image Y, which the
+// other owner reads for its `y ∓ B y` combine; the first stage of the second operator runs on the registers that still hold y.
+// ---------------------------------------------------------------------------------------------
+template <int NCOL, int OP>
+__global__ void __launch_bounds__(1024) fdm_fast_asym_kernel(FdmArgs a, FdmFast ff)
+{
+    extern __shared__ double2 U[];
+    __shared__ double red[34];
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    if ((nblk & 7) == 0) bid = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int chunk = bid % a.nchunk, sys = a.sys_first + bid / a.nchunk;
+    stamp_begin(a.stamp);
+    if (a.cg && a.cg[sys].done) return;
+    const int w = sys / a.nrhs;
+    const int Lt = a.Lt, N = a.N;
+    const int l0 = chunk * a.Tc;
+    const int nk = min(a.Tc, Lt - l0);
+    const size_t sstride = (size_t)a.nsys * N;
+    const double2 *in = a.in + (size_t)sys * N;
+    double2 *out = a.out + (size_t)sys * N;
+    const double *expV = a.expV + (size_t)w * Lt * N;
+    const double2 *csf = ff.csf + (size_t)w * Lt * ff.ptotal;
+    constexpr bool FUSED = (OP == SMOQY_OP_MTM || OP == SMOQY_OP_MMT);
+    constexpr bool M_FIRST = (OP == SMOQY_OP_M || OP == SMOQY_OP_MTM);  // the first (or only) operator is M: forward colour order
+    constexpr int CL = NCOL - 1;
+    double2 *Y = U + (size_t)(a.Tc + 1) * N;                   // fused products only
+    const int K1 = FUSED ? nk + 1 : nk;
+    const int fbase = (OP == SMOQY_OP_MT) ? l0 + 1 : l0;       // field slice of register index 0
+    const int ubase = M_FIRST ? l0 - 1 : (OP == SMOQY_OP_MT ? l0 + 1 : l0);  // source slice of U[0]
+
+    Lane ln;
+    const bool cs_varies = ff.cs_varies[w] != 0;
+#pragma unroll
+    for (int c = 0; c < kFdmColours; ++c) {
+        ln.on[c] = false;
+        ln.b[c] = make_int2(0, 0);
+        if (c < NCOL) {
+            const int idx = ff.poff[c] + (int)threadIdx.x;
+            if (idx < ff.poff[c + 1]) {
+                ln.on[c] = true;
+                ln.b[c] = ff.pbonds[idx];
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < K1 && (k == 0 || cs_varies)) ln.cs[c][k] = csf[(size_t)wrapl(fbase + k, Lt) * ff.ptotal + idx];
+                if (!cs_varies) {
+#pragma unroll
+                    for (int k = 1; k < KMAX; ++k) ln.cs[c][k] = ln.cs[c][0];
+                }
+            }
+        }
+    }
+    const bool on0 = ln.on[0], onL = ln.on[CL];
+    const int2 b0 = ln.b[0], bL = ln.b[CL];
+    const int2 s0 = on0 ? ff.psites[ff.poff[0] + (int)threadIdx.x] : make_int2(0, 0);
+    const int2 sL = onL ? ff.psites[ff.poff[CL] + (int)threadIdx.x] : make_int2(0, 0);
+    // exp(-ΔτV) at the sites of the lane's LAST-colour bond: D sits next to that colour in both B = DΓ and Bᴴ = ΓᴴD
+    double dLi[KMAX], dLj[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        dLi[k] = dLj[k] = 1.0;
+        if (k < K1 && onL) {
+            const double *e = expV + (size_t)wrapl(fbase + k, Lt) * N;
+            dLi[k] = e[sL.x];
+            dLj[k] = e[sL.y];
+        }
+    }
+    // phase-1 owner: last colour's bond for M, first colour's bond for Mᴴ
+    const bool onA = M_FIRST ? onL : on0;
+    const int2 bA = M_FIRST ? bL : b0, sA = M_FIRST ? sL : s0;
+    double2 vi[KMAX], vj[KMAX];
+    const int vbase = (OP == SMOQY_OP_MMT) ? l0 - 1 : l0;
+    constexpr int VSH = M_FIRST ? 1 : -1;  // v[k] is U[k + VSH]
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        vi[k] = vj[k] = make_double2(0.0, 0.0);
+        const int ku = k + VSH;
+        if (k < K1 && onA && (ku < 0 || ku >= K1)) {
+            const double2 *row = in + (size_t)wrapl(vbase + k, Lt) * sstride;
+            vi[k] = row[sA.x];
+            vj[k] = row[sA.y];
+        }
+    }
+    for (int idx = threadIdx.x; idx < K1 * N; idx += blockDim.x) {
+        const int k = idx / N, i = idx - k * N;
+        U[(size_t)k * N + ff.pos[i]] = in[(size_t)wrapl(ubase + k, Lt) * sstride + i];
+    }
+    __syncthreads();
+    if (onA) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int ku = k + VSH;
+            if (k < K1 && ku >= 0 && ku < K1) {
+                vi[k] = U[(size_t)ku * N + bA.x];
+                vj[k] = U[(size_t)ku * N + bA.y];
+            }
+        }
+    }
+    __syncthreads();
+
+    double2 ri[KMAX], rj[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) ri[k] = rj[k] = make_double2(0.0, 0.0);
+    // ---- first operator on K1 slices --------------------------------------------------------------------
+    if (M_FIRST) {  // B = D Γ: colours 0 … L-2 through LDS, the last colour into registers, then D
+        if (NCOL >= 2) stage<0, 0>(U, N, K1, ln);
+        if (NCOL >= 3) stage<1 < NCOL ? 1 : 0, 0>(U, N, K1, ln);
+        if (NCOL >= 4) stage<2 < NCOL ? 2 : 0, 0>(U, N, K1, ln);
+        last_stage<CL, 0>(U, N, K1, ln, ri, rj);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { ri[k] = scl(dLi[k], ri[k]); rj[k] = scl(dLj[k], rj[k]); }
+    } else {        // Bᴴ = Γᴴ D: D and the last colour on the owner's pair, colours L-2 … 1 through LDS, colour 0 into registers
+        if (onL) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                if (k < K1) {
+                    double2 *row = U + (size_t)k * N;
+                    const double2 x = scl(dLi[k], row[bL.x]), y = scl(dLj[k], row[bL.y]);
+                    const double c = ln.cs[CL][k].x, s = ln.cs[CL][k].y;
+                    if (NCOL == 1) { ri[k] = lin(c, x, s, y); rj[k] = lin(c, y, s, x); }
+                    else { row[bL.x] = lin(c, x, s, y); row[bL.y] = lin(c, y, s, x); }
+                }
+            }
+        }
+        if (NCOL >= 2) {
+            __syncthreads();
+            if (NCOL >= 4) stage<2 < NCOL ? 2 : 0, 0>(U, N, K1, ln);
+            if (NCOL >= 3) stage<1 < NCOL ? 1 : 0, 0>(U, N, K1, ln);
+            last_stage<0, 0>(U, N, K1, ln, ri, rj);
+        }
+    }
+    double2 acc = make_double2(0.0, 0.0);
+    if (!FUSED) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < nk && onA) {
+                const int l = l0 + k;
+                const bool wrap = (OP == SMOQY_OP_M) ? (l == 0) : (l == Lt - 1);
+                const double2 oi = hopcomb(vi[k], ri[k], wrap, OP == SMOQY_OP_MT, a), oj = hopcomb(vj[k], rj[k], wrap, OP == SMOQY_OP_MT, a);
+                double2 *row = out + (size_t)l * sstride;
+                row[sA.x] = oi;
+                acc.x += vi[k].x * oi.x + vi[k].y * oi.y;
+                acc.y += vi[k].x * oi.y - vi[k].y * oi.x;
+                if (bA.y != bA.x) {
+                    row[sA.y] = oj;
+                    acc.x += vj[k].x * oj.x + vj[k].y * oj.y;
+                    acc.y += vj[k].x * oj.y - vj[k].y * oj.x;
+                }
+            }
+        }
+    } else {
+        // y = first operator on K1 slices, in the registers of the phase-1 owner
+        double2 yi[KMAX], yj[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            yi[k] = yj[k] = make_double2(0.0, 0.0);
+            if (k < K1) {
+                const int l = wrapl(vbase + k, Lt);
+                const bool wrap = M_FIRST ? (l == 0) : (l == Lt - 1);
+                yi[k] = hopcomb(vi[k], ri[k], wrap, !M_FIRST, a);
+                yj[k] = hopcomb(vj[k], rj[k], wrap, !M_FIRST, a);
+            }
+        }
+        __syncthreads();  // every lane is done reading U
+        // phase-2 owner: the other end of the colour chain
+        const bool onB = M_FIRST ? on0 : onL;
+        const int2 bB = M_FIRST ? b0 : bL, sB = M_FIRST ? s0 : sL;
+        if (M_FIRST) {
+            // MᴴM: out[l0+k] = y[k] − conj(ph) Bᴴ_{l0+k+1} y[k+1]; D and the last colour act on the registers that hold y[k+1]
+            if (onL) {
+#pragma unroll
+                for (int k = 0; k < KMAX - 1; ++k) {
+                    if (k < nk) {
+                        const double2 x = scl(dLi[k + 1], yi[k + 1]), y = scl(dLj[k + 1], yj[k + 1]);
+                        const double c = ln.cs[CL][k + 1].x, s = ln.cs[CL][k + 1].y;
+                        const double2 nx = lin(c, x, s, y), ny = lin(c, y, s, x);
+                        if (NCOL == 1) { ri[k] = nx; rj[k] = ny; }
+                        else { U[(size_t)k * N + bL.x] = nx; U[(size_t)k * N + bL.y] = ny; }
+                        Y[(size_t)k * N + bL.x] = yi[k];
+                        Y[(size_t)k * N + bL.y] = yj[k];
+                    }
+                }
+            }
+            __syncthreads();
+            if (NCOL >= 2) {
+                if (NCOL >= 4) stage<2 < NCOL ? 2 : 0, 1>(U, N, nk, ln);
+                if (NCOL >= 3) stage<1 < NCOL ? 1 : 0, 1>(U, N, nk, ln);
+                last_stage<0, 1>(U, N, nk, ln, ri, rj);
+            }
+        } else {
+            // MMᴴ: out[l0+k] = y[k+1] − ph B_{l0+k} y[k]; the first colour acts on the registers that hold y[k]
+            if (on0) {
+#pragma unroll
+                for (int k = 0; k < KMAX - 1; ++k) {
+                    if (k < nk) {
+                        const double c = ln.cs[0][k].x, s = ln.cs[0][k].y;
+                        const double2 nx = lin(c, yi[k], s, yj[k]), ny = lin(c, yj[k], s, yi[k]);
+                        if (NCOL == 1) { ri[k] = scl(dLi[k], nx); rj[k] = scl(dLj[k], ny); }
+                        else { U[(size_t)k * N + b0.x] = nx; U[(size_t)k * N + b0.y] = ny; }
+                        Y[(size_t)k * N + b0.x] = yi[k + 1];
+                        Y[(size_t)k * N + b0.y] = yj[k + 1];
+                    }
+                }
+            }
+            __syncthreads();
+            if (NCOL >= 2) {
+                if (NCOL >= 3) stage<1 < NCOL ? 1 : 0, 0>(U, N, nk, ln);
+                if (NCOL >= 4) stage<2 < NCOL ? 2 : 0, 0>(U, N, nk, ln);
+                last_stage<CL, 0>(U, N, nk, ln, ri, rj);
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) { ri[k] = scl(dLi[k], ri[k]); rj[k] = scl(dLj[k], rj[k]); }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX - 1; ++k) {
+            if (k < nk && onB) {
+                const int l = l0 + k;
+                const bool wrap = M_FIRST ? (l == Lt - 1) : (l == 0);
+                const double2 bi = Y[(size_t)k * N + bB.x], bj = Y[(size_t)k * N + bB.y];
+                const double2 oi = hopcomb(bi, ri[k], wrap, M_FIRST, a), oj = hopcomb(bj, rj[k], wrap, M_FIRST, a);
+                const double2 *prow = in + (size_t)l * sstride;  // dot(in, out) needs `in` at the phase-2 owner's sites (L2 hits)
+                const double2 pi = prow[sB.x], pj = prow[sB.y];
+                double2 *row = out + (size_t)l * sstride;
+                row[sB.x] = oi;
+                acc.x += pi.x * oi.x + pi.y * oi.y;
+                acc.y += pi.x * oi.y - pi.y * oi.x;
+                if (bB.y != bB.x) {
+                    row[sB.y] = oj;
+                    acc.x += pj.x * oj.x + pj.y * oj.y;
+                    acc.y += pj.x * oj.y - pj.y * oj.x;
+                }
+            }
+        }
+    }
+    if (a.partial) {
+        for (int off = 32; off > 0; off >>= 1) {
+            acc.x += __shfl_down(acc.x, off, 64);
+            acc.y += __shfl_down(acc.y, off, 64);
+        }
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = (blockDim.x + 63) >> 6;
+        if (lane == 0) { red[2 * wave] = acc.x; red[2 * wave + 1] = acc.y; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double2 t = make_double2(0.0, 0.0);
+            for (int q = 0; q < nwave; ++q) { t.x += red[2 * q]; t.y += red[2 * q + 1]; }
+            a.partial[(size_t)sys * a.nchunk + chunk] = t;
+        }
+    }
+    stamp_end(a.stamp);
+}
+
+template <int NCOL>
+void launch_ncol_asym(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff)
+{
+    const dim3 grid((unsigned)(a.nchunk * a.sys_count)), block((unsigned)ff.threads);
+    const bool fused = (op == SMOQY_OP_MTM || op == SMOQY_OP_MMT);
+    const size_t lds = sizeof(double2) * (size_t)a.N * (size_t)(a.Tc + 1) * (fused ? 2 : 1);
+    switch (op) {
+        case SMOQY_OP_M: hipLaunchKernelGGL((fdm_fast_asym_kernel<NCOL, SMOQY_OP_M>), grid, block, lds, st, a, ff); break;
+        case SMOQY_OP_MT: hipLaunchKernelGGL((fdm_fast_asym_kernel<NCOL, SMOQY_OP_MT>), grid, block, lds, st, a, ff); break;
+        case SMOQY_OP_MTM: hipLaunchKernelGGL((fdm_fast_asym_kernel<NCOL, SMOQY_OP_MTM>), grid, block, lds, st, a, ff); break;
+        default: hipLaunchKernelGGL((fdm_fast_asym_kernel<NCOL, SMOQY_OP_MMT>), grid, block, lds, st, a, ff); break;
+    }
+}
+
 template <int NCOL>
 void launch_ncol(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff)
 {
@@ -327,11 +597,21 @@ void launch_ncol(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff)
 
 bool fdm_fast_supported(const FdmArgs &a, const FdmFast &ff, bool sym)
 {
-    return sym && ff.enabled && a.ncol >= 1 && a.ncol <= kFdmColours && a.Tc + 1 <= KMAX && sizeof(double2) * (size_t)a.N * (size_t)(a.Tc + 1) <= 60 * 1024;
+    // the Asym kernel keeps a second LDS image for the fused products
+    return ff.enabled && a.ncol >= 1 && a.ncol <= kFdmColours && a.Tc + 1 <= KMAX && sizeof(double2) * (size_t)a.N * (size_t)(a.Tc + 1) * (sym ? 1 : 2) <= 60 * 1024;
 }
 
-void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff)
+void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff, bool sym)
 {
+    if (!sym) {
+        switch (a.ncol) {
+            case 1: launch_ncol_asym<1>(st, op, a, ff); break;
+            case 2: launch_ncol_asym<2>(st, op, a, ff); break;
+            case 3: launch_ncol_asym<3>(st, op, a, ff); break;
+            default: launch_ncol_asym<4>(st, op, a, ff); break;
+        }
+        return;
+    }
     switch (a.ncol) {
         case 1: launch_ncol<1>(st, op, a, ff); break;
         case 2: launch_ncol<2>(st, op, a, ff); break;

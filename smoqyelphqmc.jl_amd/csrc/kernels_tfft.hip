@@ -215,19 +215,26 @@ __global__ void __launch_bounds__(256) tfft_kernel(TfftArgs a)
     const bool act = sb < ns;
     constexpr int U = 4;  // slices in flight per lane: all loads of a batch are issued before its first store
 
-    if (MODE == MODE_FWD_CG) {
-        // stage A p (in a.z) for the transform
-        for (int l = l0; l < Lt; l += lstep) A[l * SB + sb] = act ? a.z[(size_t)l * sstride + base + sb] : make_double2(0.0, 0.0);
-        __syncthreads();
-    } else {
-        for (int idx = threadIdx.x; idx < Lt * SB; idx += blockDim.x) {
-            const int l = idx / SB, sb = idx - l * SB;
-            double2 x = make_double2(0.0, 0.0);
-            if (sb < ns) {
-                x = a.src[(size_t)l * sstride + base + sb];
-                if (a.pre_tw) x = cm(x, a.pre_tw[l]);
+    // staging: all loads of a batch of U slices are issued before the first LDS store — a plain load/store loop keeps ONE 16-byte load
+    // per lane in flight, and with a single wave of workgroups on the chip the kernel is then bound by memory latency, not bandwidth
+    {
+        const double2 *src = (MODE == MODE_FWD_CG) ? a.z : a.src;  // forward CG mode transforms A p
+        for (int l = l0; l < Lt; l += U * lstep) {
+            double2 t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int lu = l + u * lstep;
+                t[u] = (act && lu < Lt) ? src[(size_t)lu * sstride + base + sb] : make_double2(0.0, 0.0);
             }
-            A[idx] = x;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int lu = l + u * lstep;
+                if (lu < Lt) {
+                    double2 x = t[u];
+                    if (MODE != MODE_FWD_CG && a.pre_tw && act) x = cm(x, a.pre_tw[lu]);
+                    A[lu * SB + sb] = x;
+                }
+            }
         }
         __syncthreads();
     }

@@ -158,3 +158,50 @@ def test_same_shapes_with_the_owner_computes_kernels_switched_off():
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("name", ["holstein_honeycomb_L16_Ltau128", "ossh_square_L12_Ltau100"])
+def test_asym_form_at_full_size(name):
+    """AsymFermionDetMatrix (B = D Γ, src/FermionDetMatrix.jl:430-466, 528-563) at the benchmarked batch: the register-resident Asym
+    kernel (fdm_fast_asym_kernel: 4 wavefronts, hand-over of y through the second LDS image) against the oracle and against the
+    generic kernel, and a preconditioned solve with the oracle's iteration count."""
+    nw = 16
+    batch = WalkerBatch(name, nwalkers=nw, is_sym=False)
+    h = batch.h
+    g = np.random.default_rng(51)
+    v = np.asfortranarray(g.standard_normal((batch.Lt, batch.N, nw)) + 1j * g.standard_normal((batch.Lt, batch.N, nw)))
+    a, b = h.vec_alloc(), h.vec_alloc()
+    h.vec_upload(a, v)
+    oracles = {}
+    for w in (0, nw - 1):
+        m = batch.models[w]
+        expV, ch, sh = orc.update_fields(m.fpi.V, m.fpi.t, batch.perm, m.fpi.dtau, False)
+        oracles[w] = orc.OracleFDM(batch.nt, expV, ch, sh, False)
+    for Tc in (1, 2):
+        h.call("smoqy_set_tau_chunk", Tc)
+        for op, fn in ((L.OP_M, "mul_M"), (L.OP_MT, "mul_Mt"), (L.OP_MTM, "mul_MtM"), (L.OP_MMT, "mul_MMt")):
+            h.call("smoqy_matvec_force_generic", 0)
+            h.call("smoqy_matvec_v", op, b, a)
+            fast = h.vec_download(b)
+            for w, o in oracles.items():
+                assert relerr(fast[:, :, w], getattr(o, fn)(v[:, :, w])) < OP_TOL, (fn, Tc, w)
+            h.call("smoqy_matvec_force_generic", 1)
+            h.call("smoqy_matvec_v", op, b, a)
+            assert relerr(h.vec_download(b), fast) < 4e-15, (fn, Tc)
+    h.call("smoqy_matvec_force_generic", 0)
+    h.call("smoqy_set_tau_chunk", 0)
+    rv = np.ascontiguousarray(np.random.default_rng(52).standard_normal((nw, batch.N)))
+    h.call("smoqy_precond_update_all", L.ptr(rv))
+    iters, eps = np.zeros(nw, dtype=np.int32), np.zeros(nw)
+    h.call("smoqy_cg_solve_v", b, a, C.c_double(1e-10), 10000, 1, L.ptr(iters), L.ptr(eps))  # warm start from b's current contents is fine: compare the solution
+    x = h.vec_download(b)
+    w = nw - 1
+    res = np.linalg.norm(oracles[w].mul_MtM(x[:, :, w]) - v[:, :, w]) / np.linalg.norm(v[:, :, w])
+    assert eps.max() < 1e-10 and res < 2e-10
+    h.vec_upload(b, v)
+    h.call("smoqy_cg_solve_v", b, b, C.c_double(1e-10), 10000, 1, L.ptr(iters), L.ptr(eps))
+    P = orc.OracleKPM(oracles[w])
+    P.update(rv[w])
+    xo, ito, _ = oracles[w].cg_solve(v[:, :, w], precond=P, tol=1e-10, maxiter=10000)
+    assert abs(int(iters[w]) - ito) <= 1 and relerr(h.vec_download(b)[:, :, w], xo) < 1e-8
+    h.close()
