@@ -1561,7 +1561,9 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
         if (c->hint_tol[q] > 0 && std::fabs(std::log(c->hint_tol[q] / tol)) < 0.7) { hint = c->hint_iters[q]; hslot = q; }
     while (launched < maxiter) {
         int burst = std::min(c->check_every, maxiter - launched);
-        if (launched == 0 && hint > burst) burst = std::min(hint - 1, maxiter);
+        // first burst: one iteration MORE than the previous solve at this tolerance needed.  Consecutive solves of a trajectory differ by
+        // at most an iteration or so; overshooting costs a few early-exit launches (≈ 1 µs each), a second poll costs ≈ 25 µs of idle stream
+        if (launched == 0 && hint + 1 > burst) burst = std::min(hint + 1, maxiter);
         hipGraphExec_t gexec = nullptr;
         if (c->use_graph) {
             // kGraphIters CG iterations captured once per (x, preconditioning, kernel configuration) and replayed:
@@ -1630,9 +1632,14 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
         c->hint_tol[hslot] = tol;
         c->hint_iters[hslot] = mx;
     }
-    launch_cg_finish(c->stream, a);  // x = Θᴴ x̃
-    HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    launch_cg_finish(c->stream, a);  // x = Θᴴ x̃ (asynchronous: whoever reads x next is ordered behind it on the stream)
+    if (launched == 0) {
+        // no poll has brought the state back yet (maxiter = 0): the convergence test of cg_start is all there is
+        HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    // otherwise h_st already holds the final state: the last poll ran after the last launched iteration, and iterations past `done`
+    // do not touch a system's state — a second read-back would only add a host synchronisation per solve
     if (int rc = check_launch(c, "cg finish")) return rc;
     for (int s = 0; s < g.nsys; ++s) {
         const CgState &st = c->h_st[s];
