@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--walkers-per-gpu", type=int, default=96)
     ap.add_argument("--streams", type=int, default=6, help="concurrent lock-step batches per GPU (one HIP stream + host thread each)")
     ap.add_argument("--solve-concurrency", type=int, default=3, help="at most this many batches inside the CG at once (0 = no limit)")
+    ap.add_argument("--gate", choices=["library", "python"], default="library", help="where --solve-concurrency is enforced: inside the library around each CG loop, or in Python around whole calls")
     ap.add_argument("--measure-nrv", type=int, default=0, help="add update_greens_estimator! + measure_GΔ0! with this many random vectors to every sweep (27 + Nrv solves)")
     ap.add_argument("--hmc", choices=["device", "host"], default="device",
                     help="device: the EFA leapfrog of the HMC trajectory runs on the GPU (x, p and the force never leave it; smoqy_hmc_trajectory_v); "
@@ -365,8 +366,13 @@ def main():
                            host_threads=max(2, 16 // S), measure_nrv=args.measure_nrv, device_efa=args.hmc == "device") for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
     batch = batches[0]
     if args.solve_concurrency > 0:
-        import threading
-        WalkerBatch.solve_gate = threading.Semaphore(args.solve_concurrency)
+        if args.gate == "library":
+            # the library's own process-wide gate: held around each CG loop only, so the preconditioner updates, force kernels and leapfrog
+            # steps of a trajectory overlap with the other batches' solves
+            L.load().smoqy_cg_gate(args.solve_concurrency)
+        else:
+            import threading
+            WalkerBatch.solve_gate = threading.Semaphore(args.solve_concurrency)  # held around whole library calls (a trajectory = 24 solves)
     pool = ThreadPoolExecutor(S) if S > 1 else None
 
     def run(nsweeps):

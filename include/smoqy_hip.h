@@ -183,6 +183,9 @@ int smoqy_precond_apply_real(smoqy_ctx *ctx, double *out, const double *in, int 
 int smoqy_cg_solve_v(smoqy_ctx *ctx, int x, int b, double tol, int maxiter, int use_precond, int *iters, double *eps);
 /* host form; x_is_b != 0 ignores the contents of x on entry */
 int smoqy_cg_solve(smoqy_ctx *ctx, void *x, const void *b, int x_is_b, int sys0, int count, double tol, int maxiter, int use_precond, int *iters, double *eps);
+/* process-wide gate for multi-threaded callers that drive several handles on one GPU: at most max_concurrent of them are inside a CG
+ * solve at once (0 = no limit, the default); everything around the solves still overlaps.  Not tied to a handle. */
+int smoqy_cg_gate(int max_concurrent);
 /* host <-> device convergence polling period of the on-device CG loop (iterations per poll) */
 int smoqy_cg_config(smoqy_ctx *ctx, int check_every);
 /* replay one captured CG iteration as a hipGraph instead of launching its kernels one by one (off by

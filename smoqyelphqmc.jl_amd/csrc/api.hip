@@ -12,9 +12,36 @@
 
 using namespace smoqy;
 
+#include <condition_variable>
+
 namespace {
 std::string g_create_error;
 std::once_flag g_rocfft_once;
+
+// Process-wide gate on the CG loops (smoqy_cg_gate): with several handles driven by several host threads on one GPU, at most `limit`
+// of them are inside a CG solve at once — the loops are bandwidth bound and a fourth concurrent one only evicts the others' working sets
+// (measured) — while everything around the solve (preconditioner update, force, leapfrog, transfers) still overlaps freely.
+struct CgGate {
+    std::mutex m;
+    std::condition_variable cv;
+    int limit = 0, inside = 0;
+    void enter()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (limit <= 0) { ++inside; return; }
+        cv.wait(lk, [&] { return limit <= 0 || inside < limit; });
+        ++inside;
+    }
+    void leave()
+    {
+        { std::lock_guard<std::mutex> lk(m); --inside; }
+        cv.notify_one();
+    }
+} g_cg_gate;
+struct CgGateHold {
+    CgGateHold() { g_cg_gate.enter(); }
+    ~CgGateHold() { g_cg_gate.leave(); }
+};
 }  // namespace
 
 struct WalkerPrecond {
@@ -1473,6 +1500,14 @@ int smoqy_cg_graph_status(smoqy_ctx *c, int *enabled, int *captured)
     return 0;
 }
 
+// process-wide: at most max_concurrent handles inside a CG solve at once (0 = no limit, the default); takes effect for solves that start later
+int smoqy_cg_gate(int max_concurrent)
+{
+    { std::lock_guard<std::mutex> lk(g_cg_gate.m); g_cg_gate.limit = max_concurrent > 0 ? max_concurrent : 0; }
+    g_cg_gate.cv.notify_all();
+    return 0;
+}
+
 int smoqy_cg_config(smoqy_ctx *c, int check_every)
 {
     CHECK_CTX(c);
@@ -1516,6 +1551,7 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
 {
     const Geometry &g = c->g;
     if (maxiter < 0) FAIL(c, 1, "maxiter < 0");
+    CgGateHold gate_hold;  // smoqy_cg_gate: released on every return path
     bool any_pre = false;
     for (int s = 0; s < g.nsys; ++s) {
         std::memset(&c->h_st[s], 0, sizeof(CgState));

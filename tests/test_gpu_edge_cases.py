@@ -318,3 +318,36 @@ def test_graph_replay_survives_a_coefficient_table_reallocation():
         h.close()
     for eager, replay in zip(outs[0], outs[1]):
         assert np.array_equal(eager, replay)
+
+
+def test_process_wide_cg_gate():
+    """smoqy_cg_gate: with the limit at 1, two handles solved from two host threads take turns inside the CG loop and return exactly what
+    they return alone; limit 0 switches the gate off again."""
+    import threading
+
+    lib = L.load()
+    hs, bs, want = [], [], []
+    for k in range(2):
+        h, o, *_ = make(lat.chain_neighbor_table(24), 16, 24, True, seed=20 + k, nrhs=2, vscale=0.5)
+        b = rand(16, 24, 2, 30 + k)
+        hs.append(h); bs.append(b)
+        want.append(solve(h, b, 1e-11, 5000, 0))
+    try:
+        assert lib.smoqy_cg_gate(1) == 0
+        got = [None, None]
+
+        def run(k):
+            for _ in range(5):
+                got[k] = solve(hs[k], bs[k], 1e-11, 5000, 0)
+
+        ts = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in ts)
+        for k in range(2):
+            for a, b in zip(got[k], want[k]):
+                assert np.array_equal(a, b)
+    finally:
+        lib.smoqy_cg_gate(0)
