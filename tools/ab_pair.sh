@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: historical — the paired-frequency kernel (SMOQY_CHEB_PAIR) was measured with the build of commit "real-vector ldiv! …" and then removed;
+# the switch no longer exists.  Kept as the record of how profiles/r02_solo_kernel_stats_cheb_pair_on/off.txt were taken.
 # A/B of the paired Chebyshev kernel (SMOQY_CHEB_PAIR): parity tests, solo profiles at 16 and 1 walkers, default bench
 cd $GRAFT_REPO_ROOT
 timeout -k 10 400 python -m pytest tests/test_gpu_bench_shape.py tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/r02_t2.log 2>&1
