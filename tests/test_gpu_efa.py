@@ -70,51 +70,52 @@ def test_momentum_energies_and_evolution_match_the_oracle(name):
     np.testing.assert_array_equal(x3, x2)
 
 
-def test_one_call_trajectory_equals_the_step_by_step_trajectory():
+@pytest.mark.parametrize("name,nw,Nt", [("holstein_honeycomb_L4_Ltau40", 2, 4), ("holstein_honeycomb_L16_Ltau128", 16, 2), ("ossh_square_L12_Ltau100", 4, 2)])
+def test_one_call_trajectory_equals_the_step_by_step_trajectory(name, nw, Nt):
     """smoqy_hmc_trajectory_v against the same sequence driven from the host through smoqy_pff_step_v (x uploaded, force downloaded every
-    step) and the ORACLE's evolve_eom: identical solves on identical fields, so positions and momenta agree to rounding."""
-    name = "holstein_honeycomb_L4_Ltau40"
-    Nt, dt = 4, 0.11
-    a = WalkerBatch(name, nwalkers=2, device_efa=True, Nt=Nt)
-    bb = WalkerBatch(name, nwalkers=2, device_efa=True, Nt=Nt)
+    step) and the ORACLE's evolve_eom: identical solves on identical fields, so positions and momenta agree to rounding.  The second case is
+    the batch shape bench.py drives (16 walkers of the headline lattice), the third an SSH model (hoppings follow the phonons)."""
+    dt = 0.11
+    a = WalkerBatch(name, nwalkers=nw, device_efa=True, Nt=Nt)
+    bb = WalkerBatch(name, nwalkers=nw, device_efa=True, Nt=Nt)
     g = np.random.default_rng(3)
-    Rphi = np.asfortranarray((g.standard_normal((a.Lt, a.N, 2)) + 1j * g.standard_normal((a.Lt, a.N, 2))) * np.sqrt(0.5))
-    R = np.ascontiguousarray(g.standard_normal((2, a.Lt, a.Nph_force)))
-    rv = np.ascontiguousarray(g.standard_normal((Nt, 2, a.N)))
+    Rphi = np.asfortranarray((g.standard_normal((a.Lt, a.N, nw)) + 1j * g.standard_normal((a.Lt, a.N, nw))) * np.sqrt(0.5))
+    R = np.ascontiguousarray(g.standard_normal((nw, a.Lt, a.Nph_force)))
+    rv = np.ascontiguousarray(g.standard_normal((Nt, nw, a.N)))
     outs = []
     for b in (a, bb):
         b.h.vec_upload(b.phi, Rphi)
         b.h.call("smoqy_matvec_v", L.OP_MT, b.phi, b.phi)
         b.h.call("smoqy_lambda_apply_v", L.LAMBDA_MULT, b.phi, b.phi)
-        K = np.zeros(2)
+        K = np.zeros(nw)
         b.h.call("smoqy_efa_initialize_momentum", L.ptr(R), L.ptr(K))
     # (1) one call
-    sf = np.zeros((Nt, 2)); it = np.zeros((Nt, 2), dtype=np.int32); ep = np.zeros((Nt, 2))
+    sf = np.zeros((Nt, nw)); it = np.zeros((Nt, nw), dtype=np.int32); ep = np.zeros((Nt, nw))
     a.h.call("smoqy_hmc_trajectory_v", a.phi, a.u, Nt, C.c_double(dt), C.c_double(1e-11), 10000, 1, L.ptr(rv), L.ptr(sf), L.ptr(it), L.ptr(ep))
     xa, pa = host_state(a)
     # (2) step by step on the host with the oracle's leapfrog
     x, p = host_state(bb)
     q, m = bb.efa_q, bb.efa_m
-    X = [x[w].T.copy() for w in range(2)]
-    P = [p[w].T.copy() for w in range(2)]
+    X = [x[w].T.copy() for w in range(nw)]
+    P = [p[w].T.copy() for w in range(nw)]
 
     def push():
-        for w in range(2):
+        for w in range(nw):
             bb.xs_force[w] = X[w].T
         return L.ptr(bb.xs_force)
 
-    for w in range(2):
+    for w in range(nw):
         X[w], P[w] = efa.evolve_eom(X[w], P[w], dt / 2, q, m)
-    sf2 = np.zeros((Nt, 2)); it2 = np.zeros((Nt, 2), dtype=np.int32)
+    sf2 = np.zeros((Nt, nw)); it2 = np.zeros((Nt, nw), dtype=np.int32)
     for t in range(Nt):
-        s1, i1, e1 = np.zeros(2), np.zeros(2, dtype=np.int32), np.zeros(2)
+        s1, i1, e1 = np.zeros(nw), np.zeros(nw, dtype=np.int32), np.zeros(nw)
         bb.h.call("smoqy_pff_step_v", bb.phi, bb.u, push(), L.ptr(np.ascontiguousarray(rv[t])), C.c_double(1e-11), 10000, 1, L.ptr(s1), L.ptr(i1), L.ptr(e1), L.ptr(bb.dSdx))
         sf2[t], it2[t] = s1, i1
-        for w in range(2):
+        for w in range(nw):
             X[w], P[w] = efa.evolve_eom(X[w], P[w], dt / 2 if t == Nt - 1 else dt, q, m, force=bb.dSdx[w].T, kick=dt)
     assert np.array_equal(it, it2)
     np.testing.assert_allclose(sf, sf2, rtol=1e-9)
-    for w in range(2):
+    for w in range(nw):
         np.testing.assert_allclose(xa[w].T, X[w], atol=1e-9 * np.abs(X[w]).max())
         np.testing.assert_allclose(pa[w].T, P[w], atol=1e-9 * np.abs(P[w]).max())
 
