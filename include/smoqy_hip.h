@@ -272,7 +272,8 @@ int smoqy_efa_checkpoint(smoqy_ctx *ctx, int restore);
  * evolve(Δt/2), update!; Nt times { calculate_derivative_fermionic_action! at tol_force; p -= Δt ∂S_f/∂x; evolve(Δt, last step Δt/2);
  * update! }.  Φ in vector phi, Ψ left in psi.  randvecs: N x nwalkers x Nt Lanczos start vectors (the rng stays on the host); Sf, iters,
  * eps: nwalkers x Nt (any may be NULL).  Only the fermionic force is applied: anharmonic / dispersive phonon terms (:190-193) are the
- * caller's to add through smoqy_efa_evolve step by step. */
+ * caller's to add through smoqy_efa_evolve step by step.  A non-zero return (e.g. a non-finite residual) leaves x and p wherever the
+ * trajectory stopped: the caller rejects the update with smoqy_efa_checkpoint(ctx, 1), as the reference's catch block does (:176-187). */
 int smoqy_hmc_trajectory_v(smoqy_ctx *ctx, int phi, int psi, int Nt, double dt, double tol_force, int maxiter, int use_precond, const double *randvecs, double *Sf, int *iters, double *eps);
 
 /* ---- device-side update! from the phonon fields ------------------- */
