@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=6, help="concurrent lock-step batches per GPU (one HIP stream + host thread each)")
     ap.add_argument("--solve-concurrency", type=int, default=3, help="at most this many batches inside the CG at once (0 = no limit)")
     ap.add_argument("--gate", choices=["library", "python"], default="library", help="where --solve-concurrency is enforced: inside the library around each CG loop, or in Python around whole calls")
+    ap.add_argument("--cg-split", type=int, default=1, choices=[0, 1, 2],
+                    help="two-part CG pipeline inside each handle of the TIMED batches (smoqy_cg_split): 1 = off (default here: six streams already overlap, and the roofline samples "
+                         "full-batch MtM launches), 0 = the library's automatic choice, 2 = on.  The one-stream legs always use the library default (automatic).")
+    ap.add_argument("--no-mtm-sampling", action="store_true", help="do not sample MtM launches inside the timed region (roofline falls back to the isolated leg)")
     ap.add_argument("--measure-nrv", type=int, default=0, help="add update_greens_estimator! + measure_GΔ0! with this many random vectors to every sweep (27 + Nrv solves)")
     ap.add_argument("--hmc", choices=["device", "host"], default="device",
                     help="device: the EFA leapfrog of the HMC trajectory runs on the GPU (x, p and the force never leave it; smoqy_hmc_trajectory_v); "
@@ -236,6 +240,8 @@ def roofline_record(args, batch, per, S, dev, insitu, extra, L, np):
     h = batch.h
     alg = h.algorithmic_bytes(L.OP_MTM)
     if args.timed_only:  # nothing but the timed region's own launches (rocprofv3 cross-check)
+        if not insitu["device_us"]:
+            return {"bound": "hbm", "note": "no MtM launches were sampled in this run"}
         t_s = insitu["device_us"] * 1e-6
         traffic, traffic_src = committed_traffic(args.workload, per)
         return {"bound": "hbm", "kernel": "fdm_fast_kernel<NCOL, MtM>", "achieved": alg / t_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t_s / 1e9 / HBM_PEAK_GBS,
@@ -363,7 +369,7 @@ def main():
     mine = walker_range(rank, world, wpg)  # walkers [rank*wpg, (rank+1)*wpg): no overlap between ranks, no exchange
     per = wpg // S
     batches = [WalkerBatch(args.workload, nwalkers=per, walker0=mine.start + s * per, device=dev, check_every=args.check_every or None, tau_chunk=args.tau_chunk or None,
-                           host_threads=max(2, 16 // S), measure_nrv=args.measure_nrv, device_efa=args.hmc == "device") for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
+                           host_threads=max(2, 16 // S), measure_nrv=args.measure_nrv, device_efa=args.hmc == "device", cg_split=args.cg_split) for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
     batch = batches[0]
     if args.solve_concurrency > 0:
         if args.gate == "library":
@@ -396,7 +402,8 @@ def main():
         b.stats.solves = b.stats.iters_sum = 0
         # roofline: the dominant kernel's launches inside the timed region are sampled with HIP events on the stream
         # they run on (every 16th full-batch fused MᵀM launch of the CG loop)
-        b.h.call("smoqy_matvec_timing", 16, 1024)
+        if not args.no_mtm_sampling:
+            b.h.call("smoqy_matvec_timing", 16, 1024)
     fence()
     t0 = time.perf_counter()
     run(args.steps)

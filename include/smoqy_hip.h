@@ -186,6 +186,10 @@ int smoqy_cg_solve(smoqy_ctx *ctx, void *x, const void *b, int x_is_b, int sys0,
 /* process-wide gate for multi-threaded callers that drive several handles on one GPU: at most max_concurrent of them are inside a CG
  * solve at once (0 = no limit, the default); everything around the solves still overlaps.  Not tied to a handle. */
 int smoqy_cg_gate(int max_concurrent);
+/* two-part pipeline inside one handle: the systems of a batch are independent, so the iteration kernels of one half run on the handle's
+ * stream and those of the other half on a second stream of the handle; the halves drift out of phase and overlap (what two handles on two
+ * host threads do).  parts = 0: automatic (two parts from 8 systems up, the default), 1: off, 2: on.  Bit-identical results either way. */
+int smoqy_cg_split(smoqy_ctx *ctx, int parts);
 /* host <-> device convergence polling period of the on-device CG loop (iterations per poll) */
 int smoqy_cg_config(smoqy_ctx *ctx, int check_every);
 /* replay one captured CG iteration as a hipGraph instead of launching its kernels one by one (off by

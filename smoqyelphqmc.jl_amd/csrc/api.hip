@@ -56,6 +56,10 @@ struct smoqy_ctx {
     Geometry g{};
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // second stream of the two-part CG pipeline (smoqy_cg_split): half the systems' iteration kernels run here, the other half's on `stream`
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_part = nullptr;
+    int cg_parts = 0;  // 0 = automatic (two parts from 8 systems up), 1 = off, 2 = on
     std::string err;
     int Tc = 1, nchunk = 1;
     bool user_Tc = false;
@@ -350,6 +354,9 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->mvt.d_stamp) (void)hipFree(c->mvt.d_stamp);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_part) (void)hipEventDestroy(c->ev_part);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return 0;
@@ -376,6 +383,9 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     if (cfg_err != hipSuccess) FAIL(c, 2, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for %s: %s", cfg_what, hipGetErrorString(cfg_err));
     HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_part, hipEventDisableTiming));
     HIPCHK(c, hipEventCreate(&c->ev0));
     HIPCHK(c, hipEventCreate(&c->ev1));
 
@@ -640,6 +650,7 @@ int smoqy_set_stream(smoqy_ctx *c, void *s)
 {
     CHECK_CTX(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
     c->stream = s ? (hipStream_t)s : c->own_stream;
     FFTCHK(c, rocfft_execution_info_set_stream(c->fft_info, c->stream));
     drop_graphs(c);
@@ -919,8 +930,9 @@ int smoqy_vec_dot(smoqy_ctx *c, int a, int b, void *out)
 
 // ---- matvec -------------------------------------------------------------------------------------
 
-static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, double2 *partial, const CgState *cg, int sys0, int count, bool twiddled = false)
+static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, double2 *partial, const CgState *cg, int sys0, int count, bool twiddled = false, hipStream_t st = nullptr)
 {
+    if (!st) st = c->stream;
     if (op < SMOQY_OP_M || op > SMOQY_OP_MMT) FAIL(c, 1, "unknown matvec op %d", op);
     FdmArgs a = fdm_args(c, in, out, partial, cg, sys0, count);
     if (twiddled) {  // Θ M Θᴴ: uniform hop phase exp(-iπ/Lτ), periodic in τ (kernels_vec.hip, CG section)
@@ -934,9 +946,9 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
         HIPCHK(c, hipEventRecord(T.ev[T.used].first, c->stream));
         if (T.d_stamp && T.used < T.stamp_cap && a.nchunk * a.sys_count <= T.stamp_wgs) a.stamp = T.d_stamp + 2 * (size_t)T.stamp_wgs * T.used;  // register-resident kernels only
     }
-    if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_own(c->stream, op, a, c->ff);
-    else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_fast(c->stream, op, a, c->ff, c->g.is_sym != 0);
-    else launch_fdm(c->stream, op, c->g.is_sym != 0, a, c->d_big ? 0 : fdm_lds_bytes(op, c->g.N, c->Tc));
+    if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_own(st, op, a, c->ff);
+    else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_fast(st, op, a, c->ff, c->g.is_sym != 0);
+    else launch_fdm(st, op, c->g.is_sym != 0, a, c->d_big ? 0 : fdm_lds_bytes(op, c->g.N, c->Tc));
     if (sample) HIPCHK(c, hipEventRecord(T.ev[T.used++].second, c->stream));
     return check_launch(c, "matvec");
 }
@@ -1508,6 +1520,15 @@ int smoqy_cg_gate(int max_concurrent)
     return 0;
 }
 
+// two-part pipeline of the CG loop: parts = 0 automatic (two parts from 8 systems up), 1 = off, 2 = on
+int smoqy_cg_split(smoqy_ctx *c, int parts)
+{
+    CHECK_CTX(c);
+    if (parts < 0 || parts > 2) FAIL(c, 1, "parts must be 0 (automatic), 1 or 2");
+    c->cg_parts = parts;
+    return 0;
+}
+
 int smoqy_cg_config(smoqy_ctx *c, int check_every)
 {
     CHECK_CTX(c);
@@ -1517,28 +1538,36 @@ int smoqy_cg_config(smoqy_ctx *c, int check_every)
 }
 
 // one CG iteration: ConjugateGradient.jl:216-246
+// the fused form of one CG iteration for systems [sys0, sys0 + count) on stream st: four launches
+static int cg_iteration_fused(smoqy_ctx *c, const CgArgs &a, hipStream_t st, int sys0, int count)
+{
+    if (int rc = matvec_dev(c, SMOQY_OP_MTM, c->cg_z, c->cg_p, c->part_pz, c->d_st, sys0, count, true, st)) return rc;  // z = A p, partial p·Ap (:219)
+    // the tau-FFT kernels absorb the BLAS-1 updates (kernels_tfft.hip).  In this form a.r holds the residual in FREQUENCY space (r̂):
+    // the forward kernel updates it with α·FFT(Ap), the Chebyshev kernel reads it and writes ẑ into v (out of place), the inverse
+    // kernel turns ẑ into z and updates x and p.
+    TfftArgs t = c->tf;
+    t.sys_first = sys0; t.sys_count = count;
+    t.x = a.x; t.r = a.r; t.p = a.p; t.z = a.z;
+    t.part_rz = a.part_rz; t.nrz = a.nrz; t.rz_stride = a.rz_stride;
+    t.part_pz = a.part_pz; t.npz = a.nchunk; t.pz_stride = a.nchunk;
+    t.part_rr = a.part_rr; t.nrr = t.ntile; t.rr_stride = c->pstride;
+    t.st = a.st;
+    launch_tfft(st, 2, t);                      // :219-226: α, r̂ -= α FFT(Ap), |r|²
+    KpmArgs k = kpm_args(c, c->cg_r, c->d_st);
+    k.sys_first = sys0; k.sys_count = count;
+    k.vout = c->cg_z;  // ẑ reuses the buffer of A p, which the forward kernel has consumed (one vector less in the cache-resident working set)
+    k.part_rz = c->part_rz;
+    launch_cheb(st, k, c->kg);                  // :237 in frequency space, partial r·z by Parseval
+    t.src = a.v;
+    launch_tfft(st, 3, t);                      // inverse FFT + x += α p + :229-245
+    return check_launch(c, "cg iteration");
+}
+
+// one CG iteration: ConjugateGradient.jl:216-246
 static int cg_iteration(smoqy_ctx *c, const CgArgs &a, bool any_pre)
 {
+    if (any_pre && c->tf_ok && c->use_tfft) return cg_iteration_fused(c, a, c->stream, 0, c->g.nsys);
     if (int rc = matvec_dev(c, SMOQY_OP_MTM, c->cg_z, c->cg_p, c->part_pz, c->d_st, 0, c->g.nsys, true)) return rc;  // z = A p, partial p·Ap (:219)
-    if (any_pre && c->tf_ok && c->use_tfft) {
-        // four launches per iteration: the tau-FFT kernels absorb the BLAS-1 updates (kernels_tfft.hip).  In this form a.r
-        // holds the residual in FREQUENCY space (r̂): the forward kernel updates it with α·FFT(Ap), the Chebyshev kernel reads
-        // it and writes ẑ into v (out of place), the inverse kernel turns ẑ into z and updates x and p.
-        TfftArgs t = c->tf;
-        t.x = a.x; t.r = a.r; t.p = a.p; t.z = a.z;
-        t.part_rz = a.part_rz; t.nrz = a.nrz; t.rz_stride = a.rz_stride;
-        t.part_pz = a.part_pz; t.npz = a.nchunk; t.pz_stride = a.nchunk;
-        t.part_rr = a.part_rr; t.nrr = t.ntile; t.rr_stride = c->pstride;
-        t.st = a.st;
-        launch_tfft(c->stream, 2, t);                      // :219-226: α, r̂ -= α FFT(Ap), |r|²
-        KpmArgs k = kpm_args(c, c->cg_r, c->d_st);
-        k.vout = c->cg_z;  // ẑ reuses the buffer of A p, which the forward kernel has consumed (one vector less in the cache-resident working set)
-        k.part_rz = c->part_rz;
-        launch_cheb(c->stream, k, c->kg);                  // :237 in frequency space, partial r·z by Parseval
-        t.src = a.v;
-        launch_tfft(c->stream, 3, t);                      // inverse FFT + x += α p + :229-245
-        return check_launch(c, "cg iteration");
-    }
     launch_cg_update_xr(c->stream, a);                                                                             // :220-226
     if (any_pre) if (int rc = precond_core(c, c->cg_r, c->cg_z, c->d_st, c->part_rz)) return rc;                 // z = P⁻¹ r (over A p, consumed), partial r·z (:237-240)
     launch_cg_update_p(c->stream, a);                                                                              // :229-245
@@ -1592,6 +1621,9 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
     if (int rc = check_launch(c, "cg setup")) return rc;
 
     int launched = 0;
+    // smoqy_cg_split: automatic = two parts from 8 systems up, fused path only (rocFFT plans and captured graphs cover the whole batch),
+    // and not while the fused-MᵀM launches are being sampled for bench.py's roofline (the samples are of full-batch launches)
+    const bool two_parts = (c->cg_parts == 2 || (c->cg_parts == 0 && g.nsys >= 8)) && g.nsys >= 2 && any_pre && c->tf_ok && c->use_tfft && !c->use_graph && c->mvt.every == 0;
     int hint = 0, hslot = -1;
     for (int q = 0; q < 4; ++q)
         if (c->hint_tol[q] > 0 && std::fabs(std::log(c->hint_tol[q] / tol)) < 0.7) { hint = c->hint_iters[q]; hslot = q; }
@@ -1643,6 +1675,22 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
             // whole graphs only: iterations past convergence or maxiter are workgroups that exit on their first load
             burst = ((burst + kGraphIters - 1) / kGraphIters) * kGraphIters;
             for (int it = 0; it < burst; it += kGraphIters) HIPCHK(c, hipGraphLaunch(gexec, c->stream));
+        } else if (two_parts) {
+            // two-part pipeline: the systems are independent, so the iteration kernels of the first half run on the handle's stream and
+            // those of the second half on stream2.  The two chains drift out of phase, and one half's latency-bound Chebyshev chain and
+            // load phases run under the other half's bandwidth-bound kernels — the overlap that otherwise needs two handles on two host
+            // threads.  Arithmetic per system is untouched (same kernels on a sub-range): results are bit-identical to the one-part form.
+            const int n0 = g.nsys / 2;
+            if (launched == 0) {
+                HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));          // the set-up kernels above
+                HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            }
+            for (int it = 0; it < burst; ++it) {
+                if (int rc = cg_iteration_fused(c, a, c->stream, 0, n0)) return rc;
+                if (int rc = cg_iteration_fused(c, a, c->stream2, n0, g.nsys - n0)) return rc;
+            }
+            HIPCHK(c, hipEventRecord(c->ev_part, c->stream2));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_part, 0));       // the poll below (and everything after the solve) sees both halves
         } else {
             for (int it = 0; it < burst; ++it)
                 if (int rc = cg_iteration(c, a, any_pre)) return rc;

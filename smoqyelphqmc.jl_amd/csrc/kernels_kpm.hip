@@ -319,7 +319,8 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
     const int N = k.N, Lt = k.Lt;
     // rank-major block order: the heaviest chains of all systems are dispatched first and land
     // on different CUs / XCDs (a system-major order parks them on the same CU)
-    const int sys = blockIdx.x % k.nsys, rank = blockIdx.x / k.nsys;
+    const int ncnt_ = k.sys_count > 0 ? k.sys_count : k.nsys;
+    const int sys = k.sys_first + blockIdx.x % ncnt_, rank = blockIdx.x / ncnt_;
     const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);  // heaviest orders first
     const int w = sys / k.nrhs;
     if (k.cg && k.cg[sys].done) return;
@@ -458,7 +459,8 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
     T *Wb[2] = {reinterpret_cast<T *>(lds), reinterpret_cast<T *>(lds) + 2 * Tn};
     double2 *CF = reinterpret_cast<double2 *>(reinterpret_cast<T *>(lds) + 4 * Tn);
     // heaviest orders first, rank-major; with SPLIT the two components of a frequency are neighbours in the dispatch order
-    const int sys = blockIdx.x % k.nsys, slotid = blockIdx.x / k.nsys;
+    const int ncnt_ = k.sys_count > 0 ? k.sys_count : k.nsys;
+    const int sys = k.sys_first + blockIdx.x % ncnt_, slotid = blockIdx.x / ncnt_;
     const int comp = SPLIT ? (slotid & 1) : 0, rank = SPLIT ? (slotid >> 1) : slotid;
     const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);
     const int w = sys / k.nrhs;
@@ -740,7 +742,8 @@ __global__ void __launch_bounds__(kThreads) cheb_generic_kernel(KpmArgs k)
     __shared__ double red[17];
     const int N = k.N, Lt = k.Lt;
     double2 *W = k.scratch ? k.scratch + (size_t)blockIdx.x * k.scratch_stride : lds, *A1 = W + N, *A2 = A1 + N, *ACC = A2 + N;
-    const int sys = blockIdx.x % k.nsys, rank = blockIdx.x / k.nsys;
+    const int ncnt_ = k.sys_count > 0 ? k.sys_count : k.nsys;
+    const int sys = k.sys_first + blockIdx.x % ncnt_, rank = blockIdx.x / ncnt_;
     const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);
     const int w = sys / k.nrhs;
     if (k.cg && k.cg[sys].done) return;
@@ -800,12 +803,13 @@ void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
 {
     if (kg.fast) {
         const size_t lds = sizeof(double2) * ((size_t)k.N + 2 * (size_t)k.maxorder);
-        const dim3 grid((unsigned)(k.Lt * k.nsys)), block((unsigned)kg.threads);
+        const int ncnt = k.sys_count > 0 ? k.sys_count : k.nsys;
+        const dim3 grid((unsigned)(k.Lt * ncnt)), block((unsigned)kg.threads);
 #define CHEB_LAUNCH(S_, C_) hipLaunchKernelGGL((cheb_fast_kernel<S_, C_>), grid, block, lds, st, k, kg)
         if (k.is_sym && k.ncol >= 2 && k.ncol <= 6 && kg.own && cheb_own_enabled()) {
             const bool split = cheb_split_active(k, kg);
             const size_t olds = (split ? sizeof(double) : sizeof(double2)) * 4 * (size_t)kg.threads + sizeof(double2) * (size_t)k.maxorder;
-            const dim3 sgrid((unsigned)(2 * k.Lt * k.nsys));
+            const dim3 sgrid((unsigned)(2 * k.Lt * ncnt));
 #define OWN_LAUNCH(C_)                                                                            \
     {                                                                                             \
         if (split) hipLaunchKernelGGL((cheb_own_kernel<C_, true>), sgrid, block, olds, st, k, kg); \
@@ -839,7 +843,7 @@ void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
 #undef CHEB_LAUNCH
     } else {
         const size_t lds = k.scratch ? 0 : sizeof(double2) * 4 * (size_t)k.N;
-        hipLaunchKernelGGL(cheb_generic_kernel, dim3((unsigned)(k.Lt * k.nsys)), dim3(kThreads), lds, st, k);
+        hipLaunchKernelGGL(cheb_generic_kernel, dim3((unsigned)(k.Lt * (k.sys_count > 0 ? k.sys_count : k.nsys))), dim3(kThreads), lds, st, k);
     }
 }
 

@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256) tfft_kernel(TfftArgs a)
     __shared__ double red[18];
     const int Lt = a.Lt, SB = a.SB, N = a.N;
     double2 *A = lds, *B = A + (size_t)Lt * SB, *WT = B + (size_t)Lt * SB;
-    const int tile = blockIdx.x % a.ntile, sys = blockIdx.x / a.ntile;
+    const int tile = blockIdx.x % a.ntile, sys = a.sys_first + blockIdx.x / a.ntile;
     if (MODE == MODE_FWD_CG) {
         // `done` was written by an earlier launch (inverse kernel of the previous iteration or cg_start): safe to gate on.
         // Latch it into `stop` for the inverse kernel of THIS iteration, which must not look at `done` (it writes it).
@@ -454,7 +454,7 @@ hipError_t configure_tfft_kernels(const char **what)
 void launch_tfft(hipStream_t st, int mode, const TfftArgs &a)
 {
     const size_t lds = (2 * (size_t)a.Lt * a.SB + a.Lt) * sizeof(double2);
-    const dim3 grid((unsigned)(a.ntile * a.nsys)), block(256);
+    const dim3 grid((unsigned)(a.ntile * (a.sys_count > 0 ? a.sys_count : a.nsys))), block(256);
     switch (mode) {
         case 0: hipLaunchKernelGGL((tfft_kernel<0>), grid, block, lds, st, a); break;
         case 1: hipLaunchKernelGGL((tfft_kernel<1>), grid, block, lds, st, a); break;

@@ -102,6 +102,7 @@ struct KpmArgs {
     double2 *part_rz;                   // optional [nsys][rz_stride]: Parseval partial of r·z per (system, ω)
     int rz_stride;
     double scale;                       // output scale (1/Lτ: rocFFT's inverse is unnormalised)
+    int sys_first, sys_count;           // systems [sys_first, sys_first + sys_count) are processed; sys_count = 0 means all
     int half;                           // real-vector ldiv! (KPMPreconditioner.jl:312 / :444): only ω < cld(Lτ, 2) are evaluated,
                                         // launch_conj_mirror fills in the rest
 };
@@ -252,6 +253,7 @@ void launch_ge_finalize_gd0(hipStream_t st, const double2 *S, double2 *out, int 
 // own tau-FFT (kernels_tfft.hip): Stockham passes over LDS site tiles, optionally fused with the CG updates
 struct TfftArgs {
     int Lt, N, nsys, SB, ntile, nfac;
+    int sys_first, sys_count;             // systems [sys_first, sys_first + sys_count) are processed; sys_count = 0 means all
     int fac[16];
     const double2 *wtab;                  // [Lt] exp(-2 pi i q / Lt)
     // plain modes (0 forward, 1 inverse): dst = FFT(pre_tw * src) * conj(post_tw)

@@ -48,7 +48,7 @@ class WalkerBatch:
 
     def __init__(self, workload: str, nwalkers: int = 1, walker0: int = 0, is_sym: bool = True, device: int = -1, tol: float = 1e-10, maxiter: int = 10_000, Nt: int = 24,
                  drift: float = 0.02, check_every: int | None = None, tau_chunk: int | None = None, smooth: bool = False, host_threads: int = 8, device_update: bool = True, measure_nrv: int = 0,
-                 device_efa: bool = False, omega: float = 1.0, mass: float = 1.0):
+                 device_efa: bool = False, omega: float = 1.0, mass: float = 1.0, cg_split: int | None = None):
         self.models = [lat.CONFIGS[workload](walker=walker0 + w, smooth=smooth) for w in range(nwalkers)]
         m0 = self.models[0]
         self.workload = workload
@@ -71,6 +71,8 @@ class WalkerBatch:
         self.hoppings_move = m0.kind != "holstein"  # Holstein: t is constant, only V follows the phonons
         if check_every:
             self.h.call("smoqy_cg_config", int(check_every))
+        if cg_split is not None:
+            self.h.call("smoqy_cg_split", int(cg_split))  # 0 automatic, 1 off, 2 on: two-part pipeline of the CG loop inside the handle
         if tau_chunk:
             self.h.call("smoqy_set_tau_chunk", int(tau_chunk))
         self.rng = [np.random.Generator(np.random.PCG64(lat.SEED0 + 7919 * (walker0 + w) + 1)) for w in range(nwalkers)]

@@ -351,3 +351,20 @@ def test_process_wide_cg_gate():
                 assert np.array_equal(a, b)
     finally:
         lib.smoqy_cg_gate(0)
+
+
+def test_two_part_pipeline_is_bit_identical():
+    """smoqy_cg_split: the iteration kernels of the two halves of a batch run on two streams of the handle; per system the arithmetic is the
+    same kernels on a sub-range, so solutions, iteration counts and residuals equal the one-part form bit for bit (odd batch size included)."""
+    from smoqyelphqmc_amd.walkers import WalkerBatch
+
+    outs = {}
+    for parts in (1, 2):
+        b = WalkerBatch("holstein_honeycomb_L4_Ltau40", nwalkers=9, cg_split=parts)
+        b.sample_pseudofermion_fields()
+        sf, iters, eps = b.calculate_fermionic_action(1e-10)
+        outs[parts] = (b.h.vec_download(b.u).copy(), sf.copy(), iters.copy(), eps.copy(), b.fermionic_force().copy())
+        b.h.close()
+    assert len(set(outs[1][2].tolist())) >= 1
+    for x, y in zip(outs[1], outs[2]):
+        assert np.array_equal(x, y)
