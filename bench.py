@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=6, help="concurrent lock-step batches per GPU (one HIP stream + host thread each)")
     ap.add_argument("--solve-concurrency", type=int, default=3, help="at most this many batches inside the CG at once (0 = no limit)")
     ap.add_argument("--gate", choices=["library", "python"], default="library", help="where --solve-concurrency is enforced: inside the library around each CG loop, or in Python around whole calls")
-    ap.add_argument("--cg-split", type=int, default=1, choices=[0, 1, 2],
+    ap.add_argument("--cg-split", type=int, default=1, choices=[0, 1, 2, 3, 4],
                     help="two-part CG pipeline inside each handle of the TIMED batches (smoqy_cg_split): 1 = off (default here: six streams already overlap, and the roofline samples "
                          "full-batch MtM launches), 0 = the library's automatic choice, 2 = on.  The one-stream legs always use the library default (automatic).")
     ap.add_argument("--no-mtm-sampling", action="store_true", help="do not sample MtM launches inside the timed region (roofline falls back to the isolated leg)")

@@ -57,9 +57,10 @@ struct smoqy_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     // second stream of the two-part CG pipeline (smoqy_cg_split): half the systems' iteration kernels run here, the other half's on `stream`
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_part = nullptr;
-    int cg_parts = 0;  // 0 = automatic (two parts from 8 systems up), 1 = off, 2 = on
+    static constexpr int kMaxParts = 4;
+    hipStream_t part_stream[kMaxParts - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_part[kMaxParts - 1] = {nullptr, nullptr, nullptr};
+    int cg_parts = 0;  // 0 = automatic, 1 = off, 2..4 = that many parts
     std::string err;
     int Tc = 1, nchunk = 1;
     bool user_Tc = false;
@@ -355,8 +356,8 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_part) (void)hipEventDestroy(c->ev_part);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    for (auto e : c->ev_part) if (e) (void)hipEventDestroy(e);
+    for (auto s : c->part_stream) if (s) (void)hipStreamDestroy(s);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return 0;
@@ -383,9 +384,11 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     if (cfg_err != hipSuccess) FAIL(c, 2, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for %s: %s", cfg_what, hipGetErrorString(cfg_err));
     HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_part, hipEventDisableTiming));
+    for (int q = 0; q < smoqy_ctx::kMaxParts - 1; ++q) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->part_stream[q], hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_part[q], hipEventDisableTiming));
+    }
     HIPCHK(c, hipEventCreate(&c->ev0));
     HIPCHK(c, hipEventCreate(&c->ev1));
 
@@ -650,7 +653,7 @@ int smoqy_set_stream(smoqy_ctx *c, void *s)
 {
     CHECK_CTX(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    for (auto ps : c->part_stream) HIPCHK(c, hipStreamSynchronize(ps));
     c->stream = s ? (hipStream_t)s : c->own_stream;
     FFTCHK(c, rocfft_execution_info_set_stream(c->fft_info, c->stream));
     drop_graphs(c);
@@ -1520,11 +1523,11 @@ int smoqy_cg_gate(int max_concurrent)
     return 0;
 }
 
-// two-part pipeline of the CG loop: parts = 0 automatic (two parts from 8 systems up), 1 = off, 2 = on
+// multi-part pipeline of the CG loop: parts = 0 automatic (two parts from 8 systems up), 1 = off, 2..4 = that many parts
 int smoqy_cg_split(smoqy_ctx *c, int parts)
 {
     CHECK_CTX(c);
-    if (parts < 0 || parts > 2) FAIL(c, 1, "parts must be 0 (automatic), 1 or 2");
+    if (parts < 0 || parts > smoqy_ctx::kMaxParts) FAIL(c, 1, "parts must be 0 (automatic) or 1..%d", smoqy_ctx::kMaxParts);
     c->cg_parts = parts;
     return 0;
 }
@@ -1621,9 +1624,12 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
     if (int rc = check_launch(c, "cg setup")) return rc;
 
     int launched = 0;
-    // smoqy_cg_split: automatic = two parts from 8 systems up, fused path only (rocFFT plans and captured graphs cover the whole batch),
-    // and not while the fused-MᵀM launches are being sampled for bench.py's roofline (the samples are of full-batch launches)
-    const bool two_parts = (c->cg_parts == 2 || (c->cg_parts == 0 && g.nsys >= 8)) && g.nsys >= 2 && any_pre && c->tf_ok && c->use_tfft && !c->use_graph && c->mvt.every == 0;
+    // smoqy_cg_split: fused path only (rocFFT plans and captured graphs cover the whole batch), and not while the fused-MᵀM launches are
+    // being sampled for bench.py's roofline (the samples are of full-batch launches).  Automatic: two parts from 8 systems up (measured,
+    // DESIGN.md §4.3).
+    int nparts = c->cg_parts == 0 ? (g.nsys >= 8 ? 2 : 1) : c->cg_parts;
+    if (nparts > g.nsys) nparts = g.nsys;
+    if (!(any_pre && c->tf_ok && c->use_tfft) || c->use_graph || c->mvt.every != 0) nparts = 1;
     int hint = 0, hslot = -1;
     for (int q = 0; q < 4; ++q)
         if (c->hint_tol[q] > 0 && std::fabs(std::log(c->hint_tol[q] / tol)) < 0.7) { hint = c->hint_iters[q]; hslot = q; }
@@ -1675,22 +1681,24 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
             // whole graphs only: iterations past convergence or maxiter are workgroups that exit on their first load
             burst = ((burst + kGraphIters - 1) / kGraphIters) * kGraphIters;
             for (int it = 0; it < burst; it += kGraphIters) HIPCHK(c, hipGraphLaunch(gexec, c->stream));
-        } else if (two_parts) {
-            // two-part pipeline: the systems are independent, so the iteration kernels of the first half run on the handle's stream and
-            // those of the second half on stream2.  The two chains drift out of phase, and one half's latency-bound Chebyshev chain and
-            // load phases run under the other half's bandwidth-bound kernels — the overlap that otherwise needs two handles on two host
-            // threads.  Arithmetic per system is untouched (same kernels on a sub-range): results are bit-identical to the one-part form.
-            const int n0 = g.nsys / 2;
+        } else if (nparts > 1) {
+            // multi-part pipeline: the systems are independent, so the iteration kernels of the first part run on the handle's stream and
+            // those of the other parts on the handle's extra streams.  The chains drift out of phase, and one part's latency-bound Chebyshev
+            // chain and load phases run under the other parts' bandwidth-bound kernels — the overlap that otherwise needs several handles on
+            // several host threads.  Arithmetic per system is untouched (same kernels on a sub-range): bit-identical to the one-part form.
             if (launched == 0) {
                 HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));          // the set-up kernels above
-                HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+                for (int q = 1; q < nparts; ++q) HIPCHK(c, hipStreamWaitEvent(c->part_stream[q - 1], c->ev_fork, 0));
             }
-            for (int it = 0; it < burst; ++it) {
-                if (int rc = cg_iteration_fused(c, a, c->stream, 0, n0)) return rc;
-                if (int rc = cg_iteration_fused(c, a, c->stream2, n0, g.nsys - n0)) return rc;
+            for (int it = 0; it < burst; ++it)
+                for (int q = 0; q < nparts; ++q) {
+                    const int s0 = (int)((long)g.nsys * q / nparts), s1 = (int)((long)g.nsys * (q + 1) / nparts);
+                    if (int rc = cg_iteration_fused(c, a, q == 0 ? c->stream : c->part_stream[q - 1], s0, s1 - s0)) return rc;
+                }
+            for (int q = 1; q < nparts; ++q) {
+                HIPCHK(c, hipEventRecord(c->ev_part[q - 1], c->part_stream[q - 1]));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_part[q - 1], 0));  // the poll below (and everything after the solve) sees every part
             }
-            HIPCHK(c, hipEventRecord(c->ev_part, c->stream2));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_part, 0));       // the poll below (and everything after the solve) sees both halves
         } else {
             for (int it = 0; it < burst; ++it)
                 if (int rc = cg_iteration(c, a, any_pre)) return rc;
