@@ -188,7 +188,8 @@ int smoqy_cg_solve(smoqy_ctx *ctx, void *x, const void *b, int x_is_b, int sys0,
 int smoqy_cg_gate(int max_concurrent);
 /* two-part pipeline inside one handle: the systems of a batch are independent, so the iteration kernels of one half run on the handle's
  * stream and those of the other half on a second stream of the handle; the halves drift out of phase and overlap (what two handles on two
- * host threads do).  parts = 0: automatic (two parts from 8 systems up, the default), 1: off, 2..4: that many parts.  Bit-identical results either way. */
+ * host threads do).  parts = 0: automatic (two parts from 8 systems up, the default), 1: off, 2..4: that many parts.  Results agree to rounding with identical
+ * iteration counts (bit for bit when the parts select the same kernel family as the whole batch). */
 int smoqy_cg_split(smoqy_ctx *ctx, int parts);
 /* host <-> device convergence polling period of the on-device CG loop (iterations per poll) */
 int smoqy_cg_config(smoqy_ctx *ctx, int check_every);

@@ -1685,7 +1685,8 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
             // multi-part pipeline: the systems are independent, so the iteration kernels of the first part run on the handle's stream and
             // those of the other parts on the handle's extra streams.  The chains drift out of phase, and one part's latency-bound Chebyshev
             // chain and load phases run under the other parts' bandwidth-bound kernels — the overlap that otherwise needs several handles on
-            // several host threads.  Arithmetic per system is untouched (same kernels on a sub-range): bit-identical to the one-part form.
+            // several host threads.  Per system the same kernels run on a sub-range (a part of <= 8 systems selects the owner-computes MᵀM
+            // kernel): results agree with the one-part form to rounding, bit for bit when the kernel family is the same.
             if (launched == 0) {
                 HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));          // the set-up kernels above
                 for (int q = 1; q < nparts; ++q) HIPCHK(c, hipStreamWaitEvent(c->part_stream[q - 1], c->ev_fork, 0));
