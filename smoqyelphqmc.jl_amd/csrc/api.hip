@@ -363,6 +363,9 @@ int smoqy_destroy(smoqy_ctx *c)
     return 0;
 }
 
+static int set_part_streams(smoqy_ctx *c, int nparts);
+static int auto_parts(const smoqy_ctx *c);
+
 static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
 {
     const Geometry &g = c->g;
@@ -385,9 +388,7 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    // the part streams of the CG pipeline are created on first use (ensure_part_streams): the runtime deals streams onto its few hardware
-    // queues in creation order, and three idle streams per handle put the main streams of several handles on the SAME hardware queue
-    // (measured: six handles 320 -> 251 sweeps/s)
+    if (int rc = set_part_streams(c, std::min(auto_parts(c), g.nsys))) return rc;  // see set_part_streams for why here and not on first use
     HIPCHK(c, hipEventCreate(&c->ev0));
     HIPCHK(c, hipEventCreate(&c->ev1));
 
@@ -1528,7 +1529,7 @@ int smoqy_cg_split(smoqy_ctx *c, int parts)
     CHECK_CTX(c);
     if (parts < 0 || parts > smoqy_ctx::kMaxParts) FAIL(c, 1, "parts must be 0 (automatic) or 1..%d", smoqy_ctx::kMaxParts);
     c->cg_parts = parts;
-    return 0;
+    return set_part_streams(c, std::min(parts == 0 ? auto_parts(c) : parts, c->g.nsys));
 }
 
 int smoqy_cg_config(smoqy_ctx *c, int check_every)
@@ -1540,15 +1541,30 @@ int smoqy_cg_config(smoqy_ctx *c, int check_every)
 }
 
 // one CG iteration: ConjugateGradient.jl:216-246
-static int ensure_part_streams(smoqy_ctx *c, int nparts)
+// Part streams of the CG pipeline: exactly nparts - 1 of them exist.  They are created where the number of parts is DECIDED (smoqy_create
+// for the automatic choice, smoqy_cg_split for an explicit one), not on first use, and surplus ones are destroyed: the runtime binds a new
+// stream to the least-used of its few hardware queues, so a part stream created right after the handle's own stream lands on a different
+// queue (one handle, eager: 16 walkers 183 sweeps/s; created lazily in mid-run: 167), while idle part streams of handles that do not split
+// push the main streams of several handles onto the same queue (six handles with three idle streams each: 335 -> 251 sweeps/s).
+static int set_part_streams(smoqy_ctx *c, int nparts)
 {
-    for (int q = 0; q + 1 < nparts && q < smoqy_ctx::kMaxParts - 1; ++q) {
-        if (c->part_stream[q]) continue;
-        HIPCHK(c, hipStreamCreateWithFlags(&c->part_stream[q], hipStreamNonBlocking));
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_part[q], hipEventDisableTiming));
+    for (int q = 0; q < smoqy_ctx::kMaxParts - 1; ++q) {
+        const bool want = q + 1 < nparts;
+        if (want && !c->part_stream[q]) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->part_stream[q], hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_part[q], hipEventDisableTiming));
+        } else if (!want && c->part_stream[q]) {
+            HIPCHK(c, hipStreamSynchronize(c->part_stream[q]));
+            (void)hipEventDestroy(c->ev_part[q]);
+            (void)hipStreamDestroy(c->part_stream[q]);
+            c->part_stream[q] = nullptr;
+            c->ev_part[q] = nullptr;
+        }
     }
     return 0;
 }
+
+static int auto_parts(const smoqy_ctx *c) { return c->g.nsys >= 8 ? 2 : 1; }  // measured, DESIGN.md §4.3
 
 // the fused form of one CG iteration for systems [sys0, sys0 + count) on stream st: four launches
 static int cg_iteration_fused(smoqy_ctx *c, const CgArgs &a, hipStream_t st, int sys0, int count)
@@ -1636,10 +1652,11 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
     // smoqy_cg_split: fused path only (rocFFT plans and captured graphs cover the whole batch), and not while the fused-MᵀM launches are
     // being sampled for bench.py's roofline (the samples are of full-batch launches).  Automatic: two parts from 8 systems up (measured,
     // DESIGN.md §4.3).
-    int nparts = c->cg_parts == 0 ? (g.nsys >= 8 ? 2 : 1) : c->cg_parts;
+    int nparts = c->cg_parts == 0 ? auto_parts(c) : c->cg_parts;
     if (nparts > g.nsys) nparts = g.nsys;
     if (!(any_pre && c->tf_ok && c->use_tfft) || c->use_graph || c->mvt.every != 0) nparts = 1;
-    if (nparts > 1) if (int rc = ensure_part_streams(c, nparts)) return rc;
+    for (int q = 1; q < nparts; ++q)
+        if (!c->part_stream[q - 1]) { nparts = q; break; }  // streams exist for the decided number of parts only
     int hint = 0, hslot = -1;
     for (int q = 0; q < 4; ++q)
         if (c->hint_tol[q] > 0 && std::fabs(std::log(c->hint_tol[q] / tol)) < 0.7) { hint = c->hint_iters[q]; hslot = q; }
