@@ -270,10 +270,31 @@ typedef struct {
 static void fft_rec(const orc_fft *p, int n, int stride_in, const cplx *in, cplx *out, int fi, int sign)
 {
     if (n == 1) { out[0] = in[0]; return; }
+    if (n == 2) { /* leaf butterflies written out: the element-by-element recursion below them costs more than the arithmetic */
+        const cplx a = in[0], b = in[stride_in];
+        out[0] = a + b; out[1] = a - b;
+        return;
+    }
+    if (n == 4 && p->fac[fi] == 2) {
+        const cplx a = in[0], b = in[stride_in], c = in[2 * (size_t)stride_in], d = in[3 * (size_t)stride_in];
+        const cplx e0 = a + c, e1 = a - c, o0 = b + d, o1 = (sign > 0 ? I : -I) * (b - d); /* w4 = exp(-/+ i pi/2) */
+        out[0] = e0 + o0; out[1] = e1 + o1; out[2] = e0 - o0; out[3] = e1 - o1;
+        return;
+    }
     int r = p->fac[fi], m = n / r;
     /* r sub-transforms of length m on the decimated inputs */
     for (int q = 0; q < r; ++q) fft_rec(p, m, stride_in * r, in + (size_t)q * stride_in, out + (size_t)q * m, fi + 1, sign);
     int tw = p->n / n; /* twiddle stride in the master table */
+    if (r == 2) { /* the common butterfly without the generic loops: (a, b) -> (a + w b, a - w b), w = exp(-/+ 2 pi i k / n) */
+        for (int k = 0; k < m; ++k) {
+            cplx w = p->w[k * tw];
+            if (sign > 0) w = conj(w);
+            cplx a = out[k], b = out[m + k] * w;
+            out[k] = a + b;
+            out[m + k] = a - b;
+        }
+        return;
+    }
     cplx t[r];
     for (int k = 0; k < m; ++k) {
         for (int q = 0; q < r; ++q) {
