@@ -379,6 +379,7 @@ typedef struct {
     const int64_t *nt;
     double *d, *c, *s; /* means over tau */
     double *si;        /* mean of Im sinhΔτt (all zero for T = Float64) */
+    int has_si;        /* 0 for T = Float64 */
 } orc_bbar;
 
 static void bbar_chk(const orc_bbar *B, cplx *v, int transposed)
@@ -387,9 +388,14 @@ static void bbar_chk(const orc_bbar *B, cplx *v, int transposed)
         int h = transposed ? B->Nh - 1 - k : k;
         int i = (int)B->nt[2 * h] - 1, j = (int)B->nt[2 * h + 1] - 1;
         cplx a = v[i], b = v[j];
-        cplx sij = B->s[h] + I * B->si[h];
-        v[i] = B->c[h] * a + sij * b;
-        v[j] = B->c[h] * b + conj(sij) * a;
+        if (B->has_si) { /* T = ComplexF64 */
+            cplx sij = B->s[h] + I * B->si[h];
+            v[i] = B->c[h] * a + sij * b;
+            v[j] = B->c[h] * b + conj(sij) * a;
+        } else {         /* real hoppings: real-times-complex products, as the reference's Matrix{Float64} fields give */
+            v[i] = B->c[h] * a + B->s[h] * b;
+            v[j] = B->c[h] * b + B->s[h] * a;
+        }
     }
 }
 
@@ -579,6 +585,7 @@ static void kpm_update_expansions(orc_kpm *P)
 static void lanczos(orc_kpm *P, const double *v0, const double *v0i, int use_BtB)
 {
     int N = P->N, n = P->nlanczos;
+    if (N <= 0 || n <= 0) return;
     cplx *vk = (cplx *)calloc((size_t)N, sizeof(cplx)), *vkm = (cplx *)calloc((size_t)N, sizeof(cplx)), *w = (cplx *)calloc((size_t)N, sizeof(cplx));
     double nrm = 0;
     for (int i = 0; i < N; ++i) nrm += v0[i] * v0[i] + (v0i ? v0i[i] * v0i[i] : 0.0);
@@ -615,6 +622,7 @@ void orc_kpm_update_c(orc_kpm *P, const double *expV, const double *ch, const do
         for (int l = 0; l < Lt; ++l) { a += ch[IDX(l, h, Lt)]; b += sh[IDX(l, h, Lt)]; if (shi) bi += shi[IDX(l, h, Lt)]; }
         P->B.c[h] = a / Lt; P->B.s[h] = b / Lt; P->B.si[h] = bi / Lt;
     }
+    P->B.has_si = shi != NULL;
     /* calculate_bounds! :625-658 */
     double emin, emax;
     lanczos(P, randvec, randvec_im, !P->is_sym);
