@@ -71,6 +71,7 @@ class WalkerBatch:
         self.hoppings_move = m0.kind != "holstein"  # Holstein: t is constant, only V follows the phonons
         if check_every:
             self.h.call("smoqy_cg_config", int(check_every))
+        self.cg_split = cg_split
         if cg_split is not None:
             self.h.call("smoqy_cg_split", int(cg_split))  # 0 automatic, 1 off, 2 on: two-part pipeline of the CG loop inside the handle
         if tau_chunk:
@@ -232,6 +233,8 @@ class WalkerBatch:
         Ls = (Lc, Lc) if n_orb * Lc * Lc == self.N else (Lc,)
         if getattr(self, "_ge", None) is None or self._ge[1] != Nrv:
             hg = L.Handle(self.Lt, self.N, self.nt, self.colors, True, self.nw, Nrv, self.h.device)
+            if self.cg_split is not None:
+                hg.call("smoqy_cg_split", int(self.cg_split))  # the measurement handle follows the batch's choice (and frees its part stream when that is 1)
             hg.call("smoqy_ge_config", n_orb, len(Ls), L.ptr(np.asarray(Ls, dtype=np.int64)))
             self._ge = (hg, Nrv, tuple(hg.vec_alloc() for _ in range(3)), hg.pinned_empty((self.Lt, self.N, self.nw * Nrv), dtype=np.complex128, order="F"))
         hg, _, (r, gr, mtr), R = self._ge
