@@ -113,6 +113,7 @@ struct smoqy_ctx {
     double2 *d_tw = nullptr;  // theta_l / sqrt(Lt)  (unitary FourierTransformer)
     double2 *d_th = nullptr;  // theta_l
     double2 *d_wtab = nullptr;  // exp(-2 pi i q / Lt)
+    int *d_tpos = nullptr;      // in-place tau-FFT: LDS row of each spectrum element
     TfftArgs tf{};            // plan of the own tau-FFT
     int tf_ok = 0, use_tfft = 1;
     int pstride = 0;          // per-system stride of the partial-sum arrays
@@ -337,7 +338,7 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->plan_f_oop) rocfft_plan_destroy(c->plan_f_oop);
     if (c->fft_info) rocfft_execution_info_destroy(c->fft_info);
     void *ptrs[] = {c->d_bonds, c->d_col_off, c->d_expV, c->d_ch, c->d_sh, c->d_lam, c->d_stage, c->d_stage_real, c->d_stage_int, c->scr[0], c->scr[1], c->scr[2], c->cg_r, c->cg_p,
-                    c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->fft_work, c->d_tw, c->d_th, c->d_wtab, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
+                    c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->fft_work, c->d_tw, c->d_th, c->d_wtab, c->d_tpos, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
                     c->d_rand, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_big, c->d_shi, c->d_sbari};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -500,6 +501,13 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
         HIPCHK(c, hipMalloc(&c->d_wtab, wt.size() * sizeof(double2)));
         HIPCHK(c, hipMemcpy(c->d_wtab, wt.data(), wt.size() * sizeof(double2), hipMemcpyHostToDevice));
         c->tf.wtab = c->d_wtab;
+        if (c->tf_ok) {
+            std::vector<int> pos((size_t)g.Lt);
+            tfft_positions(c->tf, pos.data());
+            HIPCHK(c, hipMalloc(&c->d_tpos, pos.size() * sizeof(int)));
+            HIPCHK(c, hipMemcpy(c->d_tpos, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice));
+            c->tf.pos = c->d_tpos;
+        }
     }
 
     // KPM preconditioner state

@@ -16,6 +16,8 @@
 //     in memory and only one LDS array (the propagating slices) is needed.
 #include "smoqy_internal.h"
 
+#include <cstdlib>
+
 namespace smoqy {
 
 namespace {
@@ -584,7 +586,8 @@ template <int NCOL>
 void launch_ncol(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff)
 {
     const dim3 grid((unsigned)(a.nchunk * a.sys_count)), block((unsigned)ff.threads);
-    const size_t lds = sizeof(double2) * (size_t)a.N * (size_t)(a.Tc + 1);
+    static size_t pad = [] { const char *e = getenv("SMOQY_FDM_PAD_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();  // occupancy experiment
+    const size_t lds = sizeof(double2) * (size_t)a.N * (size_t)(a.Tc + 1) + pad;
     switch (op) {
         case SMOQY_OP_M: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_M>), grid, block, lds, st, a, ff); break;
         case SMOQY_OP_MT: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MT>), grid, block, lds, st, a, ff); break;

@@ -139,6 +139,74 @@ __device__ __forceinline__ double2 *stockham(double2 *A, double2 *B, const doubl
     return src;
 }
 
+// ---- in-place form: one LDS image.  A butterfly reads and writes the same R rows, so a pass needs no second buffer and no
+// read-all-before-write barrier; the digit-reversed order this leaves behind is absorbed where the tile meets global memory
+// (forward: spectrum element k is read from row pos[k]; inverse: it is staged into row pos[k]).
+// DIF (forward): y_s[j] = w_n^{js} Σ_q x[j + q m] w_R^{qs} stored at row s·m + j; DIT (inverse) undoes exactly that.
+template <int R, bool DIT>
+__device__ __forceinline__ void inplace_pass(double2 *__restrict__ X, const double2 *__restrict__ wt, int Lt, int SB, int ncur, bool inv)
+{
+    const int m = ncur / R, nb = (Lt / R) * SB, tws = Lt / ncur, stride = m * SB;
+    for (int idx = threadIdx.x; idx < nb; idx += blockDim.x) {
+        const int jg = idx / SB, sb = idx - jg * SB;
+        const int blk = jg / m, j = jg - blk * m;
+        double2 *x = X + (size_t)(blk * ncur + j) * SB + sb;
+        double2 v[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = x[q * stride];
+        if (DIT && j > 0) {
+#pragma unroll
+            for (int s = 1; s < R; ++s) {
+                double2 w = wt[j * s * tws];
+                if (inv) w.y = -w.y;
+                v[s] = cm(v[s], w);
+            }
+        }
+        dft<R>(v, wt, Lt, inv);
+        if (!DIT && j > 0) {
+#pragma unroll
+            for (int s = 1; s < R; ++s) {
+                double2 w = wt[j * s * tws];
+                if (inv) w.y = -w.y;
+                v[s] = cm(v[s], w);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) x[q * stride] = v[q];
+    }
+    __syncthreads();
+}
+
+template <bool DIT>
+__device__ __forceinline__ void inplace_one(double2 *X, const double2 *wt, const TfftArgs &a, int R, int ncur, bool inv)
+{
+    switch (R) {
+        case 2: inplace_pass<2, DIT>(X, wt, a.Lt, a.SB, ncur, inv); break;
+        case 3: inplace_pass<3, DIT>(X, wt, a.Lt, a.SB, ncur, inv); break;
+        default: inplace_pass<4, DIT>(X, wt, a.Lt, a.SB, ncur, inv); break;  // radix 5 and 7 butterflies would set the register count: such lengths keep the ping-pong form
+    }
+}
+
+// forward: natural order in, spectrum element k at row pos[k] out
+__device__ __forceinline__ void inplace_forward(double2 *X, const double2 *wt, const TfftArgs &a)
+{
+    int ncur = a.Lt;
+    for (int f = 0; f < a.snfac; ++f) {
+        inplace_one<false>(X, wt, a, a.sfac[f], ncur, false);
+        ncur /= a.sfac[f];
+    }
+}
+
+// inverse: spectrum element k at row pos[k] in, natural order out (unnormalised)
+__device__ __forceinline__ void inplace_inverse(double2 *X, const double2 *wt, const TfftArgs &a)
+{
+    int ncur = 1;
+    for (int f = a.snfac - 1; f >= 0; --f) {
+        ncur *= a.sfac[f];
+        inplace_one<true>(X, wt, a, a.sfac[f], ncur, true);
+    }
+}
+
 __device__ __forceinline__ double wsum_t(double v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -186,13 +254,16 @@ __device__ __forceinline__ double2 cdivt(double2 a, double2 b)
 
 enum { MODE_PLAIN_FWD = 0, MODE_PLAIN_INV = 1, MODE_FWD_CG = 2, MODE_INV_CG = 3 };
 
-template <int MODE>
-__global__ void __launch_bounds__(256) tfft_kernel(TfftArgs a)
+// SLIM: the in-place form (one LDS image, radix <= 7): about half the LDS and two thirds of the registers of the ping-pong form, so
+// more workgroups fit a CU when several CG pipelines share the chip
+template <int MODE, bool SLIM>
+__global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
 {
     extern __shared__ double2 lds[];
     __shared__ double red[18];
     const int Lt = a.Lt, SB = a.SB, N = a.N;
-    double2 *A = lds, *B = A + (size_t)Lt * SB, *WT = B + (size_t)Lt * SB;
+    double2 *A = lds, *B = A + (size_t)Lt * SB, *WT = SLIM ? B : B + (size_t)Lt * SB;
+    int *POS = reinterpret_cast<int *>(WT + Lt);  // SLIM only
     const int tile = blockIdx.x % a.ntile, sys = a.sys_first + blockIdx.x / a.ntile;
     if (MODE == MODE_FWD_CG) {
         // `done` was written by an earlier launch (inverse kernel of the previous iteration or cg_start): safe to gate on.
@@ -207,8 +278,12 @@ __global__ void __launch_bounds__(256) tfft_kernel(TfftArgs a)
     const int i0 = tile * SB, ns = min(SB, N - i0);
     const size_t sstride = (size_t)a.nsys * N;
     const size_t base = (size_t)sys * N + i0;
-    for (int q = threadIdx.x; q < Lt; q += blockDim.x) WT[q] = a.wtab[q];
+    for (int q = threadIdx.x; q < Lt; q += blockDim.x) {
+        WT[q] = a.wtab[q];
+        if (SLIM) POS[q] = a.pos[q];
+    }
     constexpr bool INV = (MODE == MODE_PLAIN_INV || MODE == MODE_INV_CG);
+    if (SLIM && INV) __syncthreads();  // the staging below scatters through POS
 
     // 256 % SB == 0, so a lane keeps one site column sb and walks slices l0, l0 + lstep, ...
     const int sb = threadIdx.x % SB, l0 = threadIdx.x / SB, lstep = blockDim.x / SB;
@@ -232,14 +307,23 @@ __global__ void __launch_bounds__(256) tfft_kernel(TfftArgs a)
                 if (lu < Lt) {
                     double2 x = t[u];
                     if (MODE != MODE_FWD_CG && a.pre_tw && act) x = cm(x, a.pre_tw[lu]);
-                    A[lu * SB + sb] = x;
+                    A[((SLIM && INV) ? POS[lu] : lu) * SB + sb] = x;
                 }
             }
         }
         __syncthreads();
     }
 
-    const double2 *res = stockham(A, B, WT, a, INV);
+    const double2 *res;
+    if (SLIM) {
+        if (INV) inplace_inverse(A, WT, a);
+        else inplace_forward(A, WT, a);
+        res = A;
+    } else {
+        res = stockham(A, B, WT, a, INV);
+    }
+    // LDS row of output element l
+    auto row = [&](int l) { return (SLIM && !INV) ? POS[l] : l; };
 
     if (MODE == MODE_FWD_CG) {
         // ConjugateGradient.jl:219-226 in frequency space: α = (r·z)/(p·Ap), r̂ -= α·FFT(Ap), |r|² = Σ|r̂|²/Lτ
@@ -259,7 +343,7 @@ __global__ void __launch_bounds__(256) tfft_kernel(TfftArgs a)
                 for (int u = 0; u < U; ++u) {
                     const int lu = l + u * lstep;
                     if (lu < Lt) {
-                        const double2 rn = csub(rv[u], cm(alpha, res[lu * SB + sb]));
+                        const double2 rn = csub(rv[u], cm(alpha, res[row(lu) * SB + sb]));
                         a.r[(size_t)lu * sstride + base + sb] = rn;
                         acc += rn.x * rn.x + rn.y * rn.y;
                     }
@@ -320,7 +404,7 @@ __global__ void __launch_bounds__(256) tfft_kernel(TfftArgs a)
         for (int idx = threadIdx.x; idx < Lt * SB; idx += blockDim.x) {
             const int l = idx / SB, sb = idx - l * SB;
             if (sb < ns) {
-                double2 x = res[idx];
+                double2 x = res[row(l) * SB + sb];
                 if (a.post_tw) { const double2 w = a.post_tw[l]; x = cm(x, make_double2(w.x, -w.y)); }
                 a.dst[(size_t)l * sstride + base + sb] = x;
             }
@@ -428,38 +512,78 @@ bool tfft_plan(int Lt, int N, TfftArgs &a)
     // fewer, larger passes: a trailing (8, 2) pair reads better as (4, 4)
     for (int f = 0; f + 1 < a.nfac; ++f)
         if (a.fac[f] == 8 && a.fac[f + 1] == 2) { a.fac[f] = 4; a.fac[f + 1] = 4; }
+    // in-place plan: radix 4, 2, 3 only
+    a.snfac = 0;
+    m = Lt;
+    const int spref[] = {4, 2, 3};
+    for (int R : spref)
+        while (m % R == 0 && a.snfac < 16) { a.sfac[a.snfac++] = R; m /= R; }
+    static const int slim_env = [] { const char *e = getenv("SMOQY_TFFT_SLIM"); return e ? atoi(e) : 0; }();
+    a.slim = (slim_env && m == 1) ? 1 : 0;  // lengths 2^a 3^b only
     a.SB = 16;
     size_t lds_cap = 64 * 1024;  // two or more workgroups per CU
     if (const char *e = getenv("SMOQY_TFFT_SB")) {  // tuning knob: sites per tile (4, 8 or 16), also lifts the LDS cap
         const int v = atoi(e);
         if (v == 4 || v == 8 || v == 16) { a.SB = v; lds_cap = 150 * 1024; }
     }
+    // the tile width follows the ping-pong footprint in both forms (the EFA kernel always runs the ping-pong passes)
     while (a.SB > 4 && (2 * (size_t)Lt * a.SB + Lt) * sizeof(double2) > lds_cap) a.SB /= 2;
     if ((2 * (size_t)Lt * a.SB + Lt) * sizeof(double2) > 150 * 1024) return false;
     a.ntile = (N + a.SB - 1) / a.SB;
     return true;
 }
 
+// row of spectrum element k after the decimation-in-frequency passes sfac[0], sfac[1], ...: the pass of radix R on a block of n rows
+// sends the elements k ≡ s (mod R) to sub-block s (rows s·n/R ...), where the rest of the passes sort k div R
+void tfft_positions(const TfftArgs &a, int *pos)
+{
+    for (int k = 0; k < a.Lt; ++k) {
+        int n = a.Lt, kk = k, p = 0;
+        for (int f = 0; f < a.snfac; ++f) {
+            const int R = a.sfac[f];
+            n /= R;
+            p += (kk % R) * n;
+            kk /= R;
+        }
+        pos[k] = p;
+    }
+}
+
 hipError_t configure_tfft_kernels(const char **what)
 {
     hipError_t first = hipSuccess;
-    SMOQY_SET_LDS(tfft_kernel<0>, 160 * 1024 - 512);
-    SMOQY_SET_LDS(tfft_kernel<1>, 160 * 1024 - 512);
-    SMOQY_SET_LDS(tfft_kernel<2>, 160 * 1024 - 512);
-    SMOQY_SET_LDS(tfft_kernel<3>, 160 * 1024 - 512);
+    SMOQY_SET_LDS((tfft_kernel<0, false>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((tfft_kernel<1, false>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((tfft_kernel<2, false>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((tfft_kernel<3, false>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((tfft_kernel<0, true>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((tfft_kernel<1, true>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((tfft_kernel<2, true>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((tfft_kernel<3, true>), 160 * 1024 - 512);
     SMOQY_SET_LDS(efa_kernel, 160 * 1024 - 512);
     return first;
 }
 
 void launch_tfft(hipStream_t st, int mode, const TfftArgs &a)
 {
-    const size_t lds = (2 * (size_t)a.Lt * a.SB + a.Lt) * sizeof(double2);
+    static size_t pad = [] { const char *e = getenv("SMOQY_TFFT_PAD_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();  // occupancy experiment
     const dim3 grid((unsigned)(a.ntile * (a.sys_count > 0 ? a.sys_count : a.nsys))), block(256);
+    if (a.slim && a.pos) {
+        const size_t lds = ((size_t)a.Lt * a.SB + a.Lt) * sizeof(double2) + (size_t)a.Lt * sizeof(int) + pad;
+        switch (mode) {
+            case 0: hipLaunchKernelGGL((tfft_kernel<0, true>), grid, block, lds, st, a); break;
+            case 1: hipLaunchKernelGGL((tfft_kernel<1, true>), grid, block, lds, st, a); break;
+            case 2: hipLaunchKernelGGL((tfft_kernel<2, true>), grid, block, lds, st, a); break;
+            default: hipLaunchKernelGGL((tfft_kernel<3, true>), grid, block, lds, st, a); break;
+        }
+        return;
+    }
+    const size_t lds = (2 * (size_t)a.Lt * a.SB + a.Lt) * sizeof(double2) + pad;
     switch (mode) {
-        case 0: hipLaunchKernelGGL((tfft_kernel<0>), grid, block, lds, st, a); break;
-        case 1: hipLaunchKernelGGL((tfft_kernel<1>), grid, block, lds, st, a); break;
-        case 2: hipLaunchKernelGGL((tfft_kernel<2>), grid, block, lds, st, a); break;
-        default: hipLaunchKernelGGL((tfft_kernel<3>), grid, block, lds, st, a); break;
+        case 0: hipLaunchKernelGGL((tfft_kernel<0, false>), grid, block, lds, st, a); break;
+        case 1: hipLaunchKernelGGL((tfft_kernel<1, false>), grid, block, lds, st, a); break;
+        case 2: hipLaunchKernelGGL((tfft_kernel<2, false>), grid, block, lds, st, a); break;
+        default: hipLaunchKernelGGL((tfft_kernel<3, false>), grid, block, lds, st, a); break;
     }
 }
 

@@ -255,6 +255,11 @@ struct TfftArgs {
     int Lt, N, nsys, SB, ntile, nfac;
     int sys_first, sys_count;             // systems [sys_first, sys_first + sys_count) are processed; sys_count = 0 means all
     int fac[16];
+    // in-place form (one LDS image): radix <= 7 factors `sfac` applied as decimation-in-frequency passes (forward) or, in reverse
+    // order, decimation-in-time passes (inverse); element k of the spectrum sits at LDS row pos[k]
+    int slim, snfac;
+    int sfac[16];
+    const int *pos;                       // [Lt]
     const double2 *wtab;                  // [Lt] exp(-2 pi i q / Lt)
     // plain modes (0 forward, 1 inverse): dst = FFT(pre_tw * src) * conj(post_tw)
     const double2 *src;
@@ -269,6 +274,7 @@ struct TfftArgs {
     CgState *st;
 };
 bool tfft_plan(int Lt, int N, TfftArgs &a);
+void tfft_positions(const TfftArgs &a, int *pos);  // host: fills pos[0..Lt) for the in-place form
 
 // Exact-Fourier-acceleration leapfrog on the phonon fields (call sites src/EFAPFFHMCUpdater.jl:142, 150, 202,
 // 244 — SmoQyDQMC's ExactFourierAccelerator itself is not under /root/reference: parity unpinned).  x and p live as
