@@ -129,6 +129,7 @@ struct smoqy_ctx {
     FdmFast ff{};
     double2 *d_csf = nullptr;
     int *d_cs_varies = nullptr;
+    std::vector<char> cs_const;  // [nw] 1 once the HOST has shown a walker's hoppings to be τ-independent (selects the one-pair-per-colour MᵀM kernel); 0 = unknown
     int2 *d_pbonds = nullptr, *d_psites = nullptr;
     int *d_pos = nullptr;
     int *d_poff = nullptr, *d_psrc = nullptr, *d_own = nullptr, *d_own_f = nullptr;
@@ -216,6 +217,16 @@ static void drop_graphs(smoqy_ctx *c)
     for (auto &gph : c->graphs) {
         if (gph.exec) { (void)hipGraphExecDestroy(gph.exec); gph.exec = nullptr; }
         if (gph.graph) { (void)hipGraphDestroy(gph.graph); gph.graph = nullptr; }
+    }
+}
+
+// host-side proof that walker w's hoppings do (not) depend on τ; a change drops the captured CG graphs, which hold the kernel variant
+static void set_cs_const(smoqy_ctx *c, int w, bool v)
+{
+    if (c->cs_const.empty()) return;
+    if ((c->cs_const[(size_t)w] != 0) != v) {
+        c->cs_const[(size_t)w] = v ? 1 : 0;
+        drop_graphs(c);
     }
 }
 
@@ -616,6 +627,7 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
         HIPCHK(c, hipMalloc(&c->d_cs_varies, (size_t)g.nw * sizeof(int)));
         HIPCHK(c, hipMemset(c->d_cs_varies, 0, (size_t)g.nw * sizeof(int)));
         c->ff.cs_varies = c->d_cs_varies;
+        c->cs_const.assign((size_t)g.nw, 0);
         c->ff.psites = c->d_psites; c->ff.pos = c->d_pos;
         c->ff.pbonds = c->d_pbonds; c->ff.poff = c->d_poff; c->ff.csf = c->d_csf; c->ff.ptotal = c->kg.ptotal; c->ff.threads = c->kg.threads;
         c->ff.enabled = (!g.is_cplx && g.ncol >= 1 && g.ncol <= kFdmColours && maxp <= 1024) ? 1 : 0;  // Sym: fdm_fast/own kernels; Asym: fdm_fast_asym_kernel
@@ -770,6 +782,12 @@ int smoqy_update_fields(smoqy_ctx *c, int w, const double *expV, const double *c
     }
     if (int rc = upload_real_field(c, ch, c->d_ch + (size_t)w * g.Lt * g.Nh, g.Nh)) return rc;
     if (int rc = upload_real_field(c, sh, c->d_sh + (size_t)w * g.Lt * g.Nh, g.Nh)) return rc;
+    if (!c->cs_const.empty()) {  // Lτ×Nh column-major: τ-independent when every column is constant
+        bool same = true;
+        for (int h = 0; h < g.Nh && same; ++h)
+            for (int l = 1; l < g.Lt && same; ++l) same = ch[(size_t)h * g.Lt + l] == ch[(size_t)h * g.Lt] && sh[(size_t)h * g.Lt + l] == sh[(size_t)h * g.Lt];
+        set_cs_const(c, w, same);
+    }
     launch_pack_csf(c->stream, c->d_ch + (size_t)w * g.Lt * g.Nh, c->d_sh + (size_t)w * g.Lt * g.Nh, c->d_psrc, c->d_csf + (size_t)w * g.Lt * c->kg.ptotal, c->d_cs_varies + w, g.Lt, g.Lt, g.Nh, c->kg.ptotal);
     return check_launch(c, "update_fields");
 }
@@ -805,7 +823,16 @@ static int update_pi_range(smoqy_ctx *c, int w0, int nw, const double *V, const 
     }
     launch_fields_from_path_integral(c->stream, V ? dV : nullptr, do_t ? dT : nullptr, c->d_stage_int, c->d_expV + (size_t)w0 * nV, c->d_ch + (size_t)w0 * nT, c->d_sh + (size_t)w0 * nT, nw * g.Lt, g.N, g.Nh,
                                      dtau, g.is_sym ? dtau / 2 : dtau);  // FermionDetMatrix.jl:220
-    if (do_t) launch_pack_csf(c->stream, c->d_ch + (size_t)w0 * nT, c->d_sh + (size_t)w0 * nT, c->d_psrc, c->d_csf + (size_t)w0 * g.Lt * c->kg.ptotal, c->d_cs_varies + w0, nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal);
+    if (do_t) {
+        launch_pack_csf(c->stream, c->d_ch + (size_t)w0 * nT, c->d_sh + (size_t)w0 * nT, c->d_psrc, c->d_csf + (size_t)w0 * g.Lt * c->kg.ptotal, c->d_cs_varies + w0, nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal);
+        for (int w = 0; w < nw && !c->cs_const.empty(); ++w) {  // t is Nh×Lτ column-major per walker: equal hoppings on every slice give equal cosh / sinh
+            const double *tw_ = t + (size_t)w * nT;
+            bool same = true;
+            for (int l = 1; l < g.Lt && same; ++l)
+                for (int h = 0; h < g.Nh && same; ++h) same = tw_[(size_t)l * g.Nh + h] == tw_[h];
+            set_cs_const(c, w0 + w, same);
+        }
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_launch(c, "update_from_path_integral");
 }
@@ -958,7 +985,11 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
         if (T.d_stamp && T.used < T.stamp_cap && a.nchunk * a.sys_count <= T.stamp_wgs) a.stamp = T.d_stamp + 2 * (size_t)T.stamp_wgs * T.used;  // register-resident kernels only
     }
     if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_own(st, op, a, c->ff);
-    else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_fast(st, op, a, c->ff, c->g.is_sym != 0);
+    else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) {
+        bool cs_const = c->g.is_sym != 0 && !c->cs_const.empty();
+        for (int w = sys0 / c->g.nrhs; cs_const && w <= (sys0 + count - 1) / c->g.nrhs; ++w) cs_const = c->cs_const[(size_t)w] != 0;
+        launch_fdm_fast(st, op, a, c->ff, c->g.is_sym != 0, cs_const);
+    }
     else launch_fdm(st, op, c->g.is_sym != 0, a, c->d_big ? 0 : fdm_lds_bytes(op, c->g.N, c->Tc));
     if (sample) HIPCHK(c, hipEventRecord(T.ev[T.used++].second, c->stream));
     return check_launch(c, "matvec");
@@ -2044,7 +2075,10 @@ int smoqy_update_from_phonons_all(smoqy_ctx *c, const double *x_all)
     ForceArgs a = force_args(c, 0.0, nullptr, nullptr);
     const bool do_t = g.Nh > 0 && (F.Nssh > 0 || !F.t_done);  // hoppings that no phonon couples to are refreshed once
     launch_phonon_fields(c->stream, a, F.d_bare, F.d_bare + g.N, c->d_expV, c->d_ch, c->d_sh, c->d_lam, g.is_sym ? F.dtau / 2 : F.dtau, do_t);
-    if (do_t) launch_pack_csf(c->stream, c->d_ch, c->d_sh, c->d_psrc, c->d_csf, c->d_cs_varies, g.nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal);
+    if (do_t) {
+        launch_pack_csf(c->stream, c->d_ch, c->d_sh, c->d_psrc, c->d_csf, c->d_cs_varies, g.nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal);
+        for (int w = 0; w < g.nw; ++w) set_cs_const(c, w, F.Nssh == 0);  // no SSH coupling: t is the bare per-bond hopping on every slice
+    }
     F.t_done = true;
     HIPCHK(c, hipStreamSynchronize(c->stream));  // x_all is the caller's again
     return check_launch(c, "update_from_phonons");
@@ -2218,7 +2252,10 @@ static int refresh_from_device_x(smoqy_ctx *c)
     ForceArgs a = force_args(c, 0.0, nullptr, nullptr);
     const bool do_t = g.Nh > 0 && (F.Nssh > 0 || !F.t_done);
     launch_phonon_fields(c->stream, a, F.d_bare, F.d_bare + g.N, c->d_expV, c->d_ch, c->d_sh, c->d_lam, g.is_sym ? F.dtau / 2 : F.dtau, do_t);
-    if (do_t) launch_pack_csf(c->stream, c->d_ch, c->d_sh, c->d_psrc, c->d_csf, c->d_cs_varies, g.nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal);
+    if (do_t) {
+        launch_pack_csf(c->stream, c->d_ch, c->d_sh, c->d_psrc, c->d_csf, c->d_cs_varies, g.nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal);
+        for (int w = 0; w < g.nw; ++w) set_cs_const(c, w, F.Nssh == 0);  // no SSH coupling: t is the bare per-bond hopping on every slice
+    }
     F.t_done = true;
     return check_launch(c, "refresh_from_device_x");
 }
@@ -2323,6 +2360,7 @@ int smoqy_copy_fields(smoqy_ctx *dst, int dst_walker, smoqy_ctx *src, int src_wa
     }
     if (nP) HIPCHK(dst, hipMemcpyAsync(dst->d_csf + dst_walker * nP, src->d_csf + src_walker * nP, nP * sizeof(double2), hipMemcpyDeviceToDevice, dst->stream));
     HIPCHK(dst, hipMemcpyAsync(dst->d_cs_varies + dst_walker, src->d_cs_varies + src_walker, sizeof(int), hipMemcpyDeviceToDevice, dst->stream));
+    set_cs_const(dst, dst_walker, !src->cs_const.empty() && src->cs_const[(size_t)src_walker] != 0);
     HIPCHK(dst, hipStreamSynchronize(dst->stream));
     return 0;
 }

@@ -37,16 +37,21 @@ __device__ __forceinline__ double2 hopcomb(double2 v, double2 u, bool wrap, bool
     return make_double2(v.x - (pr * u.x - pi * u.y), v.y - (pr * u.y + pi * u.x));
 }
 
-struct Lane {
+// CSV = false: the host has shown the hoppings to be τ-independent (FdmFast::cs_const), one (cosh, sinh) pair per colour is kept
+// instead of one per slice — 12 fewer registers per colour and no copies
+template <bool CSV = true>
+struct LaneT {
     int2 b[kFdmColours];
     bool on[kFdmColours];
-    double2 cs[kFdmColours][KMAX];  // (cosh, sinh) of the lane's bond in colour c on slice k
-    double di[KMAX], dj[KMAX];      // exp(-ΔτV) at the two sites of the lane's first-colour bond
+    double2 cs[kFdmColours][CSV ? KMAX : 1];  // (cosh, sinh) of the lane's bond in colour c on slice k
+    double di[KMAX], dj[KMAX];                // exp(-ΔτV) at the two sites of the lane's first-colour bond
+    __device__ __forceinline__ double2 csk(int c, int k) const { return cs[c][CSV ? k : 0]; }
 };
+using Lane = LaneT<true>;
 
 // one plain colour stage on nk LDS-resident slices; SH selects the slice->register offset
-template <int C, int SH>
-__device__ __forceinline__ void stage(double2 *U, int N, int nk, const Lane &ln)
+template <int C, int SH, class LN>
+__device__ __forceinline__ void stage(double2 *U, int N, int nk, const LN &ln)
 {
     if (ln.on[C]) {
 #pragma unroll
@@ -54,7 +59,8 @@ __device__ __forceinline__ void stage(double2 *U, int N, int nk, const Lane &ln)
             if (k < nk) {
                 double2 *row = U + (size_t)k * N;
                 const double2 a = row[ln.b[C].x], d = row[ln.b[C].y];
-                const double c = ln.cs[C][k + SH].x, s = ln.cs[C][k + SH].y;
+                const double2 cs_ = ln.csk(C, k + SH);
+                const double c = cs_.x, s = cs_.y;
                 row[ln.b[C].x] = lin(c, a, s, d);
                 row[ln.b[C].y] = lin(c, d, s, a);
             }
@@ -64,8 +70,8 @@ __device__ __forceinline__ void stage(double2 *U, int N, int nk, const Lane &ln)
 }
 
 // first colour with the diagonal folded in: C₁ D C₁.  LAST: keep the result in registers.
-template <int SH, bool LAST>
-__device__ __forceinline__ void middle(double2 *U, int N, int nk, const Lane &ln, double2 (&ri)[KMAX], double2 (&rj)[KMAX])
+template <int SH, bool LAST, class LN>
+__device__ __forceinline__ void middle(double2 *U, int N, int nk, const LN &ln, double2 (&ri)[KMAX], double2 (&rj)[KMAX])
 {
     if (ln.on[0]) {
 #pragma unroll
@@ -73,7 +79,8 @@ __device__ __forceinline__ void middle(double2 *U, int N, int nk, const Lane &ln
             if (k < nk) {
                 double2 *row = U + (size_t)k * N;
                 const double2 a = row[ln.b[0].x], d = row[ln.b[0].y];
-                const double c = ln.cs[0][k + SH].x, s = ln.cs[0][k + SH].y;
+                const double2 cs_ = ln.csk(0, k + SH);
+                const double c = cs_.x, s = cs_.y;
                 const double2 x = scl(ln.di[k + SH], lin(c, a, s, d)), y = scl(ln.dj[k + SH], lin(c, d, s, a));
                 if (LAST) {
                     ri[k] = lin(c, x, s, y);
@@ -89,8 +96,8 @@ __device__ __forceinline__ void middle(double2 *U, int N, int nk, const Lane &ln
 }
 
 // last colour: results stay in registers (no LDS write, no barrier)
-template <int C, int SH>
-__device__ __forceinline__ void last_stage(const double2 *U, int N, int nk, const Lane &ln, double2 (&ri)[KMAX], double2 (&rj)[KMAX])
+template <int C, int SH, class LN>
+__device__ __forceinline__ void last_stage(const double2 *U, int N, int nk, const LN &ln, double2 (&ri)[KMAX], double2 (&rj)[KMAX])
 {
     if (ln.on[C]) {
 #pragma unroll
@@ -98,7 +105,8 @@ __device__ __forceinline__ void last_stage(const double2 *U, int N, int nk, cons
             if (k < nk) {
                 const double2 *row = U + (size_t)k * N;
                 const double2 a = row[ln.b[C].x], d = row[ln.b[C].y];
-                const double c = ln.cs[C][k + SH].x, s = ln.cs[C][k + SH].y;
+                const double2 cs_ = ln.csk(C, k + SH);
+                const double c = cs_.x, s = cs_.y;
                 ri[k] = lin(c, a, s, d);
                 rj[k] = lin(c, d, s, a);
             }
@@ -108,8 +116,8 @@ __device__ __forceinline__ void last_stage(const double2 *U, int N, int nk, cons
 
 // U[k] <- B_l U[k] for the Hermitian Sym propagator B = C_L…C_2 (C_1 D C_1) C_2…C_L; the final
 // colour's output is returned in (ri, rj) at the sites of the lane's bond in that colour.
-template <int NCOL, int SH>
-__device__ __forceinline__ void propagate_sym(double2 *U, int N, int nk, const Lane &ln, double2 (&ri)[KMAX], double2 (&rj)[KMAX])
+template <int NCOL, int SH, class LN>
+__device__ __forceinline__ void propagate_sym(double2 *U, int N, int nk, const LN &ln, double2 (&ri)[KMAX], double2 (&rj)[KMAX])
 {
     if (NCOL == 1) {
         middle<SH, true>(U, N, nk, ln, ri, rj);
@@ -124,7 +132,7 @@ __device__ __forceinline__ void propagate_sym(double2 *U, int N, int nk, const L
     last_stage<NCOL - 1, SH>(U, N, nk, ln, ri, rj);
 }
 
-template <int NCOL, int OP>
+template <int NCOL, int OP, bool CSV>
 __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
 {
     extern __shared__ double2 U[];
@@ -152,10 +160,10 @@ __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
     const int ubase = (OP == SMOQY_OP_M || OP == SMOQY_OP_MTM) ? l0 - 1 : (OP == SMOQY_OP_MT ? l0 + 1 : l0);  // source slice of U[0]
 
     // ---- everything this workgroup needs from memory is requested here, up front ----
-    Lane ln;
+    LaneT<CSV> ln;
     // hoppings that do not depend on τ (e.g. Holstein: t constant) are detected when the fields are
     // packed; the lane then fetches its (cosh, sinh) pair once instead of once per slice
-    const bool cs_varies = ff.cs_varies[w] != 0;
+    const bool cs_varies = CSV && ff.cs_varies[w] != 0;
 #pragma unroll
     for (int c = 0; c < kFdmColours; ++c) {
         ln.on[c] = false;
@@ -166,11 +174,11 @@ __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
                 ln.on[c] = true;
                 ln.b[c] = ff.pbonds[idx];
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k)
-                    if (k < K1 && (k == 0 || cs_varies)) ln.cs[c][k] = csf[(size_t)wrapl(fbase + k, Lt) * ff.ptotal + idx];
-                if (!cs_varies) {
+                for (int k = 0; k < (CSV ? KMAX : 1); ++k)
+                    if (k < K1 && (k == 0 || cs_varies)) ln.cs[c][k] = csf[(cs_varies ? (size_t)wrapl(fbase + k, Lt) : (size_t)0) * ff.ptotal + idx];  // τ-independent hoppings: every workgroup reads slice 0 (12 KB per walker, cache-resident) instead of its own copy
+                if (CSV && !cs_varies) {
 #pragma unroll
-                    for (int k = 1; k < KMAX; ++k) ln.cs[c][k] = ln.cs[c][0];
+                    for (int k = 1; k < (CSV ? KMAX : 1); ++k) ln.cs[c][k] = ln.cs[c][0];
                 }
             }
         }
@@ -361,7 +369,7 @@ __global__ void __launch_bounds__(1024) fdm_fast_asym_kernel(FdmArgs a, FdmFast 
                 ln.b[c] = ff.pbonds[idx];
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k)
-                    if (k < K1 && (k == 0 || cs_varies)) ln.cs[c][k] = csf[(size_t)wrapl(fbase + k, Lt) * ff.ptotal + idx];
+                    if (k < K1 && (k == 0 || cs_varies)) ln.cs[c][k] = csf[(cs_varies ? (size_t)wrapl(fbase + k, Lt) : (size_t)0) * ff.ptotal + idx];  // τ-independent hoppings: every workgroup reads slice 0 (12 KB per walker, cache-resident) instead of its own copy
                 if (!cs_varies) {
 #pragma unroll
                     for (int k = 1; k < KMAX; ++k) ln.cs[c][k] = ln.cs[c][0];
@@ -582,17 +590,17 @@ void launch_ncol_asym(hipStream_t st, int op, const FdmArgs &a, const FdmFast &f
     }
 }
 
-template <int NCOL>
+template <int NCOL, bool CSV>
 void launch_ncol(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff)
 {
     const dim3 grid((unsigned)(a.nchunk * a.sys_count)), block((unsigned)ff.threads);
     static size_t pad = [] { const char *e = getenv("SMOQY_FDM_PAD_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();  // occupancy experiment
     const size_t lds = sizeof(double2) * (size_t)a.N * (size_t)(a.Tc + 1) + pad;
     switch (op) {
-        case SMOQY_OP_M: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_M>), grid, block, lds, st, a, ff); break;
-        case SMOQY_OP_MT: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MT>), grid, block, lds, st, a, ff); break;
-        case SMOQY_OP_MTM: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MTM>), grid, block, lds, st, a, ff); break;
-        default: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MMT>), grid, block, lds, st, a, ff); break;
+        case SMOQY_OP_M: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_M, CSV>), grid, block, lds, st, a, ff); break;
+        case SMOQY_OP_MT: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MT, CSV>), grid, block, lds, st, a, ff); break;
+        case SMOQY_OP_MTM: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MTM, CSV>), grid, block, lds, st, a, ff); break;
+        default: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MMT, CSV>), grid, block, lds, st, a, ff); break;
     }
 }
 
@@ -604,7 +612,7 @@ bool fdm_fast_supported(const FdmArgs &a, const FdmFast &ff, bool sym)
     return ff.enabled && a.ncol >= 1 && a.ncol <= kFdmColours && a.Tc + 1 <= KMAX && sizeof(double2) * (size_t)a.N * (size_t)(a.Tc + 1) * (sym ? 1 : 2) <= 60 * 1024;
 }
 
-void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff, bool sym)
+void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff, bool sym, bool cs_const)
 {
     if (!sym) {
         switch (a.ncol) {
@@ -615,11 +623,20 @@ void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff
         }
         return;
     }
+    if (cs_const) {
+        switch (a.ncol) {
+            case 1: launch_ncol<1, false>(st, op, a, ff); break;
+            case 2: launch_ncol<2, false>(st, op, a, ff); break;
+            case 3: launch_ncol<3, false>(st, op, a, ff); break;
+            default: launch_ncol<4, false>(st, op, a, ff); break;
+        }
+        return;
+    }
     switch (a.ncol) {
-        case 1: launch_ncol<1>(st, op, a, ff); break;
-        case 2: launch_ncol<2>(st, op, a, ff); break;
-        case 3: launch_ncol<3>(st, op, a, ff); break;
-        default: launch_ncol<4>(st, op, a, ff); break;
+        case 1: launch_ncol<1, true>(st, op, a, ff); break;
+        case 2: launch_ncol<2, true>(st, op, a, ff); break;
+        case 3: launch_ncol<3, true>(st, op, a, ff); break;
+        default: launch_ncol<4, true>(st, op, a, ff); break;
     }
 }
 

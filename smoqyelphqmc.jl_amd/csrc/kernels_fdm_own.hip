@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(TMAX) fdm_own_kernel(FdmArgs a, FdmFast ff)
         for (int k = 0; k < KM; ++k) {
             ln.csx[c][k] = ln.csy[c][k] = make_double2(1.0, 0.0);
             if (ln.on && k < K1 && (k == 0 || cs_varies)) {
-                const double2 *row = csf + (size_t)wrapo(fbase + k, Lt) * ff.ptotal;
+                const double2 *row = csf + (cs_varies ? (size_t)wrapo(fbase + k, Lt) : (size_t)0) * ff.ptotal;  // τ-independent hoppings: slice 0 for everyone (cache-resident)
                 ln.csx[c][k] = row[bix[c]];
                 ln.csy[c][k] = row[biy[c]];
             }

@@ -157,7 +157,8 @@ hipError_t configure_kpm_kernels(const char **what);
         if (_e != hipSuccess && first == hipSuccess) { first = _e; *what = #fn; }                                                       \
     } while (0)
 bool fdm_fast_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
-void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff, bool sym = true);
+// cs_const: the caller has shown, on the host, that the hoppings of every walker of this launch do not depend on τ (Sym form only)
+void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff, bool sym = true, bool cs_const = false);
 bool fdm_own_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
 void launch_fdm_own(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff);
 void launch_pack_csf(hipStream_t st, const double *ch, const double *sh, const int *psrc, double2 *csf, int *cs_varies, int Lt, int Lt1, int Nh, int ptotal);

@@ -375,3 +375,59 @@ def test_cg_pipeline_parts_agree(nw, bitwise):
                 assert np.array_equal(x, y)
             else:
                 np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-11 * np.abs(x).max())
+
+
+@pytest.mark.parametrize("entry", ["path_integral", "fields"])
+def test_tau_independent_hoppings_select_and_leave_the_one_pair_kernel(entry):
+    """The Sym LDS-resident MᵀM kernel keeps one (cosh, sinh) pair per colour once the HOST has seen that no walker of the launch has
+    τ-dependent hoppings (FermionDetMatrix.jl:224-231 computes them per slice; api.hip set_cs_const).  The choice must follow the
+    fields: constant -> one walker made τ-dependent -> constant again, through both upload entry points, 12 systems per launch (the
+    LDS-resident kernel) and with a graph-captured solve in between (a captured graph holds the kernel variant)."""
+    Lt, Lc = 10, 3
+    m = lat.holstein_honeycomb(Lc, Lt)
+    nt, perm, colors = lat.checkerboard_decomposition(m.fpi.neighbor_table)
+    N, Nh, nw = m.fpi.N, nt.shape[1], 12
+    h = L.Handle(Lt, N, nt, colors, True, nw, 1)
+    g = np.random.default_rng(5)
+    tb = 1.0 + 0.2 * g.standard_normal(Nh)  # per-bond hopping, the same on every slice
+
+    def put(w, varying):
+        V = np.asfortranarray(0.7 * g.standard_normal((N, Lt)))
+        t = np.asfortranarray(np.repeat(tb[:, None], Lt, axis=1))
+        if varying:
+            t[3, Lt - 1] += 0.25  # one bond on one slice
+        expV, ch, sh = orc.update_fields(V, t, perm, 0.05, True)
+        if entry == "path_integral":
+            h.call("smoqy_update_from_path_integral", w, L.ptr(V), L.ptr(t), L.ptr(perm), C.c_double(0.05))
+        else:
+            h.call("smoqy_update_fields", w, L.ptr(expV), L.ptr(ch), L.ptr(sh))
+        return orc.OracleFDM(nt, expV, ch, sh, True)
+
+    oracles = [put(w, False) for w in range(nw)]
+    v = rand(Lt, N, nw, 3)
+    a, b = h.vec_alloc(), h.vec_alloc()
+    h.vec_upload(a, v)
+
+    def check(tag):
+        for op, name in ((L.OP_M, "mul_M"), (L.OP_MT, "mul_Mt"), (L.OP_MTM, "mul_MtM"), (L.OP_MMT, "mul_MMt")):
+            h.call("smoqy_matvec_v", op, b, a)
+            got = h.vec_download(b)
+            for s in (0, 7, 11):
+                assert relerr(got[:, :, s], getattr(oracles[s], name)(v[:, :, s])) < 1e-13, (tag, name, s)
+
+    def solve_graph(tag):
+        h.call("smoqy_cg_use_graph", 1)
+        x, it, eps = solve(h, v, 1e-10, 2000, 0)
+        h.call("smoqy_cg_use_graph", 0)
+        for s in (0, 7, 11):
+            r = v[:, :, s] - oracles[s].mul_MtM(x[:, :, s])
+            assert np.linalg.norm(r) / np.linalg.norm(v[:, :, s]) < 5e-10, (tag, s)
+
+    check("constant")
+    solve_graph("constant")
+    oracles[7] = put(7, True)
+    check("walker 7 tau-dependent")
+    solve_graph("walker 7 tau-dependent")
+    oracles[7] = put(7, False)
+    check("constant again")
+    solve_graph("constant again")
