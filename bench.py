@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--cg-split", type=int, default=1, choices=[0, 1, 2, 3, 4],
                     help="two-part CG pipeline inside each handle of the TIMED batches (smoqy_cg_split): 1 = off (default here: six streams already overlap, and the roofline samples "
                          "full-batch MtM launches), 0 = the library's automatic choice, 2 = on.  The one-stream legs always use the library default (automatic).")
+    ap.add_argument("--tfft-form", choices=["auto", "two-image", "in-place"], default="auto",
+                    help="τ-FFT of the timed batches (smoqy_tfft_form): in-place has more workgroups per CU (+2.7 %% sweeps/s with six streams), two-image is faster alone; "
+                         "auto = in-place when more than one stream shares the GPU.  The one-stream legs keep the library default (two-image).")
     ap.add_argument("--no-mtm-sampling", action="store_true", help="do not sample MtM launches inside the timed region (roofline falls back to the isolated leg)")
     ap.add_argument("--measure-nrv", type=int, default=0, help="add update_greens_estimator! + measure_GΔ0! with this many random vectors to every sweep (27 + Nrv solves)")
     ap.add_argument("--hmc", choices=["device", "host"], default="device",
@@ -369,7 +372,8 @@ def main():
     mine = walker_range(rank, world, wpg)  # walkers [rank*wpg, (rank+1)*wpg): no overlap between ranks, no exchange
     per = wpg // S
     batches = [WalkerBatch(args.workload, nwalkers=per, walker0=mine.start + s * per, device=dev, check_every=args.check_every or None, tau_chunk=args.tau_chunk or None,
-                           host_threads=max(2, 16 // S), measure_nrv=args.measure_nrv, device_efa=args.hmc == "device", cg_split=args.cg_split) for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
+                           host_threads=max(2, 16 // S), measure_nrv=args.measure_nrv, device_efa=args.hmc == "device", cg_split=args.cg_split,
+                           tfft_in_place=(S > 1) if args.tfft_form == "auto" else args.tfft_form == "in-place") for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
     batch = batches[0]
     if args.solve_concurrency > 0:
         if args.gate == "library":
@@ -478,6 +482,7 @@ def main():
                 "cg_tol": batch.tol,
                 "avg_cg_iters": sum(b.stats.iters_sum for b in batches) / max(sum(b.stats.solves for b in batches), 1),
                 "preconditioner": "KPM (Sym)",
+                "tfft_form": "in-place" if batch.tfft_in_place else "two-image",
                 "hmc": ("EFA leapfrog on the device, Nt = %d steps of dt = pi/(2 Nt), trajectory always rejected (x restored) so the field distribution stays the one SURVEY.md 8(d) defines" % batch.Nt)
                 if args.hmc == "device" else "synthetic host-side drift (round-1 form)",
                 "parallelism": f"walker-parallel, {world} rank(s) x {wpg} walkers ({S} lock-step batches of {per}), no collective",

@@ -94,6 +94,7 @@ SIGNATURES = {
     "smoqy_cg_solve": [_p, _p, _p, _i, _i, _i, _d, _i, _i, _p, _p],
     "smoqy_cg_config": [_p, _i],
     "smoqy_cg_split": [_p, _i],
+    "smoqy_tfft_form": [_p, _i],
     "smoqy_cg_gate": [_i],  # process-wide, no handle
     "smoqy_cg_use_graph": [_p, _i],
     "smoqy_cg_graph_status": [_p, _pi, _pi],

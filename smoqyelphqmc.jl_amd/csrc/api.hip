@@ -1571,6 +1571,21 @@ int smoqy_cg_split(smoqy_ctx *c, int parts)
     return set_part_streams(c, std::min(parts == 0 ? auto_parts(c) : parts, c->g.nsys));
 }
 
+// form of the handle's own τ-FFT: 0 = two LDS images (fewer passes: fastest alone), 1 = in place (fewer registers and half the LDS: more
+// workgroups per CU, better when several handles share the GPU)
+int smoqy_tfft_form(smoqy_ctx *c, int in_place)
+{
+    CHECK_CTX(c);
+    if (in_place != 0 && in_place != 1) FAIL(c, 1, "in_place must be 0 or 1");
+    const int want = (in_place && c->tf_ok && c->tf.slim_ok && c->tf.pos) ? 1 : 0;  // lengths with factors 5 or 7 keep the two-image form
+    if (want != c->tf.slim) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->tf.slim = want;
+        drop_graphs(c);
+    }
+    return 0;
+}
+
 int smoqy_cg_config(smoqy_ctx *c, int check_every)
 {
     CHECK_CTX(c);

@@ -519,7 +519,8 @@ bool tfft_plan(int Lt, int N, TfftArgs &a)
     for (int R : spref)
         while (m % R == 0 && a.snfac < 16) { a.sfac[a.snfac++] = R; m /= R; }
     static const int slim_env = [] { const char *e = getenv("SMOQY_TFFT_SLIM"); return e ? atoi(e) : 0; }();
-    a.slim = (slim_env && m == 1) ? 1 : 0;  // lengths 2^a 3^b only
+    a.slim_ok = (m == 1) ? 1 : 0;           // lengths 2^a 3^b only
+    a.slim = (slim_env && a.slim_ok) ? 1 : 0;  // default form: SMOQY_TFFT_SLIM, else smoqy_tfft_form
     a.SB = 16;
     size_t lds_cap = 64 * 1024;  // two or more workgroups per CU
     if (const char *e = getenv("SMOQY_TFFT_SB")) {  // tuning knob: sites per tile (4, 8 or 16), also lifts the LDS cap

@@ -258,7 +258,7 @@ struct TfftArgs {
     int fac[16];
     // in-place form (one LDS image): radix <= 7 factors `sfac` applied as decimation-in-frequency passes (forward) or, in reverse
     // order, decimation-in-time passes (inverse); element k of the spectrum sits at LDS row pos[k]
-    int slim, snfac;
+    int slim, slim_ok, snfac;             // slim: in-place form selected; slim_ok: Lt = 2^a 3^b, the in-place form exists
     int sfac[16];
     const int *pos;                       // [Lt]
     const double2 *wtab;                  // [Lt] exp(-2 pi i q / Lt)

@@ -48,7 +48,7 @@ class WalkerBatch:
 
     def __init__(self, workload: str, nwalkers: int = 1, walker0: int = 0, is_sym: bool = True, device: int = -1, tol: float = 1e-10, maxiter: int = 10_000, Nt: int = 24,
                  drift: float = 0.02, check_every: int | None = None, tau_chunk: int | None = None, smooth: bool = False, host_threads: int = 8, device_update: bool = True, measure_nrv: int = 0,
-                 device_efa: bool = False, omega: float = 1.0, mass: float = 1.0, cg_split: int | None = None):
+                 device_efa: bool = False, omega: float = 1.0, mass: float = 1.0, cg_split: int | None = None, tfft_in_place: bool | None = None):
         self.models = [lat.CONFIGS[workload](walker=walker0 + w, smooth=smooth) for w in range(nwalkers)]
         m0 = self.models[0]
         self.workload = workload
@@ -74,6 +74,9 @@ class WalkerBatch:
         self.cg_split = cg_split
         if cg_split is not None:
             self.h.call("smoqy_cg_split", int(cg_split))  # 0 automatic, 1 off, 2 on: two-part pipeline of the CG loop inside the handle
+        self.tfft_in_place = tfft_in_place
+        if tfft_in_place is not None:
+            self.h.call("smoqy_tfft_form", int(bool(tfft_in_place)))  # in-place τ-FFT: slower alone, faster when several batches share the GPU
         if tau_chunk:
             self.h.call("smoqy_set_tau_chunk", int(tau_chunk))
         self.rng = [np.random.Generator(np.random.PCG64(lat.SEED0 + 7919 * (walker0 + w) + 1)) for w in range(nwalkers)]
@@ -235,6 +238,8 @@ class WalkerBatch:
             hg = L.Handle(self.Lt, self.N, self.nt, self.colors, True, self.nw, Nrv, self.h.device)
             if self.cg_split is not None:
                 hg.call("smoqy_cg_split", int(self.cg_split))  # the measurement handle follows the batch's choice (and frees its part stream when that is 1)
+            if self.tfft_in_place is not None:
+                hg.call("smoqy_tfft_form", int(bool(self.tfft_in_place)))
             hg.call("smoqy_ge_config", n_orb, len(Ls), L.ptr(np.asarray(Ls, dtype=np.int64)))
             self._ge = (hg, Nrv, tuple(hg.vec_alloc() for _ in range(3)), hg.pinned_empty((self.Lt, self.N, self.nw * Nrv), dtype=np.complex128, order="F"))
         hg, _, (r, gr, mtr), R = self._ge
