@@ -232,6 +232,26 @@ __device__ __forceinline__ double2 bsum(double2 v, double *red)
     return make_double2(red[16], red[17]);
 }
 
+// two pairs at once (same shuffle tree and wave order per value as bsum: bit-identical sums); red >= 36 doubles
+__device__ __forceinline__ void bsum4(double2 &u, double2 &v, double *red)
+{
+    u.x = wsum_t(u.x); u.y = wsum_t(u.y);
+    v.x = wsum_t(v.x); v.y = wsum_t(v.y);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) { red[4 * wave] = u.x; red[4 * wave + 1] = u.y; red[4 * wave + 2] = v.x; red[4 * wave + 3] = v.y; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int w = 0; w < nwave; ++w)
+            for (int q = 0; q < 4; ++q) t[q] += red[4 * w + q];
+        for (int q = 0; q < 4; ++q) red[32 + q] = t[q];
+    }
+    __syncthreads();
+    u = make_double2(red[32], red[33]);
+    v = make_double2(red[34], red[35]);
+}
+
 __device__ __forceinline__ double2 reduce_c(const double2 *part, int n, double *red)
 {
     double2 t = make_double2(0.0, 0.0);
@@ -260,7 +280,7 @@ template <int MODE, bool SLIM>
 __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
 {
     extern __shared__ double2 lds[];
-    __shared__ double red[18];
+    __shared__ double red[36];
     const int Lt = a.Lt, SB = a.SB, N = a.N;
     double2 *A = lds, *B = A + (size_t)Lt * SB, *WT = SLIM ? B : B + (size_t)Lt * SB;
     int *POS = reinterpret_cast<int *>(WT + Lt);  // SLIM only
@@ -274,7 +294,17 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
             return;
         }
     }
-    if (MODE == MODE_INV_CG && a.st[sys].stop) return;
+    // the recurrence scalars of this system, read with the stop flag (same cache line) instead of after the transform
+    double st_normb2 = 1.0, st_tol = 0.0;
+    double2 st_alpha = make_double2(0.0, 0.0), st_rho = make_double2(1.0, 0.0);
+    if (MODE == MODE_INV_CG) {
+        const CgState &s0 = a.st[sys];
+        const int stop = s0.stop;
+        st_normb2 = s0.normb2; st_tol = s0.tol;
+        st_alpha = make_double2(s0.alpha_re, s0.alpha_im);
+        st_rho = make_double2(s0.rho_re, s0.rho_im);
+        if (stop) return;
+    }
     const int i0 = tile * SB, ns = min(SB, N - i0);
     const size_t sstride = (size_t)a.nsys * N;
     const size_t base = (size_t)sys * N + i0;
@@ -284,6 +314,21 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
     }
     constexpr bool INV = (MODE == MODE_PLAIN_INV || MODE == MODE_INV_CG);
     if (SLIM && INV) __syncthreads();  // the staging below scatters through POS
+
+    // The scalars of the CG recurrence (α; the stop test and β) depend on the partial sums the previous kernels left, not on this
+    // kernel's transform: their loads are issued here, in front of the staging loads, and reduced before the passes, so that their memory
+    // latency and barriers are not a serial step between the transform and the epilogue.
+    double2 q1 = make_double2(0.0, 0.0), q2 = make_double2(0.0, 0.0);
+    if (MODE == MODE_FWD_CG) {
+        const double2 *prz = a.part_rz + (size_t)sys * a.rz_stride, *ppz = a.part_pz + (size_t)sys * a.pz_stride;
+        if ((int)threadIdx.x < a.nrz) q1 = prz[threadIdx.x];
+        if ((int)threadIdx.x < a.npz) q2 = ppz[threadIdx.x];
+    } else if (MODE == MODE_INV_CG) {
+        const double *prr = a.part_rr + (size_t)sys * a.rr_stride;
+        const double2 *prz = a.part_rz + (size_t)sys * a.rz_stride;
+        if ((int)threadIdx.x < a.nrr) q1.x = prr[threadIdx.x];
+        if ((int)threadIdx.x < a.nrz) q2 = prz[threadIdx.x];
+    }
 
     // 256 % SB == 0, so a lane keeps one site column sb and walks slices l0, l0 + lstep, ...
     const int sb = threadIdx.x % SB, l0 = threadIdx.x / SB, lstep = blockDim.x / SB;
@@ -314,6 +359,19 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
         __syncthreads();
     }
 
+    if (MODE == MODE_FWD_CG) {
+        const double2 *prz = a.part_rz + (size_t)sys * a.rz_stride, *ppz = a.part_pz + (size_t)sys * a.pz_stride;
+        for (int c = threadIdx.x + blockDim.x; c < a.nrz; c += blockDim.x) { q1.x += prz[c].x; q1.y += prz[c].y; }
+        for (int c = threadIdx.x + blockDim.x; c < a.npz; c += blockDim.x) { q2.x += ppz[c].x; q2.y += ppz[c].y; }
+        bsum4(q1, q2, red);  // q1 = r·z, q2 = p·Ap
+    } else if (MODE == MODE_INV_CG) {
+        const double *prr = a.part_rr + (size_t)sys * a.rr_stride;
+        const double2 *prz = a.part_rz + (size_t)sys * a.rz_stride;
+        for (int c = threadIdx.x + blockDim.x; c < a.nrr; c += blockDim.x) q1.x += prr[c];
+        for (int c = threadIdx.x + blockDim.x; c < a.nrz; c += blockDim.x) { q2.x += prz[c].x; q2.y += prz[c].y; }
+        bsum4(q1, q2, red);  // q1.x = |r|², q2 = r·z
+    }
+
     const double2 *res;
     if (SLIM) {
         if (INV) inplace_inverse(A, WT, a);
@@ -327,8 +385,7 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
 
     if (MODE == MODE_FWD_CG) {
         // ConjugateGradient.jl:219-226 in frequency space: α = (r·z)/(p·Ap), r̂ -= α·FFT(Ap), |r|² = Σ|r̂|²/Lτ
-        const double2 rz = reduce_c(a.part_rz + (size_t)sys * a.rz_stride, a.nrz, red);
-        const double2 pz = reduce_c(a.part_pz + (size_t)sys * a.pz_stride, a.npz, red);
+        const double2 rz = q1, pz = q2;
         const double2 alpha = cdivt(rz, pz);
         double acc = 0.0;
         if (act) {
@@ -361,15 +418,12 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
         }
     } else if (MODE == MODE_INV_CG) {
         // ConjugateGradient.jl:220 (x += α p, deferred to here), :229-245: stop test on the unpreconditioned residual, p = z + β p
-        const double rr = reduce_r(a.part_rr + (size_t)sys * a.rr_stride, a.nrr, red);
-        const double eps = sqrt(rr) / sqrt(a.st[sys].normb2);
-        const bool conv = eps < a.st[sys].tol;
-        const double2 alpha = make_double2(a.st[sys].alpha_re, a.st[sys].alpha_im);
+        const double rr = q1.x;
+        const double eps = sqrt(rr) / sqrt(st_normb2);
+        const bool conv = eps < st_tol;
+        const double2 alpha = st_alpha;
         double2 beta = make_double2(0.0, 0.0);
-        if (!conv) {
-            const double2 rz = reduce_c(a.part_rz + (size_t)sys * a.rz_stride, a.nrz, red);
-            beta = cdivt(rz, make_double2(a.st[sys].rho_re, a.st[sys].rho_im));
-        }
+        if (!conv) beta = cdivt(q2, st_rho);
         if (act) {
             for (int l = l0; l < Lt; l += U * lstep) {
                 double2 pv[U], xv[U];
