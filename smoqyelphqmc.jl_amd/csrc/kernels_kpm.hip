@@ -464,15 +464,35 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
     const int comp = SPLIT ? (slotid & 1) : 0, rank = SPLIT ? (slotid >> 1) : slotid;
     const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);
     const int w = sys / k.nrhs;
-    if (k.cg && k.cg[sys].done) return;
     const int Lo2 = (Lt + 1) / 2;
     if (k.half && om >= Lo2) return;
+    const int slot = om >= Lo2 ? Lt - om - 1 : om;  // :387
+    // Round 1 of loads — everything addressed by the block and thread index alone, issued before any of it is looked at: the stop flag,
+    // the expansion order, the spectral bounds and the lane program (own sites, their mates' LDS slots, table indices).  The workgroup
+    // with the longest chain sets the duration of the launch and every serial round trip in front of the chain adds to it; as written
+    // naively (flag, return; active, order, return; bounds; table; gathers) that was five.
+    const bool sys_done = (k.cg ? k.cg[sys].done : 0) != 0;
+    const bool act = k.active[w] != 0;
+    const int n_raw = k.order[(size_t)w * k.nslot + slot];
+    const double emin = k.bounds[2 * w], emax = k.bounds[2 * w + 1];
+    const bool on = j < kg.own_n;
+    const int *own = kg.own;
+    const int jq = on ? j : 0;  // lanes past the list load entry 0 and ignore it
+    const int sxq = own[jq], syq = own[Tn + jq], m2q = own[2 * Tn + jq], m3q = own[3 * Tn + jq];
+    int pxq[NCOL], pyq[NCOL], cxi[NCOL], cyi[NCOL];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+        pxq[c] = own[(4 + 4 * c + 0) * Tn + jq];
+        pyq[c] = own[(4 + 4 * c + 1) * Tn + jq];
+        cxi[c] = own[(4 + 4 * c + 2) * Tn + jq];
+        cyi[c] = own[(4 + 4 * c + 3) * Tn + jq];
+    }
+    asm volatile("" ::: "memory");  // compiler fence: keeps the loads above on this side of the early returns (no instruction, no wait)
+    if (sys_done) return;
     const double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
     double2 *vo = (k.vout ? k.vout : k.v) + ((size_t)om * k.nsys + sys) * N;
     double2 *prz = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride + (SPLIT ? 2 * om + comp : om) : nullptr;
-    const int slot = om >= Lo2 ? Lt - om - 1 : om;  // :387
-    const bool act = k.active[w] != 0;
-    const int n = act ? k.order[(size_t)w * k.nslot + slot] : 1;
+    const int n = act ? n_raw : 1;
     const double2 *coefs = k.coefs + ((size_t)w * k.nslot + slot) * k.maxorder;
     if (n <= 1) {  // single-term expansion: scalar multiply (:398)
         const double f = k.scale * (act ? coefs[0].x : 1.0);
@@ -489,11 +509,8 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
         }
         return;
     }
-    const double emin = k.bounds[2 * w], emax = k.bounds[2 * w + 1];
     const double avg = 0.5 * (emax + emin), imag_ = 1.0 / (0.5 * (emax - emin));
-    const bool on = j < kg.own_n;
-    const int *own = kg.own;
-    // lane program: own sites, their LDS slots, and per colour the mates' slots and the two bonds' (c̄, s̄)
+    // Round 2: the gathers addressed through round 1 (τ-means at the own sites and their mates, the bonds' (c̄, s̄), the input vector)
     int sx = 0, sy = 0, ox = j, oy = j;
     int px[NCOL], py[NCOL];
     double2 cx[NCOL], cy[NCOL];
@@ -504,16 +521,16 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
     for (int c = 0; c < NCOL; ++c) { px[c] = py[c] = j; cx[c] = cy[c] = make_double2(1.0, 0.0); }
     T ax = zero(T{}), ay = zero(T{});
     if (on) {
-        sx = own[j]; sy = own[Tn + j];
+        sx = sxq; sy = syq;
         oy = (sy != sx) ? Tn + j : j;
         dx = dbar[sx]; dy = dbar[sy];
-        dmx = dbar[own[2 * Tn + j]]; dmy = dbar[own[3 * Tn + j]];
+        dmx = dbar[m2q]; dmy = dbar[m3q];
 #pragma unroll
         for (int c = 0; c < NCOL; ++c) {
-            px[c] = own[(4 + 4 * c + 0) * Tn + j];
-            py[c] = own[(4 + 4 * c + 1) * Tn + j];
-            cx[c] = pcs[own[(4 + 4 * c + 2) * Tn + j]];
-            cy[c] = pcs[own[(4 + 4 * c + 3) * Tn + j]];
+            px[c] = pxq[c];
+            py[c] = pyq[c];
+            cx[c] = pcs[cxi[c]];
+            cy[c] = pcs[cyi[c]];
         }
         ax = ld(v, sx, comp, T{}); ay = ld(v, sy, comp, T{});
     }
