@@ -44,8 +44,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="holstein_honeycomb_L16_Ltau128")
-    ap.add_argument("--walkers-per-gpu", type=int, default=96)
-    ap.add_argument("--streams", type=int, default=6, help="concurrent lock-step batches per GPU (one HIP stream + host thread each)")
+    ap.add_argument("--walkers-per-gpu", type=int, default=128)
+    ap.add_argument("--streams", type=int, default=8, help="concurrent lock-step batches per GPU (one HIP stream + host thread each)")
     ap.add_argument("--solve-concurrency", type=int, default=3, help="at most this many batches inside the CG at once (0 = no limit)")
     ap.add_argument("--gate", choices=["library", "python"], default="library", help="where --solve-concurrency is enforced: inside the library around each CG loop, or in Python around whole calls")
     ap.add_argument("--cg-split", type=int, default=1, choices=[0, 1, 2, 3, 4],

@@ -1,5 +1,5 @@
 #!/bin/bash
-# default bench on the other BASELINE.json lattices (device EFA trajectory, 96 walkers on 6 streams) -> gpurun_out/r02_bench_<workload>.json
+# default bench on the other BASELINE.json lattices (device EFA trajectory, 128 walkers on 8 streams) -> gpurun_out/r02_bench_<workload>.json
 cd $GRAFT_REPO_ROOT
 for wl in holstein_honeycomb_L4_Ltau40 holstein_honeycomb_L8_Ltau80 ossh_square_L12_Ltau100 bssh_chain_L256_Ltau200; do
   timeout -k 10 300 python bench.py --no-cpu-baseline --workload $wl --steps 6 > gpurun_out/r02_bench_$wl.json 2> gpurun_out/r02_bench_$wl.err; echo $wl rc=$?
