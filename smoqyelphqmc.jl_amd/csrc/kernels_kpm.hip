@@ -658,6 +658,171 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// owner-computes Chebyshev kernel, Asym form (KPMPreconditioner.jl:514-536): per frequency two polynomials in B̄ = D̄ C_{L-1} … C_0, first with
+// the coefficients of the mirrored frequency Lτ−1−ω, then with its own (M̃⁻¹ M̃⁻ᵀ).  Every colour occurs once per B̄ apply, so the owned colour
+// (the same tables as the Sym kernel: colour 1 for L >= 3, colour 0 for L = 2) is register arithmetic and each of the other L−1 colours is
+// one exchange — two per step on the honeycomb lattice where cheb_fast_kernel<Asym> pays three LDS read-modify-write stages with a
+// barrier each.  The coefficients are complex, so the two components of a vector do not separate (no SPLIT form); arithmetic per site is
+// that of kpm_poly_regs<false>.
+// ---------------------------------------------------------------------------------------------
+template <int NCOL>
+__global__ void __launch_bounds__(1024) cheb_own_asym_kernel(KpmArgs k, KpmGeom kg)
+{
+    static_assert(NCOL >= 2, "single-colour decompositions use cheb_fast_kernel");
+    using namespace ownk;
+    using T = double2;
+    constexpr int Q = NCOL >= 3 ? 1 : 0;
+    extern __shared__ double2 lds[];
+    __shared__ double red[17];
+    const int N = k.N, Lt = k.Lt, Tn = blockDim.x, j = threadIdx.x;
+    T *Wb[2] = {lds, lds + 2 * Tn};
+    double2 *CF = lds + 4 * Tn, *CF2 = CF + k.maxorder;
+    const int ncnt_ = k.sys_count > 0 ? k.sys_count : k.nsys;
+    const int sys = k.sys_first + blockIdx.x % ncnt_, rank = blockIdx.x / ncnt_;
+    const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);  // heaviest orders first
+    const int omc = Lt - om - 1;                                       // :523-530
+    const int w = sys / k.nrhs;
+    const int Lo2 = (Lt + 1) / 2;
+    if (k.half && om >= Lo2) return;
+    // round 1 of loads (see cheb_own_kernel)
+    const bool sys_done = (k.cg ? k.cg[sys].done : 0) != 0;
+    const bool act = k.active[w] != 0;
+    const int n_raw = k.order[(size_t)w * k.nslot + om], n2_raw = k.order[(size_t)w * k.nslot + omc];
+    const double emin = k.bounds[2 * w], emax = k.bounds[2 * w + 1];
+    const bool on = j < kg.own_n;
+    const int *own = kg.own;
+    const int jq = on ? j : 0;
+    const int sxq = own[jq], syq = own[Tn + jq];
+    int pxq[NCOL], pyq[NCOL], cxi[NCOL], cyi[NCOL];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+        pxq[c] = own[(4 + 4 * c + 0) * Tn + jq];
+        pyq[c] = own[(4 + 4 * c + 1) * Tn + jq];
+        cxi[c] = own[(4 + 4 * c + 2) * Tn + jq];
+        cyi[c] = own[(4 + 4 * c + 3) * Tn + jq];
+    }
+    asm volatile("" ::: "memory");  // compiler fence: keeps the loads above on this side of the early returns
+    if (sys_done) return;
+    const double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
+    double2 *vo = (k.vout ? k.vout : k.v) + ((size_t)om * k.nsys + sys) * N;
+    double2 *prz = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride + om : nullptr;
+    const int n = act ? n_raw : 1, n2 = act ? n2_raw : 1;
+    const double2 *coefs = k.coefs + ((size_t)w * k.nslot + om) * k.maxorder;
+    const double2 *coefs_c = k.coefs + ((size_t)w * k.nslot + omc) * k.maxorder;
+    if (n <= 1) {  // single-term expansion: |c₀|² (:534)
+        double f = k.scale;
+        if (act) { const double2 c0 = coefs[0]; f *= c0.x * c0.x + c0.y * c0.y; }
+        double acc = 0.0;
+        for (int i = j; i < N; i += Tn) {
+            const double2 x = v[i];
+            vo[i] = make_double2(f * x.x, f * x.y);
+            acc += f * (x.x * x.x + x.y * x.y);
+        }
+        if (prz) {
+            const double t = block_sum_real(acc, red);
+            if (j == 0) *prz = make_double2(t, 0.0);
+        }
+        return;
+    }
+    const double avg = 0.5 * (emax + emin), imag_ = 1.0 / (0.5 * (emax - emin));
+    // round 2: gathers through the lane program
+    int sx = 0, sy = 0, ox = j, oy = j;
+    int px[NCOL], py[NCOL];
+    double2 cx[NCOL], cy[NCOL];
+    double dx = 1.0, dy = 1.0;
+    const double *dbar = k.dbar + (size_t)w * N;
+    const double2 *pcs = kg.pcs + (size_t)w * kg.ptotal;
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) { px[c] = py[c] = j; cx[c] = cy[c] = make_double2(1.0, 0.0); }
+    T ax = zero(T{}), ay = zero(T{});
+    if (on) {
+        sx = sxq; sy = syq;
+        oy = (sy != sx) ? Tn + j : j;
+        dx = dbar[sx]; dy = dbar[sy];
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            px[c] = pxq[c];
+            py[c] = pyq[c];
+            cx[c] = pcs[cxi[c]];
+            cy[c] = pcs[cyi[c]];
+        }
+        ax = v[sx]; ay = v[sy];
+    }
+    const T v0x = ax, v0y = ay;
+    for (int i = j; i < n; i += Tn) CF[i] = coefs[i];      // coefficients in LDS: no global load inside the chains
+    for (int i = j; i < n2; i += Tn) CF2[i] = coefs_c[i];
+    __syncthreads();
+    int buf = 0;
+    // Σ_k cf[k] T_k(B') applied to (ax, ay), result back in (ax, ay)
+    auto poly = [&](const double2 *cf, int nn) {
+        if (nn <= 1) {  // not reached for mirrored frequencies of equal order; kept exact all the same
+            const double2 c0 = cf[0];
+            ax = cmulk(c0, ax); ay = cmulk(c0, ay);
+            return;
+        }
+        T a1x = ax, a1y = ay, a2x = zero(T{}), a2y = zero(T{}), accx = zero(T{}), accy = zero(T{});
+        for (int kk = 1; kk < nn; ++kk) {
+            const double2 ck = cf[kk];
+            // B̄ a = D̄ C_{L-1} … C_0 a on the lane's own two sites
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) {
+                if (c == Q) {
+                    const T t_ = lin(cx[Q].x, ax, cx[Q].y, ay);
+                    ay = lin(cx[Q].x, ay, cx[Q].y, ax);
+                    ax = t_;
+                } else {
+                    T *Wc = Wb[buf];
+                    buf ^= 1;
+                    if (on) { Wc[ox] = ax; Wc[oy] = ay; }
+                    __syncthreads();
+                    const T mx = Wc[px[c]], my = Wc[py[c]];
+                    ax = lin(cx[c].x, ax, cx[c].y, mx);
+                    ay = lin(cy[c].x, ay, cy[c].y, my);
+                }
+            }
+            const T xi = scl(dx, ax), xj = scl(dy, ay);
+            // three-term recurrence on the lane's own sites (kpm_lmul!)
+            T a3x, a3y;
+            if (kk == 1) {
+                a3x = scl(imag_, sub(xi, scl(avg, a1x)));
+                a3y = scl(imag_, sub(xj, scl(avg, a1y)));
+                const double2 c0 = cf[0];
+                accx = add(cmulk(c0, a1x), cmulk(ck, a3x));
+                accy = add(cmulk(c0, a1y), cmulk(ck, a3y));
+            } else {
+                a3x = sub(scl(imag_, scl(2.0, sub(xi, scl(avg, a2x)))), a1x);
+                a3y = sub(scl(imag_, scl(2.0, sub(xj, scl(avg, a2y)))), a1y);
+                accx = add(accx, cmulk(ck, a3x));
+                accy = add(accy, cmulk(ck, a3y));
+                a1x = a2x; a1y = a2y;
+            }
+            a2x = a3x; a2y = a3y;
+            ax = a3x; ay = a3y;
+        }
+        ax = accx; ay = accy;
+    };
+    poly(CF2, n2);  // M̃⁻ᵀ (:526)
+    poly(CF, n);    // M̃⁻¹ (:529)
+    double2 acc = make_double2(0.0, 0.0);
+    if (on) {
+        ax = scl(k.scale, ax);
+        ay = scl(k.scale, ay);
+        vo[sx] = ax;
+        acc.x += v0x.x * ax.x + v0x.y * ax.y;
+        acc.y += v0x.x * ax.y - v0x.y * ax.x;
+        if (sy != sx) {
+            vo[sy] = ay;
+            acc.x += v0y.x * ay.x + v0y.y * ay.y;
+            acc.y += v0y.x * ay.y - v0y.y * ay.x;
+        }
+    }
+    if (prz) {
+        const double2 t = block_sum_cplx(acc, red);
+        if (j == 0) *prz = t;
+    }
+}
+
 // A/B switch for measurements (default on)
 static int cheb_split_enabled()
 {
@@ -848,6 +1013,15 @@ void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
                 case 4: CHEB_LAUNCH(true, 4); break;
                 default: CHEB_LAUNCH(true, 0); break;
             }
+        } else if (k.ncol >= 2 && k.ncol <= 6 && kg.own && cheb_own_enabled() && k.sbari == nullptr) {
+            const size_t olds = sizeof(double2) * (4 * (size_t)kg.threads + 2 * (size_t)k.maxorder);
+            switch (k.ncol) {
+                case 2: hipLaunchKernelGGL((cheb_own_asym_kernel<2>), grid, block, olds, st, k, kg); break;
+                case 3: hipLaunchKernelGGL((cheb_own_asym_kernel<3>), grid, block, olds, st, k, kg); break;
+                case 4: hipLaunchKernelGGL((cheb_own_asym_kernel<4>), grid, block, olds, st, k, kg); break;
+                case 5: hipLaunchKernelGGL((cheb_own_asym_kernel<5>), grid, block, olds, st, k, kg); break;
+                default: hipLaunchKernelGGL((cheb_own_asym_kernel<6>), grid, block, olds, st, k, kg); break;
+            }
         } else {
             switch (k.ncol) {
                 case 1: CHEB_LAUNCH(false, 1); break;
@@ -952,6 +1126,13 @@ hipError_t configure_kpm_kernels(const char **what)
     SMOQY_SET_LDS(cheb_generic_kernel, 160 * 1024 - 256);
     SMOQY_SET_LDS((lanczos_kernel<0, false>), 160 * 1024 - 256);
     SMOQY_SET_LDS((lanczos_kernel<2, false>), 160 * 1024 - 256);
+    // owner-computes Chebyshev kernels: four images of `threads` values + the coefficient tables pass 64 KB at 1024 threads (complex values)
+#define SMOQY_OWN_LDS(C_)                                                  \
+    SMOQY_SET_LDS((cheb_own_kernel<C_, false>), 160 * 1024 - 256);         \
+    SMOQY_SET_LDS((cheb_own_kernel<C_, true>), 160 * 1024 - 256);          \
+    SMOQY_SET_LDS((cheb_own_asym_kernel<C_>), 160 * 1024 - 256);
+    SMOQY_OWN_LDS(2) SMOQY_OWN_LDS(3) SMOQY_OWN_LDS(4) SMOQY_OWN_LDS(5) SMOQY_OWN_LDS(6)
+#undef SMOQY_OWN_LDS
     return first;
 }
 
