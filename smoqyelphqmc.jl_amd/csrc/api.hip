@@ -129,6 +129,7 @@ struct smoqy_ctx {
     FdmFast ff{};
     double2 *d_csf = nullptr;
     int *d_cs_varies = nullptr;
+    int cheb_heavy = 0;  // Sym cheb_own_kernel: number of leading frequency ranks with a multi-term expansion on any walker (upload_precond keeps it)
     std::vector<char> cs_const;  // [nw] 1 once the HOST has shown a walker's hoppings to be τ-independent (selects the one-pair-per-colour MᵀM kernel); 0 = unknown
     int2 *d_pbonds = nullptr, *d_psites = nullptr;
     int *d_pos = nullptr;
@@ -293,6 +294,7 @@ static KpmArgs kpm_args(smoqy_ctx *c, double2 *v, const CgState *cg)
     k.v = v; k.cg = cg;
     k.part_rz = nullptr; k.rz_stride = 2 * g.Lt; k.scale = 1.0 / (double)g.Lt;  // two r·z slots per frequency: the component-split Chebyshev kernel fills both
     k.scratch = c->d_big; k.scratch_stride = c->big_stride;
+    k.heavy = c->cheb_heavy; k.group = 8;  // light workgroups of cheb_own_kernel: eight single-term frequencies each
     return k;
 }
 
@@ -1286,6 +1288,15 @@ static int upload_precond(smoqy_ctx *c, int w)
     HIPCHK(c, hipMemcpyAsync(c->d_bounds + 2 * (size_t)w, bnd, sizeof(bnd), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_active + w, &p.active, sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // host buffers above are temporaries
+    {   // how many leading ranks (rank 2s and 2s+1 share slot s, KPMPreconditioner.jl:387) carry a chain on at least one walker: the light
+        // workgroups of cheb_own_kernel take everything behind them.  A captured CG graph holds the old count.
+        int last = -1;
+        for (const WalkerPrecond &q : c->pre)
+            for (int sl = 0; sl < (int)q.order.size(); ++sl)
+                if (q.order[sl] > 1) last = std::max(last, sl);
+        const int heavy = std::min(c->g.Lt, 2 * (last + 1));
+        if (heavy != c->cheb_heavy) { c->cheb_heavy = heavy; drop_graphs(c); }
+    }
     return 0;
 }
 

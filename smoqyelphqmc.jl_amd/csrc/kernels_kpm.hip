@@ -446,152 +446,124 @@ __device__ __forceinline__ void st(double2 *v, int i, int comp, double x) { if (
 __device__ __forceinline__ void st(double2 *v, int i, int, double2 x) { v[i] = x; }
 }  // namespace ownk
 
-template <int NCOL, bool SPLIT>
-__global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
-{
-    static_assert(NCOL >= 2, "single-colour decompositions use cheb_fast_kernel");
-    using namespace ownk;
-    using T = typename Scalar<SPLIT>::type;
-    constexpr int Q = NCOL >= 3 ? 1 : 0, CL = NCOL - 1;
-    extern __shared__ double2 lds[];
-    __shared__ double red[17];
-    const int N = k.N, Lt = k.Lt, Tn = blockDim.x, j = threadIdx.x;
-    T *Wb[2] = {reinterpret_cast<T *>(lds), reinterpret_cast<T *>(lds) + 2 * Tn};
-    double2 *CF = reinterpret_cast<double2 *>(reinterpret_cast<T *>(lds) + 4 * Tn);
-    // heaviest orders first, rank-major; with SPLIT the two components of a frequency are neighbours in the dispatch order
-    const int ncnt_ = k.sys_count > 0 ? k.sys_count : k.nsys;
-    const int sys = k.sys_first + blockIdx.x % ncnt_, slotid = blockIdx.x / ncnt_;
-    const int comp = SPLIT ? (slotid & 1) : 0, rank = SPLIT ? (slotid >> 1) : slotid;
-    const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);
-    const int w = sys / k.nrhs;
-    const int Lo2 = (Lt + 1) / 2;
-    if (k.half && om >= Lo2) return;
-    const int slot = om >= Lo2 ? Lt - om - 1 : om;  // :387
-    // Round 1 of loads — everything addressed by the block and thread index alone, issued before any of it is looked at: the stop flag,
-    // the expansion order, the spectral bounds and the lane program (own sites, their mates' LDS slots, table indices).  The workgroup
-    // with the longest chain sets the duration of the launch and every serial round trip in front of the chain adds to it; as written
-    // naively (flag, return; active, order, return; bounds; table; gathers) that was five.
-    const bool sys_done = (k.cg ? k.cg[sys].done : 0) != 0;
-    const bool act = k.active[w] != 0;
-    const int n_raw = k.order[(size_t)w * k.nslot + slot];
-    const double emin = k.bounds[2 * w], emax = k.bounds[2 * w + 1];
-    const bool on = j < kg.own_n;
-    const int *own = kg.own;
-    const int jq = on ? j : 0;  // lanes past the list load entry 0 and ignore it
-    const int sxq = own[jq], syq = own[Tn + jq], m2q = own[2 * Tn + jq], m3q = own[3 * Tn + jq];
-    int pxq[NCOL], pyq[NCOL], cxi[NCOL], cyi[NCOL];
-#pragma unroll
-    for (int c = 0; c < NCOL; ++c) {
-        pxq[c] = own[(4 + 4 * c + 0) * Tn + jq];
-        pyq[c] = own[(4 + 4 * c + 1) * Tn + jq];
-        cxi[c] = own[(4 + 4 * c + 2) * Tn + jq];
-        cyi[c] = own[(4 + 4 * c + 3) * Tn + jq];
-    }
-    asm volatile("" ::: "memory");  // compiler fence: keeps the loads above on this side of the early returns (no instruction, no wait)
-    if (sys_done) return;
-    const double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
-    double2 *vo = (k.vout ? k.vout : k.v) + ((size_t)om * k.nsys + sys) * N;
-    double2 *prz = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride + (SPLIT ? 2 * om + comp : om) : nullptr;
-    const int n = act ? n_raw : 1;
-    const double2 *coefs = k.coefs + ((size_t)w * k.nslot + slot) * k.maxorder;
-    if (n <= 1) {  // single-term expansion: scalar multiply (:398)
-        const double f = k.scale * (act ? coefs[0].x : 1.0);
-        double acc = 0.0;
-        for (int i = j; i < N; i += Tn) {
-            const T x = ld(v, i, comp, T{});
-            st(vo, i, comp, scl(f, x));
-            if constexpr (SPLIT) acc += f * (x * x);
-            else acc += f * (x.x * x.x + x.y * x.y);
-        }
-        if (prz) {
-            const double t = block_sum_real(acc, red);
-            if (j == 0) *prz = make_double2(t, 0.0);
-        }
-        return;
-    }
-    const double avg = 0.5 * (emax + emin), imag_ = 1.0 / (0.5 * (emax - emin));
-    // Round 2: the gathers addressed through round 1 (τ-means at the own sites and their mates, the bonds' (c̄, s̄), the input vector)
-    int sx = 0, sy = 0, ox = j, oy = j;
+// the lane program of the owner-computes kernels: the lane's two sites, their LDS slots, per colour the mates' slots and the (c̄, s̄) of the two
+// bonds, the τ-means of exp(-ΔτV) at the own sites and at their colour-0 mates.  It depends on the walker only.
+template <int NCOL>
+struct OwnProg {
+    bool on;
+    int sx, sy, ox, oy;
     int px[NCOL], py[NCOL];
     double2 cx[NCOL], cy[NCOL];
-    double dx = 1.0, dy = 1.0, dmx = 1.0, dmy = 1.0;
-    const double *dbar = k.dbar + (size_t)w * N;
-    const double2 *pcs = kg.pcs + (size_t)w * kg.ptotal;
+    double dx, dy, dmx, dmy;
+};
+// table indices of a lane program: the first of its two rounds of loads (addresses known from the thread index alone)
+template <int NCOL>
+struct OwnIdx {
+    bool on;
+    int sx, sy, m2, m3;
+    int px[NCOL], py[NCOL], cxi[NCOL], cyi[NCOL];
+};
+template <int NCOL>
+__device__ __forceinline__ void own_load_idx(OwnIdx<NCOL> &I, const KpmGeom &kg, int Tn, int j)
+{
+    I.on = j < kg.own_n;
+    const int *own = kg.own;
+    const int jq = I.on ? j : 0;  // lanes past the list load entry 0 and ignore it
+    I.sx = own[jq]; I.sy = own[Tn + jq]; I.m2 = own[2 * Tn + jq]; I.m3 = own[3 * Tn + jq];
 #pragma unroll
-    for (int c = 0; c < NCOL; ++c) { px[c] = py[c] = j; cx[c] = cy[c] = make_double2(1.0, 0.0); }
-    T ax = zero(T{}), ay = zero(T{});
-    if (on) {
-        sx = sxq; sy = syq;
-        oy = (sy != sx) ? Tn + j : j;
-        dx = dbar[sx]; dy = dbar[sy];
-        dmx = dbar[m2q]; dmy = dbar[m3q];
+    for (int c = 0; c < NCOL; ++c) {
+        I.px[c] = own[(4 + 4 * c + 0) * Tn + jq];
+        I.py[c] = own[(4 + 4 * c + 1) * Tn + jq];
+        I.cxi[c] = own[(4 + 4 * c + 2) * Tn + jq];
+        I.cyi[c] = own[(4 + 4 * c + 3) * Tn + jq];
+    }
+}
+// second round: the gathers addressed through the first
+template <int NCOL>
+__device__ __forceinline__ void own_load_prog(OwnProg<NCOL> &P, const OwnIdx<NCOL> &I, const double *__restrict__ dbar, const double2 *__restrict__ pcs, int Tn, int j)
+{
+    P.on = I.on;
+    P.sx = P.sy = 0; P.ox = P.oy = j;
+    P.dx = P.dy = P.dmx = P.dmy = 1.0;
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) { P.px[c] = P.py[c] = j; P.cx[c] = P.cy[c] = make_double2(1.0, 0.0); }
+    if (I.on) {
+        P.sx = I.sx; P.sy = I.sy;
+        P.oy = (I.sy != I.sx) ? Tn + j : j;
+        P.dx = dbar[I.sx]; P.dy = dbar[I.sy];
+        P.dmx = dbar[I.m2]; P.dmy = dbar[I.m3];
 #pragma unroll
         for (int c = 0; c < NCOL; ++c) {
-            px[c] = pxq[c];
-            py[c] = pyq[c];
-            cx[c] = pcs[cxi[c]];
-            cy[c] = pcs[cyi[c]];
+            P.px[c] = I.px[c];
+            P.py[c] = I.py[c];
+            P.cx[c] = pcs[I.cxi[c]];
+            P.cy[c] = pcs[I.cyi[c]];
         }
-        ax = ld(v, sx, comp, T{}); ay = ld(v, sy, comp, T{});
     }
-    const T v0x = ax, v0y = ay;
-    for (int i = j; i < n; i += Tn) CF[i] = coefs[i];  // coefficients in LDS: no global load inside the chain
-    int buf = 0;
+}
+
+// Σ_k CF[k] T_k(B̄') applied to the values (ax, ay) of the lane's own sites, n >= 2 terms (kpm_lmul!, Sym B̄ in the basis α̃ = C_L α).
+// T = double: one component of the vector (SPLIT), T = double2: both; Wb are two LDS images of 2·Tn values of T; all lanes of the
+// workgroup call it together (it contains barriers); CF must be visible to all lanes on entry.
+template <int NCOL, class T>
+__device__ __forceinline__ void own_chain(const OwnProg<NCOL> &P, T &ax, T &ay, T *Wb0, T *Wb1, int &buf, const double2 *CF, int n, double avg, double imag_)
+{
+    using namespace ownk;
+    constexpr int Q = NCOL >= 3 ? 1 : 0, CL = NCOL - 1;
     // own values -> LDS image, barrier, the two mates of colour c_ come back in (mx_, my_)
 #define OWN_EXCHANGE(c_, mx_, my_)                       \
     {                                                    \
-        T *Wc = Wb[buf];                                 \
+        T *Wc = buf ? Wb1 : Wb0;                         \
         buf ^= 1;                                        \
-        if (on) { Wc[ox] = ax; Wc[oy] = ay; }            \
+        if (P.on) { Wc[P.ox] = ax; Wc[P.oy] = ay; }      \
         __syncthreads();                                 \
-        mx_ = Wc[px[c_]];                                \
-        my_ = Wc[py[c_]];                                \
+        mx_ = Wc[P.px[c_]];                              \
+        my_ = Wc[P.py[c_]];                              \
     }
 #define OWN_STAGE(c_)                                                        \
     {                                                                        \
         if (c_ == Q) {                                                       \
-            const T t_ = lin(cx[Q].x, ax, cx[Q].y, ay);                      \
-            ay = lin(cx[Q].x, ay, cx[Q].y, ax);                              \
+            const T t_ = lin(P.cx[Q].x, ax, P.cx[Q].y, ay);                  \
+            ay = lin(P.cx[Q].x, ay, P.cx[Q].y, ax);                          \
             ax = t_;                                                         \
         } else {                                                             \
             T mx_, my_;                                                      \
             OWN_EXCHANGE(c_, mx_, my_)                                       \
-            ax = lin(cx[c_].x, ax, cx[c_].y, mx_);                           \
-            ay = lin(cy[c_].x, ay, cy[c_].y, my_);                           \
+            ax = lin(P.cx[c_].x, ax, P.cx[c_].y, mx_);                       \
+            ay = lin(P.cy[c_].x, ay, P.cy[c_].y, my_);                       \
         }                                                                    \
     }
     // into the basis α̃ = C_L α (see cheb_fast_kernel)
     {
         T mx, my;
         OWN_EXCHANGE(CL, mx, my)
-        ax = lin(cx[CL].x, ax, cx[CL].y, mx);
-        ay = lin(cy[CL].x, ay, cy[CL].y, my);
+        ax = lin(P.cx[CL].x, ax, P.cx[CL].y, mx);
+        ay = lin(P.cy[CL].x, ay, P.cy[CL].y, my);
     }
-    const double qcx = cx[CL].x * cx[CL].x + cx[CL].y * cx[CL].y, qsx = 2.0 * cx[CL].x * cx[CL].y;  // C_L²
-    const double qcy = cy[CL].x * cy[CL].x + cy[CL].y * cy[CL].y, qsy = 2.0 * cy[CL].x * cy[CL].y;
+    const double qcx = P.cx[CL].x * P.cx[CL].x + P.cx[CL].y * P.cx[CL].y, qsx = 2.0 * P.cx[CL].x * P.cx[CL].y;  // C_L²
+    const double qcy = P.cy[CL].x * P.cy[CL].x + P.cy[CL].y * P.cy[CL].y, qsy = 2.0 * P.cy[CL].x * P.cy[CL].y;
     T a1x = ax, a1y = ay, a2x = zero(T{}), a2y = zero(T{}), accx = zero(T{}), accy = zero(T{});
-    __syncthreads();  // CF visible
     for (int kk = 1; kk < n; ++kk) {
         const double2 ck = CF[kk];
 #pragma unroll
         for (int c = NCOL - 2; c >= 1; --c) OWN_STAGE(c)
         if (Q == 0) {  // C₁ D̄ C₁ in registers
-            T x = lin(cx[0].x, ax, cx[0].y, ay), y = lin(cx[0].x, ay, cx[0].y, ax);
-            x = scl(dx, x);
-            y = scl(dy, y);
-            ax = lin(cx[0].x, x, cx[0].y, y);
-            ay = lin(cx[0].x, y, cx[0].y, x);
+            T x = lin(P.cx[0].x, ax, P.cx[0].y, ay), y = lin(P.cx[0].x, ay, P.cx[0].y, ax);
+            x = scl(P.dx, x);
+            y = scl(P.dy, y);
+            ax = lin(P.cx[0].x, x, P.cx[0].y, y);
+            ay = lin(P.cx[0].x, y, P.cx[0].y, x);
         } else {       // one exchange; the mate's value after C₁ and D̄ is recomputed here (same bond, its own d̄)
             T mx, my;
             OWN_EXCHANGE(0, mx, my)
-            T x = lin(cx[0].x, ax, cx[0].y, mx), xm = lin(cx[0].x, mx, cx[0].y, ax);
-            T y = lin(cy[0].x, ay, cy[0].y, my), ym = lin(cy[0].x, my, cy[0].y, ay);
-            x = scl(dx, x);
-            xm = scl(dmx, xm);
-            y = scl(dy, y);
-            ym = scl(dmy, ym);
-            ax = lin(cx[0].x, x, cx[0].y, xm);
-            ay = lin(cy[0].x, y, cy[0].y, ym);
+            T x = lin(P.cx[0].x, ax, P.cx[0].y, mx), xm = lin(P.cx[0].x, mx, P.cx[0].y, ax);
+            T y = lin(P.cy[0].x, ay, P.cy[0].y, my), ym = lin(P.cy[0].x, my, P.cy[0].y, ay);
+            x = scl(P.dx, x);
+            xm = scl(P.dmx, xm);
+            y = scl(P.dy, y);
+            ym = scl(P.dmy, ym);
+            ax = lin(P.cx[0].x, x, P.cx[0].y, xm);
+            ay = lin(P.cy[0].x, y, P.cy[0].y, ym);
         }
 #pragma unroll
         for (int c = 1; c <= NCOL - 2; ++c) OWN_STAGE(c)
@@ -625,28 +597,174 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
         ax = accx; ay = accy;
         T mx, my;
         OWN_EXCHANGE(CL, mx, my)
-        const double idx_ = 1.0 / (cx[CL].x * cx[CL].x - cx[CL].y * cx[CL].y), idy_ = 1.0 / (cy[CL].x * cy[CL].x - cy[CL].y * cy[CL].y);
-        ax = scl(idx_, sub(scl(cx[CL].x, accx), scl(cx[CL].y, mx)));
-        ay = scl(idy_, sub(scl(cy[CL].x, accy), scl(cy[CL].y, my)));
+        const double idx_ = 1.0 / (P.cx[CL].x * P.cx[CL].x - P.cx[CL].y * P.cx[CL].y), idy_ = 1.0 / (P.cy[CL].x * P.cy[CL].x - P.cy[CL].y * P.cy[CL].y);
+        ax = scl(idx_, sub(scl(P.cx[CL].x, accx), scl(P.cx[CL].y, mx)));
+        ay = scl(idy_, sub(scl(P.cy[CL].x, accy), scl(P.cy[CL].y, my)));
     }
 #undef OWN_STAGE
 #undef OWN_EXCHANGE
+}
+
+// Workgroups of a launch, per system: the k.heavy frequencies of lowest |ϕ| — every frequency whose expansion has more than one term; the
+// order falls off like 1/ϕ (KPMPreconditioner.jl:709-711) and the host, which computed the orders, passes the count — get a workgroup each
+// (two with SPLIT, one per component) and run their chain.  All the other frequencies are a scalar multiple of their vector (:398) and are
+// handled k.group at a time by "light" workgroups, whole 16-byte elements, both components at once.  Done by a workgroup of its own a
+// light frequency costs ≈ 2 µs of a workgroup slot for 16 KB of traffic — the round trips in front of the work — and with a workgroup per
+// frequency and component the Chebyshev kernel held more wave-slot time than any other kernel of the iteration (SQ_WAVE_CYCLES 35.4 M
+// against 31.9 M for MᵀM, profiles/r02_pmc_lds_iteration.txt), which is what the multi-stream bench is bound by.
+template <int NCOL, bool SPLIT>
+__global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
+{
+    static_assert(NCOL >= 2, "single-colour decompositions use cheb_fast_kernel");
+    using namespace ownk;
+    using T = typename Scalar<SPLIT>::type;
+    extern __shared__ double2 lds[];
+    __shared__ double red[17];
+    const int N = k.N, Lt = k.Lt, Tn = blockDim.x, j = threadIdx.x;
+    const int ncnt_ = k.sys_count > 0 ? k.sys_count : k.nsys;
+    const int sys = k.sys_first + blockIdx.x % ncnt_, slotid = blockIdx.x / ncnt_;
+    const int heavy = min(k.heavy, Lt), heavy_slots = SPLIT ? 2 * heavy : heavy;
+    const int w = sys / k.nrhs;
+    const int Lo2 = (Lt + 1) / 2;
+    double2 *przb = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride : nullptr;
+    if (slotid >= heavy_slots) {
+        // ---- light workgroup: ranks [r0, r1), single-term expansions, at most GMAX of them ----
+        // Three rounds instead of a loop of dependent ones: the orders and leading coefficients of all its frequencies, then all their
+        // elements (a lane serves the sites j and j + Tn: N <= 2 Tn), then the stores and ONE reduction pass for all the Parseval sums.
+        constexpr int GMAX = 8;
+        const int r0 = heavy + (slotid - heavy_slots) * k.group, r1 = min(Lt, r0 + min(k.group, GMAX));
+        const bool sys_done = (k.cg ? k.cg[sys].done : 0) != 0;
+        const bool act = k.active[w] != 0;
+        int omg[GMAX];
+        double fg[GMAX];
+        bool useg[GMAX];
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) {
+            const int r = min(r0 + g, Lt - 1);
+            const int om = (r & 1) ? Lt - 1 - (r >> 1) : (r >> 1);
+            const int slot = om >= Lo2 ? Lt - om - 1 : om;  // :387
+            const int n = k.order[(size_t)w * k.nslot + slot];
+            const double c0 = k.coefs[((size_t)w * k.nslot + slot) * k.maxorder].x;
+            omg[g] = om;
+            useg[g] = r0 + g < r1 && !(k.half && om >= Lo2);
+            // n > 1 here would mean the host's count of multi-term frequencies and the device's order table disagree (both come from the
+            // same host vector): poison the output so that the solve fails loudly ("non-finite residual") instead of using a wrong P⁻¹
+            fg[g] = !act ? k.scale : (n <= 1 ? k.scale * c0 : __builtin_nan(""));
+        }
+        if (sys_done) return;
+        const int ia = min(j, N - 1), ib = min(j + Tn, N - 1);
+        const bool oka = j < N, okb = j + Tn < N;
+        double2 xa[GMAX], xb[GMAX];
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) {
+            const double2 *v = k.v + ((size_t)omg[g] * k.nsys + sys) * N;
+            xa[g] = v[ia];
+            xb[g] = v[ib];
+        }
+        const int wave = j >> 6, lane = j & 63, nwave = (Tn + 63) >> 6;
+        double *part = reinterpret_cast<double *>(lds);  // [2 GMAX][nwave] wave sums
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) {
+            const double f = fg[g];
+            double accr = 0.0, acci = 0.0;
+            if (useg[g]) {
+                double2 *vo = (k.vout ? k.vout : k.v) + ((size_t)omg[g] * k.nsys + sys) * N;
+                // the Parseval sums keep the form of the launch: per component with SPLIT (two slots per frequency), one sum otherwise;
+                // per lane the terms are added in the order of the one-workgroup-per-frequency form (site j, then j + Tn)
+                if (oka) {
+                    vo[ia] = make_double2(f * xa[g].x, f * xa[g].y);
+                    if constexpr (SPLIT) { accr += f * (xa[g].x * xa[g].x); acci += f * (xa[g].y * xa[g].y); }
+                    else accr += f * (xa[g].x * xa[g].x + xa[g].y * xa[g].y);
+                }
+                if (okb) {
+                    vo[ib] = make_double2(f * xb[g].x, f * xb[g].y);
+                    if constexpr (SPLIT) { accr += f * (xb[g].x * xb[g].x); acci += f * (xb[g].y * xb[g].y); }
+                    else accr += f * (xb[g].x * xb[g].x + xb[g].y * xb[g].y);
+                }
+            }
+            accr = wsum_k(accr);
+            acci = wsum_k(acci);
+            if (lane == 0) { part[(2 * g) * nwave + wave] = accr; part[(2 * g + 1) * nwave + wave] = acci; }
+        }
+        __syncthreads();
+        if (przb && j < 2 * GMAX) {
+            const int g = j >> 1, c = j & 1;
+            double t = 0.0;
+            for (int q = 0; q < nwave; ++q) t += part[j * nwave + q];  // wave order, as block_sum_real
+            if (r0 + g < r1 && !(k.half && (((r0 + g) & 1) ? Lt - 1 - ((r0 + g) >> 1) : ((r0 + g) >> 1)) >= Lo2)) {
+                const int r = r0 + g, om = (r & 1) ? Lt - 1 - (r >> 1) : (r >> 1);
+                if (SPLIT) przb[2 * om + c] = make_double2(t, 0.0);
+                else if (c == 0) przb[om] = make_double2(t, 0.0);
+            }
+        }
+        return;
+    }
+    // ---- heavy workgroup: one frequency (one component of it with SPLIT), heaviest first, the two components neighbours in the dispatch order ----
+    T *W0 = reinterpret_cast<T *>(lds), *W1 = W0 + 2 * Tn;
+    double2 *CF = reinterpret_cast<double2 *>(W0 + 4 * Tn);
+    const int comp = SPLIT ? (slotid & 1) : 0, rank = SPLIT ? (slotid >> 1) : slotid;
+    const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);
+    if (k.half && om >= Lo2) return;
+    const int slot = om >= Lo2 ? Lt - om - 1 : om;  // :387
+    // Round 1 of loads — everything addressed by the block and thread index alone, issued before any of it is looked at: the stop flag,
+    // the expansion order, the spectral bounds and the lane program's table indices.  The workgroup with the longest chain sets the
+    // duration of the launch and every serial round trip in front of the chain adds to it; as written naively (flag, return; active,
+    // order, return; bounds; table; gathers) that was five.
+    const bool sys_done = (k.cg ? k.cg[sys].done : 0) != 0;
+    const bool act = k.active[w] != 0;
+    const int n_raw = k.order[(size_t)w * k.nslot + slot];
+    const double emin = k.bounds[2 * w], emax = k.bounds[2 * w + 1];
+    OwnIdx<NCOL> I;
+    own_load_idx<NCOL>(I, kg, Tn, j);
+    asm volatile("" ::: "memory");  // compiler fence: keeps the loads above on this side of the early returns (no instruction, no wait)
+    if (sys_done) return;
+    const double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
+    double2 *vo = (k.vout ? k.vout : k.v) + ((size_t)om * k.nsys + sys) * N;
+    double2 *prz = przb ? przb + (SPLIT ? 2 * om + comp : om) : nullptr;
+    const int n = act ? n_raw : 1;
+    const double2 *coefs = k.coefs + ((size_t)w * k.nslot + slot) * k.maxorder;
+    if (n <= 1) {  // single-term expansion: scalar multiply (:398)
+        const double f = k.scale * (act ? coefs[0].x : 1.0);
+        double acc = 0.0;
+        for (int i = j; i < N; i += Tn) {
+            const T x = ld(v, i, comp, T{});
+            st(vo, i, comp, scl(f, x));
+            if constexpr (SPLIT) acc += f * (x * x);
+            else acc += f * (x.x * x.x + x.y * x.y);
+        }
+        if (prz) {
+            const double t = block_sum_real(acc, red);
+            if (j == 0) *prz = make_double2(t, 0.0);
+        }
+        return;
+    }
+    const double avg = 0.5 * (emax + emin), imag_ = 1.0 / (0.5 * (emax - emin));
+    // Round 2: the gathers addressed through round 1 (τ-means at the own sites and their mates, the bonds' (c̄, s̄), the input vector)
+    OwnProg<NCOL> P;
+    own_load_prog<NCOL>(P, I, k.dbar + (size_t)w * N, kg.pcs + (size_t)w * kg.ptotal, Tn, j);
+    T ax = zero(T{}), ay = zero(T{});
+    if (P.on) { ax = ld(v, P.sx, comp, T{}); ay = ld(v, P.sy, comp, T{}); }
+    const T v0x = ax, v0y = ay;
+    for (int i = j; i < n; i += Tn) CF[i] = coefs[i];  // coefficients in LDS: no global load inside the chain
+    __syncthreads();  // CF visible
+    int buf = 0;
+    own_chain<NCOL, T>(P, ax, ay, W0, W1, buf, CF, n, avg, imag_);
     double2 acc = make_double2(0.0, 0.0);
-    if (on) {
+    if (P.on) {
         ax = scl(k.scale, ax);
         ay = scl(k.scale, ay);
-        st(vo, sx, comp, ax);
-        if (sy != sx) st(vo, sy, comp, ay);
+        st(vo, P.sx, comp, ax);
+        if (P.sy != P.sx) st(vo, P.sy, comp, ay);
         if constexpr (SPLIT) {
             // Re conj(r)·z = r_re z_re + r_im z_im: this workgroup adds the term of its component.  The imaginary part
             // r_re z_im − r_im z_re couples the two workgroups of a frequency (and, in place, races with the other one's stores); for the
             // real symmetric P⁻¹ of the Sym form it is rounding noise around an exact zero and is left at zero.
             acc.x += v0x * ax;
-            if (sy != sx) acc.x += v0y * ay;
+            if (P.sy != P.sx) acc.x += v0y * ay;
         } else {
             acc.x += v0x.x * ax.x + v0x.y * ax.y;
             acc.y += v0x.x * ax.y - v0x.y * ax.x;
-            if (sy != sx) {
+            if (P.sy != P.sx) {
                 acc.x += v0y.x * ay.x + v0y.y * ay.y;
                 acc.y += v0y.x * ay.y - v0y.y * ay.x;
             }
@@ -990,12 +1108,20 @@ void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
 #define CHEB_LAUNCH(S_, C_) hipLaunchKernelGGL((cheb_fast_kernel<S_, C_>), grid, block, lds, st, k, kg)
         if (k.is_sym && k.ncol >= 2 && k.ncol <= 6 && kg.own && cheb_own_enabled()) {
             const bool split = cheb_split_active(k, kg);
+            // heavy / light workgroups (see cheb_own_kernel): k.group > 0 says that k.heavy is the host's count of leading frequencies with
+            // more than one term (possibly 0); otherwise every frequency gets its own workgroup(s).  SMOQY_CHEB_GROUP=1 for A/B runs.
+            static const int env_group = [] { const char *e = getenv("SMOQY_CHEB_GROUP"); return e ? atoi(e) : 0; }();
+            KpmArgs kk = k;
+            kk.group = std::min(8, env_group > 0 ? env_group : k.group);  // light workgroups hold at most 8 frequencies in registers
+            if (kk.group <= 1) { kk.group = 1; kk.heavy = k.Lt; }
+            kk.heavy = std::max(0, std::min(k.Lt, kk.heavy));
+            const int nlight = (k.Lt - kk.heavy + kk.group - 1) / kk.group;
             const size_t olds = (split ? sizeof(double) : sizeof(double2)) * 4 * (size_t)kg.threads + sizeof(double2) * (size_t)k.maxorder;
-            const dim3 sgrid((unsigned)(2 * k.Lt * ncnt));
-#define OWN_LAUNCH(C_)                                                                            \
-    {                                                                                             \
-        if (split) hipLaunchKernelGGL((cheb_own_kernel<C_, true>), sgrid, block, olds, st, k, kg); \
-        else hipLaunchKernelGGL((cheb_own_kernel<C_, false>), grid, block, olds, st, k, kg);       \
+            const dim3 ogrid((unsigned)(((split ? 2 : 1) * kk.heavy + nlight) * ncnt));
+#define OWN_LAUNCH(C_)                                                                             \
+    {                                                                                              \
+        if (split) hipLaunchKernelGGL((cheb_own_kernel<C_, true>), ogrid, block, olds, st, kk, kg); \
+        else hipLaunchKernelGGL((cheb_own_kernel<C_, false>), ogrid, block, olds, st, kk, kg);      \
     }
             switch (k.ncol) {
                 case 2: OWN_LAUNCH(2); break;

@@ -105,6 +105,8 @@ struct KpmArgs {
     int sys_first, sys_count;           // systems [sys_first, sys_first + sys_count) are processed; sys_count = 0 means all
     int half;                           // real-vector ldiv! (KPMPreconditioner.jl:312 / :444): only ω < cld(Lτ, 2) are evaluated,
                                         // launch_conj_mirror fills in the rest
+    int heavy, group;                   // cheb_own_kernel: the `heavy` lowest-|ϕ| frequencies get a workgroup each, the others go `group` at a time
+                                        // (0, 0 = defaults of launch_cheb)
 };
 
 // geometry of the KPM fast path: per-colour bond lists padded with identity self bonds (i, i) so

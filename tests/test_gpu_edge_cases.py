@@ -438,8 +438,8 @@ def test_tau_independent_hoppings_select_and_leave_the_one_pair_kernel(entry):
 def test_in_place_tau_fft_form(Lt, is_sym):
     """smoqy_tfft_form(1): the single-image τ-FFT (decimation-in-frequency passes forward, decimation-in-time back, radix 4 / 2 / 3,
     digit-reversed order absorbed at the global-memory side) against the oracle's FourierTransformer (FourierTransformer.jl:39-64),
-    the KPM preconditioner built on it (KPMPreconditioner.jl:355-414, 488-550) and the fused CG kernels (identical iteration counts
-    with the two-image form).  Lτ = 100 has a factor 5: the call is accepted and the two-image form stays."""
+    the KPM preconditioner built on it (KPMPreconditioner.jl:355-414, 488-550) and the fused CG kernels (iteration counts within one
+    of the two-image form's).  Lτ = 100 has a factor 5: the call is accepted and the two-image form stays."""
     N = 24
     h, o, nt, colors = make(lat.chain_neighbor_table(N), Lt, N, is_sym, seed=3, nrhs=3, vscale=0.5)
     v = rand(Lt, N, 3, 4)
@@ -462,7 +462,7 @@ def test_in_place_tau_fft_form(Lt, is_sym):
         assert relerr(out[:, :, 2], P.apply(v[:, :, 2])) < 1e-10
         res[form] = solve(h, v, 1e-10, 5000, 1)
     (x0, it0, eps0), (x1, it1, eps1) = res[0], res[1]
-    np.testing.assert_array_equal(it0, it1)
+    assert np.abs(it0 - it1).max() <= 1  # the two forms differ in rounding (different pass order): a residual that lands on the tolerance may take one more step
     assert relerr(x1, x0) < 1e-9 and eps1.max() < 1e-10
     xo, ito, _ = o[0].cg_solve(v[:, :, 0], precond=P, tol=1e-10, maxiter=5000)
     assert abs(int(it1[0]) - ito) <= 1 and relerr(x1[:, :, 0], xo) < 1e-8
