@@ -14,6 +14,9 @@ nt, perm, colors = lat.checkerboard_decomposition(ms[0].fpi.neighbor_table)
 h = L.Handle(128, 512, nt, colors, True, nb, 1, -1)
 for w, m in enumerate(ms):
     h.call("smoqy_update_from_path_integral", w, L.ptr(m.fpi.V), L.ptr(m.fpi.t), L.ptr(perm), C.c_double(m.fpi.dtau))
+import os
+if os.environ.get("SMOQY_TC"):
+    h.call("smoqy_set_tau_chunk", int(os.environ["SMOQY_TC"]))  # τ-chunk override for A/B runs
 a, b = h.vec_alloc(), h.vec_alloc()
 g = np.random.default_rng(0)
 h.vec_upload(a, np.asfortranarray(g.standard_normal((128, 512, nb)) + 1j * g.standard_normal((128, 512, nb))))
