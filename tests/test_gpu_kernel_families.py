@@ -16,3 +16,12 @@ def test_parity_suite_with_the_lds_resident_kernels():
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_parity_suite_with_a_chebyshev_workgroup_per_frequency():
+    """SMOQY_CHEB_GROUP=1: every frequency gets its own Chebyshev workgroup(s) (the form before the light workgroups of cheb_own_kernel,
+    kept as the A/B twin) — same parity files, same tolerances."""
+    env = dict(os.environ, SMOQY_CHEB_GROUP="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
