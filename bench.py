@@ -200,6 +200,14 @@ def cpu_sample(workload, tol, Nt, walker=0):
     }
 
 
+def _only_factors_2_3(n):
+    """The in-place τ-FFT exists for Lτ = 2^a 3^b (smoqy_tfft_form keeps the two-image form otherwise)."""
+    for f in (2, 3):
+        while n % f == 0:
+            n //= f
+    return n == 1
+
+
 def measure_copy_ceiling(h, L, gib=1.0, reps=10):
     """Device stream-copy ceiling measured on THIS box: a plain 16-byte-per-lane copy kernel over 2 x `gib` GiB
     (far beyond the 256 MiB Infinity Cache), HIP events on the handle's stream.  Moved bytes = read + write."""
@@ -482,7 +490,7 @@ def main():
                 "cg_tol": batch.tol,
                 "avg_cg_iters": sum(b.stats.iters_sum for b in batches) / max(sum(b.stats.solves for b in batches), 1),
                 "preconditioner": "KPM (Sym)",
-                "tfft_form": "in-place" if batch.tfft_in_place else "two-image",
+                "tfft_form": ("in-place" if _only_factors_2_3(batch.Lt) else "two-image (in-place requested; Ltau has a factor 5 or 7)") if batch.tfft_in_place else "two-image",
                 "hmc": ("EFA leapfrog on the device, Nt = %d steps of dt = pi/(2 Nt), trajectory always rejected (x restored) so the field distribution stays the one SURVEY.md 8(d) defines" % batch.Nt)
                 if args.hmc == "device" else "synthetic host-side drift (round-1 form)",
                 "parallelism": f"walker-parallel, {world} rank(s) x {wpg} walkers ({S} lock-step batches of {per}), no collective",
