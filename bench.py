@@ -53,7 +53,7 @@ def parse():
                          "full-batch MtM launches), 0 = the library's automatic choice, 2 = on.  The one-stream legs always use the library default (automatic).")
     ap.add_argument("--tfft-form", choices=["auto", "two-image", "in-place"], default="auto",
                     help="τ-FFT of the timed batches (smoqy_tfft_form): in-place has more workgroups per CU (+2.7 %% sweeps/s with six streams), two-image is faster alone; "
-                         "auto = in-place when more than one stream shares the GPU.  The one-stream legs keep the library default (two-image).")
+                         "auto = in-place when more than one stream shares the GPU and Ltau = 2^a 3^b.  The one-stream legs keep the library default (two-image).")
     ap.add_argument("--no-mtm-sampling", action="store_true", help="do not sample MtM launches inside the timed region (roofline falls back to the isolated leg)")
     ap.add_argument("--measure-nrv", type=int, default=0, help="add update_greens_estimator! + measure_GΔ0! with this many random vectors to every sweep (27 + Nrv solves)")
     ap.add_argument("--hmc", choices=["device", "host"], default="device",
@@ -200,12 +200,16 @@ def cpu_sample(workload, tol, Nt, walker=0):
     }
 
 
-def _only_factors_2_3(n):
-    """The in-place τ-FFT exists for Lτ = 2^a 3^b (smoqy_tfft_form keeps the two-image form otherwise)."""
-    for f in (2, 3):
+def _only_factors(n, primes):
+    for f in primes:
         while n % f == 0:
             n //= f
     return n == 1
+
+
+def _only_factors_2_3(n):
+    """The in-place τ-FFT exists for Lτ = 2^a 3^b 5^c (smoqy_tfft_form keeps the two-image form otherwise)."""
+    return _only_factors(n, (2, 3, 5))
 
 
 def measure_copy_ceiling(h, L, gib=1.0, reps=10):
@@ -379,9 +383,13 @@ def main():
         raise SystemExit("--walkers-per-gpu must be a multiple of --streams")
     mine = walker_range(rank, world, wpg)  # walkers [rank*wpg, (rank+1)*wpg): no overlap between ranks, no exchange
     per = wpg // S
+    # auto: the in-place τ-FFT pays where the launches fill the chip and the transform has no radix-5 pass (headline lattice +2.7 %;
+    # measured slower on the Lτ = 80 / 100 / 200 lattices of BASELINE.json, whose launches are half a chip or less)
+    from smoqyelphqmc_amd import lattice as _lat
+    lat_Lt = _lat.CONFIGS[args.workload](walker=0).fpi.Ltau
     batches = [WalkerBatch(args.workload, nwalkers=per, walker0=mine.start + s * per, device=dev, check_every=args.check_every or None, tau_chunk=args.tau_chunk or None,
                            host_threads=max(2, 16 // S), measure_nrv=args.measure_nrv, device_efa=args.hmc == "device", cg_split=args.cg_split,
-                           tfft_in_place=(S > 1) if args.tfft_form == "auto" else args.tfft_form == "in-place") for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
+                           tfft_in_place=(S > 1 and _only_factors(lat_Lt, (2, 3))) if args.tfft_form == "auto" else args.tfft_form == "in-place") for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
     batch = batches[0]
     if args.solve_concurrency > 0:
         if args.gate == "library":
@@ -490,7 +498,7 @@ def main():
                 "cg_tol": batch.tol,
                 "avg_cg_iters": sum(b.stats.iters_sum for b in batches) / max(sum(b.stats.solves for b in batches), 1),
                 "preconditioner": "KPM (Sym)",
-                "tfft_form": ("in-place" if _only_factors_2_3(batch.Lt) else "two-image (in-place requested; Ltau has a factor 5 or 7)") if batch.tfft_in_place else "two-image",
+                "tfft_form": ("in-place" if _only_factors_2_3(batch.Lt) else "two-image (in-place requested; Ltau has a factor 7)") if batch.tfft_in_place else "two-image",
                 "hmc": ("EFA leapfrog on the device, Nt = %d steps of dt = pi/(2 Nt), trajectory always rejected (x restored) so the field distribution stays the one SURVEY.md 8(d) defines" % batch.Nt)
                 if args.hmc == "device" else "synthetic host-side drift (round-1 form)",
                 "parallelism": f"walker-parallel, {world} rank(s) x {wpg} walkers ({S} lock-step batches of {per}), no collective",

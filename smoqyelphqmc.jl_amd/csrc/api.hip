@@ -1588,7 +1588,7 @@ int smoqy_tfft_form(smoqy_ctx *c, int in_place)
 {
     CHECK_CTX(c);
     if (in_place != 0 && in_place != 1) FAIL(c, 1, "in_place must be 0 or 1");
-    const int want = (in_place && c->tf_ok && c->tf.slim_ok && c->tf.pos) ? 1 : 0;  // lengths with factors 5 or 7 keep the two-image form
+    const int want = (in_place && c->tf_ok && c->tf.slim_ok && c->tf.pos) ? 1 : 0;  // lengths with a factor 7 keep the two-image form
     if (want != c->tf.slim) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->tf.slim = want;

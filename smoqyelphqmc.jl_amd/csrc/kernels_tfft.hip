@@ -73,6 +73,26 @@ __device__ __forceinline__ void dft<4>(double2 (&v)[4], const double2 *__restric
     v[3] = csub(b, d);
 }
 
+// radix 5 written out (two real constants per conjugate pair instead of the table-driven sum: what lets the in-place form take
+// lengths with a factor 5 without the register count of the generic butterfly)
+template <>
+__device__ __forceinline__ void dft<5>(double2 (&v)[5], const double2 *__restrict__, int, bool inv)
+{
+    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;  // cos 72°, cos 144°
+    const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;   // sin 72°, sin 144°
+    const double2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    const double2 m1 = make_double2(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
+    const double2 m2 = make_double2(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
+    // forward: X_k = m − i (…); inverse: + i (…)
+    const double2 u1 = mul_mi(make_double2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y), inv);
+    const double2 u2 = mul_mi(make_double2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y), inv);
+    v[0] = cadd(v[0], cadd(t1, t2));
+    v[1] = cadd(m1, u1);
+    v[4] = csub(m1, u1);
+    v[2] = cadd(m2, u2);
+    v[3] = csub(m2, u2);
+}
+
 template <>
 __device__ __forceinline__ void dft<8>(double2 (&v)[8], const double2 *__restrict__, int, bool inv)
 {
@@ -183,7 +203,8 @@ __device__ __forceinline__ void inplace_one(double2 *X, const double2 *wt, const
     switch (R) {
         case 2: inplace_pass<2, DIT>(X, wt, a.Lt, a.SB, ncur, inv); break;
         case 3: inplace_pass<3, DIT>(X, wt, a.Lt, a.SB, ncur, inv); break;
-        default: inplace_pass<4, DIT>(X, wt, a.Lt, a.SB, ncur, inv); break;  // radix 5 and 7 butterflies would set the register count: such lengths keep the ping-pong form
+        case 5: inplace_pass<5, DIT>(X, wt, a.Lt, a.SB, ncur, inv); break;  // written-out butterfly (the table-driven radix 7 would set the register count: such lengths keep the two-image form)
+        default: inplace_pass<4, DIT>(X, wt, a.Lt, a.SB, ncur, inv); break;
     }
 }
 
@@ -566,14 +587,14 @@ bool tfft_plan(int Lt, int N, TfftArgs &a)
     // fewer, larger passes: a trailing (8, 2) pair reads better as (4, 4)
     for (int f = 0; f + 1 < a.nfac; ++f)
         if (a.fac[f] == 8 && a.fac[f + 1] == 2) { a.fac[f] = 4; a.fac[f + 1] = 4; }
-    // in-place plan: radix 4, 2, 3 only
+    // in-place plan: radix 4, 2, 3, 5
     a.snfac = 0;
     m = Lt;
-    const int spref[] = {4, 2, 3};
+    const int spref[] = {4, 2, 3, 5};
     for (int R : spref)
         while (m % R == 0 && a.snfac < 16) { a.sfac[a.snfac++] = R; m /= R; }
     static const int slim_env = [] { const char *e = getenv("SMOQY_TFFT_SLIM"); return e ? atoi(e) : 0; }();
-    a.slim_ok = (m == 1) ? 1 : 0;           // lengths 2^a 3^b only
+    a.slim_ok = (m == 1) ? 1 : 0;           // lengths 2^a 3^b 5^c only
     a.slim = (slim_env && a.slim_ok) ? 1 : 0;  // default form: SMOQY_TFFT_SLIM, else smoqy_tfft_form
     a.SB = 16;
     size_t lds_cap = 64 * 1024;  // two or more workgroups per CU

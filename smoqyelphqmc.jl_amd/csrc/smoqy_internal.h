@@ -258,9 +258,9 @@ struct TfftArgs {
     int Lt, N, nsys, SB, ntile, nfac;
     int sys_first, sys_count;             // systems [sys_first, sys_first + sys_count) are processed; sys_count = 0 means all
     int fac[16];
-    // in-place form (one LDS image): radix <= 7 factors `sfac` applied as decimation-in-frequency passes (forward) or, in reverse
+    // in-place form (one LDS image): radix 2 / 3 / 4 / 5 factors `sfac` applied as decimation-in-frequency passes (forward) or, in reverse
     // order, decimation-in-time passes (inverse); element k of the spectrum sits at LDS row pos[k]
-    int slim, slim_ok, snfac;             // slim: in-place form selected; slim_ok: Lt = 2^a 3^b, the in-place form exists
+    int slim, slim_ok, snfac;             // slim: in-place form selected; slim_ok: Lt = 2^a 3^b 5^c, the in-place form exists
     int sfac[16];
     const int *pos;                       // [Lt]
     const double2 *wtab;                  // [Lt] exp(-2 pi i q / Lt)

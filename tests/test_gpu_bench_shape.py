@@ -129,7 +129,7 @@ def test_kpm_apply_at_the_benchmarked_shape(shape):
 @pytest.mark.parametrize("in_place", [False, True], ids=["two-image-fft", "in-place-fft"])  # bench.py's timed batches run the in-place τ-FFT (smoqy_tfft_form)
 @pytest.mark.parametrize("tol", [1e-10, 1e-5])  # tol_action and tol_force = sqrt(tol) of the sweep
 def test_pcg_at_the_benchmarked_shape(shape, tol, in_place):
-    shape.h.call("smoqy_tfft_form", int(in_place))  # a no-op for Lτ with a factor 5 or 7 (the two-image form stays)
+    shape.h.call("smoqy_tfft_form", int(in_place))  # a no-op for Lτ with a factor 7 (the two-image form stays)
     Ps = shape.precond(41)
     bv = shape.rand(42)
     xb, bb = shape.h.vec_alloc(), shape.h.vec_alloc()

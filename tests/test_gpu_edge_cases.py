@@ -433,13 +433,13 @@ def test_tau_independent_hoppings_select_and_leave_the_one_pair_kernel(entry):
     solve_graph("constant again")
 
 
-@pytest.mark.parametrize("Lt", [2, 4, 6, 12, 16, 18, 24, 36, 48, 64, 96, 100, 128])
+@pytest.mark.parametrize("Lt", [2, 4, 5, 6, 10, 12, 14, 16, 18, 20, 24, 36, 40, 48, 50, 64, 80, 96, 100, 128, 200])
 @pytest.mark.parametrize("is_sym", [True, False])
 def test_in_place_tau_fft_form(Lt, is_sym):
-    """smoqy_tfft_form(1): the single-image τ-FFT (decimation-in-frequency passes forward, decimation-in-time back, radix 4 / 2 / 3,
+    """smoqy_tfft_form(1): the single-image τ-FFT (decimation-in-frequency passes forward, decimation-in-time back, radix 4 / 2 / 3 / 5,
     digit-reversed order absorbed at the global-memory side) against the oracle's FourierTransformer (FourierTransformer.jl:39-64),
     the KPM preconditioner built on it (KPMPreconditioner.jl:355-414, 488-550) and the fused CG kernels (iteration counts within one
-    of the two-image form's).  Lτ = 100 has a factor 5: the call is accepted and the two-image form stays."""
+    of the two-image form's).  Lτ = 14 has a factor 7: the call is accepted and the two-image form stays."""
     N = 24
     h, o, nt, colors = make(lat.chain_neighbor_table(N), Lt, N, is_sym, seed=3, nrhs=3, vscale=0.5)
     v = rand(Lt, N, 3, 4)
