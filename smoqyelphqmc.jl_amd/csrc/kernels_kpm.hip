@@ -771,8 +771,13 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
         }
     }
     if (prz) {
-        const double2 t = block_sum_cplx(acc, red);
-        if (j == 0) *prz = t;
+        if constexpr (SPLIT) {  // the imaginary part is not formed: one reduction pass
+            const double t = block_sum_real(acc.x, red);
+            if (j == 0) *prz = make_double2(t, 0.0);
+        } else {
+            const double2 t = block_sum_cplx(acc, red);
+            if (j == 0) *prz = t;
+        }
     }
 }
 
