@@ -22,6 +22,10 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 duration.  `isolated`: the kernel alone on the GPU.  `copy_ceiling`: a device stream copy measured in this run.
                 `batch_scan`: 1..128 systems per launch; `hbm_resident_point`: the 128-system launch (working set > Infinity Cache).
   one_stream    sweeps/s of 1, 8, 16 walkers on one stream (single_walker = BASELINE.json's literal configuration)
+  procs_per_gpu_scan    the reference's own execution model (one walker per MPI rank, tutorials/holstein_honeycomb_mpi.jl:60-72) on ONE
+                GPU: K fresh child processes, each with a single-walker handle, started together; aggregate sweeps/s per K.  Runs before
+                this process touches the GPU.  K stops at 6: the GPU pool admits at most six processes on a card at once.
+  threads_per_gpu_scan  the same with K host threads in one process, each owning a single-walker handle (its own HIP stream).
   cpu_baseline  the CPU oracle (a single-threaded restatement of the reference algorithm, NOT the Julia reference, which cannot run
                 here) timed on a bounded sample of the same workload, one walker per host core, all at once.
 """
@@ -66,6 +70,11 @@ def parse():
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)  # child process of cpu_baseline: time the oracle sample for this walker
     ap.add_argument("--cpu-tol", type=float, default=1e-10, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-nt", type=int, default=24, help=argparse.SUPPRESS)
+    ap.add_argument("--rank-worker", type=int, default=-1, help=argparse.SUPPRESS)  # child process of procs_per_gpu_scan: one single-walker handle, walker id = this
+    ap.add_argument("--scan-sweeps", type=int, default=6, help="sweeps each rank / thread of the procs_per_gpu / threads_per_gpu scans times")
+    ap.add_argument("--proc-scan", default="1,2,4,6", help="process counts of procs_per_gpu_scan (the pool admits at most 6 GPU processes per card)")
+    ap.add_argument("--thread-scan", default="1,2,4,8,16", help="thread counts of threads_per_gpu_scan")
+    ap.add_argument("--no-proc-scan", action="store_true", help="skip procs_per_gpu_scan and threads_per_gpu_scan")
     ap.add_argument("--roofline-only", action="store_true", help="run only the isolated roofline leg (for a rocprofv3 pass whose kernel average must match roofline.avg_launch_us)")
     ap.add_argument("--batch-scan", action="store_true", help="try tau chunks 1..4 at every point of the batch scan (the default scan uses the heuristic chunk)")
     ap.add_argument("--timed-only", action="store_true",
@@ -207,9 +216,113 @@ def _only_factors(n, primes):
     return n == 1
 
 
-def _only_factors_2_3(n):
+def _in_place_tfft_exists(n):
     """The in-place τ-FFT exists for Lτ = 2^a 3^b 5^c (smoqy_tfft_form keeps the two-image form otherwise)."""
     return _only_factors(n, (2, 3, 5))
+
+
+def rank_worker(args):
+    """Child process of procs_per_gpu_scan: ONE walker behind ONE single-walker handle — exactly what an MPI rank of the reference owns
+    (tutorials/holstein_honeycomb_mpi.jl:60-72) — sharing the GPU with its sibling ranks.  Protocol on stdin/stdout: build + one warm-up
+    sweep, print "ready", wait for a line, time `--scan-sweeps` sweeps, print one JSON line with the wall-clock start / end."""
+    from smoqyelphqmc_amd.walkers import WalkerBatch
+
+    b = WalkerBatch(args.workload, nwalkers=1, walker0=args.rank_worker, device=0, device_efa=args.hmc == "device")
+    b.sweep()
+    b.h.call("smoqy_sync")
+    b.stats.solves = b.stats.iters_sum = 0
+    print("ready", flush=True)
+    sys.stdin.readline()
+    t0 = time.time()
+    for _ in range(args.scan_sweeps):
+        b.sweep()
+    b.h.call("smoqy_sync")
+    t1 = time.time()
+    print(json.dumps({"start": t0, "end": t1, "sweeps": args.scan_sweeps, "avg_cg_iters": b.stats.iters_sum / max(b.stats.solves, 1)}), flush=True)
+    b.h.close()
+
+
+def procs_per_gpu_scan(args, counts):
+    """The reference's execution model on one GPU: K processes ("MPI ranks"), one single-walker handle each, all started together.
+    Called BEFORE this process initialises the GPU, so the children are the only processes on the card.  Aggregate sweeps/s =
+    K * sweeps / (last end - first start).  A failed point is reported as such, never substituted."""
+    import subprocess
+
+    out = []
+    for K in counts:
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--hmc", args.hmc, "--scan-sweeps", str(args.scan_sweeps)]
+        procs = [subprocess.Popen(cmd + ["--rank-worker", str(1000 + w)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for w in range(K)]
+        rec = {"procs": K, "walkers_per_proc": 1}
+        try:
+            for pr in procs:
+                line = pr.stdout.readline()
+                if line.strip() != "ready":
+                    raise RuntimeError("worker did not come up: " + (pr.stderr.read() or "")[-300:])
+            for pr in procs:
+                pr.stdin.write("go\n")
+                pr.stdin.flush()
+            res = []
+            for pr in procs:
+                o, e = pr.communicate(timeout=300)
+                if pr.returncode != 0:
+                    raise RuntimeError(f"worker exit code {pr.returncode}: " + (e or "")[-300:])
+                res.append(json.loads(o.strip().splitlines()[-1]))
+            span = max(r["end"] for r in res) - min(r["start"] for r in res)
+            rec.update({"sweeps_per_s": K * args.scan_sweeps / span, "per_proc_sweeps_per_s": [r["sweeps"] / (r["end"] - r["start"]) for r in res],
+                        "avg_cg_iters": sum(r["avg_cg_iters"] for r in res) / K, "sweeps_each": args.scan_sweeps})
+        except Exception as ex:  # noqa: BLE001 — the scan must never take the bench line down with it
+            rec["error"] = str(ex)[:400]
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+            for pr in procs:
+                try:
+                    pr.communicate(timeout=30)
+                except Exception:  # noqa: BLE001
+                    pass
+        out.append(rec)
+    return out
+
+
+def threads_per_gpu_scan(args, counts, dev, walker0):
+    """K host threads in ONE process, each owning a single-walker handle (its own HIP stream) — what a threaded driver that keeps the
+    reference's one-walker objects gets.  Same timing rule as procs_per_gpu_scan."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from smoqyelphqmc_amd.walkers import WalkerBatch
+
+    out = []
+    for K in counts:
+        bs = [WalkerBatch(args.workload, nwalkers=1, walker0=walker0 + 2000 + w, device=dev, device_efa=args.hmc == "device", host_threads=1) for w in range(K)]
+        with ThreadPoolExecutor(K) as pool:
+            list(pool.map(lambda b: (b.sweep(), b.h.call("smoqy_sync")), bs))
+            for b in bs:
+                b.stats.solves = b.stats.iters_sum = 0
+            t0 = time.perf_counter()
+            list(pool.map(lambda b: ([b.sweep() for _ in range(args.scan_sweeps)], b.h.call("smoqy_sync")), bs))
+            span = time.perf_counter() - t0
+        out.append({"threads": K, "walkers_per_thread": 1, "sweeps_per_s": K * args.scan_sweeps / span, "sweeps_each": args.scan_sweeps,
+                    "avg_cg_iters": sum(b.stats.iters_sum for b in bs) / max(sum(b.stats.solves for b in bs), 1)})
+        for b in bs:
+            b.h.close()
+    return out
+
+
+def committed_iteration_traffic(workload):
+    """HBM-side bytes of ONE CG iteration at 16 systems per launch (all four kernels), from the newest committed rocprofv3 PMC pass
+    (profiles/r*_pmc_iteration.json; FETCH_SIZE x 2 + WRITE_SIZE per kernel, medians over a sweep).  Headline lattice only."""
+    import glob
+    if workload != "holstein_honeycomb_L16_Ltau128":
+        return None, None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_iteration.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+            per_kernel = {k.split("smoqy::")[-1].split("(")[0].replace("(anonymous namespace)::", ""): v["traffic_MB"] * 2**20 for k, v in pmc.items() if isinstance(v, dict) and "traffic_MB" in v}
+        except (OSError, ValueError, KeyError):
+            continue
+        if per_kernel:
+            return sum(per_kernel.values()), per_kernel, "profiles/" + os.path.basename(path)
+    return None, None, None
 
 
 def measure_copy_ceiling(h, L, gib=1.0, reps=10):
@@ -250,7 +363,11 @@ def roofline_record(args, batch, per, S, dev, insitu, extra, L, np):
                              ~0.41 of the two-pass algorithmic count) over the same duration.
     isolated                 the same kernel alone on the GPU (back-to-back launches, HIP events; `--roofline-only` repeats this leg).
     copy_ceiling             device stream-copy rate measured in this run; every fraction is also quoted against it.
-    batch_scan               1..64 systems per launch; the 64-system point is the HBM-resident one (working set > Infinity Cache).
+    frac_single_pass         (2S+F) per system over the same duration: what the fused kernel must at least move (it reads v, the fields and
+                             writes MᵀM v once); cannot exceed 1.  `frac` counts two passes because SURVEY.md §8(d) says to, so at large
+                             batch it can — every value above 1 is flagged `"physical": false`.
+    batch_scan               1..128 systems per launch; the 128-system point is the HBM-resident one (`hbm_resident_point`, working set
+                             512 MiB > the 256 MiB Infinity Cache).
     """
     h = batch.h
     alg = h.algorithmic_bytes(L.OP_MTM)
@@ -260,7 +377,7 @@ def roofline_record(args, batch, per, S, dev, insitu, extra, L, np):
         t_s = insitu["device_us"] * 1e-6
         traffic, traffic_src = committed_traffic(args.workload, per)
         return {"bound": "hbm", "kernel": "fdm_fast_kernel<NCOL, MtM>", "achieved": alg / t_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t_s / 1e9 / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_live": False, "frac_traffic": (traffic / t_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "frac_single_pass": 0.5 * alg / t_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_live": False, "frac_traffic": (traffic / t_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "avg_launch_us": insitu["device_us"], "duration_source": "timed region, device clock", "launches_sampled": insitu["device_n"], "event_pair_avg_us": insitu["event_us"],
                 "algorithmic_bytes_per_launch": alg, "systems_per_launch": per, "concurrent_streams": S}
     a, b = h.vec_alloc(), h.vec_alloc()
@@ -278,7 +395,7 @@ def roofline_record(args, batch, per, S, dev, insitu, extra, L, np):
         gbs = bytes_ / sec / 1e9
         return {"GBs": gbs, "frac": gbs / HBM_PEAK_GBS, "frac_of_copy_ceiling": gbs / copy["GBs"]}
 
-    isolated = {"avg_launch_us": iso_s * 1e6, "launches": args.matvec_reps, "algorithmic": fr(alg, iso_s), "traffic": fr(traffic, iso_s) if traffic else None,
+    isolated = {"avg_launch_us": iso_s * 1e6, "launches": args.matvec_reps, "algorithmic": fr(alg, iso_s), "single_pass": fr(0.5 * alg, iso_s), "traffic": fr(traffic, iso_s) if traffic else None,
                 "note": "back-to-back launches of the kernel alone on the handle's stream, HIP events around all of them; 16 systems (64 MiB in + out + fields) sit in the Infinity Cache"}
     timed_s = insitu["device_us"] * 1e-6 if insitu["device_us"] else None
     prim_s, prim_src = (timed_s, "timed region, device clock") if timed_s else (iso_s, "isolated leg (no timed region in this run)")
@@ -289,6 +406,8 @@ def roofline_record(args, batch, per, S, dev, insitu, extra, L, np):
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": alg / prim_s / 1e9 / HBM_PEAK_GBS,
+        "achieved_is": "algorithmic bytes (SURVEY.md §8(d): two passes counted for MᵀM although the kernel is fused) / launch duration; the physical readings are frac_single_pass and frac_traffic",
+        "frac_single_pass": 0.5 * alg / prim_s / 1e9 / HBM_PEAK_GBS,
         "traffic": traffic,
         "traffic_source": traffic_src,
         "traffic_measured_live": False,
@@ -309,8 +428,9 @@ def roofline_record(args, batch, per, S, dev, insitu, extra, L, np):
         },
         "isolated": isolated,
         "copy_ceiling": copy,
-        "note": "frac = algorithmic bytes (two passes counted for the fused kernel) over the in-run duration; frac_traffic = bytes really moved beyond L2 over the same duration; "
-                "at 16 systems per launch the working set is Infinity-Cache resident, the HBM-resident figure is batch_scan's 64-system point",
+        "note": "frac = algorithmic bytes (two passes counted for the fused kernel) over the in-run duration; frac_single_pass = one pass (2S+F per system), the least the fused kernel "
+                "can move; frac_traffic = bytes really moved beyond L2 over the same duration; at 16 systems per launch the working set is Infinity-Cache resident, "
+                "the HBM-resident figure is batch_scan's 128-system point (hbm_resident_point)",
     }
     # GB/s versus batch size (SURVEY.md §8(d) latency caveat), always reported: heuristic tau chunk, 200 launches per point
     scan = []
@@ -331,6 +451,7 @@ def roofline_record(args, batch, per, S, dev, insitu, extra, L, np):
             hb.call("smoqy_get_tau_chunk", L.C.byref(tcv))
             tr, _ = committed_traffic(args.workload, nb)
             rec = {"batch": nb, "tau_chunk": tcv.value, "us": t_s * 1e6, "GBs": algb / t_s / 1e9, "frac": algb / t_s / 1e9 / HBM_PEAK_GBS,
+                   "frac_single_pass": 0.5 * algb / t_s / 1e9 / HBM_PEAK_GBS, "physical": algb / t_s / 1e9 <= HBM_PEAK_GBS,
                    "working_set_MiB": (2 * 16.0 * batch.Lt * batch.N * nb + nb * (8.0 * batch.Lt * batch.N + 16.0 * batch.Lt * batch.Nh)) / 2**20,
                    "traffic_GBs": (tr / t_s / 1e9) if tr else None, "frac_traffic": (tr / t_s / 1e9 / HBM_PEAK_GBS) if tr else None}
             rec["hbm_resident"] = rec["working_set_MiB"] > 256.0  # beyond the 256 MiB Infinity Cache
@@ -351,6 +472,14 @@ def main():
     if args.cpu_worker >= 0:  # CPU-only child of cpu_baseline(): never touches the GPU
         print(json.dumps(cpu_sample(args.workload, args.cpu_tol, args.cpu_nt, walker=args.cpu_worker)))
         return
+    if args.rank_worker >= 0:  # GPU child of procs_per_gpu_scan
+        rank_worker(args)
+        return
+    # the reference's rank-per-walker model on one GPU, measured first: this process has not touched the GPU yet, so the K children are
+    # the only processes on the card (N = 1 only; outside the timed region)
+    proc_scan = None
+    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not (args.no_proc_scan or args.roofline_only or args.timed_only)):
+        proc_scan = procs_per_gpu_scan(args, [int(k) for k in args.proc_scan.split(",") if k])
     import torch
     import torch.distributed as dist
 
@@ -387,8 +516,12 @@ def main():
     # measured slower on the Lτ = 80 / 100 / 200 lattices of BASELINE.json, whose launches are half a chip or less)
     from smoqyelphqmc_amd import lattice as _lat
     lat_Lt = _lat.CONFIGS[args.workload](walker=0).fpi.Ltau
+    # host threads of this rank: S stream threads + a small RNG pool per batch, bounded by the cores the rank can count on (a full node
+    # gives every rank available_cores() // world; one GPU box gives 16)
+    cores_rank = max(1, available_cores() // world)
+    rng_threads = max(1, min(max(2, 16 // S), cores_rank // S))
     batches = [WalkerBatch(args.workload, nwalkers=per, walker0=mine.start + s * per, device=dev, check_every=args.check_every or None, tau_chunk=args.tau_chunk or None,
-                           host_threads=max(2, 16 // S), measure_nrv=args.measure_nrv, device_efa=args.hmc == "device", cg_split=args.cg_split,
+                           host_threads=rng_threads, measure_nrv=args.measure_nrv, device_efa=args.hmc == "device", cg_split=args.cg_split,
                            tfft_in_place=(S > 1 and _only_factors(lat_Lt, (2, 3))) if args.tfft_form == "auto" else args.tfft_form == "in-place") for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
     batch = batches[0]
     if args.solve_concurrency > 0:
@@ -463,6 +596,14 @@ def main():
                 one_stream.append({"walkers_per_gpu": nw1, "streams": 1, "sweeps_per_s": nw1 * 1e3 / ms_one, "ms_per_sweep": ms_one})
             extra["single_walker"] = dict(one_stream[0], note="one walker on one stream: the launch-latency regime (4 dependent launches per CG iteration)")
             extra["one_stream"] = one_stream
+            if proc_scan is not None:
+                extra["procs_per_gpu_scan"] = {"model": "K processes ('MPI ranks', tutorials/holstein_honeycomb_mpi.jl:60-72), one single-walker handle each, sharing cuda:0; "
+                                                        "started together after a warm-up sweep; K <= 6 (the GPU pool's process guard)", "points": proc_scan}
+                try:
+                    extra["threads_per_gpu_scan"] = {"model": "K host threads in one process, one single-walker handle (own HIP stream) each",
+                                                     "points": threads_per_gpu_scan(args, [int(k) for k in args.thread_scan.split(",") if k], dev, mine.start)}
+                except Exception as ex:  # noqa: BLE001 — reported, never fatal to the bench line
+                    extra["threads_per_gpu_scan"] = {"error": str(ex)[:400]}
         # the CPU baseline is a rank-0, N = 1 measurement (it would only hold the other ranks at the final barrier)
         cpu = None if (args.no_cpu_baseline or args.roofline_only or args.timed_only or world > 1) else cpu_baseline(args.workload, batch.tol, batch.Nt)
         # the whole sweep against the roofline: algorithmic bytes of one preconditioned CG iteration per walker as SURVEY.md §8(d)
@@ -476,6 +617,17 @@ def main():
         extra["sweep_roofline"] = {"algorithmic_bytes_per_cg_iteration_per_walker": it_bytes, "achieved": sweep_gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS * world,
                                    "frac": sweep_gbs / (HBM_PEAK_GBS * world),
                                    "note": "CG iterations only (the solves are >85 % of the sweep); the fused kernels move 12 vectors per iteration where this count assumes 20S + 2F"}
+        # real bytes: one CG iteration of a 16-system batch moves `it_traffic` bytes beyond L2 (committed PMC pass); iterations per second
+        # come from this run
+        it_traffic, it_per_kernel, it_src = committed_iteration_traffic(args.workload)
+        if it_traffic and per == 16 and args.steps:
+            its_per_s = value * batch.solves_per_sweep * avg_iters / 16.0  # 16-system iterations per second over all streams and ranks
+            gbs = its_per_s * it_traffic / 1e9
+            copy_gbs = (roofline.get("copy_ceiling") or {}).get("GBs")
+            extra["cg_iteration_traffic"] = {"bytes_per_16_system_iteration": it_traffic, "per_kernel_bytes": it_per_kernel, "source": it_src, "measured_live": False,
+                                             "iterations_per_s_16_systems": its_per_s, "achieved": gbs, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * world),
+                                             "frac_of_copy_ceiling": (gbs / (copy_gbs * world)) if copy_gbs else None,
+                                             "note": "whole step, everything outside the CG loops counted as zero bytes: measured traffic of the four iteration kernels x the iterations all walkers ran per second"}
         out = {
             "metric": "QMC sweeps/sec (27 preconditioned CG solves per sweep) + FermionDetMatrix matvec GB/s vs HBM roofline, fp64",
             "value": value,
@@ -498,7 +650,7 @@ def main():
                 "cg_tol": batch.tol,
                 "avg_cg_iters": sum(b.stats.iters_sum for b in batches) / max(sum(b.stats.solves for b in batches), 1),
                 "preconditioner": "KPM (Sym)",
-                "tfft_form": ("in-place" if _only_factors_2_3(batch.Lt) else "two-image (in-place requested; Ltau has a factor 7)") if batch.tfft_in_place else "two-image",
+                "tfft_form": ("in-place" if _in_place_tfft_exists(batch.Lt) else "two-image (in-place requested; Ltau has a factor 7)") if batch.tfft_in_place else "two-image",
                 "hmc": ("EFA leapfrog on the device, Nt = %d steps of dt = pi/(2 Nt), trajectory always rejected (x restored) so the field distribution stays the one SURVEY.md 8(d) defines" % batch.Nt)
                 if args.hmc == "device" else "synthetic host-side drift (round-1 form)",
                 "parallelism": f"walker-parallel, {world} rank(s) x {wpg} walkers ({S} lock-step batches of {per}), no collective",

@@ -166,7 +166,9 @@ def as_state(a, Lt, N, count=1):
     want = Lt * N * count
     if a.size != want:
         raise ValueError(f"state vector has {a.size} elements, expected {want} (Ltau={Lt}, N={N}, count={count})")
-    if a.dtype == np.complex128 and (a.flags.f_contiguous or a.ndim == 1):
+    # f_contiguous only: a strided 1-D view (a[::2], a[::-1]) is NOT a valid boundary array — the library reads / writes Lτ·N contiguous
+    # elements from the first-element pointer; contiguous 1-D arrays are f_contiguous anyway
+    if a.dtype == np.complex128 and a.flags.f_contiguous:
         return a
     return np.asfortranarray(a, dtype=np.complex128)
 

@@ -366,8 +366,8 @@ def ldiv(*args, preconditioner=I, rng=None, maxiter=None, tol=None):
         if isinstance(up, np.ndarray) and up.dtype == np.float64:
             # the real-vector methods (KPMPreconditioner.jl:288-352, 417-485): the device evaluates the frequencies ω < cld(Lτ, 2),
             # mirrors them as complex conjugates (:334) and returns the real part of the back-transform (:344)
-            if not (up.flags.f_contiguous or up.ndim == 1) or up.size != h.Lt * h.N:
-                raise ValueError("output vector must be a float64 Fortran-contiguous (tau-fastest) array of Ltau*N elements")
+            if not up.flags.f_contiguous or not up.flags.writeable or up.size != h.Lt * h.N:  # strided views (a[::2], a[::-1]) are refused: the library writes Lτ·N contiguous doubles
+                raise ValueError("output vector must be a writable float64 Fortran-contiguous (tau-fastest) array of Ltau*N elements")
             uin = np.asfortranarray(np.asarray(u, dtype=np.float64))
             h.call("smoqy_precond_apply_real", L.ptr(up), L.ptr(uin), 0, 1)
             return None

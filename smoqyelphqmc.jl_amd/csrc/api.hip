@@ -74,6 +74,10 @@ struct smoqy_ctx {
     std::vector<double2 *> vecs;
     // scratch
     double2 *d_stage = nullptr;     // nsys vectors in host layout
+    // page-locked bounce arena for SMALL transfers whose host side is caller memory of unknown kind or a library temporary (pin_h2d /
+    // pin_d2h): several handle threads never drive the runtime's own pageable-copy path at once
+    char *h_pin = nullptr;
+    size_t pin_cap = 0, pin_cur = 0;
     double *d_stage_real = nullptr; // max(N,Nh,Nph?) * Lt doubles (+ growth on demand)
     size_t stage_real_cap = 0;
     int *d_stage_int = nullptr;
@@ -318,6 +322,51 @@ static int ensure_stage_int(smoqy_ctx *c, size_t n)
     return 0;
 }
 
+// Small host -> device transfer through the handle's page-locked arena: the bytes are copied out of `src` before the call returns (the
+// caller's buffer may be a temporary), the device copy is asynchronous on the handle's stream.  When the arena is full the stream is
+// drained first — every earlier copy out of it has then landed — and the arena is reused from its start.
+static int pin_reserve(smoqy_ctx *c, size_t bytes, char **slot)
+{
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (c->pin_cur + need > c->pin_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->pin_cur = 0;
+        if (need > c->pin_cap) {
+            if (c->h_pin) (void)hipHostFree(c->h_pin);
+            c->h_pin = nullptr;
+            c->pin_cap = 0;
+            const size_t cap = std::max(need, (size_t)1 << 20);
+            HIPCHK(c, hipHostMalloc((void **)&c->h_pin, cap, hipHostMallocDefault));
+            c->pin_cap = cap;
+        }
+    }
+    *slot = c->h_pin + c->pin_cur;
+    c->pin_cur += need;
+    return 0;
+}
+
+static int pin_h2d(smoqy_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return 0;
+    char *slot = nullptr;
+    if (int rc = pin_reserve(c, bytes, &slot)) return rc;
+    std::memcpy(slot, src, bytes);
+    HIPCHK(c, hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+// small device -> host transfer into caller memory: lands in the arena, the stream is synchronised, then a plain memcpy
+static int pin_d2h(smoqy_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return 0;
+    char *slot = nullptr;
+    if (int rc = pin_reserve(c, bytes, &slot)) return rc;
+    HIPCHK(c, hipMemcpyAsync(slot, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(dst, slot, bytes);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -341,6 +390,8 @@ int smoqy_destroy(smoqy_ctx *c)
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto ps : c->part_stream)
+        if (ps) (void)hipStreamSynchronize(ps);  // a solve that failed in mid-burst may have left kernels queued there: nothing is freed under them
     for (auto &gph : c->graphs) {
         if (gph.exec) (void)hipGraphExecDestroy(gph.exec);
         if (gph.graph) (void)hipGraphDestroy(gph.graph);
@@ -358,6 +409,7 @@ int smoqy_destroy(smoqy_ctx *c)
     for (double2 *v : c->vecs)
         if (v) (void)hipFree(v);
     if (c->h_st) (void)hipHostFree(c->h_st);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_poll_dot) (void)hipHostFree(c->h_poll_dot);
     if (c->h_lan) (void)hipHostFree(c->h_lan);
     if (c->force.h_out) (void)hipHostFree(c->force.h_out);
@@ -387,18 +439,29 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     hipDeviceProp_t prop;
     HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) FAIL(c, 4, "this library is built for gfx950 (MI355X) only; device %d is %s", c->device, prop.gcnArchName);
-    static std::once_flag cfg_once;
-    static hipError_t cfg_err = hipSuccess;
-    static const char *cfg_what = "";
-    std::call_once(cfg_once, [] {
-        hipError_t (*cfgs[])(const char **) = {configure_fdm_kernels, configure_kpm_kernels, configure_tfft_kernels, configure_force_kernels};
-        for (auto f : cfgs) {
-            const char *w = "";
-            const hipError_t e = f(&w);
-            if (e != hipSuccess && cfg_err == hipSuccess) { cfg_err = e; cfg_what = w; }
+    {   // hipFuncSetAttribute applies to the CURRENT device only: one configuration pass (and one remembered error) per device ordinal,
+        // made with that device current — a handle on a second GPU of the process gets the raised dynamic-LDS limit too
+        constexpr int kMaxDev = 64;
+        static std::mutex cfg_mu;
+        static bool cfg_done[kMaxDev] = {};
+        static hipError_t cfg_err[kMaxDev] = {};
+        static const char *cfg_what[kMaxDev] = {};
+        if (c->device < 0 || c->device >= kMaxDev) FAIL(c, 1, "device ordinal %d out of range", c->device);
+        std::lock_guard<std::mutex> lk(cfg_mu);
+        if (!cfg_done[c->device]) {
+            cfg_err[c->device] = hipSuccess;
+            cfg_what[c->device] = "";
+            hipError_t (*cfgs[])(const char **) = {configure_fdm_kernels, configure_kpm_kernels, configure_tfft_kernels, configure_force_kernels};
+            for (auto f : cfgs) {
+                const char *w = "";
+                const hipError_t e = f(&w);
+                if (e != hipSuccess && cfg_err[c->device] == hipSuccess) { cfg_err[c->device] = e; cfg_what[c->device] = w; }
+            }
+            cfg_done[c->device] = true;
         }
-    });
-    if (cfg_err != hipSuccess) FAIL(c, 2, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for %s: %s", cfg_what, hipGetErrorString(cfg_err));
+        if (cfg_err[c->device] != hipSuccess)
+            FAIL(c, 2, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for %s on device %d: %s", cfg_what[c->device], c->device, hipGetErrorString(cfg_err[c->device]));
+    }
     HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -813,8 +876,7 @@ static int update_pi_range(smoqy_ctx *c, int w0, int nw, const double *V, const 
             p0[h] = (int)perm[h] - 1;
         }
         HIPCHK(c, hipMemcpyAsync(dT, t, (size_t)nw * nT * tw * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_stage_int, p0.data(), p0.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));  // p0 is a temporary
+        if (int rc = pin_h2d(c, c->d_stage_int, p0.data(), p0.size() * sizeof(int))) return rc;  // p0 is a temporary: through the page-locked arena
     }
     const bool do_t = t && nT;
     if (g.is_cplx) {
@@ -963,8 +1025,7 @@ int smoqy_vec_dot(smoqy_ctx *c, int a, int b, void *out)
     if (int rc = check_vec(c, b)) return rc;
     const Geometry &g = c->g;
     launch_dot(c->stream, c->vecs[a], c->vecs[b], c->part_c, c->d_dot_out, g.Lt, g.N, g.nsys, c->Tc, c->nchunk);
-    HIPCHK(c, hipMemcpyAsync(out, c->d_dot_out, (size_t)g.nsys * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int rc = pin_d2h(c, out, c->d_dot_out, (size_t)g.nsys * sizeof(double2))) return rc;
     return check_launch(c, "vec_dot");
 }
 
@@ -1088,10 +1149,10 @@ static int lambda_update_range(smoqy_ctx *c, int w0, int nw, const double *x, in
     if (nx && c->force.set && c->force.Nph == Nph)
         HIPCHK(c, hipMemcpyAsync(c->force.d_x + (size_t)w0 * g.Lt * Nph, c->d_stage_real, nx * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     if (ncoup) {
-        HIPCHK(c, hipMemcpyAsync(c->d_stage_real + nx, alpha, (size_t)ncoup * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_stage_real + nx + ncoup, alpha3, (size_t)ncoup * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (int rc = pin_h2d(c, c->d_stage_real + nx, alpha, (size_t)ncoup * sizeof(double))) return rc;
+        if (int rc = pin_h2d(c, c->d_stage_real + nx + ncoup, alpha3, (size_t)ncoup * sizeof(double))) return rc;
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_stage_int, ib.data(), ib.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (int rc = pin_h2d(c, c->d_stage_int, ib.data(), ib.size() * sizeof(int))) return rc;
     launch_lambda_update(c->stream, c->d_lam + (size_t)w0 * g.Lt * g.N, nw * g.Lt, g.N, c->d_stage_real, Nph, dtau, ncoup, c->d_stage_int, c->d_stage_int + ncoup, c->d_stage_real + nx, c->d_stage_real + nx + ncoup,
                          c->d_stage_int + 2 * ncoup, c->d_stage_int + 4 * (size_t)ncoup, c->d_stage_int + 3 * (size_t)ncoup, g.Lt);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1283,11 +1344,11 @@ static int upload_precond(smoqy_ctx *c, int w)
     for (int s = 0; s < c->nslot; ++s)
         for (size_t k = 0; k < p.coefs[s].size(); ++k) tab[(size_t)s * c->maxorder + k] = p.coefs[s][k];
     const double bnd[2] = {p.emin, p.emax};
-    HIPCHK(c, hipMemcpyAsync(c->d_coefs + (size_t)w * c->nslot * c->maxorder, tab.data(), tab.size() * sizeof(double2), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_order + (size_t)w * c->nslot, p.order.data(), (size_t)c->nslot * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_bounds + 2 * (size_t)w, bnd, sizeof(bnd), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_active + w, &p.active, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // host buffers above are temporaries
+    // the host sides are temporaries (a local table, a stack pair, members of a vector that may be reallocated): through the page-locked arena
+    if (int rc = pin_h2d(c, c->d_coefs + (size_t)w * c->nslot * c->maxorder, tab.data(), tab.size() * sizeof(double2))) return rc;
+    if (int rc = pin_h2d(c, c->d_order + (size_t)w * c->nslot, p.order.data(), (size_t)c->nslot * sizeof(int))) return rc;
+    if (int rc = pin_h2d(c, c->d_bounds + 2 * (size_t)w, bnd, sizeof(bnd))) return rc;
+    if (int rc = pin_h2d(c, c->d_active + w, &p.active, sizeof(int))) return rc;
     {   // how many leading ranks (rank 2s and 2s+1 share slot s, KPMPreconditioner.jl:387) carry a chain on at least one walker: the light
         // workgroups of cheb_own_kernel take everything behind them.  A captured CG graph holds the old count.
         int last = -1;
@@ -1342,7 +1403,7 @@ static int precond_update_range(smoqy_ctx *c, int w0, int nw, const double *rand
     // update_B̄! :604-621
     launch_tau_means(c->stream, c->kg, c->d_expV, c->d_ch, c->d_sh, c->d_dbar, c->d_cbar, c->d_sbar, g.Lt, g.N, g.Nh, w0, nw, c->d_shi, c->d_sbari);
     // calculate_bounds! :625-658 (start vectors drawn by the caller's rng at :634 / :652)
-    HIPCHK(c, hipMemcpyAsync(c->d_rand, randvecs, (size_t)nw * g.N * (g.is_cplx ? 2 : 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));  // complex T: N complex deviates per walker (:634)
+    if (int rc = pin_h2d(c, c->d_rand, randvecs, (size_t)nw * g.N * (g.is_cplx ? 2 : 1) * sizeof(double))) return rc;  // complex T: N complex deviates per walker (:634); the caller's array may be pageable
     KpmArgs k = kpm_args(c, nullptr, nullptr);
     launch_lanczos(c->stream, k, c->kg, w0, nw, c->d_rand, n, c->d_lan, c->d_lan + (size_t)g.nw * 1024, !g.is_sym);
     HIPCHK(c, hipMemcpy2DAsync(c->h_lan, 1024 * sizeof(double), c->d_lan, 1024 * sizeof(double), (size_t)n * sizeof(double), (size_t)nw, hipMemcpyDeviceToHost, c->stream));
@@ -1375,8 +1436,7 @@ static int precond_update_range(smoqy_ctx *c, int w0, int nw, const double *rand
         if (changed) {
             if (int rc = upload_precond(c, w)) return rc;
         } else if (p.active != was_active) {
-            HIPCHK(c, hipMemcpyAsync(c->d_active + w, &p.active, sizeof(int), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (int rc = pin_h2d(c, c->d_active + w, &p.active, sizeof(int))) return rc;
         }
     }
     return 0;
@@ -1786,7 +1846,12 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
             for (int it = 0; it < burst; ++it)
                 for (int q = 0; q < nparts; ++q) {
                     const int s0 = (int)((long)g.nsys * q / nparts), s1 = (int)((long)g.nsys * (q + 1) / nparts);
-                    if (int rc = cg_iteration_fused(c, a, q == 0 ? c->stream : c->part_stream[q - 1], s0, s1 - s0)) return rc;
+                    if (int rc = cg_iteration_fused(c, a, q == 0 ? c->stream : c->part_stream[q - 1], s0, s1 - s0)) {
+                        // the part streams may still hold queued kernels that touch cg_r / cg_p / cg_z and the partial sums: drain them before
+                        // the caller sees the error and reuses (or frees) those buffers on c->stream
+                        for (int qq = 1; qq < nparts; ++qq) (void)hipStreamSynchronize(c->part_stream[qq - 1]);
+                        return rc;
+                    }
                 }
             for (int q = 1; q < nparts; ++q) {
                 HIPCHK(c, hipEventRecord(c->ev_part[q - 1], c->part_stream[q - 1]));
@@ -2552,8 +2617,7 @@ int smoqy_ge_boundary_dot(smoqy_ctx *c, int gr, int r, int orbital_gr, int orbit
     launch_ge_boundary(c->stream, c->vecs[gr], c->vecs[r], G.bpart, G.bout, g.Lt, g.N, g.nsys, g.nrhs, G.n_orb, orbital_gr - 1, orbital_r - 1, G.Nc, G.Ld[0], G.Ld[1], (int)(shift[0] % G.Ld[0]),
                        G.D > 1 ? (int)(shift[1] % G.Ld[1]) : 0, tD ? G.tw[0] : nullptr, conj_tD, tD ? (int)(tshift[0] % G.Ld[0]) : 0, (tD && G.D > 1) ? (int)(tshift[1] % G.Ld[1]) : 0,
                        tD ? G.tw[1] : nullptr, conj_t0, 64, scale);
-    HIPCHK(c, hipMemcpyAsync(out, G.bout, (size_t)g.nw * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int rc = pin_d2h(c, out, G.bout, (size_t)g.nw * sizeof(double2))) return rc;
     return check_launch(c, "ge_boundary_dot");
 }
 

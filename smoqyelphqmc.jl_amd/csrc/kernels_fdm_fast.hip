@@ -594,8 +594,7 @@ template <int NCOL, bool CSV>
 void launch_ncol(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff)
 {
     const dim3 grid((unsigned)(a.nchunk * a.sys_count)), block((unsigned)ff.threads);
-    static size_t pad = [] { const char *e = getenv("SMOQY_FDM_PAD_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();  // occupancy experiment
-    const size_t lds = sizeof(double2) * (size_t)a.N * (size_t)(a.Tc + 1) + pad;
+    const size_t lds = sizeof(double2) * (size_t)a.N * (size_t)(a.Tc + 1);
     switch (op) {
         case SMOQY_OP_M: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_M, CSV>), grid, block, lds, st, a, ff); break;
         case SMOQY_OP_MT: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MT, CSV>), grid, block, lds, st, a, ff); break;

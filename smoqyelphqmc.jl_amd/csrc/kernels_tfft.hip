@@ -642,10 +642,9 @@ hipError_t configure_tfft_kernels(const char **what)
 
 void launch_tfft(hipStream_t st, int mode, const TfftArgs &a)
 {
-    static size_t pad = [] { const char *e = getenv("SMOQY_TFFT_PAD_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();  // occupancy experiment
     const dim3 grid((unsigned)(a.ntile * (a.sys_count > 0 ? a.sys_count : a.nsys))), block(256);
     if (a.slim && a.pos) {
-        const size_t lds = ((size_t)a.Lt * a.SB + a.Lt) * sizeof(double2) + (size_t)a.Lt * sizeof(int) + pad;
+        const size_t lds = ((size_t)a.Lt * a.SB + a.Lt) * sizeof(double2) + (size_t)a.Lt * sizeof(int);
         switch (mode) {
             case 0: hipLaunchKernelGGL((tfft_kernel<0, true>), grid, block, lds, st, a); break;
             case 1: hipLaunchKernelGGL((tfft_kernel<1, true>), grid, block, lds, st, a); break;
@@ -654,7 +653,7 @@ void launch_tfft(hipStream_t st, int mode, const TfftArgs &a)
         }
         return;
     }
-    const size_t lds = (2 * (size_t)a.Lt * a.SB + a.Lt) * sizeof(double2) + pad;
+    const size_t lds = (2 * (size_t)a.Lt * a.SB + a.Lt) * sizeof(double2);
     switch (mode) {
         case 0: hipLaunchKernelGGL((tfft_kernel<0, false>), grid, block, lds, st, a); break;
         case 1: hipLaunchKernelGGL((tfft_kernel<1, false>), grid, block, lds, st, a); break;

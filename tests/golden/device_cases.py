@@ -17,7 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 JSON_PATH = os.path.join(HERE, "device_cg_iterations.json")
 
-BENCH_SHAPES = [("holstein_honeycomb_L16_Ltau128", 16), ("holstein_honeycomb_L16_Ltau128", 8), ("ossh_square_L12_Ltau100", 16), ("bssh_chain_L256_Ltau200", 16)]
+BENCH_SHAPES = [("holstein_honeycomb_L16_Ltau128", 16), ("holstein_honeycomb_L16_Ltau128", 8), ("ossh_square_L12_Ltau100", 16), ("bssh_chain_L256_Ltau200", 16),
+                ("ossh_square_L12_Ltau100_alpha0p2", 16), ("bssh_chain_L256_Ltau200_alpha0p2", 16)]
 
 
 def compute(with_oracle=False):
