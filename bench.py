@@ -317,7 +317,8 @@ def committed_iteration_traffic(workload):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_iteration.json")), reverse=True):
         try:
             pmc = json.load(open(path))
-            per_kernel = {k.split("smoqy::")[-1].split("(")[0].replace("(anonymous namespace)::", ""): v["traffic_MB"] * 2**20 for k, v in pmc.items() if isinstance(v, dict) and "traffic_MB" in v}
+            per_kernel = {k.replace("void ", "").replace("smoqy::", "").replace("(anonymous namespace)::", "").split("(")[0]: v["traffic_MB"] * 2**20
+                          for k, v in pmc.items() if isinstance(v, dict) and "traffic_MB" in v}
         except (OSError, ValueError, KeyError):
             continue
         if per_kernel:

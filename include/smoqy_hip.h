@@ -107,6 +107,12 @@ int smoqy_vec_dot(smoqy_ctx *ctx, int a, int b, void *out);
 int smoqy_matvec_v(smoqy_ctx *ctx, int op, int out, int in);
 /* testing aid: route the applies through the generic kernels (any colouring / Asym path) */
 int smoqy_matvec_force_generic(smoqy_ctx *ctx, int on);
+/* kernel choice for mul_MtM! (src/FermionDetMatrix.jl:329-340) on Sym handles with real hoppings: run_len = 0 keeps one workgroup per τ-chunk;
+ * run_len >= 2 makes every workgroup walk a run of that many time slices with its loads two slices ahead of the stage chain
+ * (fdm_stream_kernel); run_len = -1 (the default) lets the library choose: streaming from 16 systems per launch, run length by launch
+ * size.  Same stage order per site (outputs equal to rounding, FMA contraction aside); the p·Ap partial is formed as |M p|² instead of
+ * p·(MᵀM p) (equal up to rounding, real and non-negative by construction). */
+int smoqy_matvec_stream(smoqy_ctx *ctx, int run_len);
 /* host form: `count` vectors starting at system sys0 (fields of walker sys/nrhs); out == in allowed */
 int smoqy_matvec(smoqy_ctx *ctx, int op, void *out, const void *in, int sys0, int count);
 

@@ -66,6 +66,7 @@ SIGNATURES = {
     "smoqy_vec_dot": [_p, _i, _i, _p],
     "smoqy_matvec_v": [_p, _i, _i, _i],
     "smoqy_matvec_force_generic": [_p, _i],
+    "smoqy_matvec_stream": [_p, _i],
     "smoqy_matvec": [_p, _i, _p, _p, _i, _i],
     "smoqy_checkerboard_v": [_p, _i, _i, _i, _i, _i],
     "smoqy_checkerboard": [_p, _p, _i, _i, _i, _i, _i, _i],

@@ -133,6 +133,7 @@ struct smoqy_ctx {
     FdmFast ff{};
     double2 *d_csf = nullptr;
     int *d_cs_varies = nullptr;
+    int stream_R = -1;   // run length of the streaming MᵀM kernel: -1 automatic, 0 = chunked kernels only, >= 2 forced; smoqy_matvec_stream
     int cheb_heavy = 0;  // Sym cheb_own_kernel: number of leading frequency ranks with a multi-term expansion on any walker (upload_precond keeps it)
     std::vector<char> cs_const;  // [nw] 1 once the HOST has shown a walker's hoppings to be τ-independent (selects the one-pair-per-colour MᵀM kernel); 0 = unknown
     int2 *d_pbonds = nullptr, *d_psites = nullptr;
@@ -140,6 +141,12 @@ struct smoqy_ctx {
     int *d_poff = nullptr, *d_psrc = nullptr, *d_own = nullptr, *d_own_f = nullptr;
     double2 *d_pcs = nullptr;
     double *h_lan = nullptr;  // pinned [nw][2][1024]
+    // device-resident bookkeeping of update_preconditioner! (PreUpd, kernels_kpm.hip): the host reads a 16-byte status record per
+    // walker, and waits for it only where it needs what it says (the launch geometry of the Chebyshev kernel), with other work queued
+    int *d_rebuild = nullptr, *d_pstat = nullptr, *h_pstat = nullptr;  // h_pstat pinned [nw][4]
+    hipEvent_t ev_pstat = nullptr;
+    bool pstat_pending = false;
+    bool mirrors_stale = false;  // host copies of order / coefs / Lanczos coefficients are older than the device's (refreshed on demand by smoqy_precond_get*)
     // force terms
     struct ForceState {
         bool set = false;
@@ -412,6 +419,10 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_poll_dot) (void)hipHostFree(c->h_poll_dot);
     if (c->h_lan) (void)hipHostFree(c->h_lan);
+    if (c->h_pstat) (void)hipHostFree(c->h_pstat);
+    if (c->d_rebuild) (void)hipFree(c->d_rebuild);
+    if (c->d_pstat) (void)hipFree(c->d_pstat);
+    if (c->ev_pstat) (void)hipEventDestroy(c->ev_pstat);
     if (c->force.h_out) (void)hipHostFree(c->force.h_out);
     if (c->force.h_part) (void)hipHostFree(c->force.h_part);
     for (void *q : {c->force.blob, (void *)c->force.d_x, (void *)c->force.d_contrib, (void *)c->force.d_out, (void *)c->force.d_bare, (void *)c->force.d_p, (void *)c->force.d_x0, (void *)c->force.d_q,
@@ -432,6 +443,15 @@ int smoqy_destroy(smoqy_ctx *c)
 static int set_part_streams(smoqy_ctx *c, int nparts);
 static int auto_parts(const smoqy_ctx *c);
 
+// Stride of the per-slot coefficient table: the largest expansion order an ACTIVE preconditioner can ask for.  order = ⌊(ϵmax − ϵmin)(a1/ϕ + a2)⌋
+// (KPMPreconditioner.jl:711) with 0 < ϵmin < 1 < ϵmax < 2 (:573) and ϕ ≥ π/Lτ (:220, folded :710), so order < 2 (a1 Lτ/π + a2).  Sizing the
+// table for it once means the device can accept new bounds without the host growing anything (at Lτ = 128: 165 entries per slot).
+static int coef_table_stride(const smoqy_ctx *c)
+{
+    const double a1 = c->g.is_sym ? 2.0 * c->a1 : c->a1;  // :263
+    return (int)std::floor(2.0 * (a1 * c->g.Lt / M_PI + c->a2)) + 2;
+}
+
 static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
 {
     const Geometry &g = c->g;
@@ -451,7 +471,7 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
         if (!cfg_done[c->device]) {
             cfg_err[c->device] = hipSuccess;
             cfg_what[c->device] = "";
-            hipError_t (*cfgs[])(const char **) = {configure_fdm_kernels, configure_kpm_kernels, configure_tfft_kernels, configure_force_kernels};
+            hipError_t (*cfgs[])(const char **) = {configure_fdm_kernels, configure_fdm_stream_kernels, configure_kpm_kernels, configure_tfft_kernels, configure_force_kernels};
             for (auto f : cfgs) {
                 const char *w = "";
                 const hipError_t e = f(&w);
@@ -683,6 +703,23 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
             const int q_cheb = g.ncol >= 3 ? 1 : 0, q_fdm = g.ncol >= 2 ? 1 : 0;
             if (int rc = build_own(q_cheb, &c->d_own, &c->kg.own_n)) return rc;
             c->kg.own = c->d_own; c->kg.own_q = q_cheb;
+            {   // is the colour-0 exchange of the Chebyshev lane program wave-local (KpmGeom::wl0)?  Lane j holds site b.x in slot j and b.y
+                // in slot T + j; the mate of b.x must sit in a second slot and the mate of b.y in a first slot of the same 64-lane wavefront
+                const int nb = poff[q_cheb + 1] - poff[q_cheb];
+                std::vector<int> slot((size_t)g.N, 0);
+                for (int j = 0; j < nb; ++j) {
+                    const int2 b = pb[(size_t)poff[q_cheb] + j];
+                    slot[b.x] = j;
+                    if (b.y != b.x) slot[b.y] = T + j;
+                }
+                bool ok = g.ncol >= 3;
+                for (int j = 0; j < nb && ok; ++j) {
+                    const int2 b = pb[(size_t)poff[q_cheb] + j];
+                    const int sx = slot[mate[0][b.x]], sy = slot[mate[0][b.y]];
+                    ok = sx >= T && (sx - T) / 64 == j / 64 && sy < T && sy / 64 == j / 64;
+                }
+                c->kg.wl0 = ok ? 1 : 0;
+            }
             if (q_fdm == q_cheb) { c->d_own_f = c->d_own; c->ff.own_n = c->kg.own_n; }
             else if (int rc = build_own(q_fdm, &c->d_own_f, &c->ff.own_n)) return rc;
             c->ff.own = c->d_own_f;
@@ -696,13 +733,29 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
         c->ff.psites = c->d_psites; c->ff.pos = c->d_pos;
         c->ff.pbonds = c->d_pbonds; c->ff.poff = c->d_poff; c->ff.csf = c->d_csf; c->ff.ptotal = c->kg.ptotal; c->ff.threads = c->kg.threads;
         c->ff.enabled = (!g.is_cplx && g.ncol >= 1 && g.ncol <= kFdmColours && maxp <= 1024) ? 1 : 0;  // Sym: fdm_fast/own kernels; Asym: fdm_fast_asym_kernel
+        {   // FdmFast::full: no padded self bond anywhere and every list exactly one bond per lane
+            bool full = g.ncol >= 1 && g.N == 2 * c->kg.threads;
+            for (int col = 0; col < g.ncol && full; ++col) full = poff[col + 1] - poff[col] == c->kg.threads;
+            for (size_t k = 0; k < psrc.size() && full; ++k) full = psrc[k] >= 0;
+            c->ff.full = full ? 1 : 0;
+        }
         choose_chunking(c);
     }
     HIPCHK(c, hipMalloc(&c->d_order, (size_t)g.nw * c->nslot * sizeof(int)));
     HIPCHK(c, hipMalloc(&c->d_active, (size_t)g.nw * sizeof(int)));
     HIPCHK(c, hipMemset(c->d_active, 0, (size_t)g.nw * sizeof(int)));
     HIPCHK(c, hipMemset(c->d_order, 0, (size_t)g.nw * c->nslot * sizeof(int)));
+    c->maxorder = std::max(c->maxorder, coef_table_stride(c));
     HIPCHK(c, hipMalloc(&c->d_coefs, (size_t)g.nw * c->nslot * c->maxorder * sizeof(double2)));
+    HIPCHK(c, hipMemset(c->d_coefs, 0, (size_t)g.nw * c->nslot * c->maxorder * sizeof(double2)));
+    HIPCHK(c, hipMemset(c->d_bounds, 0, (size_t)g.nw * 2 * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_rebuild, (size_t)g.nw * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->d_pstat, (size_t)g.nw * 4 * sizeof(int)));
+    HIPCHK(c, hipMemset(c->d_rebuild, 0, (size_t)g.nw * sizeof(int)));
+    HIPCHK(c, hipMemset(c->d_pstat, 0, (size_t)g.nw * 4 * sizeof(int)));
+    HIPCHK(c, hipHostMalloc((void **)&c->h_pstat, (size_t)g.nw * 4 * sizeof(int), hipHostMallocDefault));
+    std::memset(c->h_pstat, 0, (size_t)g.nw * 4 * sizeof(int));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_pstat, hipEventDisableTiming));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_launch(c, "create");
 }
@@ -1031,6 +1084,31 @@ int smoqy_vec_dot(smoqy_ctx *c, int a, int b, void *out)
 
 // ---- matvec -------------------------------------------------------------------------------------
 
+// Run length (output slices per workgroup) of the streaming MᵀM kernel for a launch over `count` systems, 0 = use the chunked kernels.
+// SMOQY_FDM_STREAM=R forces R (0 switches the kernel off) for A/B measurements.
+static int stream_run_length(const smoqy_ctx *c, int count, bool cs_const)
+{
+    static const int env = [] { const char *e = getenv("SMOQY_FDM_STREAM"); return e ? atoi(e) : -1; }();
+    const Geometry &g = c->g;
+    if (!g.is_sym || g.is_cplx || !c->ff.enabled || c->d_big) return 0;
+    if (!cs_const && g.ncol >= 3) return 0;  // τ-dependent hoppings on three or more colours: the field registers of two slices do not fit beside the pipeline
+    int R = env;
+    if (R < 0) R = c->stream_R;
+    if (R < 0) {
+        // automatic (measured on MI355X): from 16 systems per launch the streaming kernel wins (16 systems 17.0 -> 14.1 µs,
+        // 128 systems 116.7 -> 75.4 µs); at 8 and fewer the owner-computes kernel does.  Run length: about 512 workgroups of 256 lanes per
+        // launch, at least 4 slices (prologue + last iteration are two extra stage chains per run), at most 32.
+        if (count < 16) return 0;
+        const long want = (long)g.Lt * count * c->ff.threads / (512L * 256L);
+        R = 4;
+        while (2 * R <= want && R < 32) R *= 2;
+    }
+    if (R <= 0) return 0;
+    R = std::min(R, g.Lt);
+    R -= R % c->Tc;
+    return R >= 2 ? R : 0;
+}
+
 static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, double2 *partial, const CgState *cg, int sys0, int count, bool twiddled = false, hipStream_t st = nullptr)
 {
     if (!st) st = c->stream;
@@ -1047,15 +1125,28 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
         HIPCHK(c, hipEventRecord(T.ev[T.used].first, c->stream));
         if (T.d_stamp && T.used < T.stamp_cap && a.nchunk * a.sys_count <= T.stamp_wgs) a.stamp = T.d_stamp + 2 * (size_t)T.stamp_wgs * T.used;  // register-resident kernels only
     }
-    if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_own(st, op, a, c->ff);
-    else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) {
-        bool cs_const = c->g.is_sym != 0 && !c->cs_const.empty();
-        for (int w = sys0 / c->g.nrhs; cs_const && w <= (sys0 + count - 1) / c->g.nrhs; ++w) cs_const = c->cs_const[(size_t)w] != 0;
-        launch_fdm_fast(st, op, a, c->ff, c->g.is_sym != 0, cs_const);
-    }
+    bool cs_const = c->g.is_sym != 0 && !c->cs_const.empty();
+    for (int w = sys0 / c->g.nrhs; cs_const && w <= (sys0 + count - 1) / c->g.nrhs; ++w) cs_const = c->cs_const[(size_t)w] != 0;
+    // streaming MᵀM (fdm_stream_kernel): workgroups walk runs of slices with their loads two iterations ahead — for launches big enough that
+    // the chunked kernel's load-wait-compute workgroups leave the memory system idle
+    a.run_len = (op == SMOQY_OP_MTM && in != out) ? stream_run_length(c, count, cs_const) : 0;
+    if (a.run_len > 0 && fdm_stream_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_stream(st, a, c->ff, cs_const);
+    else if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_own(st, op, a, c->ff);
+    else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_fast(st, op, a, c->ff, c->g.is_sym != 0, cs_const);
     else launch_fdm(st, op, c->g.is_sym != 0, a, c->d_big ? 0 : fdm_lds_bytes(op, c->g.N, c->Tc));
     if (sample) HIPCHK(c, hipEventRecord(T.ev[T.used++].second, c->stream));
     return check_launch(c, "matvec");
+}
+
+// run length of the streaming MᵀM kernel: -1 = automatic (the default), 0 = chunked kernels only, R >= 2 = workgroups walk runs of R
+// slices (rounded down to a multiple of the τ-chunk)
+int smoqy_matvec_stream(smoqy_ctx *c, int run_len)
+{
+    CHECK_CTX(c);
+    if (run_len < -1) FAIL(c, 1, "run_len must be -1 (automatic), 0 (off) or >= 2");
+    c->stream_R = run_len;
+    drop_graphs(c);
+    return 0;
 }
 
 int smoqy_matvec_v(smoqy_ctx *c, int op, int out, int in)
@@ -1269,60 +1360,35 @@ int smoqy_precond_config(smoqy_ctx *c, double rbuf, int n_lanczos, double a1, do
     CHECK_CTX(c);
     if (n_lanczos < 2 || n_lanczos > 1024 || !(rbuf > 0) || !(a1 > 0) || !(a2 >= 0)) FAIL(c, 1, "invalid preconditioner configuration");
     c->rbuf = rbuf; c->nlanczos = n_lanczos; c->a1 = a1; c->a2 = a2;
+    // a1 / a2 set the largest order an active preconditioner can reach: resize the coefficient table and forget the expansions, so that the
+    // next update rebuilds them with the new parameters
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int stride = std::max(64, coef_table_stride(c));
+    if (stride != c->maxorder) {
+        drop_graphs(c);
+        HIPCHK(c, hipFree(c->d_coefs));
+        c->d_coefs = nullptr;
+        HIPCHK(c, hipMalloc(&c->d_coefs, (size_t)c->g.nw * c->nslot * stride * sizeof(double2)));
+        c->maxorder = stride;
+    }
+    HIPCHK(c, hipMemset(c->d_coefs, 0, (size_t)c->g.nw * c->nslot * c->maxorder * sizeof(double2)));
+    HIPCHK(c, hipMemset(c->d_bounds, 0, (size_t)c->g.nw * 2 * sizeof(double)));
+    HIPCHK(c, hipMemset(c->d_active, 0, (size_t)c->g.nw * sizeof(int)));
+    HIPCHK(c, hipMemset(c->d_order, 0, (size_t)c->g.nw * c->nslot * sizeof(int)));
+    HIPCHK(c, hipMemset(c->d_pstat, 0, (size_t)c->g.nw * 4 * sizeof(int)));
+    for (auto &p : c->pre) { p.active = 0; p.emin = p.emax = 0.0; std::fill(p.order.begin(), p.order.end(), 0); for (auto &v : p.coefs) v.clear(); }
+    c->pstat_pending = false;
+    c->mirrors_stale = false;
+    c->cheb_heavy = 0;
     return 0;
 }
 
-// extreme eigenvalues of the Lanczos tridiagonal matrix (eigmin/eigmax at KPMPreconditioner.jl:636)
-static int sturm(const double *a, const double *b, int n, double x)
-{
-    int cnt = 0;
-    double q = a[0] - x;
-    if (q < 0) ++cnt;
-    for (int i = 1; i < n; ++i) {
-        const double den = (std::fabs(q) < 1e-300) ? (q < 0 ? -1e-300 : 1e-300) : q;
-        q = a[i] - x - b[i - 1] * b[i - 1] / den;
-        if (q < 0) ++cnt;
-    }
-    return cnt;
-}
+static void pstat_consume(smoqy_ctx *c);
+static int pstat_wait(smoqy_ctx *c);
+static int refresh_mirrors(smoqy_ctx *c);
 
-static void tridiag_extremes(const double *a, const double *b, int n, double &emin, double &emax)
-{
-    double lo = a[0], hi = a[0];
-    for (int i = 0; i < n; ++i) {
-        const double r = (i > 0 ? std::fabs(b[i - 1]) : 0.0) + (i < n - 1 ? std::fabs(b[i]) : 0.0);
-        lo = std::min(lo, a[i] - r);
-        hi = std::max(hi, a[i] + r);
-    }
-    double l = lo, h = hi;
-    for (int it = 0; it < 64; ++it) { const double m = 0.5 * (l + h); if (sturm(a, b, n, m) >= 1) h = m; else l = m; }
-    emin = 0.5 * (l + h);
-    l = lo; h = hi;
-    for (int it = 0; it < 64; ++it) { const double m = 0.5 * (l + h); if (sturm(a, b, n, m) >= n) h = m; else l = m; }
-    emax = 0.5 * (l + h);
-}
-
-// kpm_coefs! (SmoQyKPMCore, restated): n Chebyshev coefficients of f on [emin, emax] from
-// Chebyshev-Gauss quadrature with 2n nodes (buffer of 2n at KPMPreconditioner.jl:749); no damping kernel.
-}  // extern "C" (templates need C++ linkage)
-template <typename F>
-static void kpm_coefs(std::vector<double> &out, int n, F f, double emin, double emax)
-{
-    const int M = 2 * n;
-    const double avg = 0.5 * (emax + emin), mag = 0.5 * (emax - emin);
-    std::vector<double> g((size_t)M), ctab((size_t)4 * M);
-    for (int m = 0; m < 4 * M; ++m) ctab[m] = std::cos(M_PI * m / (2.0 * M));  // cos(pi k (j+1/2)/M) = ctab[k(2j+1) mod 4M]
-    for (int j = 0; j < M; ++j) g[j] = f(avg + mag * ctab[2 * j + 1]);
-    out.assign((size_t)n, 0.0);
-    for (int k = 0; k < n; ++k) {
-        double acc = 0;
-        for (int j = 0; j < M; ++j) acc += g[j] * ctab[(size_t)((long long)k * (2 * j + 1) % (4 * M))];
-        out[k] = (k == 0 ? 1.0 : 2.0) * acc / M;
-    }
-}
-
-extern "C" {
-
+// host-supplied preconditioner state of one walker (smoqy_precond_set) -> device tables and status record
 static int upload_precond(smoqy_ctx *c, int w)
 {
     const WalkerPrecond &p = c->pre[w];
@@ -1349,96 +1415,110 @@ static int upload_precond(smoqy_ctx *c, int w)
     if (int rc = pin_h2d(c, c->d_order + (size_t)w * c->nslot, p.order.data(), (size_t)c->nslot * sizeof(int))) return rc;
     if (int rc = pin_h2d(c, c->d_bounds + 2 * (size_t)w, bnd, sizeof(bnd))) return rc;
     if (int rc = pin_h2d(c, c->d_active + w, &p.active, sizeof(int))) return rc;
-    {   // how many leading ranks (rank 2s and 2s+1 share slot s, KPMPreconditioner.jl:387) carry a chain on at least one walker: the light
-        // workgroups of cheb_own_kernel take everything behind them.  A captured CG graph holds the old count.
+    {   // this walker's status record, as the device bookkeeping would have written it: how many leading ranks (rank 2s and 2s+1 share
+        // slot s, KPMPreconditioner.jl:387; Asym: slots l and Lτ-1-l) carry a chain — the light workgroups of cheb_own_kernel take
+        // everything behind them
         int last = -1;
-        for (const WalkerPrecond &q : c->pre)
-            for (int sl = 0; sl < (int)q.order.size(); ++sl)
-                if (q.order[sl] > 1) last = std::max(last, sl);
-        const int heavy = std::min(c->g.Lt, 2 * (last + 1));
-        if (heavy != c->cheb_heavy) { c->cheb_heavy = heavy; drop_graphs(c); }
+        for (int sl = 0; sl < (int)p.order.size(); ++sl)
+            if (p.order[sl] > 1) last = std::max(last, c->g.is_sym ? sl : std::min(sl, c->g.Lt - 1 - sl));
+        int *st = c->h_pstat + 4 * (size_t)w;
+        st[0] += 1;
+        st[1] = std::min(c->g.Lt, 2 * (last + 1));
+        st[2] = need;
+        st[3] = p.active;
+        if (int rc = pin_h2d(c, c->d_pstat + 4 * (size_t)w, st, 4 * sizeof(int))) return rc;
+        const int zero = 0;
+        if (int rc = pin_h2d(c, c->d_rebuild + w, &zero, sizeof(int))) return rc;
+        pstat_consume(c);
     }
     return 0;
 }
 
-// update_kpm_expansion_order! (:696-731) + update_kpm_expansion_coefs! (:734-795)
-static void update_expansions(smoqy_ctx *c, WalkerPrecond &p)
+// the PreUpd argument of the Lanczos / expansion kernels (kernels_kpm.hip)
+static PreUpd pre_upd(smoqy_ctx *c)
 {
-    const int Lt = c->g.Lt, Lo2 = (Lt + 1) / 2;
-    const double a1 = c->g.is_sym ? 2.0 * c->a1 : c->a1;  // :263
-    for (int l = 0; l < c->nslot; ++l) {
-        double phi = 2.0 * M_PI / Lt * (l + 0.5);  // :220
-        if (phi > M_PI) phi = 2.0 * M_PI - phi;    // :710
-        int n = (int)std::floor((p.emax - p.emin) * (a1 / phi + c->a2));  // :711
-        n = std::max(n, 1);
-        p.order[l] = n;
-        p.coefs[l].assign((size_t)n, make_double2(0.0, 0.0));
-    }
-    std::vector<double> re, im;
-    for (int l = 0; l < Lo2; ++l) {
-        const int n = p.order[l];
-        const double phi = 2.0 * M_PI / Lt * (l + 0.5);
-        const double cp = std::cos(phi), sp = std::sin(phi);
-        if (c->g.is_sym) {
-            kpm_coefs(re, n, [cp](double b) { return 1.0 / (b * b - 2.0 * b * cp + 1.0); }, p.emin, p.emax);  // f_B̄_sym :800
-            for (int k = 0; k < n; ++k) p.coefs[l][k] = make_double2(re[k], 0.0);
-        } else {
-            // f_B̄_asym = 1/(1 - e^{-iφ} b) :804 -> (1 - b cosφ - i b sinφ) / ((1 - b cosφ)² + (b sinφ)²)
-            kpm_coefs(re, n, [cp, sp](double b) { const double x = 1.0 - b * cp, y = b * sp; return x / (x * x + y * y); }, p.emin, p.emax);
-            kpm_coefs(im, n, [cp, sp](double b) { const double x = 1.0 - b * cp, y = b * sp; return -y / (x * x + y * y); }, p.emin, p.emax);
-            for (int k = 0; k < n; ++k) {
-                p.coefs[l][k] = make_double2(re[k], im[k]);
-                p.coefs[Lt - l - 1][k] = make_double2(re[k], -im[k]);  // :791
-            }
-        }
-    }
+    PreUpd u{};
+    u.bounds = c->d_bounds; u.active = c->d_active; u.order = c->d_order; u.coefs = c->d_coefs; u.rebuild = c->d_rebuild; u.status = c->d_pstat;
+    u.rbuf = c->rbuf; u.a1 = c->g.is_sym ? 2.0 * c->a1 : c->a1; u.a2 = c->a2;  // :263
+    u.nslot = c->nslot; u.maxorder = c->maxorder; u.Lt = c->g.Lt; u.is_sym = c->g.is_sym;
+    return u;
 }
 
-// update_preconditioner! (:554-597) for walkers [w0, w0 + nw): one means launch, one Lanczos
-// launch (a workgroup per walker), one readback; the scalar bookkeeping stays on the host.
+// The status records of the last update_preconditioner! have landed: refresh what the host keeps of them — the activation flags (they
+// choose the CG path) and the count of leading frequencies with a multi-term expansion (the launch geometry of cheb_own_kernel).
+static void pstat_consume(smoqy_ctx *c)
+{
+    int last = 0;
+    for (int w = 0; w < c->g.nw; ++w) {
+        const int *st = c->h_pstat + 4 * (size_t)w;
+        c->pre[w].active = st[3];
+        last = std::max(last, st[1]);
+    }
+    const int heavy = std::min(c->g.Lt, last);
+    if (heavy != c->cheb_heavy) { c->cheb_heavy = heavy; drop_graphs(c); }  // a captured CG graph holds the old count
+}
+
+// Block until the status records of the last update have arrived (no-op when none is outstanding).  The copy sits in the stream right
+// behind the bookkeeping kernel, so with other work queued behind it the GPU does not idle while the host wakes up.
+static int pstat_wait(smoqy_ctx *c)
+{
+    if (!c->pstat_pending) return 0;
+    HIPCHK(c, hipEventSynchronize(c->ev_pstat));
+    c->pstat_pending = false;
+    pstat_consume(c);
+    return 0;
+}
+
+// update_preconditioner! (:554-597) for walkers [w0, w0 + nw), entirely on the device and without a host synchronisation: τ-means
+// (update_B̄! :604-621), Lanczos from the caller's start vectors (calculate_bounds! :625-658) ending with the tridiagonal extremes, the
+// widening, the activation test and the "bounds moved by more than rbuf/2" decision (:569-593), then the expansion coefficients of the
+// walkers whose bounds were accepted (:734-795).  A 16-byte status record per walker follows the kernels to the host (pstat_wait).
 static int precond_update_range(smoqy_ctx *c, int w0, int nw, const double *randvecs)
 {
     const Geometry &g = c->g;
     const int n = c->nlanczos;
-    // update_B̄! :604-621
+    if (int rc = pstat_wait(c)) return rc;  // one outstanding record at a time (h_pstat is about to be overwritten)
     launch_tau_means(c->stream, c->kg, c->d_expV, c->d_ch, c->d_sh, c->d_dbar, c->d_cbar, c->d_sbar, g.Lt, g.N, g.Nh, w0, nw, c->d_shi, c->d_sbari);
-    // calculate_bounds! :625-658 (start vectors drawn by the caller's rng at :634 / :652)
     if (int rc = pin_h2d(c, c->d_rand, randvecs, (size_t)nw * g.N * (g.is_cplx ? 2 : 1) * sizeof(double))) return rc;  // complex T: N complex deviates per walker (:634); the caller's array may be pageable
     KpmArgs k = kpm_args(c, nullptr, nullptr);
-    launch_lanczos(c->stream, k, c->kg, w0, nw, c->d_rand, n, c->d_lan, c->d_lan + (size_t)g.nw * 1024, !g.is_sym);
-    HIPCHK(c, hipMemcpy2DAsync(c->h_lan, 1024 * sizeof(double), c->d_lan, 1024 * sizeof(double), (size_t)n * sizeof(double), (size_t)nw, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpy2DAsync(c->h_lan + (size_t)g.nw * 1024, 1024 * sizeof(double), c->d_lan + (size_t)g.nw * 1024, 1024 * sizeof(double), (size_t)n * sizeof(double), (size_t)nw, hipMemcpyDeviceToHost, c->stream));
+    const PreUpd u = pre_upd(c);
+    launch_lanczos(c->stream, k, c->kg, w0, nw, c->d_rand, n, c->d_lan + (size_t)w0 * 1024, c->d_lan + (size_t)(g.nw + w0) * 1024, !g.is_sym, u);
+    launch_kpm_expansions(c->stream, u, w0, nw);
+    HIPCHK(c, hipMemcpyAsync(c->h_pstat + 4 * (size_t)w0, c->d_pstat + 4 * (size_t)w0, (size_t)nw * 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_pstat, c->stream));
+    c->pstat_pending = true;
+    c->mirrors_stale = true;
+    return check_launch(c, "precond_update");
+}
+
+// host copies of one walker's preconditioner state (smoqy_precond_get*): bounds, order, coefficients, Lanczos coefficients
+static int refresh_mirrors(smoqy_ctx *c)
+{
+    if (int rc = pstat_wait(c)) return rc;
+    if (!c->mirrors_stale) return 0;
+    const Geometry &g = c->g;
+    const int n = c->nlanczos;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (int rc = check_launch(c, "precond_update")) return rc;
-    for (int j = 0; j < nw; ++j) {
-        const int w = w0 + j;
+    std::vector<double> bnd((size_t)g.nw * 2), lan((size_t)g.nw * 2 * 1024);
+    std::vector<int> ord((size_t)g.nw * c->nslot);
+    std::vector<double2> cf((size_t)g.nw * c->nslot * c->maxorder);
+    HIPCHK(c, hipMemcpy(bnd.data(), c->d_bounds, bnd.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(lan.data(), c->d_lan, lan.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ord.data(), c->d_order, ord.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(cf.data(), c->d_coefs, cf.size() * sizeof(double2), hipMemcpyDeviceToHost));
+    for (int w = 0; w < g.nw; ++w) {
         WalkerPrecond &p = c->pre[w];
-        p.lan_a.assign(c->h_lan + (size_t)j * 1024, c->h_lan + (size_t)j * 1024 + n);
-        p.lan_b.assign(c->h_lan + (size_t)(g.nw + j) * 1024, c->h_lan + (size_t)(g.nw + j) * 1024 + n - 1);
-        double emin, emax;
-        tridiag_extremes(p.lan_a.data(), p.lan_b.data(), n, emin, emax);
-        if (!g.is_sym) { emin = std::sqrt(emin); emax = std::sqrt(emax); }  // :655
-        emin *= (1.0 - c->rbuf);  // :569-570
-        emax *= (1.0 + c->rbuf);
-        const int was_active = p.active;
-        bool changed = false;
-        if (0.0 < emin && emin < 1.0 && 1.0 < emax && emax < 2.0) {  // :573
-            p.active = 1;
-            if (std::fabs((emin - p.emin) / p.emin) > c->rbuf / 2 || std::fabs((emax - p.emax) / p.emax) > c->rbuf / 2) {  // :582
-                p.emin = emin;
-                p.emax = emax;
-                update_expansions(c, p);
-                changed = true;
-            }
-        } else {
-            p.active = 0;  // :593
-        }
-        if (changed) {
-            if (int rc = upload_precond(c, w)) return rc;
-        } else if (p.active != was_active) {
-            if (int rc = pin_h2d(c, c->d_active + w, &p.active, sizeof(int))) return rc;
+        p.emin = bnd[2 * (size_t)w];
+        p.emax = bnd[2 * (size_t)w + 1];
+        p.lan_a.assign(lan.begin() + (size_t)w * 1024, lan.begin() + (size_t)w * 1024 + n);
+        p.lan_b.assign(lan.begin() + (size_t)(g.nw + w) * 1024, lan.begin() + (size_t)(g.nw + w) * 1024 + n - 1);
+        for (int sl = 0; sl < c->nslot; ++sl) {
+            p.order[sl] = ord[(size_t)w * c->nslot + sl];
+            const double2 *src = cf.data() + ((size_t)w * c->nslot + sl) * c->maxorder;
+            p.coefs[sl].assign(src, src + std::max(p.order[sl], 0));
         }
     }
+    c->mirrors_stale = false;
     return 0;
 }
 
@@ -1483,6 +1563,8 @@ int smoqy_precond_get(smoqy_ctx *c, int w, int *active, double *bounds, int *ord
 {
     CHECK_CTX(c);
     CHECK_WALKER(c, w);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = refresh_mirrors(c)) return rc;  // the state lives on the device since round 3: fetched on demand
     const WalkerPrecond &p = c->pre[w];
     if (active) *active = p.active;
     if (bounds) { bounds[0] = p.emin; bounds[1] = p.emax; }
@@ -1498,6 +1580,8 @@ int smoqy_precond_get_coefs(smoqy_ctx *c, int w, int slot, void *coefs)
     CHECK_CTX(c);
     CHECK_WALKER(c, w);
     if (slot < 0 || slot >= c->nslot) FAIL(c, 1, "slot %d out of range", slot);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = refresh_mirrors(c)) return rc;
     const auto &v = c->pre[w].coefs[slot];
     std::memcpy(coefs, v.data(), v.size() * sizeof(double2));
     return 0;
@@ -1509,6 +1593,7 @@ int smoqy_precond_set(smoqy_ctx *c, int w, int active, const double *bounds, con
     CHECK_WALKER(c, w);
     const Geometry &g = c->g;
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = refresh_mirrors(c)) return rc;  // the other walkers' mirrors must be current: a table growth re-uploads them
     WalkerPrecond &p = c->pre[w];
     p.active = active ? 1 : 0;
     p.emin = bounds[0];
@@ -1531,6 +1616,7 @@ static int precond_core(smoqy_ctx *c, const double2 *src, double2 *v, const CgSt
 {
     const bool own = c->tf_ok && c->use_tfft;
     void *in[1] = {(void *)src}, *out[1] = {v};
+    if (int rc = pstat_wait(c)) return rc;  // the Chebyshev launch below takes its geometry from the last update's status record
     if (own) {
         TfftArgs t = c->tf;
         t.src = src; t.dst = v; t.pre_tw = nullptr; t.post_tw = nullptr;
@@ -1734,13 +1820,11 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
     const Geometry &g = c->g;
     if (maxiter < 0) FAIL(c, 1, "maxiter < 0");
     CgGateHold gate_hold;  // smoqy_cg_gate: released on every return path
-    bool any_pre = false;
     for (int s = 0; s < g.nsys; ++s) {
         std::memset(&c->h_st[s], 0, sizeof(CgState));
-        c->h_st[s].precond_on = (use_precond && c->pre[s / g.nrhs].active) ? 1 : 0;
+        c->h_st[s].precond_on = use_precond ? 1 : 0;  // informational (the Chebyshev kernel reads each walker's `active` flag from the device)
         c->h_st[s].tol = tol;
         c->h_st[s].maxiter = maxiter;
-        any_pre = any_pre || c->h_st[s].precond_on;
     }
     HIPCHK(c, hipMemcpyAsync(c->d_st, c->h_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyHostToDevice, c->stream));
 
@@ -1749,15 +1833,22 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
     a.x = x; a.r = c->cg_r; a.p = c->cg_p; a.z = c->cg_z; a.th = c->d_th; a.b = b;
     a.v = c->cg_z;  // z = P⁻¹ r shares the buffer of A p: their lifetimes do not overlap
     a.part_pz = c->part_pz; a.part_rz = c->part_rz; a.part_rr = c->part_rr; a.part_bb = c->part_bb;
-    a.st = c->d_st; a.tol = tol; a.maxiter = maxiter; a.use_precond = any_pre ? 1 : 0;
+    a.st = c->d_st; a.tol = tol; a.maxiter = maxiter;
     a.rz_stride = 2 * g.Lt;
-    a.nrz = any_pre ? (cheb_split_active(kpm_args(c, nullptr, nullptr), c->kg) ? 2 * g.Lt : g.Lt) : c->nchunk;
 
     if (!x_is_b) {  // r0 = b - A x0  (ConjugateGradient.jl:119-120), in the twiddled basis
         launch_fft_twiddle(c->stream, x, c->d_th, g.Lt, g.N, g.nsys, 0);
         if (int rc = matvec_dev(c, SMOQY_OP_MTM, c->cg_z, x, nullptr, nullptr, 0, g.nsys, true)) return rc;
     }
-    launch_cg_init(c->stream, a, x_is_b);
+    launch_cg_init(c->stream, a, x_is_b);  // needs neither of the two fields set below
+    // Whether any walker's preconditioner is active — and the launch geometry of the Chebyshev kernel — is in the status record the last
+    // update_preconditioner! sent after its kernels.  The host waits for it HERE, with the right-hand side's preparation and cg_init queued
+    // behind those kernels, so the stream keeps working while the record travels (round 2 synchronised right after the Lanczos kernel).
+    if (int rc = pstat_wait(c)) return rc;
+    bool any_pre = false;
+    for (int w = 0; w < g.nw; ++w) any_pre = any_pre || (use_precond && c->pre[w].active);
+    a.use_precond = any_pre ? 1 : 0;
+    a.nrz = any_pre ? (cheb_split_active(kpm_args(c, nullptr, nullptr), c->kg) ? 2 * g.Lt : g.Lt) : c->nchunk;
     if (any_pre && c->tf_ok && c->use_tfft) {
         // fused iteration: the residual lives in frequency space from here on (r̂0 = FFT r0, in place), z0 = FFT⁻¹ P̂ r̂0 (:200)
         TfftArgs t = c->tf;

@@ -576,6 +576,306 @@ __global__ void __launch_bounds__(1024) fdm_fast_asym_kernel(FdmArgs a, FdmFast 
     stamp_end(a.stamp);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming form of the fused MᵀM (round 3; src/FermionDetMatrix.jl:329-340 = mul_Mt!(mul_M!)), for launches whose working set is
+// beyond the caches.  fdm_fast_kernel gives every τ-chunk its own workgroup: load four slices, wait, run twenty-odd barrier stages,
+// store two slices, exit — at 128 systems per launch the loads of a workgroup are not in flight while it computes, the launch is as
+// long as (workgroup lifetime) x (workgroups per slot) and reaches 0.46 of the measured copy rate.  Here a workgroup WALKS a run of
+// consecutive slices of one system and the two propagates of the fused product are software-pipelined against each other:
+//
+//     y[m]     = v[m] − h·B_m v[m−1]                     (row m of M;  P1(m))
+//     out[m−1] = y[m−1] − h̄·B_m y[m]                     (row m−1 of Mᵀ; P2(m))        — both use the fields of slice m only
+//
+// Iteration j applies B_{j+1} to v[j] (→ y[j+1]) and B_j to y[j] (→ out[j−1]) in the SAME barrier stages (two independent slices per
+// stage), while the slices v[j+2], v[j+3] are on their way from memory into registers (loaded two iterations ahead, 16 bytes per lane
+// each) and land in a free LDS image at the top of a later iteration.  Every input slice is read ONCE per run (+2 halo slices per run,
+// where the chunked kernel re-reads two of four), the memory stream of a workgroup never stops, and an output slice costs five
+// barriers (chunked: 6.5).  Four LDS images of one slice each (32 KB at N = 512): slot-1 input v[j], slot-2 input y[j], the landed
+// v[j+1] (its values at the lane's own site pair feed the `v − B v` combine), and the image that receives y[j+1] for the next iteration.
+// p·Ap is accumulated as Σ|y[m]|² over the run's own slices — (Mp)·(Mp) — which is the same number as p·(MᵀM p) up to rounding, real and
+// non-negative by construction, and needs no `p` at the own sites two iterations later.
+// Arithmetic per site is that of fdm_fast_kernel (same stage order, same folded C₁DC₁): outputs are bit-identical.
+// ---------------------------------------------------------------------------------------------
+// FULL: every colour is a perfect matching of the lattice (padded lists of exactly blockDim.x two-site bonds, N = 2·blockDim.x — the host
+// checks it): no lane is ever switched off, so every LDS access and every store of the pipeline is unconditional.  Besides the saved
+// exec-mask juggling this keeps the compiler's count of outstanding memory operations exact: with a store inside a branch it falls back to
+// waiting for all but the newest three, i.e. for the slice requested one iteration ago.
+template <int NCOL, bool CSV, bool FULL>
+__global__ void __launch_bounds__(1024) fdm_stream_kernel(FdmArgs a, FdmFast ff)
+{
+    extern __shared__ double2 U[];
+    __shared__ double red[34];
+    constexpr int CL = NCOL - 1;
+    const int Lt = a.Lt, N = a.N, Tn = blockDim.x, t = threadIdx.x;
+    const int R = a.run_len, nrun = (Lt + R - 1) / R;
+    // XCD-aware order (as fdm_fast_kernel): consecutive runs of one system share their halo slices
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    if ((nblk & 7) == 0) bid = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int run = bid % nrun, sys = a.sys_first + bid / nrun;
+    stamp_begin(a.stamp);
+    if (a.cg && a.cg[sys].done) return;
+    const int w = sys / a.nrhs;
+    const int la = run * R, lb = min(Lt, la + R);  // output slices [la, lb)
+    const size_t sstride = (size_t)a.nsys * N;
+    const double2 *in = a.in + (size_t)sys * N;
+    double2 *out = a.out + (size_t)sys * N;
+    const double *expV = a.expV + (size_t)w * Lt * N;
+    const double2 *csf = ff.csf + (size_t)w * Lt * ff.ptotal;
+    const bool cs_varies = CSV && ff.cs_varies[w] != 0;
+
+    // ---- the lane's bond program ----
+    int2 b[NCOL];
+    bool on[NCOL];
+    int cidx[NCOL];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+        cidx[c] = ff.poff[c] + t;
+        on[c] = FULL || cidx[c] < ff.poff[c + 1];
+        if (!on[c]) cidx[c] = ff.poff[c];
+        b[c] = ff.pbonds[cidx[c]];
+    }
+    const int2 s0 = ff.psites[cidx[0]];
+    const int2 bL = b[CL];
+    const bool onL = FULL || on[CL];
+    const int2 sL = ff.psites[cidx[CL]];
+    const bool twoL = FULL || bL.y != bL.x;  // the lane's last-colour bond has two distinct sites
+    // a slice in load layout: lane t holds elements t and t + Tn (N <= 2 Tn: every colour's padded list covers all sites)
+    const int e0 = t, e1 = t + Tn;
+    const bool ok0 = FULL || e0 < N, ok1 = FULL || e1 < N;
+    const int p0 = ok0 ? ff.pos[e0] : 0, p1 = ok1 ? ff.pos[e1] : 0;  // their LDS positions
+#define X_(i_) (U + (size_t)(i_) * (size_t)N)  // image i (computed, not looked up: a dynamically indexed pointer array would live in scratch memory)
+
+    // fields of one slice at the lane's bonds: (cosh, sinh) per colour and exp(-ΔτV) at the colour-0 pair.  Three sets: slot 1, slot 2 and
+    // the slice after them (loaded one iteration ahead).  τ-independent hoppings (CSV = false, or a walker whose table says so): one pair
+    // per colour for the whole run, read from slice 0 of the packed table.
+    constexpr int NC = CSV ? NCOL : 1;
+    double2 cs_const[NCOL], cs1[NC], cs2[NC], csn[NC];
+    double d1i, d1j, d2i, d2j, dni, dnj;
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) cs_const[c] = csf[cidx[c]];  // used by CSV = false only (the host has shown the hoppings to be τ-independent)
+    (void)cs_varies;
+    // Every global load of the pipeline is UNCONDITIONAL (clamped addresses, values of switched-off lanes never used): a load inside a
+    // branch makes the compiler lose count of what is in flight and fall back to `s_waitcnt vmcnt(0)` — a full memory round trip per
+    // iteration, which is what the first form of this kernel measured (3.9 µs per iteration).
+#define LOAD_FLD(cs_, di_, dj_, m_)                                                                                   \
+    {                                                                                                                 \
+        const int l_ = wrapl((m_), Lt);                                                                               \
+        if (CSV) {                                                                                                    \
+            _Pragma("unroll") for (int c = 0; c < NC; ++c) cs_[c] = csf[(size_t)l_ * ff.ptotal + cidx[c]];           \
+        }                                                                                                             \
+        di_ = expV[(size_t)l_ * N + s0.x];                                                                            \
+        dj_ = expV[(size_t)l_ * N + s0.y];                                                                            \
+    }
+#define ROTATE_FLD()                                                                                                  \
+    {                                                                                                                 \
+        _Pragma("unroll") for (int c = 0; c < NC; ++c) { cs2[c] = cs1[c]; cs1[c] = csn[c]; }                          \
+        d2i = d1i; d2j = d1j; d1i = dni; d1j = dnj;                                                                   \
+    }
+    const int e0c = min(e0, N - 1), e1c = min(e1, N - 1);
+    // (macros on named scalars, not lambdas on arrays: the prefetch registers must not be demoted to scratch memory)
+#define LOAD_SLICE(r0_, r1_, m_)                                                  \
+    {                                                                             \
+        const double2 *row_ = in + (size_t)wrapl((m_), Lt) * sstride;             \
+        r0_ = row_[e0c];                                                          \
+        r1_ = row_[e1c];                                                          \
+    }
+#define LAND(r0_, r1_, img_)                                                      \
+    {                                                                             \
+        double2 *img__ = (img_);                                                  \
+        if (ok0) img__[p0] = r0_;                                                 \
+        if (ok1) img__[p1] = r1_;                                                 \
+    }
+    // the stage chain of B = C_L…C_2 (C_1 D C_1) C_2…C_L on two independent slices at once: slot 1 = image A with fields f1, slot 2 =
+    // image Bm with fields f2 (either may be switched off); the last colour's results come back in registers at the lane's own pair
+#define CS1(c_) (CSV ? cs1[CSV ? (c_) : 0] : cs_const[c_])
+#define CS2(c_) (CSV ? cs2[CSV ? (c_) : 0] : cs_const[c_])
+#define ST_PLAIN(c_)                                                                                   \
+    {                                                                                                  \
+        if (FULL || on[c_]) {                                                                                  \
+            if (e1on) {                                                                                \
+                const double2 x_ = A[b[c_].x], y_ = A[b[c_].y], k_ = CS1(c_);                          \
+                A[b[c_].x] = lin(k_.x, x_, k_.y, y_);                                                  \
+                A[b[c_].y] = lin(k_.x, y_, k_.y, x_);                                                  \
+            }                                                                                          \
+            if (e2on) {                                                                                \
+                const double2 x_ = Bm[b[c_].x], y_ = Bm[b[c_].y], k_ = CS2(c_);                        \
+                Bm[b[c_].x] = lin(k_.x, x_, k_.y, y_);                                                 \
+                Bm[b[c_].y] = lin(k_.x, y_, k_.y, x_);                                                 \
+            }                                                                                          \
+        }                                                                                              \
+        __syncthreads();                                                                               \
+    }
+#define ST_MIDDLE(last_)                                                                               \
+    {                                                                                                  \
+        if (FULL || on[0]) {                                                                                   \
+            if (e1on) {                                                                                \
+                const double2 x_ = A[b[0].x], y_ = A[b[0].y], k_ = CS1(0);                             \
+                const double2 u_ = scl(d1i, lin(k_.x, x_, k_.y, y_)), v_ = scl(d1j, lin(k_.x, y_, k_.y, x_)); \
+                if (last_) { r1i = lin(k_.x, u_, k_.y, v_); r1j = lin(k_.x, v_, k_.y, u_); }           \
+                else { A[b[0].x] = lin(k_.x, u_, k_.y, v_); A[b[0].y] = lin(k_.x, v_, k_.y, u_); }     \
+            }                                                                                          \
+            if (e2on) {                                                                                \
+                const double2 x_ = Bm[b[0].x], y_ = Bm[b[0].y], k_ = CS2(0);                           \
+                const double2 u_ = scl(d2i, lin(k_.x, x_, k_.y, y_)), v_ = scl(d2j, lin(k_.x, y_, k_.y, x_)); \
+                if (last_) { r2i = lin(k_.x, u_, k_.y, v_); r2j = lin(k_.x, v_, k_.y, u_); }           \
+                else { Bm[b[0].x] = lin(k_.x, u_, k_.y, v_); Bm[b[0].y] = lin(k_.x, v_, k_.y, u_); }   \
+            }                                                                                          \
+        }                                                                                              \
+        if (!(last_)) __syncthreads();                                                                 \
+    }
+#define ST_LAST(c_)                                                                                    \
+    {                                                                                                  \
+        if (FULL || on[c_]) {                                                                                  \
+            if (e1on) {                                                                                \
+                const double2 x_ = A[b[c_].x], y_ = A[b[c_].y], k_ = CS1(c_);                          \
+                r1i = lin(k_.x, x_, k_.y, y_);                                                         \
+                r1j = lin(k_.x, y_, k_.y, x_);                                                         \
+            }                                                                                          \
+            if (e2on) {                                                                                \
+                const double2 x_ = Bm[b[c_].x], y_ = Bm[b[c_].y], k_ = CS2(c_);                        \
+                r2i = lin(k_.x, x_, k_.y, y_);                                                         \
+                r2j = lin(k_.x, y_, k_.y, x_);                                                         \
+            }                                                                                          \
+        }                                                                                              \
+    }
+#define PROPAGATE2()                                                                                   \
+    {                                                                                                  \
+        if (NCOL == 1) {                                                                               \
+            ST_MIDDLE(true)                                                                            \
+        } else {                                                                                       \
+            if (NCOL >= 4) ST_PLAIN((3 < NCOL ? 3 : 0))                                                \
+            if (NCOL >= 3) ST_PLAIN((2 < NCOL ? 2 : 0))                                                \
+            if (NCOL >= 2) ST_PLAIN((1 < NCOL ? 1 : 0))                                                \
+            ST_MIDDLE(false)                                                                           \
+            if (NCOL >= 3) ST_PLAIN((1 < NCOL ? 1 : 0))                                                \
+            if (NCOL >= 4) ST_PLAIN((2 < NCOL ? 2 : 0))                                                \
+            ST_LAST(CL)                                                                                \
+        }                                                                                              \
+    }
+
+    // ---- prologue: slices la-1, la, la+1 straight into their images, the next two on their way; P1(la+1) and P1(la) together ----
+    double2 pfa0, pfa1, pfb0, pfb1;
+    {
+        double2 t0, t1, t2, t3, t4, t5;
+        LOAD_SLICE(t0, t1, la - 1)
+        LOAD_SLICE(t2, t3, la)
+        LOAD_SLICE(t4, t5, la + 1)
+        LAND(t0, t1, X_(0))
+        LAND(t2, t3, X_(1))
+        LAND(t4, t5, X_(2))
+    }
+    LOAD_FLD(cs2, d2i, d2j, la)        // slot 2 of the prologue: B_la on v[la-1]
+    LOAD_FLD(cs1, d1i, d1j, la + 1)    // slot 1: B_{la+1} on v[la]
+    LOAD_FLD(csn, dni, dnj, la + 2)
+    LOAD_SLICE(pfa0, pfa1, min(la + 2, lb))  // needed as slices up to lb (the last one only for its values at the own sites)
+    LOAD_SLICE(pfb0, pfb1, min(la + 3, lb))
+    __syncthreads();
+    double2 vown_i = make_double2(0.0, 0.0), vown_j = vown_i, vnext_i = vown_i, vnext_j = vown_i;
+    if (onL) { vown_i = X_(1)[bL.x]; vown_j = X_(1)[bL.y]; vnext_i = X_(2)[bL.x]; vnext_j = X_(2)[bL.y]; }  // v[la], v[la+1] at the own pair (the first stage
+                                                                                                       // writes exactly these positions of X_(1): same lane, no race)
+    double2 r1i = make_double2(0.0, 0.0), r1j = r1i, r2i = r1i, r2j = r1i;
+    double accr = 0.0;
+    double2 yprev_i, yprev_j, ycur_i, ycur_j;
+    {
+        double2 *A = X_(1), *Bm = X_(0);
+        const bool e1on = true, e2on = true;
+        PROPAGATE2()
+        yprev_i = hopcomb(vown_i, r2i, wrapl(la, Lt) == 0, false, a);       // y[la]
+        yprev_j = hopcomb(vown_j, r2j, wrapl(la, Lt) == 0, false, a);
+        ycur_i = hopcomb(vnext_i, r1i, wrapl(la + 1, Lt) == 0, false, a);   // y[la+1]
+        ycur_j = hopcomb(vnext_j, r1j, wrapl(la + 1, Lt) == 0, false, a);
+        if (onL) {
+            accr += yprev_i.x * yprev_i.x + yprev_i.y * yprev_i.y;
+            if (twoL) accr += yprev_j.x * yprev_j.x + yprev_j.y * yprev_j.y;
+            X_(3)[bL.x] = ycur_i;  // hand y[la+1] over to slot 2 of the next iteration (X_(3) is free)
+            X_(3)[bL.y] = ycur_j;
+        }
+        __syncthreads();
+    }
+    int iV = 2, iY = 3, iN = 0, iF = 1;  // images: v[j] (slot 1), y[j] (slot 2), landing of v[j+1], receiver of y[j+1]
+    ROTATE_FLD()
+    // ---- steady state: iteration j does P1(j+1) (unless j = lb) and P2(j).  Written out twice per trip so that the two prefetch register
+    // sets alternate without a copy (a copy would be a use, i.e. a wait for the younger load) ----
+#define STREAM_ITER(pf0_, pf1_, j_)                                                                                       \
+    {                                                                                                                 \
+        const int jj = (j_);                                                                                          \
+        const bool e1on = jj < lb, e2on = true;                                                                       \
+        /* issue order = age at first use: fields of slice jj+2 (next iteration) first, the slice v[jj+3] behind them */ \
+        LOAD_FLD(csn, dni, dnj, min(jj + 2, lb))                                                                      \
+        LAND(pf0_, pf1_, X_(iN)) /* v[jj+1], loaded two iterations ago (unused in the last iteration: the image is free) */ \
+        LOAD_SLICE(pf0_, pf1_, min(jj + 3, lb))                                                                       \
+        double2 *A = X_(iV), *Bm = X_(iY);                                                                            \
+        PROPAGATE2()                                                                                                  \
+        if (onL) { /* out[jj-1] = y[jj-1] − h̄ B_jj y[jj] */                                                            \
+            const bool wrap = (jj - 1) == Lt - 1;                                                                     \
+            const double2 oi = hopcomb(yprev_i, r2i, wrap, true, a), oj = hopcomb(yprev_j, r2j, wrap, true, a);       \
+            double2 *row = out + (size_t)(jj - 1) * sstride;                                                          \
+            row[sL.x] = oi;                                                                                           \
+            if (twoL) row[sL.y] = oj;                                                                         \
+        }                                                                                                             \
+        yprev_i = ycur_i; yprev_j = ycur_j;                                                                           \
+        if (e1on) {                                                                                                   \
+            /* y[jj+1] = v[jj+1] − h B_{jj+1} v[jj]; v[jj+1] at the own pair comes out of the image it landed in */     \
+            double2 vi_ = make_double2(0.0, 0.0), vj_ = vi_;                                                          \
+            if (onL) { vi_ = X_(iN)[bL.x]; vj_ = X_(iN)[bL.y]; }                                                      \
+            ycur_i = hopcomb(vi_, r1i, wrapl(jj + 1, Lt) == 0, false, a);                                             \
+            ycur_j = hopcomb(vj_, r1j, wrapl(jj + 1, Lt) == 0, false, a);                                             \
+            if (onL) {                                                                                                \
+                accr += yprev_i.x * yprev_i.x + yprev_i.y * yprev_i.y; /* |y[jj]|², jj < lb: a slice of this run */    \
+                if (twoL) accr += yprev_j.x * yprev_j.x + yprev_j.y * yprev_j.y;                              \
+                X_(iF)[bL.x] = ycur_i;                                                                                \
+                X_(iF)[bL.y] = ycur_j;                                                                                \
+            }                                                                                                         \
+            __syncthreads(); /* y[jj+1] visible; every lane is done with the images of this iteration */              \
+            const int oV = iV, oY = iY;                                                                               \
+            iV = iN; iY = iF; iN = oV; iF = oY;                                                                       \
+            ROTATE_FLD()                                                                                              \
+        }                                                                                                             \
+    }
+    for (int j = la + 1; j <= lb; j += 2) {
+        STREAM_ITER(pfa0, pfa1, j)
+        if (j + 1 <= lb) STREAM_ITER(pfb0, pfb1, j + 1)
+    }
+#undef STREAM_ITER
+#undef LAND
+#undef LOAD_SLICE
+#undef X_
+#undef PROPAGATE2
+#undef ST_LAST
+#undef ST_MIDDLE
+#undef ST_PLAIN
+#undef CS1
+#undef CS2
+#undef ROTATE_FLD
+#undef LOAD_FLD
+    if (a.partial) {
+        for (int off = 32; off > 0; off >>= 1) accr += __shfl_down(accr, off, 64);
+        const int wave = t >> 6, lane = t & 63, nwave = (Tn + 63) >> 6;
+        if (lane == 0) red[wave] = accr;
+        __syncthreads();
+        if (t == 0) {
+            double s = 0.0;
+            for (int q = 0; q < nwave; ++q) s += red[q];
+            // the consumers reduce a.nchunk partials per system: the run's sum goes to its first chunk, its other chunks are zero
+            const int c0 = la / a.Tc, c1 = (lb + a.Tc - 1) / a.Tc;
+            a.partial[(size_t)sys * a.nchunk + c0] = make_double2(s, 0.0);
+            for (int c = c0 + 1; c < c1; ++c) a.partial[(size_t)sys * a.nchunk + c] = make_double2(0.0, 0.0);
+        }
+    }
+    stamp_end(a.stamp);
+}
+
+template <int NCOL, bool CSV>
+void launch_stream_ncol(hipStream_t st, const FdmArgs &a, const FdmFast &ff)
+{
+    const int nrun = (a.Lt + a.run_len - 1) / a.run_len;
+    const dim3 grid((unsigned)(nrun * a.sys_count)), block((unsigned)ff.threads);
+    const size_t lds = sizeof(double2) * 4 * (size_t)a.N;
+    if (ff.full) hipLaunchKernelGGL((fdm_stream_kernel<NCOL, CSV, true>), grid, block, lds, st, a, ff);
+    else hipLaunchKernelGGL((fdm_stream_kernel<NCOL, CSV, false>), grid, block, lds, st, a, ff);
+}
+
 template <int NCOL>
 void launch_ncol_asym(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff)
 {
@@ -637,6 +937,54 @@ void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff
         case 3: launch_ncol<3, true>(st, op, a, ff); break;
         default: launch_ncol<4, true>(st, op, a, ff); break;
     }
+}
+
+// streaming MᵀM: Sym, real hoppings, run length a multiple of the τ-chunk (the p·Ap partials keep the chunk layout), at least two slices
+bool fdm_stream_supported(const FdmArgs &a, const FdmFast &ff, bool sym)
+{
+    return sym && ff.enabled && a.ncol >= 1 && a.ncol <= kFdmColours && a.run_len >= 2 && a.run_len % a.Tc == 0 && a.Lt >= 4 && a.N <= 2 * ff.threads &&
+           sizeof(double2) * 4 * (size_t)a.N <= 150 * 1024;
+}
+
+void launch_fdm_stream(hipStream_t st, const FdmArgs &a, const FdmFast &ff, bool cs_const)
+{
+    if (cs_const) {
+        switch (a.ncol) {
+            case 1: launch_stream_ncol<1, false>(st, a, ff); break;
+            case 2: launch_stream_ncol<2, false>(st, a, ff); break;
+            case 3: launch_stream_ncol<3, false>(st, a, ff); break;
+            default: launch_stream_ncol<4, false>(st, a, ff); break;
+        }
+        return;
+    }
+    switch (a.ncol) {
+        case 1: launch_stream_ncol<1, true>(st, a, ff); break;
+        case 2: launch_stream_ncol<2, true>(st, a, ff); break;
+        case 3: launch_stream_ncol<3, true>(st, a, ff); break;
+        default: launch_stream_ncol<4, true>(st, a, ff); break;
+    }
+}
+
+hipError_t configure_fdm_stream_kernels(const char **what)
+{
+    hipError_t first = hipSuccess;
+    SMOQY_SET_LDS((fdm_stream_kernel<1, false, false>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<1, false, true>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<2, false, false>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<2, false, true>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<3, false, false>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<3, false, true>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<4, false, false>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<4, false, true>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<1, true, false>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<1, true, true>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<2, true, false>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<2, true, true>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<3, true, false>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<3, true, true>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<4, true, false>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<4, true, true>), 160 * 1024 - 512);
+    return first;
 }
 
 // pack cosh/sinh into the padded interleaved table csf[l][idx] = (c, s) (self bonds: (1, 0)) and note

@@ -440,6 +440,8 @@ __device__ __forceinline__ double2 sub(double2 x, double2 y) { return make_doubl
 // coefficient times vector: the complex kernel keeps the general complex product (Sym coefficients have an exact zero imaginary part)
 __device__ __forceinline__ double cmul(double2 c, double x) { return c.x * x; }
 __device__ __forceinline__ double2 cmul(double2 c, double2 x) { return cmulk(c, x); }
+__device__ __forceinline__ double shfl(double x, int lane) { return __shfl(x, lane, 64); }
+__device__ __forceinline__ double2 shfl(double2 x, int lane) { return make_double2(__shfl(x.x, lane, 64), __shfl(x.y, lane, 64)); }
 __device__ __forceinline__ double ld(const double2 *v, int i, int comp, double) { return comp ? v[i].y : v[i].x; }
 __device__ __forceinline__ double2 ld(const double2 *v, int i, int, double2) { return v[i]; }
 __device__ __forceinline__ void st(double2 *v, int i, int comp, double x) { if (comp) v[i].y = x; else v[i].x = x; }
@@ -502,15 +504,8 @@ __device__ __forceinline__ void own_load_prog(OwnProg<NCOL> &P, const OwnIdx<NCO
     }
 }
 
-// Σ_k CF[k] T_k(B̄') applied to the values (ax, ay) of the lane's own sites, n >= 2 terms (kpm_lmul!, Sym B̄ in the basis α̃ = C_L α).
-// T = double: one component of the vector (SPLIT), T = double2: both; Wb are two LDS images of 2·Tn values of T; all lanes of the
-// workgroup call it together (it contains barriers); CF must be visible to all lanes on entry.
-template <int NCOL, class T>
-__device__ __forceinline__ void own_chain(const OwnProg<NCOL> &P, T &ax, T &ay, T *Wb0, T *Wb1, int &buf, const double2 *CF, int n, double avg, double imag_)
-{
-    using namespace ownk;
-    constexpr int Q = NCOL >= 3 ? 1 : 0, CL = NCOL - 1;
-    // own values -> LDS image, barrier, the two mates of colour c_ come back in (mx_, my_)
+// Exchange and stage of the owner-computes lane program (used inside functions that define P, ax, ay, Wb0, Wb1, buf and the constants
+// Q = owned colour, T = value type): own values -> LDS image, ONE barrier (the images ping-pong), the two mates of colour c_ come back.
 #define OWN_EXCHANGE(c_, mx_, my_)                       \
     {                                                    \
         T *Wc = buf ? Wb1 : Wb0;                         \
@@ -533,6 +528,58 @@ __device__ __forceinline__ void own_chain(const OwnProg<NCOL> &P, T &ax, T &ay, 
             ay = lin(P.cy[c_].x, ay, P.cy[c_].y, my_);                       \
         }                                                                    \
     }
+// the fused centre stage C₀ D̄ C₀ on the own sites: register arithmetic when colour 0 is the owned one, otherwise one exchange with the
+// mate's intermediate value recomputed here (same bond, the mate's own d̄)
+#define OWN_CENTRE()                                                                                          \
+    {                                                                                                         \
+        if (Q == 0) {                                                                                         \
+            T x_ = lin(P.cx[0].x, ax, P.cx[0].y, ay), y_ = lin(P.cx[0].x, ay, P.cx[0].y, ax);                 \
+            x_ = scl(P.dx, x_);                                                                               \
+            y_ = scl(P.dy, y_);                                                                               \
+            ax = lin(P.cx[0].x, x_, P.cx[0].y, y_);                                                           \
+            ay = lin(P.cx[0].x, y_, P.cx[0].y, x_);                                                           \
+        } else {                                                                                              \
+            T mx_, my_;                                                                                       \
+            OWN_EXCHANGE(0, mx_, my_)                                                                         \
+            T x_ = lin(P.cx[0].x, ax, P.cx[0].y, mx_), xm_ = lin(P.cx[0].x, mx_, P.cx[0].y, ax);              \
+            T y_ = lin(P.cy[0].x, ay, P.cy[0].y, my_), ym_ = lin(P.cy[0].x, my_, P.cy[0].y, ay);              \
+            x_ = scl(P.dx, x_);                                                                               \
+            xm_ = scl(P.dmx, xm_);                                                                            \
+            y_ = scl(P.dy, y_);                                                                               \
+            ym_ = scl(P.dmy, ym_);                                                                            \
+            ax = lin(P.cx[0].x, x_, P.cx[0].y, xm_);                                                          \
+            ay = lin(P.cy[0].x, y_, P.cy[0].y, ym_);                                                          \
+        }                                                                                                     \
+    }
+
+// (ax, ay) <- B̄ (ax, ay) for the Sym propagator in its plain form B̄ = C_{L-1} … C_1 (C_0 D̄ C_0) C_1 … C_{L-1} (no basis change: what
+// Lanczos needs, KPMPreconditioner.jl:625-639) on the lane's own two sites; all lanes of the workgroup call it together
+template <int NCOL, class T>
+__device__ __forceinline__ void own_bbar_apply(const OwnProg<NCOL> &P, T &ax, T &ay, T *Wb0, T *Wb1, int &buf)
+{
+    using namespace ownk;
+    constexpr int Q = NCOL >= 3 ? 1 : 0;
+#pragma unroll
+    for (int c = NCOL - 1; c >= 1; --c) OWN_STAGE(c)
+    OWN_CENTRE()
+#pragma unroll
+    for (int c = 1; c <= NCOL - 1; ++c) OWN_STAGE(c)
+}
+
+// Σ_k CF[k] T_k(B̄') applied to the values (ax, ay) of the lane's own sites, n >= 2 terms (kpm_lmul!, Sym B̄ in the basis α̃ = C_L α).
+// T = double: one component of the vector (SPLIT), T = double2: both; Wb are two LDS images of 2·Tn values of T; all lanes of the
+// workgroup call it together (it contains barriers); CF must be visible to all lanes on entry.
+// WL0 (round 3): the host has verified that the colour-0 mates of every lane's two sites sit in lanes of the SAME wavefront, the mate of
+// the first site in some lane's second slot and vice versa (KpmGeom::wl0; honeycomb L = 16: the colour-0 partner is the neighbouring cell
+// of the same row of 16).  The centre exchange of a Chebyshev step then needs no LDS image and no barrier: two wave shuffles
+// (ds_bpermute) bring the mates.  Same values, same arithmetic: bit-identical to the LDS form.
+template <int NCOL, class T, bool WL0 = false>
+__device__ __forceinline__ void own_chain(const OwnProg<NCOL> &P, T &ax, T &ay, T *Wb0, T *Wb1, int &buf, const double2 *CF, int n, double avg, double imag_)
+{
+    using namespace ownk;
+    constexpr int Q = NCOL >= 3 ? 1 : 0, CL = NCOL - 1;
+    const int wl_x = (P.px[0] - (int)blockDim.x) & 63, wl_y = P.py[0] & 63;  // source lanes of the two colour-0 mates (used with WL0 only)
+    (void)wl_x; (void)wl_y;
     // into the basis α̃ = C_L α (see cheb_fast_kernel)
     {
         T mx, my;
@@ -555,7 +602,12 @@ __device__ __forceinline__ void own_chain(const OwnProg<NCOL> &P, T &ax, T &ay, 
             ay = lin(P.cx[0].x, y, P.cx[0].y, x);
         } else {       // one exchange; the mate's value after C₁ and D̄ is recomputed here (same bond, its own d̄)
             T mx, my;
-            OWN_EXCHANGE(0, mx, my)
+            if constexpr (WL0) {
+                mx = shfl(ay, wl_x);
+                my = shfl(ax, wl_y);
+            } else {
+                OWN_EXCHANGE(0, mx, my)
+            }
             T x = lin(P.cx[0].x, ax, P.cx[0].y, mx), xm = lin(P.cx[0].x, mx, P.cx[0].y, ax);
             T y = lin(P.cy[0].x, ay, P.cy[0].y, my), ym = lin(P.cy[0].x, my, P.cy[0].y, ay);
             x = scl(P.dx, x);
@@ -601,8 +653,6 @@ __device__ __forceinline__ void own_chain(const OwnProg<NCOL> &P, T &ax, T &ay, 
         ax = scl(idx_, sub(scl(P.cx[CL].x, accx), scl(P.cx[CL].y, mx)));
         ay = scl(idy_, sub(scl(P.cy[CL].x, accy), scl(P.cy[CL].y, my)));
     }
-#undef OWN_STAGE
-#undef OWN_EXCHANGE
 }
 
 // Workgroups of a launch, per system: the k.heavy frequencies of lowest |ϕ| — every frequency whose expansion has more than one term; the
@@ -612,7 +662,7 @@ __device__ __forceinline__ void own_chain(const OwnProg<NCOL> &P, T &ax, T &ay, 
 // light frequency costs ≈ 2 µs of a workgroup slot for 16 KB of traffic — the round trips in front of the work — and with a workgroup per
 // frequency and component the Chebyshev kernel held more wave-slot time than any other kernel of the iteration (SQ_WAVE_CYCLES 35.4 M
 // against 31.9 M for MᵀM, profiles/r02_pmc_lds_iteration.txt), which is what the multi-stream bench is bound by.
-template <int NCOL, bool SPLIT>
+template <int NCOL, bool SPLIT, bool WL0 = false>
 __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
 {
     static_assert(NCOL >= 2, "single-colour decompositions use cheb_fast_kernel");
@@ -748,7 +798,7 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
     for (int i = j; i < n; i += Tn) CF[i] = coefs[i];  // coefficients in LDS: no global load inside the chain
     __syncthreads();  // CF visible
     int buf = 0;
-    own_chain<NCOL, T>(P, ax, ay, W0, W1, buf, CF, n, avg, imag_);
+    own_chain<NCOL, T, WL0>(P, ax, ay, W0, W1, buf, CF, n, avg, imag_);
     double2 acc = make_double2(0.0, 0.0);
     if (P.on) {
         ax = scl(k.scale, ax);
@@ -1123,10 +1173,14 @@ void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
             const int nlight = (k.Lt - kk.heavy + kk.group - 1) / kk.group;
             const size_t olds = (split ? sizeof(double) : sizeof(double2)) * 4 * (size_t)kg.threads + sizeof(double2) * (size_t)k.maxorder;
             const dim3 ogrid((unsigned)(((split ? 2 : 1) * kk.heavy + nlight) * ncnt));
-#define OWN_LAUNCH(C_)                                                                             \
-    {                                                                                              \
-        if (split) hipLaunchKernelGGL((cheb_own_kernel<C_, true>), ogrid, block, olds, st, kk, kg); \
-        else hipLaunchKernelGGL((cheb_own_kernel<C_, false>), ogrid, block, olds, st, kk, kg);      \
+            static const int env_wl = [] { const char *e = getenv("SMOQY_CHEB_WL0"); return (e && e[0] == '0') ? 0 : 1; }();  // A/B switch, default on
+            const bool wl0 = kg.wl0 && k.ncol >= 3 && env_wl;
+#define OWN_LAUNCH(C_)                                                                                          \
+    {                                                                                                           \
+        if (split && wl0) hipLaunchKernelGGL((cheb_own_kernel<C_, true, true>), ogrid, block, olds, st, kk, kg); \
+        else if (split) hipLaunchKernelGGL((cheb_own_kernel<C_, true>), ogrid, block, olds, st, kk, kg);         \
+        else if (wl0) hipLaunchKernelGGL((cheb_own_kernel<C_, false, true>), ogrid, block, olds, st, kk, kg);    \
+        else hipLaunchKernelGGL((cheb_own_kernel<C_, false>), ogrid, block, olds, st, kk, kg);                   \
     }
             switch (k.ncol) {
                 case 2: OWN_LAUNCH(2); break;
@@ -1190,11 +1244,165 @@ void launch_conj_mirror(hipStream_t st, double2 *v, int Lt, int N, int nsys)
 }
 
 // ---------------------------------------------------------------------------------------------
+// device-side bookkeeping of update_preconditioner! (KPMPreconditioner.jl:565-597, 696-731): runs at the end of the Lanczos kernel,
+// in the same workgroup (one per walker)
+// ---------------------------------------------------------------------------------------------
+// number of eigenvalues of the symmetric tridiagonal (a, b) below x (Sturm sequence; the host restatement it replaces: api.hip `sturm`)
+__device__ __forceinline__ int sturm_count_dev(const double *a, const double *b, int n, double x)
+{
+    int cnt = 0;
+    double q = a[0] - x;
+    if (q < 0) ++cnt;
+    for (int i = 1; i < n; ++i) {
+        const double den = (fabs(q) < 1e-300) ? (q < 0 ? -1e-300 : 1e-300) : q;
+        q = a[i] - x - b[i - 1] * b[i - 1] / den;
+        if (q < 0) ++cnt;
+    }
+    return cnt;
+}
+
+// smallest (target = 1) or largest (target = n) eigenvalue by 64-section inside one wavefront: every round the 64 lanes evaluate the
+// Sturm count at 64 interior points of [l, h] and a ballot picks the sub-interval where the count crosses `target`; eleven rounds
+// shrink the Gershgorin interval by 65^11 > 2^64 (the host form did 64 halvings).  All lanes return the same value.
+__device__ __forceinline__ double tridiag_extreme_wave(const double *a, const double *b, int n, double lo, double hi, int target)
+{
+    const int lane = threadIdx.x & 63;
+    double l = lo, h = hi;
+    for (int round = 0; round < 11; ++round) {
+        const double step = (h - l) / 65.0;
+        const double x = l + step * (double)(lane + 1);
+        const unsigned long long m = __ballot(sturm_count_dev(a, b, n, x) >= target);
+        if (m == 0ull) {
+            l = l + step * 64.0;
+        } else {
+            const int f = __ffsll((long long)m) - 1;  // first point at which the count has reached the target
+            h = l + step * (double)(f + 1);
+            l = l + step * (double)f;
+        }
+    }
+    return 0.5 * (l + h);
+}
+
+// a, b: the Lanczos coefficients of this workgroup's walker (n and n - 1 of them; LDS or global memory, written before the last barrier).
+// sh: >= 4 doubles + 4 ints of LDS scratch.  Every lane of the workgroup must call it.
+__device__ __forceinline__ void precond_bookkeeping(const double *a, const double *b, int n, int w, const PreUpd &u, double *sh)
+{
+    int *shi_ = reinterpret_cast<int *>(sh + 4);
+    const int wave = threadIdx.x >> 6, nwave = (blockDim.x + 63) >> 6;
+    if (threadIdx.x == 0) { shi_[0] = 0; shi_[1] = 0; }
+    if (wave < 2) {
+        // Gershgorin interval (every lane the same arithmetic), then wave 0 takes the smallest and wave 1 (or wave 0 again) the largest eigenvalue
+        double lo = a[0], hi = a[0];
+        for (int i = 0; i < n; ++i) {
+            const double r = (i > 0 ? fabs(b[i - 1]) : 0.0) + (i < n - 1 ? fabs(b[i]) : 0.0);
+            lo = fmin(lo, a[i] - r);
+            hi = fmax(hi, a[i] + r);
+        }
+        if (wave == 0) {
+            const double e = tridiag_extreme_wave(a, b, n, lo, hi, 1);
+            if (threadIdx.x == 0) sh[0] = e;
+        }
+        if (wave == (nwave > 1 ? 1 : 0)) {
+            const double e = tridiag_extreme_wave(a, b, n, lo, hi, n);
+            if ((threadIdx.x & 63) == 0) sh[1] = e;
+        }
+    }
+    __syncthreads();
+    double emin = sh[0], emax = sh[1];
+    if (!u.is_sym) { emin = sqrt(emin); emax = sqrt(emax); }  // Lanczos ran on B̄ᵀB̄ (:655)
+    emin *= (1.0 - u.rbuf);                                   // :569-570
+    emax *= (1.0 + u.rbuf);
+    const double oe = u.bounds[2 * w], oE = u.bounds[2 * w + 1];
+    const bool ok = 0.0 < emin && emin < 1.0 && 1.0 < emax && emax < 2.0;                                       // :573
+    const bool moved = ok && (fabs((emin - oe) / oe) > u.rbuf / 2 || fabs((emax - oE) / oE) > u.rbuf / 2);    // :582 (first update: oe = 0, the quotient is +inf)
+    int nrebuild = u.status[4 * w];
+    __syncthreads();  // every lane has read the old bounds before lane 0 replaces them
+    if (moved) {
+        // update_kpm_expansion_order! (:696-731)
+        int mx = 1, last = -1;
+        for (int l = threadIdx.x; l < u.nslot; l += blockDim.x) {
+            double phi = 2.0 * M_PI / u.Lt * (l + 0.5);  // :220
+            if (phi > M_PI) phi = 2.0 * M_PI - phi;       // :710
+            int o = (int)floor((emax - emin) * (u.a1 / phi + u.a2));  // :711
+            o = max(o, 1);
+            o = min(o, u.maxorder);  // cannot bind: the table is sized for emax - emin < 2, which `ok` guarantees
+            u.order[(size_t)w * u.nslot + l] = o;
+            mx = max(mx, o);
+            if (o > 1) last = max(last, u.is_sym ? l : min(l, u.Lt - 1 - l));
+        }
+        atomicMax(&shi_[0], mx);
+        atomicMax(&shi_[1], last + 1);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u.bounds[2 * w] = emin;
+            u.bounds[2 * w + 1] = emax;
+            u.status[4 * w] = nrebuild + 1;
+            u.status[4 * w + 1] = min(u.Lt, 2 * shi_[1]);  // ranks 2s and 2s+1 share slot s (:387): the heavy frequencies of cheb_own_kernel
+            u.status[4 * w + 2] = shi_[0];
+        }
+    }
+    if (threadIdx.x == 0) {
+        u.active[w] = ok ? 1 : 0;       // :575 / :593
+        u.rebuild[w] = moved ? 1 : 0;
+        u.status[4 * w + 3] = ok ? 1 : 0;
+    }
+}
+
+// update_kpm_expansion_coefs! (:734-795) with kpm_coefs! restated (SmoQyKPMCore: Chebyshev-Gauss quadrature with 2n nodes, no damping
+// kernel): workgroup (slot l < cld(Lτ, 2), walker), one wavefront.  coefs[k] = (2 - δ_k0)/M Σ_j f(x_j) cos(π k (j + ½)/M), M = 2n,
+// x_j = avg + mag cos(π (j + ½)/M), summed over j in the order of the host restatement it replaces.
+__global__ void __launch_bounds__(64) kpm_expansions_kernel(PreUpd u, int w0)
+{
+    extern __shared__ double gl[];  // [2][M]
+    const int w = w0 + blockIdx.y, l = blockIdx.x;
+    if (!u.rebuild[w]) return;
+    const int n = u.order[(size_t)w * u.nslot + l], M = 2 * n;
+    const double emin = u.bounds[2 * w], emax = u.bounds[2 * w + 1];
+    const double avg = 0.5 * (emax + emin), mag = 0.5 * (emax - emin);
+    const double phi = 2.0 * M_PI / u.Lt * (l + 0.5);
+    const double cp = cos(phi), sp = sin(phi);
+    double *gre = gl, *gim = gl + M;
+    const double inv2M = 1.0 / (2.0 * M);
+    for (int j = threadIdx.x; j < M; j += 64) {
+        const double bx = avg + mag * cospi((double)(2 * j + 1) * inv2M);
+        if (u.is_sym) {
+            gre[j] = 1.0 / (bx * bx - 2.0 * bx * cp + 1.0);  // f_B̄_sym :800
+        } else {
+            const double x = 1.0 - bx * cp, y = bx * sp;      // f_B̄_asym = 1/(1 - e^{-iφ} b) :804
+            gre[j] = x / (x * x + y * y);
+            gim[j] = -y / (x * x + y * y);
+        }
+    }
+    __syncthreads();
+    double2 *out = u.coefs + ((size_t)w * u.nslot + l) * u.maxorder;
+    double2 *outc = u.is_sym ? nullptr : u.coefs + ((size_t)w * u.nslot + (u.Lt - l - 1)) * u.maxorder;
+    for (int k = threadIdx.x; k < n; k += 64) {
+        double are = 0.0, aim = 0.0;
+        for (int j = 0; j < M; ++j) {
+            const int m = (int)(((long long)k * (2 * j + 1)) % (4 * M));
+            const double cc = cospi((double)m * inv2M);
+            are += gre[j] * cc;
+            if (!u.is_sym) aim += gim[j] * cc;
+        }
+        const double f = (k == 0 ? 1.0 : 2.0) / M;
+        out[k] = make_double2(f * are, f * aim);
+        if (outc) outc[k] = make_double2(f * are, -f * aim);  // :791 (the middle frequency of an odd Lτ mirrors onto itself and ends up conjugated, as in the reference)
+    }
+}
+
+void launch_kpm_expansions(hipStream_t st, const PreUpd &u, int w0, int nw)
+{
+    const int Lo2 = (u.Lt + 1) / 2;
+    const size_t lds = sizeof(double) * 4 * (size_t)u.maxorder;
+    hipLaunchKernelGGL(kpm_expansions_kernel, dim3((unsigned)Lo2, (unsigned)nw), dim3(64), lds, st, u, w0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // lanczos! (SmoQyKPMCore, restated): n-step Lanczos on B̄ (Sym) or B̄ᵀB̄ (Asym) from the host
 // supplied start vectors; one workgroup per walker, everything in LDS / registers.
 // ---------------------------------------------------------------------------------------------
 template <int MODE, bool FAST>
-__global__ void __launch_bounds__(1024) lanczos_kernel(KpmArgs k, KpmGeom kg, int w0, const double *__restrict__ randvec, int nsteps, double *alpha, double *beta)
+__global__ void __launch_bounds__(1024) lanczos_kernel(KpmArgs k, KpmGeom kg, int w0, const double *__restrict__ randvec, int nsteps, double *alpha, double *beta, PreUpd u)
 {
     extern __shared__ double2 lds[];
     __shared__ double red[17];
@@ -1248,6 +1456,66 @@ __global__ void __launch_bounds__(1024) lanczos_kernel(KpmArgs k, KpmGeom kg, in
         bprev = nb;
         __syncthreads();
     }
+    // lane 0's stores of alpha / beta are visible to the workgroup behind the loop's last barrier
+    precond_bookkeeping(alpha, beta, nsteps, w, u, red);
+}
+
+// Owner-computes Lanczos (Sym, real hoppings, 2..kMaxColours colours): the lane keeps its two sites of v_k, v_{k-1} and w in registers,
+// B̄ is applied through the lane program of cheb_own_kernel (three exchanges per apply on the honeycomb lattice instead of five LDS
+// read-modify-write stages) and each of the two inner products of a step costs one barrier (wave sums ping-pong between two LDS rows).
+// Arithmetic per site is that of lanczos_kernel; the inner products add the sites in lane order instead of LDS-position order.
+template <int NCOL>
+__global__ void __launch_bounds__(1024) lanczos_own_kernel(KpmArgs k, KpmGeom kg, int w0, const double *__restrict__ randvec, int nsteps, double *alpha, double *beta, PreUpd u)
+{
+    using namespace ownk;
+    using T = double;
+    extern __shared__ double2 lds[];
+    __shared__ double red2[2][16];
+    __shared__ double sh[8];
+    const int N = k.N, w = w0 + blockIdx.x, Tn = blockDim.x, j = threadIdx.x;
+    T *Wb0 = reinterpret_cast<T *>(lds), *Wb1 = Wb0 + 2 * Tn;
+    double *sa = Wb1 + 2 * Tn, *sb = sa + nsteps;  // the Lanczos coefficients stay in LDS for the bookkeeping at the end
+    randvec += (size_t)blockIdx.x * N;
+    alpha += (size_t)blockIdx.x * 1024;
+    beta += (size_t)blockIdx.x * 1024;
+    OwnIdx<NCOL> I;
+    own_load_idx<NCOL>(I, kg, Tn, j);
+    OwnProg<NCOL> P;
+    own_load_prog<NCOL>(P, I, k.dbar + (size_t)w * N, kg.pcs + (size_t)w * kg.ptotal, Tn, j);
+    const bool two = P.on && P.sy != P.sx;
+    const int wave = j >> 6, lane = j & 63, nwave = (Tn + 63) >> 6;
+    int rb = 0;
+    auto bsum = [&](double v) {  // workgroup sum, one barrier: safe because consecutive calls alternate rows and a barrier lies between two uses of a row
+        v = wsum_k(v);
+        if (lane == 0) red2[rb][wave] = v;
+        __syncthreads();
+        double t = 0.0;
+        for (int q = 0; q < nwave; ++q) t += red2[rb][q];
+        rb ^= 1;
+        return t;
+    };
+    double vkx = P.on ? randvec[P.sx] : 0.0, vky = two ? randvec[P.sy] : 0.0;
+    const double nrm = sqrt(bsum(vkx * vkx + vky * vky));
+    vkx /= nrm; vky /= nrm;
+    double vmx = 0.0, vmy = 0.0, bprev = 0.0;
+    int buf = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        T ax = vkx, ay = two ? vky : vkx;  // a self bond's lane carries its one site in both slots
+        own_bbar_apply<NCOL, T>(P, ax, ay, Wb0, Wb1, buf);
+        const double al = bsum(P.on ? vkx * ax + (two ? vky * ay : 0.0) : 0.0);
+        const double wx = ax - al * vkx - bprev * vmx;
+        const double wy = two ? ay - al * vky - bprev * vmy : 0.0;
+        const double nb = sqrt(bsum(P.on ? wx * wx + wy * wy : 0.0));
+        if (j == 0) {
+            alpha[s] = al; sa[s] = al;
+            if (s < nsteps - 1) { beta[s] = nb; sb[s] = nb; }
+        }
+        vmx = vkx; vmy = vky;
+        vkx = wx / nb; vky = wy / nb;
+        bprev = nb;
+    }
+    __syncthreads();
+    precond_bookkeeping(sa, sb, nsteps, w, u, sh);
 }
 
 // raise the dynamic-LDS limit of the generic kernels once, outside any stream capture
@@ -1257,26 +1525,45 @@ hipError_t configure_kpm_kernels(const char **what)
     SMOQY_SET_LDS(cheb_generic_kernel, 160 * 1024 - 256);
     SMOQY_SET_LDS((lanczos_kernel<0, false>), 160 * 1024 - 256);
     SMOQY_SET_LDS((lanczos_kernel<2, false>), 160 * 1024 - 256);
+    SMOQY_SET_LDS(kpm_expansions_kernel, 160 * 1024 - 256);
+    SMOQY_SET_LDS((lanczos_own_kernel<2>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
+    SMOQY_SET_LDS((lanczos_own_kernel<3>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
+    SMOQY_SET_LDS((lanczos_own_kernel<4>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
+    SMOQY_SET_LDS((lanczos_own_kernel<5>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
+    SMOQY_SET_LDS((lanczos_own_kernel<6>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
     // owner-computes Chebyshev kernels: four images of `threads` values + the coefficient tables pass 64 KB at 1024 threads (complex values)
 #define SMOQY_OWN_LDS(C_)                                                  \
     SMOQY_SET_LDS((cheb_own_kernel<C_, false>), 160 * 1024 - 256);         \
     SMOQY_SET_LDS((cheb_own_kernel<C_, true>), 160 * 1024 - 256);          \
+    SMOQY_SET_LDS((cheb_own_kernel<C_, false, true>), 160 * 1024 - 256);   \
+    SMOQY_SET_LDS((cheb_own_kernel<C_, true, true>), 160 * 1024 - 256);    \
     SMOQY_SET_LDS((cheb_own_asym_kernel<C_>), 160 * 1024 - 256);
     SMOQY_OWN_LDS(2) SMOQY_OWN_LDS(3) SMOQY_OWN_LDS(4) SMOQY_OWN_LDS(5) SMOQY_OWN_LDS(6)
 #undef SMOQY_OWN_LDS
     return first;
 }
 
-void launch_lanczos(hipStream_t st, const KpmArgs &k, const KpmGeom &kg, int w0, int nw, const double *randvec, int nsteps, double *alpha, double *beta, bool use_BtB)
+void launch_lanczos(hipStream_t st, const KpmArgs &k, const KpmGeom &kg, int w0, int nw, const double *randvec, int nsteps, double *alpha, double *beta, bool use_BtB, const PreUpd &u)
 {
     const size_t lds = (!kg.fast && k.scratch) ? 0 : sizeof(double2) * 3 * (size_t)k.N;
     const int threads = kg.fast ? kg.threads : kThreads;
+    if (kg.fast && !use_BtB && k.ncol >= 2 && k.ncol <= kMaxColours && kg.own && cheb_own_enabled() && k.sbari == nullptr) {
+        const size_t olds = sizeof(double) * (4 * (size_t)kg.threads + 2 * (size_t)nsteps);
+        switch (k.ncol) {
+            case 2: hipLaunchKernelGGL((lanczos_own_kernel<2>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u); break;
+            case 3: hipLaunchKernelGGL((lanczos_own_kernel<3>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u); break;
+            case 4: hipLaunchKernelGGL((lanczos_own_kernel<4>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u); break;
+            case 5: hipLaunchKernelGGL((lanczos_own_kernel<5>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u); break;
+            default: hipLaunchKernelGGL((lanczos_own_kernel<6>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u); break;
+        }
+        return;
+    }
     if (kg.fast) {
-        if (use_BtB) hipLaunchKernelGGL((lanczos_kernel<2, true>), dim3(nw), dim3(threads), lds, st, k, kg, w0, randvec, nsteps, alpha, beta);
-        else hipLaunchKernelGGL((lanczos_kernel<0, true>), dim3(nw), dim3(threads), lds, st, k, kg, w0, randvec, nsteps, alpha, beta);
+        if (use_BtB) hipLaunchKernelGGL((lanczos_kernel<2, true>), dim3(nw), dim3(threads), lds, st, k, kg, w0, randvec, nsteps, alpha, beta, u);
+        else hipLaunchKernelGGL((lanczos_kernel<0, true>), dim3(nw), dim3(threads), lds, st, k, kg, w0, randvec, nsteps, alpha, beta, u);
     } else {
-        if (use_BtB) hipLaunchKernelGGL((lanczos_kernel<2, false>), dim3(nw), dim3(threads), lds, st, k, kg, w0, randvec, nsteps, alpha, beta);
-        else hipLaunchKernelGGL((lanczos_kernel<0, false>), dim3(nw), dim3(threads), lds, st, k, kg, w0, randvec, nsteps, alpha, beta);
+        if (use_BtB) hipLaunchKernelGGL((lanczos_kernel<2, false>), dim3(nw), dim3(threads), lds, st, k, kg, w0, randvec, nsteps, alpha, beta, u);
+        else hipLaunchKernelGGL((lanczos_kernel<0, false>), dim3(nw), dim3(threads), lds, st, k, kg, w0, randvec, nsteps, alpha, beta, u);
     }
 }
 

@@ -71,6 +71,7 @@ struct FdmArgs {
     // the 1024 workgroups at ~12 ns each and lengthen the launch it measures); the host takes min(start) / max(end): first start
     // -> last end of the launch, the interval rocprofv3 reports, free of the inter-launch gap an event pair includes
     unsigned long long *stamp;
+    int run_len;  // fdm_stream_kernel: output slices per workgroup (a multiple of Tc); 0 = not a streaming launch
 };
 
 // stamps for FdmArgs::stamp
@@ -109,6 +110,21 @@ struct KpmArgs {
                                         // (0, 0 = defaults of launch_cheb)
 };
 
+// Device-resident bookkeeping of update_preconditioner! (src/KPMPreconditioner.jl:565-597): the Lanczos kernel ends with the tridiagonal
+// extremes, the (1 ∓ rbuf) widening, the activation test and the "bounds moved by more than rbuf/2" decision; when the bounds are
+// accepted it also fills the expansion orders (:696-731) and raises `rebuild`, which the expansion kernel (:734-795) acts on.  The host
+// never waits for any of it: it reads `status` whenever it next synchronises with the stream for another reason.
+struct PreUpd {
+    double *bounds;   // [nw][2] the ACCEPTED bounds: what order / coefs were built for (Chebyshev kernels read these)
+    int *active;      // [nw]
+    int *order;       // [nw][nslot]
+    double2 *coefs;   // [nw][nslot][maxorder]
+    int *rebuild;     // [nw] 1: this update accepted new bounds, the expansion kernel must refill the coefficients
+    int *status;      // [nw][4] = {number of rebuilds so far, 2·(last slot with order > 1) + 2 capped at Lτ (0: none), largest order, active}
+    double rbuf, a1, a2;  // a1 already doubled for Sym (:263)
+    int nslot, maxorder, Lt, is_sym;
+};
+
 // geometry of the KPM fast path: per-colour bond lists padded with identity self bonds (i, i) so
 // that every colour covers all N sites; lane t of a workgroup owns padded bond poff[c] + t
 struct KpmGeom {
@@ -128,6 +144,8 @@ struct KpmGeom {
     // indices (into pcs) of the two bonds.
     const int *own;
     int own_q, own_n;
+    int wl0;             // the colour-0 mates of every lane's two sites are held by lanes of the same wavefront, first site's mate in a second
+                         // slot and vice versa: the centre exchange of cheb_own_kernel runs on wave shuffles (own_chain<…, WL0>)
 };
 
 // geometry + packed hopping table of the register-resident FermionDetMatrix kernels
@@ -143,6 +161,7 @@ struct FdmFast {
     int enabled;
     const int *own;      // owner-computes tables (layout as KpmGeom::own) for owned colour 1 (0 when there is one colour)
     int own_n;
+    int full;            // every colour is a perfect matching: `threads` two-site bonds per padded list, N = 2·threads (fdm_stream_kernel<…, FULL>)
 };
 
 // ---- launchers (defined in the .hip files) -----------------------------------------------
@@ -161,6 +180,10 @@ hipError_t configure_kpm_kernels(const char **what);
 bool fdm_fast_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
 // cs_const: the caller has shown, on the host, that the hoppings of every walker of this launch do not depend on τ (Sym form only)
 void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff, bool sym = true, bool cs_const = false);
+// streaming form of the fused MᵀM (workgroups walk runs of a.run_len slices, loads two iterations ahead of the stage chain)
+bool fdm_stream_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
+void launch_fdm_stream(hipStream_t st, const FdmArgs &a, const FdmFast &ff, bool cs_const);
+hipError_t configure_fdm_stream_kernels(const char **what);
 bool fdm_own_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
 void launch_fdm_own(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff);
 void launch_pack_csf(hipStream_t st, const double *ch, const double *sh, const int *psrc, double2 *csf, int *cs_varies, int Lt, int Lt1, int Nh, int ptotal);
@@ -182,7 +205,10 @@ void launch_make_twiddle(hipStream_t st, double2 *tw, int Lt, double scale);
 void launch_tau_means(hipStream_t st, const KpmGeom &kg, const double *expV, const double *ch, const double *sh, double *dbar, double *cbar, double *sbar, int Lt, int N, int Nh, int w0, int nw, const double *shi = nullptr,
                       double *sbari = nullptr);
 // alpha/beta: [nw][1024] each; randvec: [nw][N] doubles, or [nw][N] complex128 when k.sbari != nullptr (T = ComplexF64)
-void launch_lanczos(hipStream_t st, const KpmArgs &k, const KpmGeom &kg, int w0, int nw, const double *randvec, int nsteps, double *alpha, double *beta, bool use_BtB);
+// the kernel ends with the device-side bookkeeping of update_preconditioner! (PreUpd) for its walker
+void launch_lanczos(hipStream_t st, const KpmArgs &k, const KpmGeom &kg, int w0, int nw, const double *randvec, int nsteps, double *alpha, double *beta, bool use_BtB, const PreUpd &u);
+// update_kpm_expansion_coefs! (:734-795) on the device for walkers [w0, w0 + nw) whose `rebuild` flag is set
+void launch_kpm_expansions(hipStream_t st, const PreUpd &u, int w0, int nw);
 void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg);
 bool cheb_split_active(const KpmArgs &k, const KpmGeom &kg);  // true: the Chebyshev kernel writes 2·Lτ r·z partials per system instead of Lτ
 // v[Lτ-1-ω] = conj(v[ω]) for ω < cld(Lτ, 2) (KPMPreconditioner.jl:334 / :468; the middle frequency of an odd Lτ conjugates itself)
