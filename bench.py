@@ -26,6 +26,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 GPU: K fresh child processes, each with a single-walker handle, started together; aggregate sweeps/s per K.  Runs before
                 this process touches the GPU.  K stops at 6: the GPU pool admits at most six processes on a card at once.
   threads_per_gpu_scan  the same with K host threads in one process, each owning a single-walker handle (its own HIP stream).
+  team_threads_scan     K host threads, each driving ONE walker through a walker team (smoqy_team_*): per-walker control flow, batched launches.
   cpu_baseline  the CPU oracle (a single-threaded restatement of the reference algorithm, NOT the Julia reference, which cannot run
                 here) timed on a bounded sample of the same workload, one walker per host core, all at once.
 """
@@ -74,7 +75,8 @@ def parse():
     ap.add_argument("--scan-sweeps", type=int, default=6, help="sweeps each rank / thread of the procs_per_gpu / threads_per_gpu scans times")
     ap.add_argument("--proc-scan", default="1,2,4,6", help="process counts of procs_per_gpu_scan (the pool admits at most 6 GPU processes per card)")
     ap.add_argument("--thread-scan", default="1,2,4,8,16", help="thread counts of threads_per_gpu_scan")
-    ap.add_argument("--no-proc-scan", action="store_true", help="skip procs_per_gpu_scan and threads_per_gpu_scan")
+    ap.add_argument("--team-scan", default="8,16,32", help="member counts of team_threads_scan")
+    ap.add_argument("--no-proc-scan", action="store_true", help="skip procs_per_gpu_scan, threads_per_gpu_scan and team_threads_scan")
     ap.add_argument("--roofline-only", action="store_true", help="run only the isolated roofline leg (for a rocprofv3 pass whose kernel average must match roofline.avg_launch_us)")
     ap.add_argument("--batch-scan", action="store_true", help="try tau chunks 1..4 at every point of the batch scan (the default scan uses the heuristic chunk)")
     ap.add_argument("--timed-only", action="store_true",
@@ -305,6 +307,38 @@ def threads_per_gpu_scan(args, counts, dev, walker0):
                     "avg_cg_iters": sum(b.stats.iters_sum for b in bs) / max(sum(b.stats.solves for b in bs), 1)})
         for b in bs:
             b.h.close()
+    return out
+
+
+def team_scan(args, counts, dev, walker0):
+    """K host threads, each running the per-walker sweep of the reference against ITS OWN walker only, through a walker team (C ABI
+    "walker teams"): the calls of the K members rendezvous inside the library and run as one batched call.  Next to it the same sweep
+    (host-driven HMC: x uploaded, force downloaded every step) driven by one caller through the batched entry points."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from smoqyelphqmc_amd.walkers import WalkerBatch, WalkerTeam
+
+    out = []
+    for K in counts:
+        team = WalkerTeam(args.workload, K, walker0=walker0 + 3000, device=dev)
+        with ThreadPoolExecutor(K) as pool:
+            list(pool.map(lambda m: m.sweep(), team.members))
+            t0 = time.perf_counter()
+            list(pool.map(lambda m: [m.sweep() for _ in range(args.scan_sweeps)], team.members))
+            span = time.perf_counter() - t0
+        iters = sum(m.iters_sum for m in team.members) / max(sum(m.solves for m in team.members), 1)
+        team.close()
+        ob = WalkerBatch(args.workload, nwalkers=K, walker0=walker0 + 3000, device=dev, device_efa=False)
+        ob.sweep()
+        ob.h.call("smoqy_sync")
+        t1 = time.perf_counter()
+        for _ in range(args.scan_sweeps):
+            ob.sweep()
+        ob.h.call("smoqy_sync")
+        span_b = time.perf_counter() - t1
+        ob.h.close()
+        out.append({"threads": K, "walkers_per_thread": 1, "handles": 1, "sweeps_per_s": K * args.scan_sweeps / span, "avg_cg_iters": iters,
+                    "one_caller_batched_sweeps_per_s": K * args.scan_sweeps / span_b, "sweeps_each": args.scan_sweeps})
     return out
 
 
@@ -605,6 +639,13 @@ def main():
                                                      "points": threads_per_gpu_scan(args, [int(k) for k in args.thread_scan.split(",") if k], dev, mine.start)}
                 except Exception as ex:  # noqa: BLE001 — reported, never fatal to the bench line
                     extra["threads_per_gpu_scan"] = {"error": str(ex)[:400]}
+                try:
+                    extra["team_threads_scan"] = {"model": "K host threads, each driving ONE walker with the reference's per-walker update sequence, through a walker team "
+                                                           "(smoqy_team_*: the members' calls rendezvous in the library and run as one batched call on one handle); "
+                                                           "host-driven HMC (x uploaded, force downloaded every step), so compare with one_caller_batched, not with `value`",
+                                                  "points": team_scan(args, [int(k) for k in args.team_scan.split(",") if k], dev, mine.start)}
+                except Exception as ex:  # noqa: BLE001
+                    extra["team_threads_scan"] = {"error": str(ex)[:400]}
         # the CPU baseline is a rank-0, N = 1 measurement (it would only hold the other ranks at the final barrier)
         cpu = None if (args.no_cpu_baseline or args.roofline_only or args.timed_only or world > 1) else cpu_baseline(args.workload, batch.tol, batch.Nt)
         # the whole sweep against the roofline: algorithmic bytes of one preconditioned CG iteration per walker as SURVEY.md §8(d)

@@ -341,6 +341,35 @@ int smoqy_ge_measure_pairs(smoqy_ctx *ctx, int gr, int r, const smoqy_ge_slot *s
  * from the device-resident vectors (circshift(a, s)[c] = a[c - s]; tD = t0 = NULL drops the weights).  out: nwalkers complex. */
 int smoqy_ge_boundary_dot(smoqy_ctx *ctx, int gr, int r, int orbital_gr, int orbital_r, const int64_t *shift, const void *tD, int conj_tD, const int64_t *tshift, const void *t0, int conj_t0, void *out);
 
+/* ---- walker teams: the reference's one-walker-per-rank control flow on one batched handle ------------------ */
+
+/* The reference runs each walker as its own MPI rank with single-walker objects (tutorials/holstein_honeycomb_mpi.jl:60-72).  On one GPU
+ * that model does not scale (ranks time-slice the device); a handle with nwalkers = K does, but it needs the K control flows in lock step.
+ * A team is that rendezvous: K host threads (one per replica) each run the UNCHANGED per-walker update sequence and call the entry points
+ * below with their walker index w; a call blocks until all K members have made the same call, the last arrival runs the batched library
+ * call for everybody, every member returns with its own results.  All members of a round must pass the same tol / maxiter / use_precond.
+ * A non-zero return (e.g. a non-finite residual in any member's solve, or a member that never arrives: rendezvous time-out, code 9) is
+ * delivered to every member of the round; each rejects its update, as the reference's catch block does (src/EFAPFFHMCUpdater.jl:168-187).
+ * The handle needs smoqy_force_set_couplings and smoqy_set_bare_model (the field update from x runs on the device); Nph is the number of
+ * phonon modes of those couplings.  While a team is in use, nothing else may call into its handle. */
+typedef struct smoqy_team smoqy_team;
+int smoqy_team_create(smoqy_team **out, smoqy_ctx *ctx, int Nph);
+int smoqy_team_destroy(smoqy_team *team);
+const char *smoqy_team_last_error(const smoqy_team *team);
+int smoqy_team_size(const smoqy_team *team, int *K);
+/* seconds a member waits for the others before it gives up with code 9 (default 600) */
+int smoqy_team_set_timeout(smoqy_team *team, double seconds);
+/* the device-resident Φ / Ψ of the team's PFFCalculator (src/PFFCalculator.jl:9-16), e.g. for smoqy_vec_download between rounds */
+int smoqy_team_vectors(const smoqy_team *team, int *phi, int *psi);
+/* sample_pseudofermion_fields! (src/PFFCalculator.jl:56-76) for member w: R is the member's Ltau x N complex normal deviates (randn! on
+ * its own rng, :67); Φ = Λᵀ Mᵀ R stays on the device; *RdotR = |R|² */
+int smoqy_team_sample_phi(smoqy_team *team, int w, const void *R, double *RdotR);
+/* calculate_fermionic_action! (dSdx == NULL) / calculate_derivative_fermionic_action! (src/PFFCalculator.jl:79-157) for member w, with the
+ * field update of the member's move in front: x = the member's Nph x Ltau phonon fields after its move (SmoQyDQMC.update! + update!(fdm) +
+ * update_Λ! on the device, src/EFAPFFHMCUpdater.jl:200-205) or NULL if they did not change; randvec = N normal deviates for the Lanczos
+ * start vector (KPMPreconditioner.jl:634; needed when use_precond != 0).  Out: S_f, (iters, eps) of the solve, ∂S_f/∂x (Nph x Ltau, stored). */
+int smoqy_team_pff_step(smoqy_team *team, int w, const double *x, const double *randvec, double tol, int maxiter, int use_precond, double *Sf, int *iters, double *eps, double *dSdx);
+
 /* ---- measurement aids (bench.py) -------------------------------------------------------- */
 
 /* HIP events on the handle's stream */

@@ -67,6 +67,13 @@ SIGNATURES = {
     "smoqy_matvec_v": [_p, _i, _i, _i],
     "smoqy_matvec_force_generic": [_p, _i],
     "smoqy_matvec_stream": [_p, _i],
+    "smoqy_team_create": [C.POINTER(_p), _p, _i],
+    "smoqy_team_destroy": [_p],
+    "smoqy_team_size": [_p, _pi],
+    "smoqy_team_set_timeout": [_p, _d],
+    "smoqy_team_vectors": [_p, _pi, _pi],
+    "smoqy_team_sample_phi": [_p, _i, _p, _pd],
+    "smoqy_team_pff_step": [_p, _i, _p, _p, _d, _i, _i, _pd, _pi, _pd, _p],
     "smoqy_matvec": [_p, _i, _p, _p, _i, _i],
     "smoqy_checkerboard_v": [_p, _i, _i, _i, _i, _i],
     "smoqy_checkerboard": [_p, _p, _i, _i, _i, _i, _i, _i],
@@ -149,6 +156,8 @@ def load():
         fn.restype = C.c_int
     lib.smoqy_last_error.argtypes = [_p]
     lib.smoqy_last_error.restype = C.c_char_p
+    lib.smoqy_team_last_error.argtypes = [_p]
+    lib.smoqy_team_last_error.restype = C.c_char_p
     _lib = lib
     return lib
 

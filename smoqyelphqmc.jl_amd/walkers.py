@@ -376,3 +376,91 @@ class WalkerBatch:
     @property
     def solves_per_sweep(self):
         return 2 + self.Nt + 1 + self.measure_nrv
+
+
+class WalkerTeam:
+    """K single-walker control flows on ONE batched handle (C ABI "walker teams", csrc/team.hip).
+
+    The reference runs each walker as its own MPI rank around single-walker objects (tutorials/holstein_honeycomb_mpi.jl:60-72).  A team
+    keeps that per-walker code shape — every member below is driven by its own host thread and only ever sees its own walker — while the
+    library advances all K walkers with one launch per kernel: a member's call blocks until the other K - 1 members have made the same
+    call, the last arrival runs the batched call, everybody returns with its own results.
+
+    ``WalkerTeam(workload, K)`` builds the batched handle exactly as ``WalkerBatch`` does (same lattice tables, couplings, bare model) and
+    hands out ``members[w]``; ``member.sweep()`` is the host-driven sweep of ``WalkerBatch.sweep`` (device_efa = False) for ONE walker.
+    """
+
+    def __init__(self, workload: str, nwalkers: int, walker0: int = 0, device: int = -1, **kw):
+        self.batch = WalkerBatch(workload, nwalkers=nwalkers, walker0=walker0, device=device, device_efa=False, host_threads=1, **kw)
+        b = self.batch
+        self._t = C.c_void_p()
+        lib = L.load()
+        rc = lib.smoqy_team_create(C.byref(self._t), b.h._h, int(b.Nph_force))
+        if rc:
+            raise L.SmoqyError(f"smoqy_team_create failed ({rc}): " + (lib.smoqy_team_last_error(None) or b"").decode())
+        self.lib = lib
+        self.members = [TeamMember(self, w) for w in range(nwalkers)]
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, name)(self._t, *args)
+        if rc:
+            raise L.SmoqyError(f"{name} failed ({rc}): " + (self.lib.smoqy_team_last_error(self._t) or b"").decode())
+
+    def close(self):
+        if self._t:
+            self.lib.smoqy_team_destroy(self._t)
+            self._t = C.c_void_p()
+        self.batch.h.close()
+
+
+class TeamMember:
+    """One walker of a WalkerTeam: the per-walker state a rank of the reference owns (phonon fields x, rng) and the update sequence of
+    tutorials/holstein_honeycomb.jl:611-684 written for ONE walker; every library call goes through the team."""
+
+    def __init__(self, team: WalkerTeam, w: int):
+        self.team, self.w = team, w
+        b = team.batch
+        self.Lt, self.N, self.Nph = b.Lt, b.N, b.Nph_force
+        self.rng = b.rng[w]
+        self.x = np.array(b.xs_force[w], copy=True)          # (Lt, Nph) C order == Nph x Ltau column-major
+        self.free = b.Nph                                     # bond-SSH: the last mode is the frozen partner
+        self.R = np.empty((self.Lt, self.N), dtype=np.complex128, order="F")
+        self.dSdx = np.zeros((self.Lt, self.Nph))
+        self.tol, self.tol_force, self.maxiter, self.Nt, self.drift = b.tol, b.tol_force, b.maxiter, b.Nt, b.drift
+        self.solves = self.iters_sum = 0
+
+    def sample_pseudofermion_fields(self):
+        flat = self.R.reshape(-1, order="F").view(np.float64)
+        self.rng.standard_normal(out=flat)                    # randn!(rng, Φ), src/PFFCalculator.jl:67
+        flat *= np.sqrt(0.5)
+        rr = C.c_double(0.0)
+        self.team.call("smoqy_team_sample_phi", self.w, L.ptr(self.R), C.byref(rr))
+        return rr.value
+
+    def pff_step(self, tol, moved, want_force):
+        rv = self.rng.standard_normal(self.N)                 # randn!(rng, v), KPMPreconditioner.jl:634
+        sf, eps, it = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
+        self.team.call("smoqy_team_pff_step", self.w, L.ptr(self.x) if moved else None, L.ptr(rv), C.c_double(tol), int(self.maxiter), 1, C.byref(sf), C.byref(it), C.byref(eps),
+                       L.ptr(self.dSdx) if want_force else None)
+        self.solves += 1
+        self.iters_sum += it.value
+        return sf.value, it.value, eps.value
+
+    def sweep(self):
+        """reflection-like + swap-like move + HMC(Nt) with the synthetic host-side drift: WalkerBatch.sweep (device_efa = False), one walker"""
+        last = None
+        for _ in range(2):
+            self.sample_pseudofermion_fields()
+            pi = self.rng.standard_normal((self.Lt, self.free))
+            self.x[:, : self.free] += self.drift * pi
+            last = self.pff_step(self.tol, moved=True, want_force=False)
+            self.x[:, : self.free] -= self.drift * pi         # "rejected": restore x (the next call sends it)
+        self.sample_pseudofermion_fields()
+        pi = self.rng.standard_normal((self.Lt, self.free))
+        dx = pi * (self.drift / self.Nt)
+        for t in range(self.Nt):
+            self.pff_step(self.tol_force, moved=True, want_force=True)
+            self.x[:, : self.free] += dx
+        last = self.pff_step(self.tol, moved=True, want_force=False)
+        self.x[:, : self.free] -= self.drift * pi
+        return last

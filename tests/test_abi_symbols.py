@@ -25,7 +25,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in smoqy_hip.h but not exported"
     # and the Python binding covers the same set
-    assert set(names) == set(L.SIGNATURES) | {"smoqy_last_error"}
+    assert set(names) == set(L.SIGNATURES) | {"smoqy_last_error", "smoqy_team_last_error"}  # the two that return a string
 
 
 def test_no_cpu_fallback_without_gpu():

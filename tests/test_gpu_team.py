@@ -1,0 +1,89 @@
+"""Walker teams (include/smoqy_hip.h "walker teams", csrc/team.hip): K host threads, each running the per-walker update sequence of
+the reference (one walker per MPI rank, tutorials/holstein_honeycomb_mpi.jl:60-72) against its own walker index, must get exactly what
+the batched entry points give when one caller drives all K walkers in lock step."""
+import ctypes as C
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from smoqyelphqmc_amd import _lib as L
+from smoqyelphqmc_amd.walkers import WalkerBatch, WalkerTeam
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,K", [("holstein_honeycomb_L4_Ltau40", 4), ("bssh_chain_L256_Ltau200_alpha0p2", 3)])
+def test_team_members_equal_the_batched_calls(name, K):
+    team = WalkerTeam(name, K)
+    ref = WalkerBatch(name, nwalkers=K, device_efa=False)
+    g = np.random.default_rng(11)
+    Lt, N, Nph = ref.Lt, ref.N, ref.Nph_force
+    Rs = np.asfortranarray((g.standard_normal((Lt, N, K)) + 1j * g.standard_normal((Lt, N, K))) * np.sqrt(0.5))
+    xs = np.array(ref.xs_force, copy=True)
+    xs[:, :, : ref.Nph] += 0.05 * g.standard_normal((K, Lt, ref.Nph))
+    rvs = np.ascontiguousarray(g.standard_normal((K, N)))
+    # reference: one caller, batched entry points
+    ref.h.vec_upload(ref.phi, Rs)
+    rr_ref = ref.h.vec_dot(ref.phi, ref.phi).real
+    ref.h.call("smoqy_matvec_v", L.OP_MT, ref.phi, ref.phi)
+    ref.h.call("smoqy_lambda_apply_v", L.LAMBDA_MULT, ref.phi, ref.phi)
+    sf, it, ep = np.zeros(K), np.zeros(K, dtype=np.int32), np.zeros(K)
+    dS = np.zeros((K, Lt, Nph))
+    ref.h.call("smoqy_pff_step_v", ref.phi, ref.u, L.ptr(xs), L.ptr(rvs), C.c_double(1e-10), 10000, 1, L.ptr(sf), L.ptr(it), L.ptr(ep), L.ptr(dS))
+    # team: K threads, each with its own walker only, arriving in scrambled order
+    out = [None] * K
+
+    def member(w):
+        m = team.members[w]
+        threading.Event().wait(0.01 * ((w * 7) % K))
+        rr = C.c_double(0.0)
+        R = np.asfortranarray(Rs[:, :, w])
+        team.call("smoqy_team_sample_phi", w, L.ptr(R), C.byref(rr))
+        s, e, i = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
+        d = np.zeros((Lt, Nph))
+        x = np.ascontiguousarray(xs[w])
+        team.call("smoqy_team_pff_step", w, L.ptr(x), L.ptr(np.ascontiguousarray(rvs[w])), C.c_double(1e-10), 10000, 1, C.byref(s), C.byref(i), C.byref(e), L.ptr(d))
+        # a second round with x unchanged (NULL) and no force
+        s2, e2, i2 = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
+        team.call("smoqy_team_pff_step", w, None, L.ptr(np.ascontiguousarray(rvs[w])), C.c_double(1e-10), 10000, 1, C.byref(s2), C.byref(i2), C.byref(e2), None)
+        out[w] = (rr.value, s.value, i.value, e.value, d, s2.value, i2.value)
+        assert m.w == w
+
+    with ThreadPoolExecutor(K) as pool:
+        list(pool.map(member, range(K)))
+    for w in range(K):
+        rr, s, i, e, d, s2, i2 = out[w]
+        assert rr == rr_ref[w] and s == sf[w] and i == it[w] and e == ep[w]  # same kernels on the same batch: bit for bit
+        assert np.array_equal(d, dS[w])
+        assert i2 == i and abs(s2 - s) <= 1e-9 * abs(s)  # same fields, a fresh Lanczos with the same start vector: the same solve
+    team.close()
+    ref.h.close()
+
+
+def test_team_sweeps_and_errors():
+    K = 4
+    team = WalkerTeam("holstein_honeycomb_L4_Ltau40", K)
+    with ThreadPoolExecutor(K) as pool:
+        res = list(pool.map(lambda m: m.sweep(), team.members))
+    assert all(r[1] > 0 and r[2] < 1e-10 for r in res)
+    # a member that never arrives: the others time out with an error instead of hanging
+    team.call("smoqy_team_set_timeout", C.c_double(0.5))
+    errs = []
+
+    def lonely(w):
+        try:
+            team.members[w].sample_pseudofermion_fields()
+        except L.SmoqyError as ex:
+            errs.append(str(ex))
+
+    with ThreadPoolExecutor(K - 1) as pool:
+        list(pool.map(lonely, range(K - 1)))
+    assert len(errs) == K - 1 and all("timed out" in e for e in errs)
+    # the team is usable again afterwards
+    team.call("smoqy_team_set_timeout", C.c_double(600.0))
+    with ThreadPoolExecutor(K) as pool:
+        rr = list(pool.map(lambda m: m.sample_pseudofermion_fields(), team.members))
+    assert all(r > 0 for r in rr)
+    team.close()
