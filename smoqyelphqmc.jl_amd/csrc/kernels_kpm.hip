@@ -28,26 +28,38 @@
 
 namespace smoqy {
 
+// Sum over the 64 lanes of a wavefront on the DPP data path (row shifts inside the rows of 16, then the two row broadcasts): six dependent
+// steps of two v_mov_b32_dpp + one v_add_f64 each, against six ds_bpermute round trips through the LDS crossbar for the __shfl_down tree
+// it replaces (round 3: the reductions sit at the end of the longest Chebyshev chain and inside every Lanczos step).  The total is
+// returned in EVERY lane (read out of lane 63); the order of the additions is fixed, so results are reproducible run to run.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __hiloint2double(hi, lo);  // lanes outside ROW_MASK (or with no source lane) add an exact zero
+}
 __device__ __forceinline__ double wsum_k(double v)
 {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds its row's sum
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wavefront's sum
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 __device__ __forceinline__ double block_sum_real(double v, double *red /* >= 17 doubles */)
 {
     v = wsum_k(v);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = (blockDim.x + 63) >> 6;
-    __syncthreads();
+    __syncthreads();  // the readers of an earlier call are done with red[]
     if (lane == 0) red[wave] = v;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0;
-        for (int w = 0; w < nwave; ++w) t += red[w];
-        red[16] = t;
-    }
-    __syncthreads();
-    return red[16];
+    double t = 0;
+    for (int w = 0; w < nwave; ++w) t += red[w];  // every lane adds the wave sums in the same order: one value, no third barrier
+    return t;
 }
 
 __device__ __forceinline__ double2 cmulk(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -554,13 +566,24 @@ __device__ __forceinline__ void own_load_prog(OwnProg<NCOL> &P, const OwnIdx<NCO
 
 // (ax, ay) <- B̄ (ax, ay) for the Sym propagator in its plain form B̄ = C_{L-1} … C_1 (C_0 D̄ C_0) C_1 … C_{L-1} (no basis change: what
 // Lanczos needs, KPMPreconditioner.jl:625-639) on the lane's own two sites; all lanes of the workgroup call it together
-template <int NCOL, class T>
+template <int NCOL, class T, bool WL0 = false>
 __device__ __forceinline__ void own_bbar_apply(const OwnProg<NCOL> &P, T &ax, T &ay, T *Wb0, T *Wb1, int &buf)
 {
     using namespace ownk;
     constexpr int Q = NCOL >= 3 ? 1 : 0;
 #pragma unroll
     for (int c = NCOL - 1; c >= 1; --c) OWN_STAGE(c)
+    if constexpr (WL0 && Q != 0) {  // the colour-0 mates sit in this wavefront (KpmGeom::wl0): shuffles instead of an LDS exchange
+        const T mx_ = shfl(ay, (P.px[0] - (int)blockDim.x) & 63), my_ = shfl(ax, P.py[0] & 63);
+        T x_ = lin(P.cx[0].x, ax, P.cx[0].y, mx_), xm_ = lin(P.cx[0].x, mx_, P.cx[0].y, ax);
+        T y_ = lin(P.cy[0].x, ay, P.cy[0].y, my_), ym_ = lin(P.cy[0].x, my_, P.cy[0].y, ay);
+        x_ = scl(P.dx, x_);
+        xm_ = scl(P.dmx, xm_);
+        y_ = scl(P.dy, y_);
+        ym_ = scl(P.dmy, ym_);
+        ax = lin(P.cx[0].x, x_, P.cx[0].y, xm_);
+        ay = lin(P.cy[0].x, y_, P.cy[0].y, ym_);
+    } else
     OWN_CENTRE()
 #pragma unroll
     for (int c = 1; c <= NCOL - 1; ++c) OWN_STAGE(c)
@@ -1464,7 +1487,7 @@ __global__ void __launch_bounds__(1024) lanczos_kernel(KpmArgs k, KpmGeom kg, in
 // B̄ is applied through the lane program of cheb_own_kernel (three exchanges per apply on the honeycomb lattice instead of five LDS
 // read-modify-write stages) and each of the two inner products of a step costs one barrier (wave sums ping-pong between two LDS rows).
 // Arithmetic per site is that of lanczos_kernel; the inner products add the sites in lane order instead of LDS-position order.
-template <int NCOL>
+template <int NCOL, bool WL0>
 __global__ void __launch_bounds__(1024) lanczos_own_kernel(KpmArgs k, KpmGeom kg, int w0, const double *__restrict__ randvec, int nsteps, double *alpha, double *beta, PreUpd u)
 {
     using namespace ownk;
@@ -1501,7 +1524,7 @@ __global__ void __launch_bounds__(1024) lanczos_own_kernel(KpmArgs k, KpmGeom kg
     int buf = 0;
     for (int s = 0; s < nsteps; ++s) {
         T ax = vkx, ay = two ? vky : vkx;  // a self bond's lane carries its one site in both slots
-        own_bbar_apply<NCOL, T>(P, ax, ay, Wb0, Wb1, buf);
+        own_bbar_apply<NCOL, T, WL0>(P, ax, ay, Wb0, Wb1, buf);
         const double al = bsum(P.on ? vkx * ax + (two ? vky * ay : 0.0) : 0.0);
         const double wx = ax - al * vkx - bprev * vmx;
         const double wy = two ? ay - al * vky - bprev * vmy : 0.0;
@@ -1526,11 +1549,16 @@ hipError_t configure_kpm_kernels(const char **what)
     SMOQY_SET_LDS((lanczos_kernel<0, false>), 160 * 1024 - 256);
     SMOQY_SET_LDS((lanczos_kernel<2, false>), 160 * 1024 - 256);
     SMOQY_SET_LDS(kpm_expansions_kernel, 160 * 1024 - 256);
-    SMOQY_SET_LDS((lanczos_own_kernel<2>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
-    SMOQY_SET_LDS((lanczos_own_kernel<3>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
-    SMOQY_SET_LDS((lanczos_own_kernel<4>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
-    SMOQY_SET_LDS((lanczos_own_kernel<5>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
-    SMOQY_SET_LDS((lanczos_own_kernel<6>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
+    SMOQY_SET_LDS((lanczos_own_kernel<2, false>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
+    SMOQY_SET_LDS((lanczos_own_kernel<2, true>), 160 * 1024 - 1024);
+    SMOQY_SET_LDS((lanczos_own_kernel<3, false>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
+    SMOQY_SET_LDS((lanczos_own_kernel<3, true>), 160 * 1024 - 1024);
+    SMOQY_SET_LDS((lanczos_own_kernel<4, false>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
+    SMOQY_SET_LDS((lanczos_own_kernel<4, true>), 160 * 1024 - 1024);
+    SMOQY_SET_LDS((lanczos_own_kernel<5, false>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
+    SMOQY_SET_LDS((lanczos_own_kernel<5, true>), 160 * 1024 - 1024);
+    SMOQY_SET_LDS((lanczos_own_kernel<6, false>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
+    SMOQY_SET_LDS((lanczos_own_kernel<6, true>), 160 * 1024 - 1024);
     // owner-computes Chebyshev kernels: four images of `threads` values + the coefficient tables pass 64 KB at 1024 threads (complex values)
 #define SMOQY_OWN_LDS(C_)                                                  \
     SMOQY_SET_LDS((cheb_own_kernel<C_, false>), 160 * 1024 - 256);         \
@@ -1549,13 +1577,20 @@ void launch_lanczos(hipStream_t st, const KpmArgs &k, const KpmGeom &kg, int w0,
     const int threads = kg.fast ? kg.threads : kThreads;
     if (kg.fast && !use_BtB && k.ncol >= 2 && k.ncol <= kMaxColours && kg.own && cheb_own_enabled() && k.sbari == nullptr) {
         const size_t olds = sizeof(double) * (4 * (size_t)kg.threads + 2 * (size_t)nsteps);
+        const bool wl0 = kg.wl0 && k.ncol >= 3;
+#define LANCZOS_OWN(C_)                                                                                                                         \
+    {                                                                                                                                           \
+        if (wl0) hipLaunchKernelGGL((lanczos_own_kernel<C_, true>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u);  \
+        else hipLaunchKernelGGL((lanczos_own_kernel<C_, false>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u);     \
+    }
         switch (k.ncol) {
-            case 2: hipLaunchKernelGGL((lanczos_own_kernel<2>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u); break;
-            case 3: hipLaunchKernelGGL((lanczos_own_kernel<3>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u); break;
-            case 4: hipLaunchKernelGGL((lanczos_own_kernel<4>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u); break;
-            case 5: hipLaunchKernelGGL((lanczos_own_kernel<5>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u); break;
-            default: hipLaunchKernelGGL((lanczos_own_kernel<6>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u); break;
+            case 2: LANCZOS_OWN(2); break;
+            case 3: LANCZOS_OWN(3); break;
+            case 4: LANCZOS_OWN(4); break;
+            case 5: LANCZOS_OWN(5); break;
+            default: LANCZOS_OWN(6); break;
         }
+#undef LANCZOS_OWN
         return;
     }
     if (kg.fast) {
