@@ -755,7 +755,16 @@ __global__ void __launch_bounds__(1024) fdm_stream_kernel(FdmArgs a, FdmFast ff)
     }
 
     // ---- prologue: slices la-1, la, la+1 straight into their images, the next two on their way; P1(la+1) and P1(la) together ----
+    // Order of issue: what the steady-state loop will wait for first (the two prefetched slices, the fields of slice la+2) goes out FIRST,
+    // the slices and fields the prologue itself needs behind it.  Results return in issue order, so by the time the prologue has its
+    // own data the prefetches have landed as well, and the loop is entered with nothing of them outstanding — otherwise the compiler
+    // merges "entered from the prologue" with "came around the loop" and settles for the shorter of the two distances at every wait.
     double2 pfa0, pfa1, pfb0, pfb1;
+    LOAD_SLICE(pfa0, pfa1, min(la + 2, lb))  // needed as slices up to lb (the last one only for its values at the own sites)
+    LOAD_SLICE(pfb0, pfb1, min(la + 3, lb))
+    LOAD_FLD(csn, dni, dnj, la + 2)
+    LOAD_FLD(cs2, d2i, d2j, la)        // slot 2 of the prologue: B_la on v[la-1]
+    LOAD_FLD(cs1, d1i, d1j, la + 1)    // slot 1: B_{la+1} on v[la]
     {
         double2 t0, t1, t2, t3, t4, t5;
         LOAD_SLICE(t0, t1, la - 1)
@@ -765,11 +774,6 @@ __global__ void __launch_bounds__(1024) fdm_stream_kernel(FdmArgs a, FdmFast ff)
         LAND(t2, t3, X_(1))
         LAND(t4, t5, X_(2))
     }
-    LOAD_FLD(cs2, d2i, d2j, la)        // slot 2 of the prologue: B_la on v[la-1]
-    LOAD_FLD(cs1, d1i, d1j, la + 1)    // slot 1: B_{la+1} on v[la]
-    LOAD_FLD(csn, dni, dnj, la + 2)
-    LOAD_SLICE(pfa0, pfa1, min(la + 2, lb))  // needed as slices up to lb (the last one only for its values at the own sites)
-    LOAD_SLICE(pfb0, pfb1, min(la + 3, lb))
     __syncthreads();
     double2 vown_i = make_double2(0.0, 0.0), vown_j = vown_i, vnext_i = vown_i, vnext_j = vown_i;
     if (onL) { vown_i = X_(1)[bL.x]; vown_j = X_(1)[bL.y]; vnext_i = X_(2)[bL.x]; vnext_j = X_(2)[bL.y]; }  // v[la], v[la+1] at the own pair (the first stage
@@ -833,10 +837,14 @@ __global__ void __launch_bounds__(1024) fdm_stream_kernel(FdmArgs a, FdmFast ff)
             ROTATE_FLD()                                                                                              \
         }                                                                                                             \
     }
-    for (int j = la + 1; j <= lb; j += 2) {
+    // (both halves in every trip, the odd one out behind the loop: a conditional second half would give the compiler a path around the loop
+    // on which the first set's load is only one iteration old, and it would wait for that distance everywhere)
+    int j = la + 1;
+    for (; j + 1 <= lb; j += 2) {
         STREAM_ITER(pfa0, pfa1, j)
-        if (j + 1 <= lb) STREAM_ITER(pfb0, pfb1, j + 1)
+        STREAM_ITER(pfb0, pfb1, j + 1)
     }
+    if (j <= lb) STREAM_ITER(pfa0, pfa1, j)
 #undef STREAM_ITER
 #undef LAND
 #undef LOAD_SLICE
