@@ -19,8 +19,9 @@
  *     the hopping-derived arrays cross the boundary as complex128 (interleaved re, im) exactly where the reference holds a
  *     Matrix{T}: cosh_dtt / sinh_dtt of smoqy_update_fields / smoqy_get_fields (Ltau x Nh), t of
  *     smoqy_update_from_path_integral[_all] (Nh x Ltau), and the Lanczos start vectors of smoqy_precond_update[_all] (N complex
- *     deviates per walker: randn! on a Vector{ComplexF64}).  V, expV and Λ stay real.  Complex handles run on the generic kernels;
- *     the force terms and the device-side update! from phonon fields are real-T only and return an error for them.
+ *     deviates per walker: randn! on a Vector{ComplexF64}).  V, expV and Λ stay real.  Complex handles run on the generic kernels.
+ *     Round 3: the force terms and the device-side update! from the phonon fields take complex T as well — t0 of smoqy_set_bare_model is
+ *     complex128 (Nh) and the SSH couplings carry their imaginary parts in smoqy_couplings.s_alpha*_im.
  *
  * A handle carries `nwalkers` independent field sets (one FermionDetMatrix + Λ + KPM
  * preconditioner each) times `nrhs` right-hand sides per walker; system s belongs to walker
@@ -233,6 +234,9 @@ typedef struct {
     const double *s_alpha, *s_alpha2, *s_alpha3, *s_alpha4;
     const int64_t *s_coupling_to_phonon; /* 2 x Nssh */
     const int64_t *s_bond;
+    /* T = ComplexF64 only (ssh_parameters.α::Vector{T}): imaginary parts of the SSH couplings, Nssh doubles each; NULL = real couplings.
+     * Ignored by real handles. */
+    const double *s_alpha_im, *s_alpha2_im, *s_alpha3_im, *s_alpha4_im;
 } smoqy_couplings;
 
 int smoqy_force_set_couplings(smoqy_ctx *ctx, const smoqy_couplings *cp);
@@ -297,7 +301,7 @@ int smoqy_hmc_trajectory_v(smoqy_ctx *ctx, int phi, int psi, int Nt, double dt, 
 
 /* bare on-site energies V⁰ (N) and hoppings t⁰ (Nh, FermionPathIntegral order) — what
  * SmoQyDQMC.update!(fermion_path_integral, elph, x, -1) leaves behind (src/EFAPFFHMCUpdater.jl:148, 200);
- * perm is the 1-based checkerboard permutation.  Needs smoqy_force_set_couplings. */
+ * perm is the 1-based checkerboard permutation.  Needs smoqy_force_set_couplings.  T = ComplexF64: t0 is complex128 (interleaved re, im). */
 int smoqy_set_bare_model(smoqy_ctx *ctx, const double *V0, const double *t0, const int64_t *perm);
 /* SmoQyDQMC.update!(fermion_path_integral, elph, x, +1); update!(fdm, fpi); update_Λ! for every walker
  * from ONE upload of x (Nph x Ltau x nwalkers): V = V⁰ + Σ(αx+α₂x²+α₃x³+α₄x⁴), t = t⁰ - Σ(αΔx+…),

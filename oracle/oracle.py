@@ -282,7 +282,8 @@ class _ElphStruct(C.Structure):
                 ("Nhol", C.c_int), ("ha", C.c_void_p), ("ha2", C.c_void_p), ("ha3", C.c_void_p), ("ha4", C.c_void_p),
                 ("h_c2p", C.c_void_p), ("h_c2s", C.c_void_p), ("h_phsym", C.c_void_p),
                 ("Nssh", C.c_int), ("sa", C.c_void_p), ("sa2", C.c_void_p), ("sa3", C.c_void_p), ("sa4", C.c_void_p),
-                ("s_c2p", C.c_void_p), ("s_bond", C.c_void_p)]
+                ("s_c2p", C.c_void_p), ("s_bond", C.c_void_p),
+                ("sa_im", C.c_void_p), ("sa2_im", C.c_void_p), ("sa3_im", C.c_void_p), ("sa4_im", C.c_void_p)]
 
 
 class OracleElph:
@@ -297,8 +298,14 @@ class OracleElph:
                      f(c.h_c2p, np.int64), f(c.h_c2s, np.int64), f(c.h_phsym, np.int32), f(c.s_alpha, np.float64), f(c.s_alpha2, np.float64), f(c.s_alpha3, np.float64),
                      f(c.s_alpha4, np.float64), np.asfortranarray(c.s_c2p, dtype=np.int64), f(c.s_bond, np.int64)]
         k = self.keep
+        # T = ComplexF64: the SSH couplings are complex (ssh_parameters.α::Vector{T}); their imaginary parts ride in four more arrays
+        im = [getattr(c, n, None) for n in ("s_alpha_im", "s_alpha2_im", "s_alpha3_im", "s_alpha4_im")]
+        self.keep_im = [None if a is None else f(a, np.float64) for a in im] if im[0] is not None else [None] * 4
+        if self.keep_im[0] is not None:
+            self.keep_im = [np.zeros(len(k[9])) if a is None else a for a in self.keep_im]
+        pim = [None if a is None else _p(a) for a in self.keep_im]
         self.s = _ElphStruct(self.x.shape[0], _p(k[0]), c.dtau, _p(k[1]), len(k[2]), _p(k[2]), _p(k[3]), _p(k[4]), _p(k[5]), _p(k[6]), _p(k[7]), _p(k[8]),
-                             len(k[9]), _p(k[9]), _p(k[10]), _p(k[11]), _p(k[12]), _p(k[13]), _p(k[14]))
+                             len(k[9]), _p(k[9]), _p(k[10]), _p(k[11]), _p(k[12]), _p(k[13]), _p(k[14]), *pim)
 
 
 def mul_dMdx(fdm: OracleFDM, elph: OracleElph, colors, nu, u, v, out=None):
@@ -333,7 +340,9 @@ def fields_from_phonons(c, V0, t0, perm):
     x = np.asarray(c.x, dtype=np.float64)
     Lt = x.shape[1]
     V = np.repeat(np.asarray(V0, dtype=np.float64)[:, None], Lt, axis=1)
-    t = np.repeat(np.asarray(t0, dtype=np.float64)[:, None], Lt, axis=1)
+    # T = ComplexF64: complex bare hoppings and / or complex SSH couplings (s_alpha*_im) give a complex t
+    cplx = np.iscomplexobj(t0) or getattr(c, "s_alpha_im", None) is not None
+    t = np.repeat(np.asarray(t0, dtype=np.complex128 if cplx else np.float64)[:, None], Lt, axis=1)
     for k in range(len(c.h_alpha)):
         xp = x[int(c.h_c2p[k]) - 1]
         V[int(c.h_c2s[k]) - 1] += c.h_alpha[k] * xp + c.h_alpha2[k] * xp**2 + c.h_alpha3[k] * xp**3 + c.h_alpha4[k] * xp**4
@@ -342,4 +351,6 @@ def fields_from_phonons(c, V0, t0, perm):
         dx = x[int(s_c2p[1, k]) - 1] - x[int(s_c2p[0, k]) - 1]
         h = int(perm[int(c.s_bond[k]) - 1]) - 1  # sorted bond n is model hopping perm[n]
         t[h] -= c.s_alpha[k] * dx + c.s_alpha2[k] * dx**2 + c.s_alpha3[k] * dx**3 + c.s_alpha4[k] * dx**4
+        if getattr(c, "s_alpha_im", None) is not None:
+            t[h] -= 1j * (c.s_alpha_im[k] * dx + c.s_alpha2_im[k] * dx**2 + c.s_alpha3_im[k] * dx**3 + c.s_alpha4_im[k] * dx**4)
     return np.asfortranarray(V), np.asfortranarray(t)

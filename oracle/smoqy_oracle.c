@@ -801,6 +801,8 @@ typedef struct {
     int Nssh;
     const double *sa, *sa2, *sa3, *sa4;
     const int64_t *s_c2p, *s_bond;
+    /* T = ComplexF64: imaginary parts of the SSH couplings (ssh_parameters.α::Vector{T}); NULL for real couplings */
+    const double *sa_im, *sa2_im, *sa3_im, *sa4_im;
 } orc_elph;
 
 /* _mul_νReΔτ∂Kc∂x! — :189-245, for the bonds [h0, h1) of one colour */
@@ -814,8 +816,9 @@ static void dKc_dx(const orc_fdm *f, const orc_elph *e, double nu, const cplx *u
         int i = (int)f->nt[2 * n] - 1, j = (int)f->nt[2 * n + 1] - 1;
         for (int l = 0; l < Lt; ++l) {
             double dx = e->x[pp + (size_t)e->Nph * l] - e->x[p + (size_t)e->Nph * l];
-            double dK = dtau_k * (e->sa[c] + 2 * e->sa2[c] * dx + 3 * e->sa3[c] * dx * dx + 4 * e->sa4[c] * dx * dx * dx);
-            double val = nu * creal(conj(up[IDX(l, j, Lt)]) * dK * vp[IDX(l, i, Lt)] + conj(up[IDX(l, i, Lt)]) * dK * vp[IDX(l, j, Lt)]);
+            cplx dK = dtau_k * (e->sa[c] + 2 * e->sa2[c] * dx + 3 * e->sa3[c] * dx * dx + 4 * e->sa4[c] * dx * dx * dx);   /* :225 */
+            if (e->sa_im) dK += I * dtau_k * (e->sa_im[c] + 2 * e->sa2_im[c] * dx + 3 * e->sa3_im[c] * dx * dx + 4 * e->sa4_im[c] * dx * dx * dx);
+            double val = nu * creal(conj(up[IDX(l, j, Lt)]) * dK * vp[IDX(l, i, Lt)] + conj(up[IDX(l, i, Lt)]) * conj(dK) * vp[IDX(l, j, Lt)]);  /* :227 */
             if (e->finite_mass[p]) out[p + (size_t)e->Nph * l] -= val;
             if (e->finite_mass[pp]) out[pp + (size_t)e->Nph * l] += val;
         }
@@ -848,20 +851,20 @@ void orc_mul_dMdx(const orc_fdm *f, const orc_elph *e, const int64_t *colors, in
         for (int l = 1; l < Lt; ++l) vp[IDX(l, i, Lt)] = -v[IDX(l - 1, i, Lt)];
     }
     if (f->is_sym) {
-        orc_checkerboard_lmul(vp, Lt, N, f->nt, f->ch, f->sh, 1, 0, f->Nh);      /* :33 */
+        orc_checkerboard_lmul_c(vp, Lt, N, f->nt, f->ch, f->sh, f->shi, 1, 0, f->Nh);      /* :33 */
         for (size_t k = 0; k < V; ++k) vp[k] *= f->expV[k];                       /* :36 */
-        orc_checkerboard_lmul(vp, Lt, N, f->nt, f->ch, f->sh, 0, 0, f->Nh);      /* :39 */
+        orc_checkerboard_lmul_c(vp, Lt, N, f->nt, f->ch, f->sh, f->shi, 0, 0, f->Nh);      /* :39 */
         memcpy(up, u, V * sizeof(cplx));                                           /* :42 */
         if (e->Nssh > 0) {
             for (int c = ncol - 1; c >= 0; --c) {                                 /* :50-63 */
                 int h0 = (int)colors[2 * c] - 1, h1 = (int)colors[2 * c + 1];
                 dKc_dx(f, e, -nu, up, vp, e->dtau / 2, h0, h1, out);
-                orc_checkerboard_lmul(up, Lt, N, f->nt, f->ch, f->sh, 0, h0, h1);
-                orc_checkerboard_ldiv(vp, Lt, N, f->nt, f->ch, f->sh, 0, h0, h1);
+                orc_checkerboard_lmul_c(up, Lt, N, f->nt, f->ch, f->sh, f->shi, 0, h0, h1);
+                orc_checkerboard_ldiv_c(vp, Lt, N, f->nt, f->ch, f->sh, f->shi, 0, h0, h1);
             }
         } else {                                                                   /* :64-75 */
-            orc_checkerboard_lmul(up, Lt, N, f->nt, f->ch, f->sh, 1, 0, f->Nh);
-            orc_checkerboard_ldiv(vp, Lt, N, f->nt, f->ch, f->sh, 1, 0, f->Nh);   /* transposed = true, as in the reference */
+            orc_checkerboard_lmul_c(up, Lt, N, f->nt, f->ch, f->sh, f->shi, 1, 0, f->Nh);
+            orc_checkerboard_ldiv_c(vp, Lt, N, f->nt, f->ch, f->sh, f->shi, 1, 0, f->Nh);   /* transposed = true, as in the reference */
         }
         if (e->Nhol > 0) dV_dx(f, e, -nu, up, vp, out);                            /* :81-84 */
         for (size_t k = 0; k < V; ++k) { up[k] *= f->expV[k]; vp[k] *= 1.0 / f->expV[k]; } /* :87, :90 */
@@ -869,12 +872,12 @@ void orc_mul_dMdx(const orc_fdm *f, const orc_elph *e, const int64_t *colors, in
             for (int c = 0; c < ncol; ++c) {                                      /* :95-109 */
                 int h0 = (int)colors[2 * c] - 1, h1 = (int)colors[2 * c + 1];
                 dKc_dx(f, e, -nu, up, vp, e->dtau / 2, h0, h1, out);
-                orc_checkerboard_lmul(up, Lt, N, f->nt, f->ch, f->sh, 0, h0, h1);
-                orc_checkerboard_ldiv(vp, Lt, N, f->nt, f->ch, f->sh, 0, h0, h1);
+                orc_checkerboard_lmul_c(up, Lt, N, f->nt, f->ch, f->sh, f->shi, 0, h0, h1);
+                orc_checkerboard_ldiv_c(vp, Lt, N, f->nt, f->ch, f->sh, f->shi, 0, h0, h1);
             }
         }
     } else {
-        orc_checkerboard_lmul(vp, Lt, N, f->nt, f->ch, f->sh, 0, 0, f->Nh);      /* :146 */
+        orc_checkerboard_lmul_c(vp, Lt, N, f->nt, f->ch, f->sh, f->shi, 0, 0, f->Nh);      /* :146 */
         for (size_t k = 0; k < V; ++k) vp[k] *= f->expV[k];                       /* :149 */
         memcpy(up, u, V * sizeof(cplx));                                           /* :152 */
         if (e->Nhol > 0) dV_dx(f, e, -nu, up, vp, out);                            /* :158-161 */
@@ -883,8 +886,8 @@ void orc_mul_dMdx(const orc_fdm *f, const orc_elph *e, const int64_t *colors, in
             for (int c = ncol - 1; c >= 0; --c) {
                 int h0 = (int)colors[2 * c] - 1, h1 = (int)colors[2 * c + 1];
                 dKc_dx(f, e, -nu, up, vp, e->dtau, h0, h1, out);
-                orc_checkerboard_lmul(up, Lt, N, f->nt, f->ch, f->sh, 0, h0, h1);
-                orc_checkerboard_ldiv(vp, Lt, N, f->nt, f->ch, f->sh, 1, h0, h1);
+                orc_checkerboard_lmul_c(up, Lt, N, f->nt, f->ch, f->sh, f->shi, 0, h0, h1);
+                orc_checkerboard_ldiv_c(vp, Lt, N, f->nt, f->ch, f->sh, f->shi, 1, h0, h1);
             }
         }
     }

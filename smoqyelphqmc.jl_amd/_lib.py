@@ -198,7 +198,7 @@ class CouplingsStruct(C.Structure):
     _fields_ = [("Nph", C.c_int), ("dtau", C.c_double), ("finite_mass", C.c_void_p), ("Nholstein", C.c_int), ("h_alpha", C.c_void_p), ("h_alpha2", C.c_void_p),
                 ("h_alpha3", C.c_void_p), ("h_alpha4", C.c_void_p), ("h_coupling_to_phonon", C.c_void_p), ("h_coupling_to_site", C.c_void_p), ("h_ph_sym", C.c_void_p),
                 ("Nssh", C.c_int), ("s_alpha", C.c_void_p), ("s_alpha2", C.c_void_p), ("s_alpha3", C.c_void_p), ("s_alpha4", C.c_void_p), ("s_coupling_to_phonon", C.c_void_p),
-                ("s_bond", C.c_void_p)]
+                ("s_bond", C.c_void_p), ("s_alpha_im", C.c_void_p), ("s_alpha2_im", C.c_void_p), ("s_alpha3_im", C.c_void_p), ("s_alpha4_im", C.c_void_p)]
 
 
 def couplings_struct(fc):
@@ -207,9 +207,12 @@ def couplings_struct(fc):
     k = [f(fc.finite_mass, np.int32), f(fc.h_alpha, np.float64), f(fc.h_alpha2, np.float64), f(fc.h_alpha3, np.float64), f(fc.h_alpha4, np.float64), f(fc.h_c2p, np.int64),
          f(fc.h_c2s, np.int64), f(fc.h_phsym, np.int32), f(fc.s_alpha, np.float64), f(fc.s_alpha2, np.float64), f(fc.s_alpha3, np.float64), f(fc.s_alpha4, np.float64),
          np.asfortranarray(fc.s_c2p, dtype=np.int64), f(fc.s_bond, np.int64)]
+    # T = ComplexF64: imaginary parts of the SSH couplings (None / absent = real couplings)
+    im = [getattr(fc, n, None) for n in ("s_alpha_im", "s_alpha2_im", "s_alpha3_im", "s_alpha4_im")]
+    kim = [None] * 4 if im[0] is None else [f(np.zeros(len(k[8])) if a is None else a, np.float64) for a in im]
     s = CouplingsStruct(int(np.shape(fc.x)[0]), float(fc.dtau), ptr(k[0]), len(k[1]), ptr(k[1]), ptr(k[2]), ptr(k[3]), ptr(k[4]), ptr(k[5]), ptr(k[6]), ptr(k[7]), len(k[8]), ptr(k[8]),
-                        ptr(k[9]), ptr(k[10]), ptr(k[11]), ptr(k[12]), ptr(k[13]))
-    return s, k
+                        ptr(k[9]), ptr(k[10]), ptr(k[11]), ptr(k[12]), ptr(k[13]), *[ptr(a) for a in kim])
+    return s, k + kim
 
 
 class GeSlot(C.Structure):

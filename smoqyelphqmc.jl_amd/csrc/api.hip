@@ -2035,7 +2035,6 @@ int smoqy_force_set_couplings(smoqy_ctx *c, const smoqy_couplings *cp)
     CHECK_CTX(c);
     const Geometry &g = c->g;
     if (g.nrhs != 1) FAIL(c, 1, "the force entry points need a handle with nrhs = 1");
-    if (g.is_cplx) FAIL(c, 6, "the force terms and the device-side update! from phonon fields are implemented for real hoppings only (T = Float64)");
     if (!cp || cp->Nph < 0 || cp->Nholstein < 0 || cp->Nssh < 0) FAIL(c, 1, "invalid couplings");
     auto &F = c->force;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2092,7 +2091,7 @@ int smoqy_force_set_couplings(smoqy_ctx *c, const smoqy_couplings *cp)
     }
     // one blob: [ints | doubles]
     const size_t n_int = h_c2p.size() + h_c2s.size() + h_ps.size() + s_c2p.size() + bond_ptr.size() + bond_cpl.size() + ph_ptr.size() + ph_slot.size() + site_ptr.size() + site_cpl.size();
-    const size_t n_dbl = 4 * (size_t)Nhol + 4 * (size_t)Nssh + ph_sign.size();
+    const size_t n_dbl = 4 * (size_t)Nhol + (g.is_cplx ? 8 : 4) * (size_t)Nssh + ph_sign.size();
     const size_t int_bytes = ((n_int * sizeof(int) + 15) / 16) * 16;
     HIPCHK(c, hipMalloc(&F.blob, int_bytes + n_dbl * sizeof(double) + 16));
     std::vector<int> ib;
@@ -2110,6 +2109,14 @@ int smoqy_force_set_couplings(smoqy_ctx *c, const smoqy_couplings *cp)
     t.h_alpha = put_d(cp->h_alpha, Nhol); t.h_alpha2 = put_d(cp->h_alpha2, Nhol); t.h_alpha3 = put_d(cp->h_alpha3, Nhol); t.h_alpha4 = put_d(cp->h_alpha4, Nhol);
     t.s_alpha = put_d(cp->s_alpha, Nssh); t.s_alpha2 = put_d(cp->s_alpha2, Nssh); t.s_alpha3 = put_d(cp->s_alpha3, Nssh); t.s_alpha4 = put_d(cp->s_alpha4, Nssh);
     t.ph_sign = put_d(ph_sign.data(), ph_sign.size());
+    if (g.is_cplx) {
+        // T = ComplexF64: ssh_parameters.α::Vector{T} — the imaginary parts arrive in four more arrays of the struct (NULL = a real coupling)
+        const std::vector<double> zero((size_t)Nssh, 0.0);
+        t.s_alpha_im = put_d(cp->s_alpha_im ? cp->s_alpha_im : zero.data(), Nssh);
+        t.s_alpha2_im = put_d(cp->s_alpha2_im ? cp->s_alpha2_im : zero.data(), Nssh);
+        t.s_alpha3_im = put_d(cp->s_alpha3_im ? cp->s_alpha3_im : zero.data(), Nssh);
+        t.s_alpha4_im = put_d(cp->s_alpha4_im ? cp->s_alpha4_im : zero.data(), Nssh);
+    }
     if (!ib.empty()) HIPCHK(c, hipMemcpy(F.blob, ib.data(), ib.size() * sizeof(int), hipMemcpyHostToDevice));
     if (!db.empty()) HIPCHK(c, hipMemcpy((char *)F.blob + int_bytes, db.data(), db.size() * sizeof(double), hipMemcpyHostToDevice));
     const size_t nx = (size_t)g.nw * g.Lt * std::max(Nph, 1);
@@ -2118,7 +2125,7 @@ int smoqy_force_set_couplings(smoqy_ctx *c, const smoqy_couplings *cp)
     HIPCHK(c, hipMalloc(&F.d_out, nx * sizeof(double)));
     HIPCHK(c, hipHostMalloc(&F.h_out, nx * sizeof(double)));
     HIPCHK(c, hipMalloc(&F.d_contrib, (size_t)g.nw * g.Lt * std::max(Q, 1) * sizeof(double)));
-    HIPCHK(c, hipMalloc(&F.d_bare, ((size_t)g.N + g.Nh + 1) * sizeof(double)));
+    HIPCHK(c, hipMalloc(&F.d_bare, ((size_t)g.N + 2 * (size_t)g.Nh + 1) * sizeof(double)));  // [V⁰ | Re t⁰ | Im t⁰ (complex T)] in checkerboard order
     F.Nph = Nph; F.Nhol = Nhol; F.Nssh = Nssh; F.Q = Q; F.dtau = cp->dtau; F.set = true;
     F.finite_mass.assign((size_t)std::max(Nph, 1), 1);
     for (int p = 0; p < Nph; ++p) F.finite_mass[p] = cp->finite_mass[p] ? 1 : 0;
@@ -2142,6 +2149,7 @@ static ForceArgs force_args(smoqy_ctx *c, double nu, const double2 *u, const dou
     a.Lt = g.Lt; a.N = g.N; a.Nh = g.Nh; a.ncol = g.ncol; a.nsys = g.nsys; a.nrhs = g.nrhs; a.nw = g.nw;
     a.Tc = 1; a.nchunk = g.Lt;  // one slice per workgroup: the kernel keeps two N-vectors per slice in LDS
     a.bonds = c->d_bonds; a.col_off = c->d_col_off; a.expV = c->d_expV; a.ch = c->d_ch; a.sh = c->d_sh; a.lam = c->d_lam;
+    a.shi = c->d_shi;  // nullptr for real hoppings
     a.u = u; a.v = v; a.nu = nu; a.dtau = c->force.dtau;
     a.Nph = c->force.Nph; a.Nhol = c->force.Nhol; a.Nssh = c->force.Nssh; a.Q = c->force.Q;
     a.x = c->force.d_x; a.contrib = c->force.d_contrib;
@@ -2230,11 +2238,17 @@ int smoqy_set_bare_model(smoqy_ctx *c, const double *V0, const double *t0, const
     if (!c->force.set) FAIL(c, 1, "call smoqy_force_set_couplings first");
     if (!V0 || (c->g.Nh && (!t0 || !perm))) FAIL(c, 1, "V0, t0 and perm must be given");
     const Geometry &g = c->g;
-    std::vector<double> b((size_t)g.N + g.Nh);
+    std::vector<double> b((size_t)g.N + 2 * (size_t)g.Nh, 0.0);
     for (int i = 0; i < g.N; ++i) b[i] = V0[i];
     for (int n = 0; n < g.Nh; ++n) {
         if (perm[n] < 1 || perm[n] > g.Nh) FAIL(c, 1, "perm[%d] = %lld out of range", n + 1, (long long)perm[n]);
-        b[(size_t)g.N + n] = t0[perm[n] - 1];  // FermionDetMatrix.jl:224-228: sorted bond n is model hopping perm[n]
+        // FermionDetMatrix.jl:224-228: sorted bond n is model hopping perm[n].  T = ComplexF64: t0 is complex128 (interleaved re, im)
+        if (g.is_cplx) {
+            b[(size_t)g.N + n] = t0[2 * (perm[n] - 1)];
+            b[(size_t)g.N + g.Nh + n] = t0[2 * (perm[n] - 1) + 1];
+        } else {
+            b[(size_t)g.N + n] = t0[perm[n] - 1];
+        }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(c->force.d_bare, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -2256,7 +2270,8 @@ int smoqy_update_from_phonons_all(smoqy_ctx *c, const double *x_all)
     }
     ForceArgs a = force_args(c, 0.0, nullptr, nullptr);
     const bool do_t = g.Nh > 0 && (F.Nssh > 0 || !F.t_done);  // hoppings that no phonon couples to are refreshed once
-    launch_phonon_fields(c->stream, a, F.d_bare, F.d_bare + g.N, c->d_expV, c->d_ch, c->d_sh, c->d_lam, g.is_sym ? F.dtau / 2 : F.dtau, do_t);
+    launch_phonon_fields(c->stream, a, F.d_bare, F.d_bare + g.N, c->d_expV, c->d_ch, c->d_sh, c->d_lam, g.is_sym ? F.dtau / 2 : F.dtau, do_t, g.is_cplx ? F.d_bare + g.N + g.Nh : nullptr,
+                         c->d_shi);
     if (do_t) {
         launch_pack_csf(c->stream, c->d_ch, c->d_sh, c->d_psrc, c->d_csf, c->d_cs_varies, g.nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal);
         for (int w = 0; w < g.nw; ++w) set_cs_const(c, w, F.Nssh == 0);  // no SSH coupling: t is the bare per-bond hopping on every slice
@@ -2433,7 +2448,8 @@ static int refresh_from_device_x(smoqy_ctx *c)
     const Geometry &g = c->g;
     ForceArgs a = force_args(c, 0.0, nullptr, nullptr);
     const bool do_t = g.Nh > 0 && (F.Nssh > 0 || !F.t_done);
-    launch_phonon_fields(c->stream, a, F.d_bare, F.d_bare + g.N, c->d_expV, c->d_ch, c->d_sh, c->d_lam, g.is_sym ? F.dtau / 2 : F.dtau, do_t);
+    launch_phonon_fields(c->stream, a, F.d_bare, F.d_bare + g.N, c->d_expV, c->d_ch, c->d_sh, c->d_lam, g.is_sym ? F.dtau / 2 : F.dtau, do_t, g.is_cplx ? F.d_bare + g.N + g.Nh : nullptr,
+                         c->d_shi);
     if (do_t) {
         launch_pack_csf(c->stream, c->d_ch, c->d_sh, c->d_psrc, c->d_csf, c->d_cs_varies, g.nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal);
         for (int w = 0; w < g.nw; ++w) set_cs_const(c, w, F.Nssh == 0);  // no SSH coupling: t is the bare per-bond hopping on every slice

@@ -19,7 +19,10 @@ namespace {
 __device__ __forceinline__ int wrapf(int l, int Lt) { return l >= Lt ? l - Lt : (l < 0 ? l + Lt : l); }
 
 // one colour: optional SSH accumulation, then u' <- C u', v' <- C⁻¹ v'  (:53-62 / :98-108 / :170-182)
-__device__ __forceinline__ void colour_step(const ForceArgs &a, double2 *UP, double2 *VP, int nk, int l0, int w, int c, const double *ch, const double *sh, bool accumulate, int pass,
+// T = ComplexF64 (shi != nullptr): the factor is [[c, s], [conj(s), c]], its inverse [[c, -s], [-conj(s), c]] (src/checkerboard_matrix_multiply.jl:60-68,
+// 132-141), and the SSH derivative ΔτdK is complex: ν Re[conj(u'_j) dK v'_i + conj(u'_i) conj(dK) v'_j] (:225-227).  Real handles take the
+// branches they always took.
+__device__ __forceinline__ void colour_step(const ForceArgs &a, double2 *UP, double2 *VP, int nk, int l0, int w, int c, const double *ch, const double *sh, const double *shi, bool accumulate, int pass,
                                             double dtau_k, double nu, bool apply_u, bool apply_v)
 {
     const int N = a.N, Lt = a.Lt;
@@ -37,11 +40,27 @@ __device__ __forceinline__ void colour_step(const ForceArgs &a, double2 *UP, dou
                     const double dx = xs[pp] - xs[p];                                                            // :223
                     const double dK = dtau_k * (a.s_alpha[cpl] + 2 * a.s_alpha2[cpl] * dx + 3 * a.s_alpha3[cpl] * dx * dx + 4 * a.s_alpha4[cpl] * dx * dx * dx);  // :225
                     // ν Re[conj(u'_j) dK v'_i + conj(u'_i) conj(dK) v'_j]                                        // :227
-                    const double val = nu * dK * ((uj.x * vi.x + uj.y * vi.y) + (ui.x * vj.x + ui.y * vj.y));
+                    double val = nu * dK * ((uj.x * vi.x + uj.y * vi.y) + (ui.x * vj.x + ui.y * vj.y));
+                    if (a.s_alpha_im) {  // complex coupling: Re[dK (A + iB)] + Re[conj(dK) (C + iD)] = dK_re (A + C) - dK_im (B - D)
+                        const double dKi = dtau_k * (a.s_alpha_im[cpl] + 2 * a.s_alpha2_im[cpl] * dx + 3 * a.s_alpha3_im[cpl] * dx * dx + 4 * a.s_alpha4_im[cpl] * dx * dx * dx);
+                        val -= nu * dKi * ((uj.x * vi.y - uj.y * vi.x) - (ui.x * vj.y - ui.y * vj.x));
+                    }
                     a.contrib[((size_t)w * Lt + l) * a.Q + a.Nhol + 2 * cpl + pass] = val;
                 }
             }
             const double cc = ch[(size_t)l * a.Nh + h], ss = sh[(size_t)l * a.Nh + h];
+            if (shi) {
+                const double ti = shi[(size_t)l * a.Nh + h];  // s = ss + i ti
+                if (apply_u) {
+                    ur[b.x] = make_double2(cc * ui.x + (ss * uj.x - ti * uj.y), cc * ui.y + (ss * uj.y + ti * uj.x));
+                    ur[b.y] = make_double2(cc * uj.x + (ss * ui.x + ti * ui.y), cc * uj.y + (ss * ui.y - ti * ui.x));
+                }
+                if (apply_v) {
+                    vr[b.x] = make_double2(cc * vi.x - (ss * vj.x - ti * vj.y), cc * vi.y - (ss * vj.y + ti * vj.x));
+                    vr[b.y] = make_double2(cc * vj.x - (ss * vi.x + ti * vi.y), cc * vj.y - (ss * vi.y - ti * vi.x));
+                }
+                continue;
+            }
             if (apply_u) {
                 ur[b.x] = make_double2(cc * ui.x + ss * uj.x, cc * ui.y + ss * uj.y);
                 ur[b.y] = make_double2(cc * uj.x + ss * ui.x, cc * uj.y + ss * ui.y);
@@ -56,7 +75,7 @@ __device__ __forceinline__ void colour_step(const ForceArgs &a, double2 *UP, dou
 }
 
 // plain colour on one array (building B v)
-__device__ __forceinline__ void colour_plain(const ForceArgs &a, double2 *X, int nk, int l0, int c, const double *ch, const double *sh)
+__device__ __forceinline__ void colour_plain(const ForceArgs &a, double2 *X, int nk, int l0, int c, const double *ch, const double *sh, const double *shi)
 {
     const int N = a.N;
     for (int h = a.col_off[c] + (int)threadIdx.x; h < a.col_off[c + 1]; h += (int)blockDim.x) {
@@ -65,6 +84,12 @@ __device__ __forceinline__ void colour_plain(const ForceArgs &a, double2 *X, int
             const double cc = ch[(size_t)(l0 + k) * a.Nh + h], ss = sh[(size_t)(l0 + k) * a.Nh + h];
             double2 *r = X + (size_t)k * N;
             const double2 x = r[b.x], y = r[b.y];
+            if (shi) {
+                const double ti = shi[(size_t)(l0 + k) * a.Nh + h];
+                r[b.x] = make_double2(cc * x.x + (ss * y.x - ti * y.y), cc * x.y + (ss * y.y + ti * y.x));
+                r[b.y] = make_double2(cc * y.x + (ss * x.x + ti * x.y), cc * y.y + (ss * x.y - ti * x.x));
+                continue;
+            }
             r[b.x] = make_double2(cc * x.x + ss * y.x, cc * x.y + ss * y.y);
             r[b.y] = make_double2(cc * y.x + ss * x.x, cc * y.y + ss * x.y);
         }
@@ -81,6 +106,7 @@ __global__ void __launch_bounds__(kThreads) dmdx_kernel(ForceArgs a)
     const int l0 = chunk * a.Tc, nk = min(a.Tc, Lt - l0);
     double2 *UP = a.scratch ? a.scratch + (size_t)blockIdx.x * a.scratch_stride : lds, *VP = UP + (size_t)a.Tc * N;
     const double *expV = a.expV + (size_t)w * Lt * N, *ch = a.ch + (size_t)w * Lt * a.Nh, *sh = a.sh + (size_t)w * Lt * a.Nh;
+    const double *shi = a.shi ? a.shi + (size_t)w * Lt * a.Nh : nullptr;
     const size_t sstride = (size_t)a.nsys * N;
     const double2 *u = a.u + (size_t)sys * N, *v = a.v + (size_t)sys * N;
     const double nu = -a.nu;  // the reference passes -ν to the helpers (:52, :83, :97, :160, :173)
@@ -93,24 +119,24 @@ __global__ void __launch_bounds__(kThreads) dmdx_kernel(ForceArgs a)
     }
     __syncthreads();
     if (SYM) {
-        for (int c = a.ncol - 1; c >= 0; --c) colour_plain(a, VP, nk, l0, c, ch, sh);              // :33
+        for (int c = a.ncol - 1; c >= 0; --c) colour_plain(a, VP, nk, l0, c, ch, sh, shi);              // :33
         for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {                              // :36
             const int k = idx / N, i = idx - k * N;
             const double d = expV[(size_t)(l0 + k) * N + i];
             VP[idx] = make_double2(d * VP[idx].x, d * VP[idx].y);
         }
         __syncthreads();
-        for (int c = 0; c < a.ncol; ++c) colour_plain(a, VP, nk, l0, c, ch, sh);                   // :39
+        for (int c = 0; c < a.ncol; ++c) colour_plain(a, VP, nk, l0, c, ch, sh, shi);                   // :39
         if (a.Nssh > 0) {
-            for (int c = a.ncol - 1; c >= 0; --c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, true, 0, a.dtau / 2, nu, true, true);  // :50-63
+            for (int c = a.ncol - 1; c >= 0; --c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, shi, true, 0, a.dtau / 2, nu, true, true);  // :50-63
         } else {
             // |u'> := Γᵀ|u'> (colours last..first), |v'> := checkerboard_ldiv!(transposed = true) = colours
             // first..last with inverted factors, exactly as the reference does it (:66-74)
-            for (int c = a.ncol - 1; c >= 0; --c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, false, 0, 0.0, 0.0, true, false);
-            for (int c = 0; c < a.ncol; ++c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, false, 0, 0.0, 0.0, false, true);
+            for (int c = a.ncol - 1; c >= 0; --c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, shi, false, 0, 0.0, 0.0, true, false);
+            for (int c = 0; c < a.ncol; ++c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, shi, false, 0, 0.0, 0.0, false, true);
         }
     } else {
-        for (int c = 0; c < a.ncol; ++c) colour_plain(a, VP, nk, l0, c, ch, sh);                   // :146
+        for (int c = 0; c < a.ncol; ++c) colour_plain(a, VP, nk, l0, c, ch, sh, shi);                   // :146
         for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {                              // :149
             const int k = idx / N, i = idx - k * N;
             const double d = expV[(size_t)(l0 + k) * N + i];
@@ -138,9 +164,9 @@ __global__ void __launch_bounds__(kThreads) dmdx_kernel(ForceArgs a)
         }
         __syncthreads();
         if (SYM) {
-            for (int c = 0; c < a.ncol; ++c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, true, 1, a.dtau / 2, nu, true, true);     // :95-109
+            for (int c = 0; c < a.ncol; ++c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, shi, true, 1, a.dtau / 2, nu, true, true);     // :95-109
         } else {
-            for (int c = a.ncol - 1; c >= 0; --c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, true, 0, a.dtau, nu, true, true);    // :172-183
+            for (int c = a.ncol - 1; c >= 0; --c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, shi, true, 0, a.dtau, nu, true, true);    // :172-183
         }
     }
 }
@@ -189,7 +215,7 @@ __global__ void force_reduce_kernel(ForceArgs a, double *out)
 // t_h = t⁰_h - Σ_c (αΔx + α₂Δx² + α₃Δx³ + α₄Δx⁴), Δx = x[p′] - x[p].  Then FermionDetMatrix.jl:217, :230-231
 // and holstein_shift_matrix.jl:11-12, :37 exactly as fields_kernel / lambda_couple_kernel do them.
 __global__ void phonon_fields_kernel(ForceArgs a, const double *__restrict__ V0, const double *__restrict__ t0s, double *__restrict__ expV, double *__restrict__ ch, double *__restrict__ sh,
-                                     double *__restrict__ lam, double dtau_k, int do_t)
+                                     double *__restrict__ lam, double dtau_k, int do_t, const double *__restrict__ t0s_im, double *__restrict__ shi)
 {
     const size_t nV = (size_t)a.nw * a.Lt * a.N, nT = do_t ? (size_t)a.nw * a.Lt * a.Nh : 0;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nV + nT; idx += (size_t)gridDim.x * blockDim.x) {
@@ -215,6 +241,20 @@ __global__ void phonon_fields_kernel(ForceArgs a, const double *__restrict__ V0,
                 const int c = a.bond_cpl[q];
                 const double dx = x[a.s_c2p[2 * c + 1]] - x[a.s_c2p[2 * c]];
                 tt -= (((a.s_alpha4[c] * dx + a.s_alpha3[c]) * dx + a.s_alpha2[c]) * dx + a.s_alpha[c]) * dx;
+            }
+            if (shi) {  // T = ComplexF64: complex bare hopping and couplings; sinh = sign(conj t) sinh(Δτ'|t|), as fields_kernel_c
+                double ti = t0s_im ? t0s_im[n] : 0.0;
+                if (a.s_alpha_im)
+                    for (int q = a.bond_ptr[n]; q < a.bond_ptr[n + 1]; ++q) {
+                        const int c = a.bond_cpl[q];
+                        const double dx = x[a.s_c2p[2 * c + 1]] - x[a.s_c2p[2 * c]];
+                        ti -= (((a.s_alpha4_im[c] * dx + a.s_alpha3_im[c]) * dx + a.s_alpha2_im[c]) * dx + a.s_alpha_im[c]) * dx;
+                    }
+                const double ab = hypot(tt, ti), arg = dtau_k * ab, sn = sinh(arg);
+                ch[j] = cosh(arg);
+                sh[j] = ab > 0.0 ? tt / ab * sn : 0.0;
+                shi[j] = ab > 0.0 ? -ti / ab * sn : 0.0;
+                continue;
             }
             const double arg = dtau_k * fabs(tt);
             ch[j] = cosh(arg);
@@ -259,13 +299,14 @@ void launch_force_reduce(hipStream_t st, const ForceArgs &a, double *out)
     hipLaunchKernelGGL(force_reduce_kernel, dim3(blocks), dim3(256), 0, st, a, out);
 }
 
-void launch_phonon_fields(hipStream_t st, const ForceArgs &a, const double *V0, const double *t0s, double *expV, double *ch, double *sh, double *lam, double dtau_k, bool do_t)
+void launch_phonon_fields(hipStream_t st, const ForceArgs &a, const double *V0, const double *t0s, double *expV, double *ch, double *sh, double *lam, double dtau_k, bool do_t, const double *t0s_im,
+                          double *shi)
 {
     const size_t tot = (size_t)a.nw * a.Lt * (a.N + (do_t ? a.Nh : 0));
     if (tot == 0) return;
     int blocks = (int)((tot + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(phonon_fields_kernel, dim3(blocks), dim3(256), 0, st, a, V0, t0s, expV, ch, sh, lam, dtau_k, do_t ? 1 : 0);
+    hipLaunchKernelGGL(phonon_fields_kernel, dim3(blocks), dim3(256), 0, st, a, V0, t0s, expV, ch, sh, lam, dtau_k, do_t ? 1 : 0, t0s_im, shi);
 }
 
 }  // namespace smoqy

@@ -244,6 +244,7 @@ struct ForceArgs {
     const int2 *bonds;
     const int *col_off;
     const double *expV, *ch, *sh, *lam;
+    const double *shi;                  // Im sinhΔτt for T = ComplexF64 (bond factor [[c, s], [conj(s), c]]), nullptr for real hoppings
     const double2 *u, *v;
     double nu, dtau;
     int Nph, Nhol, Nssh, Q;             // Q = Nhol (dV) + 2 Nssh (dK, two passes) + Nhol (dΛ) contribution slots per (walker, slice)
@@ -252,6 +253,7 @@ struct ForceArgs {
     const double *h_alpha, *h_alpha2, *h_alpha3, *h_alpha4;
     const int *s_c2p;                   // [Nssh][2]
     const double *s_alpha, *s_alpha2, *s_alpha3, *s_alpha4;
+    const double *s_alpha_im, *s_alpha2_im, *s_alpha3_im, *s_alpha4_im;  // T = ComplexF64: imaginary parts of the SSH couplings (nullptr: real)
     const int *bond_ptr, *bond_cpl;     // CSR: checkerboard bond -> SSH couplings
     const int *ph_ptr, *ph_slot;        // CSR: phonon -> contribution slots
     const int *site_ptr, *site_cpl;     // CSR: site -> Holstein couplings, in coupling order
@@ -265,7 +267,9 @@ void launch_dmdx(hipStream_t st, const ForceArgs &a, bool sym);
 void launch_dldx(hipStream_t st, const ForceArgs &a);
 void launch_force_reduce(hipStream_t st, const ForceArgs &a, double *out);
 // V(x), t(x) -> expV, cosh, sinh (+ Λ) for every walker from the device copy of the phonon fields
-void launch_phonon_fields(hipStream_t st, const ForceArgs &a, const double *V0, const double *t0s, double *expV, double *ch, double *sh, double *lam, double dtau_k, bool do_t);
+// t0s_im / shi: imaginary part of the bare hoppings / of sinhΔτt for T = ComplexF64 (nullptr for real hoppings)
+void launch_phonon_fields(hipStream_t st, const ForceArgs &a, const double *V0, const double *t0s, double *expV, double *ch, double *sh, double *lam, double dtau_k, bool do_t,
+                          const double *t0s_im = nullptr, double *shi = nullptr);
 
 // GreensEstimator contractions (kernels_greens.hip)
 void launch_ge_gather(hipStream_t st, const double2 *v, double2 *A, int Lt, int N, int nsys, int n_orb, int orb, int Nc, int conj);

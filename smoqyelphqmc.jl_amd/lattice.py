@@ -149,6 +149,11 @@ class ForceCouplings:
     s_alpha4: np.ndarray
     s_c2p: np.ndarray        # (2, Nssh)
     s_bond: np.ndarray       # (Nssh,)
+    # T = ComplexF64 (ssh_parameters.α::Vector{T}): imaginary parts of the SSH couplings, None for real couplings
+    s_alpha_im: np.ndarray | None = None
+    s_alpha2_im: np.ndarray | None = None
+    s_alpha3_im: np.ndarray | None = None
+    s_alpha4_im: np.ndarray | None = None
 
 
 @dataclass

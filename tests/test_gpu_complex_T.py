@@ -192,10 +192,71 @@ def test_mirror_with_complex_hoppings():
     assert eps < 1e-10 and relerr(o.mul_MtM(x), v) < 1e-9
 
 
-def test_force_entry_points_reject_complex_T():
-    h, *_ = complex_problem("chain", True)
-    m = lat.bssh_chain(24, 9)
+def _flux_ssh(kind, seed=0):
+    """An SSH model threaded by a static flux (tests/test_oracle_complex_T.py::flux_ssh_model): complex bare hoppings e^{iθ_h} and complex
+    couplings α e^{iθ_h}, so that t_h = (1 - αΔx) e^{iθ_h}."""
+    m = lat.bssh_chain(24, 9, walker=seed) if kind == "bssh" else lat.ossh_square(6, 12, walker=seed)
     nt, perm, colors = lat.checkerboard_decomposition(m.fpi.neighbor_table)
-    cs, keep = L.couplings_struct(m.force_couplings(perm))
-    with pytest.raises(L.SmoqyError, match="real hoppings only"):
-        h.call("smoqy_force_set_couplings", C.byref(cs))
+    g = np.random.default_rng(200 + seed)
+    Nh = m.fpi.t.shape[0]
+    theta = g.uniform(0, 2 * np.pi, Nh)
+    fc = m.force_couplings(perm)
+    ph = np.exp(1j * theta[perm[np.asarray(fc.s_bond) - 1] - 1])
+    fc.s_alpha_im = fc.s_alpha * ph.imag
+    fc.s_alpha2_im, fc.s_alpha3_im, fc.s_alpha4_im = np.zeros(len(ph)), np.zeros(len(ph)), np.zeros(len(ph))
+    fc.s_alpha = fc.s_alpha * ph.real
+    V0, _ = m.bare_model()
+    return m, nt, perm, colors, fc, V0, np.exp(1j * theta)
+
+
+@pytest.mark.parametrize("kind", ["bssh", "ossh"])
+@pytest.mark.parametrize("is_sym", [True, False])
+def test_force_and_update_from_phonons_complex_T(kind, is_sym):
+    """mul_νRe∂M∂x! (src/fermion_det_matrix_dervative.jl:2-245, generic in T) and the device-side update! from the phonon fields for
+    T = ComplexF64, against the oracle (itself pinned by finite differences of the dense complex action,
+    tests/test_oracle_complex_T.py::test_force_complex_T_against_finite_differences)."""
+    m, nt, perm, colors, fc, V0, t0 = _flux_ssh(kind)
+    Lt, N, Nh = m.fpi.Ltau, m.fpi.N, m.fpi.t.shape[0]
+    h = L.Handle(Lt, N, nt, colors, is_sym, 1, 1, is_complex=True)
+    cs, keep = L.couplings_struct(fc)
+    h.call("smoqy_force_set_couplings", C.byref(cs))
+    h.call("smoqy_set_bare_model", L.ptr(V0), L.ptr(np.ascontiguousarray(t0)), L.ptr(perm))
+    x = np.asfortranarray(fc.x)
+    h.call("smoqy_update_from_phonons_all", L.ptr(np.ascontiguousarray(x.T[None])))  # Nph x Ltau column-major == (Lt, Nph) C order per walker
+    # fields: device update! from x against the oracle's V(x), t(x) -> exp / cosh / sinh
+    V, t = orc.fields_from_phonons(fc, V0, t0, perm)
+    expV, ch, sh = orc.update_fields(V, t, perm, m.fpi.dtau, is_sym)
+    g_e = np.zeros((Lt, N), order="F")
+    g_c, g_s = np.zeros((Lt, Nh), dtype=np.complex128, order="F"), np.zeros((Lt, Nh), dtype=np.complex128, order="F")
+    h.call("smoqy_get_fields", 0, L.ptr(g_e), L.ptr(g_c), L.ptr(g_s))
+    np.testing.assert_allclose(g_e, expV, rtol=1e-14)
+    np.testing.assert_allclose(g_c.real, ch, rtol=1e-13)
+    np.testing.assert_allclose(g_s, sh, rtol=1e-12, atol=1e-15)
+    assert np.abs(g_s.imag).max() > 1e-3
+    # force: ν Re<u|∂M/∂x|v> with random u, v
+    o = orc.OracleFDM(nt, expV, ch, sh, is_sym)
+    e = orc.OracleElph(fc)
+    uv = rand(Lt, N, 2, 17)
+    want = orc.mul_dMdx(o, e, colors, -2.0, uv[:, :, 0], uv[:, :, 1])
+    a, b = h.vec_alloc(), h.vec_alloc()
+    h.vec_upload(a, np.asfortranarray(uv[:, :, :1]))
+    h.vec_upload(b, np.asfortranarray(uv[:, :, 1:]))
+    out = np.zeros((1, Lt, fc.x.shape[0]))
+    h.call("smoqy_force_dMdx_v", C.c_double(-2.0), a, b, L.ptr(out))
+    assert np.abs(out[0].T - want).max() < 1e-11 * np.abs(want).max()
+    # the whole force evaluation behind a solve (smoqy_pff_step_v) runs and gives a finite force on the free modes only
+    phi, psi = h.vec_alloc(), h.vec_alloc()
+    h.vec_upload(phi, np.asfortranarray(uv[:, :, :1]))
+    rv = np.ascontiguousarray(np.random.default_rng(5).standard_normal(2 * N))  # complex T: N complex deviates
+    sf, it, ep = np.zeros(1), np.zeros(1, dtype=np.int32), np.zeros(1)
+    dS = np.zeros((1, Lt, fc.x.shape[0]))
+    h.call("smoqy_pff_step_v", phi, psi, None, L.ptr(rv), C.c_double(1e-10), 10000, 1, L.ptr(sf), L.ptr(it), L.ptr(ep), L.ptr(dS))
+    Psi = np.asarray(h.vec_download(psi)).reshape(Lt, N, order="F")
+    Lam = orc.update_lambda(Lt, N, x, m.elph.dtau, [], [], [], [], [])
+    LP = orc.lambda_apply(Lam, Psi, "mul")
+    AP = o.mul_M(LP)
+    wantF = orc.mul_dMdx(o, e, colors, -2.0, AP, LP)
+    assert ep[0] < 1e-10 and np.abs(dS[0].T - wantF).max() < 1e-9 * np.abs(wantF).max()
+    if kind == "bssh":
+        assert np.all(dS[0][:, -1] == 0)  # the infinite-mass partner mode receives no force
+    h.close()

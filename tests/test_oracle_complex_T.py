@@ -152,3 +152,66 @@ def test_preconditioned_cg_complex_T(is_sym):
     herm_tol = 1e-10 if is_sym else 5e-2
     assert abs(np.vdot(u, P.apply(v)) - np.vdot(P.apply(u), v)) < herm_tol * abs(np.vdot(u, P.apply(v)))
     assert np.vdot(u, P.apply(u)).real > 0
+
+
+# ---- force terms and update! from the phonon fields with T = ComplexF64 (round 3) -------------------------------------------
+# mul_νRe∂M∂x! is generic in T<:Number (src/fermion_det_matrix_dervative.jl:2-10): the bond factors are [[c, s], [conj(s), c]] and the SSH
+# term is ν Re[conj(u_j) ΔτdK v_i + conj(u_i) conj(ΔτdK) v_j] with a COMPLEX ΔτdK (:225-227, ssh_parameters.α::Vector{T}).  Pinned here
+# against central finite differences of the action computed with dense complex matrices, before the HIP path is trusted with it.
+def flux_ssh_model(kind, seed=0):
+    """An SSH model of lattice.py threaded by a static flux: hopping h carries the phase e^{iθ_h}, t_h = (1 - αΔx) e^{iθ_h}, i.e. a complex
+    bare hopping t⁰ = e^{iθ} and complex couplings α e^{iθ}."""
+    m = lat.bssh_chain(6, 5, walker=seed) if kind == "bssh" else lat.ossh_square(4, 4, walker=seed)
+    nt, perm, colors = lat.checkerboard_decomposition(m.fpi.neighbor_table)
+    g = np.random.default_rng(200 + seed)
+    Nh = m.fpi.t.shape[0]
+    theta = g.uniform(0, 2 * np.pi, Nh)  # model hopping order
+    fc = m.force_couplings(perm)
+    ph = np.exp(1j * theta[perm[np.asarray(fc.s_bond) - 1] - 1])  # coupling c acts on sorted bond s_bond[c] = model hopping perm[...]
+    fc.s_alpha_im = fc.s_alpha * ph.imag
+    fc.s_alpha2_im, fc.s_alpha3_im, fc.s_alpha4_im = np.zeros(len(ph)), np.zeros(len(ph)), np.zeros(len(ph))
+    fc.s_alpha = fc.s_alpha * ph.real
+    V0, _ = m.bare_model()
+    t0 = np.exp(1j * theta)
+    return m, nt, perm, colors, fc, V0, t0
+
+
+def _action_and_fields(m, nt, perm, fc, V0, t0, is_sym, Phi):
+    V, t = orc.fields_from_phonons(fc, V0, t0, perm)
+    expV, ch, sh = orc.update_fields(V, t, perm, m.fpi.dtau, is_sym)
+    M, _ = dense.dense_M(nt, expV, ch, sh, is_sym)
+    Lt, N = expV.shape
+    Lam = orc.update_lambda(Lt, N, m.elph.x, m.elph.dtau, [], [], [], [], [])
+    A = M @ dense.lambda_dense(Lam)
+    psi = np.linalg.solve(A.conj().T @ A, dense.vec(Phi))
+    return float(np.vdot(dense.vec(Phi), psi).real), psi, Lam, (expV, ch, sh), t
+
+
+@pytest.mark.parametrize("kind", ["bssh", "ossh"])
+@pytest.mark.parametrize("is_sym", [True, False])
+def test_force_complex_T_against_finite_differences(kind, is_sym):
+    m, nt, perm, colors, fc, V0, t0 = flux_ssh_model(kind)
+    Lt, N = m.fpi.Ltau, m.fpi.N
+    g = np.random.default_rng(3)
+    Phi = g.standard_normal((Lt, N)) + 1j * g.standard_normal((Lt, N))
+    S, psi, Lam, (expV, ch, sh), t = _action_and_fields(m, nt, perm, fc, V0, t0, is_sym, Phi)
+    assert np.iscomplexobj(t) and np.abs(t.imag).max() > 0.1 and np.iscomplexobj(sh)
+    o = orc.OracleFDM(nt, expV, ch, sh, is_sym)
+    e = orc.OracleElph(fc)
+    Psi = dense.unvec(psi, Lt, N)
+    LPsi = orc.lambda_apply(Lam, Psi, "mul")
+    APsi = o.mul_M(LPsi)
+    F = orc.mul_dMdx(o, e, colors, -2.0, APsi, LPsi)       # src/PFFCalculator.jl:146-150 (no Holstein coupling: ∂Λ/∂x = 0)
+    x = fc.x
+    h = 1e-5
+    scale = np.abs(F).max()
+    nfree = m.elph.x.shape[0]
+    for (p, l) in [(0, 0), (1, 2), (nfree - 1, Lt - 1), (2, 1)]:
+        x0 = x[p, l]
+        x[p, l] = x0 + h
+        Sp = _action_and_fields(m, nt, perm, fc, V0, t0, is_sym, Phi)[0]
+        x[p, l] = x0 - h
+        Sm = _action_and_fields(m, nt, perm, fc, V0, t0, is_sym, Phi)[0]
+        x[p, l] = x0
+        fd = (Sp - Sm) / (2 * h)
+        assert abs(F[p, l] - fd) < 2e-6 * scale, (kind, is_sym, p, l, F[p, l], fd)
