@@ -92,6 +92,8 @@ struct smoqy_ctx {
     double *part_rr = nullptr, *part_bb = nullptr;
     CgState *d_st = nullptr, *h_st = nullptr;
     void *h_poll_dot = nullptr;  // pinned staging for per-system scalars (smoqy_pff_step_v)
+    double2 *h_traj_dot = nullptr;  // pinned [Nt][nsys]: S_f of every step of a device trajectory, read once at its end
+    size_t traj_cap = 0;
     int check_every = 4;
     // iterations the previous solve at (about) the same tolerance needed: consecutive solves of an HMC
     // trajectory converge in nearly the same number of iterations, so the first burst runs that far
@@ -146,6 +148,7 @@ struct smoqy_ctx {
     int *d_rebuild = nullptr, *d_pstat = nullptr, *h_pstat = nullptr;  // h_pstat pinned [nw][4]
     hipEvent_t ev_pstat = nullptr;
     bool pstat_pending = false;
+    bool pstat_ever = false;     // a status record has been consumed at least once (the host's hints are meaningful)
     bool mirrors_stale = false;  // host copies of order / coefs / Lanczos coefficients are older than the device's (refreshed on demand by smoqy_precond_get*)
     // force terms
     struct ForceState {
@@ -418,6 +421,7 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->h_st) (void)hipHostFree(c->h_st);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_poll_dot) (void)hipHostFree(c->h_poll_dot);
+    if (c->h_traj_dot) (void)hipHostFree(c->h_traj_dot);
     if (c->h_lan) (void)hipHostFree(c->h_lan);
     if (c->h_pstat) (void)hipHostFree(c->h_pstat);
     if (c->d_rebuild) (void)hipFree(c->d_rebuild);
@@ -1456,6 +1460,7 @@ static void pstat_consume(smoqy_ctx *c)
     }
     const int heavy = std::min(c->g.Lt, last);
     if (heavy != c->cheb_heavy) { c->cheb_heavy = heavy; drop_graphs(c); }  // a captured CG graph holds the old count
+    c->pstat_ever = true;
 }
 
 // Block until the status records of the last update have arrived (no-op when none is outstanding).  The copy sits in the stream right
@@ -1820,6 +1825,17 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
     const Geometry &g = c->g;
     if (maxiter < 0) FAIL(c, 1, "maxiter < 0");
     CgGateHold gate_hold;  // smoqy_cg_gate: released on every return path
+    // Speculation on the preconditioner's status record (round 3).  The record of the update_preconditioner! in front of this solve is
+    // still on its way; what it can change for the launches below is (i) the count of multi-term frequencies (cheb_own_kernel's geometry)
+    // and (ii) whether any walker is active at all.  Along a trajectory neither changes from solve to solve (the bounds move by more than
+    // rbuf/2 a few times per run), so a solve that CAN be restarted — x === b: the right-hand side survives in its scratch copy and x
+    // starts from zero — is launched on the host's current knowledge and checked at its first convergence poll, by which time the record
+    // has landed in stream order.  If it says the launches were wrong in a way that matters (more chains than workgroups were given: those
+    // frequencies were poisoned with NaN by the light workgroups; or a preconditioner became active while the plain path was running), the
+    // solve starts over with the record consumed.  A stale count that is too LARGE, or walkers that became inactive, are harmless: the
+    // kernels read orders and activation flags from device memory.  Warm-started solves and the very first solve of a handle wait as before.
+    bool speculate = x_is_b && c->pstat_pending && c->pstat_ever;
+restart:
     for (int s = 0; s < g.nsys; ++s) {
         std::memset(&c->h_st[s], 0, sizeof(CgState));
         c->h_st[s].precond_on = use_precond ? 1 : 0;  // informational (the Chebyshev kernel reads each walker's `active` flag from the device)
@@ -1844,9 +1860,10 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
     // Whether any walker's preconditioner is active — and the launch geometry of the Chebyshev kernel — is in the status record the last
     // update_preconditioner! sent after its kernels.  The host waits for it HERE, with the right-hand side's preparation and cg_init queued
     // behind those kernels, so the stream keeps working while the record travels (round 2 synchronised right after the Lanczos kernel).
-    if (int rc = pstat_wait(c)) return rc;
+    if (!speculate) if (int rc = pstat_wait(c)) return rc;
     bool any_pre = false;
     for (int w = 0; w < g.nw; ++w) any_pre = any_pre || (use_precond && c->pre[w].active);
+    const int used_heavy = c->cheb_heavy;
     a.use_precond = any_pre ? 1 : 0;
     a.nrz = any_pre ? (cheb_split_active(kpm_args(c, nullptr, nullptr), c->kg) ? 2 * g.Lt : g.Lt) : c->nchunk;
     if (any_pre && c->tf_ok && c->use_tfft) {
@@ -1956,6 +1973,14 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (int rc = check_launch(c, "cg loop")) return rc;
+        if (speculate) {
+            // the status record was queued in front of everything this solve launched: it has landed
+            speculate = false;
+            if (int rc = pstat_wait(c)) return rc;
+            bool now_active = false;
+            for (int w = 0; w < g.nw; ++w) now_active = now_active || (use_precond && c->pre[w].active);
+            if (c->cheb_heavy > used_heavy || (now_active && !any_pre)) goto restart;  // the launches above were made on stale knowledge that mattered
+        }
         bool all_done = true;
         for (int s = 0; s < g.nsys; ++s) all_done = all_done && (c->h_st[s].done != 0);
         if (all_done) break;
@@ -2515,24 +2540,35 @@ int smoqy_hmc_trajectory_v(smoqy_ctx *c, int phi, int psi, int Nt, double dt, do
     if (use_precond && !randvecs) FAIL(c, 1, "randvecs is NULL");
     std::vector<int> it((size_t)g.nw);
     std::vector<double> ep((size_t)g.nw);
-    double2 *hdot = reinterpret_cast<double2 *>(c->h_poll_dot);
+    // S_f of every step lands in its own page-locked slot and is read once, behind the last step: no host synchronisation per step besides
+    // the solve's own (round 2 synchronised here 24 times per trajectory)
+    if ((size_t)Nt * g.nsys > c->traj_cap) {
+        if (c->h_traj_dot) (void)hipHostFree(c->h_traj_dot);
+        c->h_traj_dot = nullptr;
+        c->traj_cap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_traj_dot, (size_t)Nt * g.nsys * sizeof(double2), hipHostMallocDefault));
+        c->traj_cap = (size_t)Nt * g.nsys;
+    }
+    double2 *hdot = c->h_traj_dot;
     // evolve_eom!(x, p, Δt/2); update!(fdm)                                                            EFAPFFHMCUpdater.jl:148-152
     if (int rc = efa_launch(c, 0, 0.5 * dt, 0.0, false)) return rc;
     if (int rc = refresh_from_device_x(c)) return rc;
     for (int t = 0; t < Nt; ++t) {                                                                   // :162
         const double *rv = use_precond ? randvecs + (size_t)t * g.nw * g.N : nullptr;
         if (int rc = pff_core(c, phi, psi, rv, tol_force, maxiter, use_precond, true, it.data(), ep.data())) return rc;  // :172 (force stays in force.d_out)
-        HIPCHK(c, hipMemcpyAsync(hdot, c->d_dot_out, (size_t)g.nsys * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hdot + (size_t)t * g.nsys, c->d_dot_out, (size_t)g.nsys * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
         // p -= Δt ∂S/∂x (:196) fused into evolve_eom!(x, p, Δt′) (:201-202); update!(fdm) (:204-205)
         if (int rc = efa_launch(c, 0, (t == Nt - 1) ? 0.5 * dt : dt, dt, true)) return rc;
         if (int rc = refresh_from_device_x(c)) return rc;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
         for (int w = 0; w < g.nw; ++w) {
-            if (Sf) Sf[(size_t)t * g.nw + w] = hdot[w].x;
             if (iters) iters[(size_t)t * g.nw + w] = it[w];
             if (eps) eps[(size_t)t * g.nw + w] = ep[w];
         }
     }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (Sf)
+        for (int t = 0; t < Nt; ++t)
+            for (int w = 0; w < g.nw; ++w) Sf[(size_t)t * g.nw + w] = hdot[(size_t)t * g.nsys + w].x;
     return check_launch(c, "hmc_trajectory");
 }
 

@@ -466,3 +466,64 @@ def test_in_place_tau_fft_form(Lt, is_sym):
     assert relerr(x1, x0) < 1e-9 and eps1.max() < 1e-10
     xo, ito, _ = o[0].cg_solve(v[:, :, 0], precond=P, tol=1e-10, maxiter=5000)
     assert abs(int(it1[0]) - ito) <= 1 and relerr(x1[:, :, 0], xo) < 1e-8
+
+
+def test_speculative_solve_restarts_when_the_preconditioner_grows():
+    """Round 3: a solve that can be restarted (x === b) is launched on the host's CURRENT knowledge of the preconditioner (how many
+    frequencies carry a chain, whether any walker is active) while the status record of the update in front of it is still on its way,
+    and starts over if the record says that knowledge was stale in a way that matters.  Provoked here: fields with a narrow spectrum
+    (few multi-term frequencies), then fields with a wide one on the SAME handle — the second solve's first launches are sized for the
+    narrow spectrum, its light workgroups meet chains and poison them, the first poll consumes the record and the solve restarts.  The
+    result must be bit for bit what a fresh handle (which waits for its first record) gives on the wide-spectrum fields, and the
+    oracle's iteration count."""
+    m = lat.holstein_honeycomb(4, 40)
+    nt, perm, colors = lat.checkerboard_decomposition(m.fpi.neighbor_table)
+    Lt, N, Nh = 40, 32, m.fpi.t.shape[0]
+    g = np.random.default_rng(77)
+    V = np.asfortranarray(0.3 * g.standard_normal((N, Lt)))
+    t_narrow = np.asfortranarray(np.full((Nh, Lt), 0.15))
+    t_wide = np.asfortranarray(np.full((Nh, Lt), 2.2))
+    rv = g.standard_normal(N)
+    b = rand(Lt, N, 1, 5)
+
+    def heavy_count(h):
+        act, norder = C.c_int(0), C.c_int(0)
+        order = np.zeros(Lt, dtype=np.int32)
+        h.call("smoqy_precond_get", 0, C.byref(act), None, order.ctypes.data_as(C.POINTER(C.c_int)), C.byref(norder), None, None)
+        return int(act.value), int((order[: norder.value] > 1).sum())
+
+    def solve_xb(h):
+        x = h.vec_alloc()
+        h.vec_upload(x, b)
+        it, eps = np.zeros(1, dtype=np.int32), np.zeros(1)
+        h.call("smoqy_cg_solve_v", x, x, C.c_double(1e-10), 10000, 1, L.ptr(it), L.ptr(eps))
+        out = h.vec_download(x)
+        h.call("smoqy_vec_free", x)
+        return out, int(it[0]), float(eps[0])
+
+    # handle A: narrow spectrum first (its record is consumed by the first solve), then the wide one with the record still in flight
+    hA = L.Handle(Lt, N, nt, colors, True, 1, 1)
+    hA.call("smoqy_update_from_path_integral", 0, L.ptr(V), L.ptr(t_narrow), L.ptr(perm), C.c_double(0.05))
+    hA.call("smoqy_precond_update", 0, L.ptr(rv))
+    solve_xb(hA)
+    act_n, heavy_n = heavy_count(hA)
+    hA.call("smoqy_update_from_path_integral", 0, L.ptr(V), L.ptr(t_wide), L.ptr(perm), C.c_double(0.05))
+    hA.call("smoqy_precond_update", 0, L.ptr(rv))   # no host synchronisation: the status record is pending
+    xA, itA, epsA = solve_xb(hA)                    # speculates with the narrow-spectrum count, restarts
+    act_w, heavy_w = heavy_count(hA)
+    assert act_n == 1 and act_w == 1 and heavy_w > heavy_n, (heavy_n, heavy_w)
+    # handle B: the wide spectrum from scratch (first solve of a handle waits for its record)
+    hB = L.Handle(Lt, N, nt, colors, True, 1, 1)
+    hB.call("smoqy_update_from_path_integral", 0, L.ptr(V), L.ptr(t_wide), L.ptr(perm), C.c_double(0.05))
+    hB.call("smoqy_precond_update", 0, L.ptr(rv))
+    xB, itB, epsB = solve_xb(hB)
+    assert np.all(np.isfinite(xA)) and epsA < 1e-10
+    assert itA == itB and np.array_equal(xA, xB)
+    expV, ch, sh = orc.update_fields(V, t_wide, perm, 0.05, True)
+    o = orc.OracleFDM(nt, expV, ch, sh, True)
+    P = orc.OracleKPM(o)
+    P.update(rv)
+    xo, ito, _ = o.cg_solve(b[:, :, 0], precond=P, tol=1e-10, maxiter=10000)
+    assert abs(itA - ito) <= 1 and relerr(np.asarray(xA).reshape(Lt, N, order="F"), xo) < 1e-8
+    hA.close()
+    hB.close()
