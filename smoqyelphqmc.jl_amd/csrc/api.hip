@@ -1095,16 +1095,22 @@ static int stream_run_length(const smoqy_ctx *c, int count, bool cs_const)
     static const int env = [] { const char *e = getenv("SMOQY_FDM_STREAM"); return e ? atoi(e) : -1; }();
     const Geometry &g = c->g;
     if (!g.is_sym || g.is_cplx || !c->ff.enabled || c->d_big) return 0;
-    if (!cs_const && g.ncol >= 3) return 0;  // τ-dependent hoppings on three or more colours: the field registers of two slices do not fit beside the pipeline
+    // τ-dependent hoppings on three or more colours (optical SSH): measured even with the chunked kernel (11.3 against 11.9 µs at 16 systems,
+    // 28.4 against 29.4 at 64, worse at the run lengths in between) — the two field sets of four colours cost the occupancy the pipeline
+    // gains; those handles keep the chunked kernel unless a run length is forced
+    static const bool forced = env >= 0;
+    if (!cs_const && g.ncol >= 3 && !(forced || c->stream_R > 0)) return 0;
+    if (!cs_const && g.ncol >= 3 && c->ff.threads > 256) return 0;  // (and they need the 256-lane instantiation: no 128-VGPR cap)
     int R = env;
     if (R < 0) R = c->stream_R;
     if (R < 0) {
         // automatic (measured on MI355X): from 16 systems per launch the streaming kernel wins (16 systems 17.0 -> 14.1 µs,
         // 128 systems 116.7 -> 75.4 µs); at 8 and fewer the owner-computes kernel does.  Run length: about 512 workgroups of 256 lanes per
-        // launch, at least 4 slices (prologue + last iteration are two extra stage chains per run), at most 32.
+        // launch, between 2 and 32 slices (small lattices want the short runs: honeycomb L = 8 at 16 systems 6.0 µs at R = 2, 7.6 at R = 4,
+        // 7.8 chunked).
         if (count < 16) return 0;
         const long want = (long)g.Lt * count * c->ff.threads / (512L * 256L);
-        R = 4;
+        R = 2;
         while (2 * R <= want && R < 32) R *= 2;
     }
     if (R <= 0) return 0;

@@ -600,8 +600,11 @@ __global__ void __launch_bounds__(1024) fdm_fast_asym_kernel(FdmArgs a, FdmFast 
 // checks it): no lane is ever switched off, so every LDS access and every store of the pipeline is unconditional.  Besides the saved
 // exec-mask juggling this keeps the compiler's count of outstanding memory operations exact: with a store inside a branch it falls back to
 // waiting for all but the newest three, i.e. for the slice requested one iteration ago.
-template <int NCOL, bool CSV, bool FULL>
-__global__ void __launch_bounds__(1024) fdm_stream_kernel(FdmArgs a, FdmFast ff)
+// LB: the launch bound.  1024 lanes cap the kernel at 128 VGPRs, which two field sets of three or four colours (CSV) do not fit beside
+// the pipeline; lattices of up to 256 padded bonds per colour (every BASELINE.json lattice) are launched with the 256-lane instantiation,
+// which may use what it needs.
+template <int NCOL, bool CSV, bool FULL, int LB>
+__global__ void __launch_bounds__(LB) fdm_stream_kernel(FdmArgs a, FdmFast ff)
 {
     extern __shared__ double2 U[];
     __shared__ double red[34];
@@ -880,8 +883,13 @@ void launch_stream_ncol(hipStream_t st, const FdmArgs &a, const FdmFast &ff)
     const int nrun = (a.Lt + a.run_len - 1) / a.run_len;
     const dim3 grid((unsigned)(nrun * a.sys_count)), block((unsigned)ff.threads);
     const size_t lds = sizeof(double2) * 4 * (size_t)a.N;
-    if (ff.full) hipLaunchKernelGGL((fdm_stream_kernel<NCOL, CSV, true>), grid, block, lds, st, a, ff);
-    else hipLaunchKernelGGL((fdm_stream_kernel<NCOL, CSV, false>), grid, block, lds, st, a, ff);
+    if (ff.threads <= 256) {
+        if (ff.full) hipLaunchKernelGGL((fdm_stream_kernel<NCOL, CSV, true, 256>), grid, block, lds, st, a, ff);
+        else hipLaunchKernelGGL((fdm_stream_kernel<NCOL, CSV, false, 256>), grid, block, lds, st, a, ff);
+    } else {
+        if (ff.full) hipLaunchKernelGGL((fdm_stream_kernel<NCOL, CSV, true, 1024>), grid, block, lds, st, a, ff);
+        else hipLaunchKernelGGL((fdm_stream_kernel<NCOL, CSV, false, 1024>), grid, block, lds, st, a, ff);
+    }
 }
 
 template <int NCOL>
@@ -976,22 +984,38 @@ void launch_fdm_stream(hipStream_t st, const FdmArgs &a, const FdmFast &ff, bool
 hipError_t configure_fdm_stream_kernels(const char **what)
 {
     hipError_t first = hipSuccess;
-    SMOQY_SET_LDS((fdm_stream_kernel<1, false, false>), 160 * 1024 - 512);
-    SMOQY_SET_LDS((fdm_stream_kernel<1, false, true>), 160 * 1024 - 512);
-    SMOQY_SET_LDS((fdm_stream_kernel<2, false, false>), 160 * 1024 - 512);
-    SMOQY_SET_LDS((fdm_stream_kernel<2, false, true>), 160 * 1024 - 512);
-    SMOQY_SET_LDS((fdm_stream_kernel<3, false, false>), 160 * 1024 - 512);
-    SMOQY_SET_LDS((fdm_stream_kernel<3, false, true>), 160 * 1024 - 512);
-    SMOQY_SET_LDS((fdm_stream_kernel<4, false, false>), 160 * 1024 - 512);
-    SMOQY_SET_LDS((fdm_stream_kernel<4, false, true>), 160 * 1024 - 512);
-    SMOQY_SET_LDS((fdm_stream_kernel<1, true, false>), 160 * 1024 - 512);
-    SMOQY_SET_LDS((fdm_stream_kernel<1, true, true>), 160 * 1024 - 512);
-    SMOQY_SET_LDS((fdm_stream_kernel<2, true, false>), 160 * 1024 - 512);
-    SMOQY_SET_LDS((fdm_stream_kernel<2, true, true>), 160 * 1024 - 512);
-    SMOQY_SET_LDS((fdm_stream_kernel<3, true, false>), 160 * 1024 - 512);
-    SMOQY_SET_LDS((fdm_stream_kernel<3, true, true>), 160 * 1024 - 512);
-    SMOQY_SET_LDS((fdm_stream_kernel<4, true, false>), 160 * 1024 - 512);
-    SMOQY_SET_LDS((fdm_stream_kernel<4, true, true>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<1, false, false, 256>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<1, false, false, 1024>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<1, false, true, 256>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<1, false, true, 1024>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<2, false, false, 256>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<2, false, false, 1024>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<2, false, true, 256>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<2, false, true, 1024>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<3, false, false, 256>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<3, false, false, 1024>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<3, false, true, 256>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<3, false, true, 1024>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<4, false, false, 256>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<4, false, false, 1024>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<4, false, true, 256>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<4, false, true, 1024>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<1, true, false, 256>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<1, true, false, 1024>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<1, true, true, 256>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<1, true, true, 1024>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<2, true, false, 256>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<2, true, false, 1024>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<2, true, true, 256>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<2, true, true, 1024>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<3, true, false, 256>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<3, true, false, 1024>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<3, true, true, 256>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<3, true, true, 1024>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<4, true, false, 256>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<4, true, false, 1024>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<4, true, true, 256>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((fdm_stream_kernel<4, true, true, 1024>), 160 * 1024 - 512);
     return first;
 }
 

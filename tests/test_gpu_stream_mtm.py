@@ -30,7 +30,7 @@ def _handle(m, nw, walkers=None):
     return h, nt, perm
 
 
-@pytest.mark.parametrize("case", ["honeycomb_L4_Lt12", "honeycomb_L4_Lt13", "chain_L24_Lt9", "chain_L24_Lt16_const", "square_L6_Lt12_const", "honeycomb_L3_Lt5"])
+@pytest.mark.parametrize("case", ["honeycomb_L4_Lt12", "honeycomb_L4_Lt13", "chain_L24_Lt9", "chain_L24_Lt16_const", "square_L6_Lt12_const", "square_L6_Lt12_ssh", "honeycomb_L3_Lt5"])
 @pytest.mark.parametrize("R", [2, 4, 6, 64])
 def test_stream_equals_chunked_and_oracle(case, R):
     """Odd and even Lτ, runs that do not divide Lτ, a run longer than Lτ, 1 / 2 / 3 / 4 colours, τ-dependent hoppings on two colours."""
@@ -44,6 +44,8 @@ def test_stream_equals_chunked_and_oracle(case, R):
         ms = [lat.bssh_chain(24, 9, walker=w) for w in range(3)]       # two colours, hoppings depend on τ
     elif case == "chain_L24_Lt16_const":
         ms = [lat.bssh_chain(24, 16, alpha=0.0, walker=w) for w in range(2)]
+    elif case == "square_L6_Lt12_ssh":
+        ms = [lat.ossh_square(6, 12, walker=w) for w in range(2)]              # four colours, hoppings depend on τ (256-lane instantiation)
     else:
         ms = [lat.ossh_square(6, 12, alpha=0.0, walker=w) for w in range(2)]  # four colours, constant hoppings
     nw = len(ms)
