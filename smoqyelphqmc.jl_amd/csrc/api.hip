@@ -1826,7 +1826,10 @@ static int cg_iteration(smoqy_ctx *c, const CgArgs &a, bool any_pre)
 
 constexpr int kGraphIters = 4;  // iterations per captured graph (smoqy_cg_use_graph)
 
-static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, double tol, int maxiter, int use_precond, int *iters, double *eps)
+// pff_phi / pff_out: the solve of calculate_fermionic_action! with its Λ applies folded in (CgArgs::lam): b = Λ⁻ᵀ·pff_phi is formed by
+// cg_init (b itself is not read), Ψ = Λ⁻¹x lands in pff_out with the partials of Φ·Ψ in part_c; x then holds the twiddled iterate only.
+static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, double tol, int maxiter, int use_precond, int *iters, double *eps, const double2 *pff_phi = nullptr,
+                  double2 *pff_out = nullptr)
 {
     const Geometry &g = c->g;
     if (maxiter < 0) FAIL(c, 1, "maxiter < 0");
@@ -1857,6 +1860,7 @@ restart:
     a.part_pz = c->part_pz; a.part_rz = c->part_rz; a.part_rr = c->part_rr; a.part_bb = c->part_bb;
     a.st = c->d_st; a.tol = tol; a.maxiter = maxiter;
     a.rz_stride = 2 * g.Lt;
+    if (pff_phi) { a.lam = c->d_lam; a.phi = pff_phi; a.x_out = pff_out; a.part_dot = c->part_c; }
 
     if (!x_is_b) {  // r0 = b - A x0  (ConjugateGradient.jl:119-120), in the twiddled basis
         launch_fft_twiddle(c->stream, x, c->d_th, g.Lt, g.N, g.nsys, 0);
@@ -2334,12 +2338,11 @@ static int pff_core(smoqy_ctx *c, int phi, int psi, const double *randvec_all, d
 {
     const Geometry &g = c->g;
     if (randvec_all && use_precond) if (int rc = precond_update_range(c, 0, g.nw, randvec_all)) return rc;  // FermionDetMatrix.jl:259
-    launch_lambda_apply(c->stream, SMOQY_LAMBDA_LDIVT, c->vecs[psi], c->vecs[phi], c->d_lam, g.Lt, g.N, g.nsys, g.nrhs, -1);  // Ψ = Λ⁻ᵀΦ  PFFCalculator.jl:97
-    HIPCHK(c, hipMemcpyAsync(c->scr[0], c->vecs[psi], c->vec_elems() * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
-    if (int rc = cg_dev(c, c->vecs[psi], c->scr[0], true, tol, maxiter, use_precond, iters, eps)) return rc;                   // ldiv!(Ψ, fdm, Ψ)  :99
-    launch_lambda_apply(c->stream, SMOQY_LAMBDA_LDIV, c->scr[0], c->vecs[psi], c->d_lam, g.Lt, g.N, g.nsys, g.nrhs, -1);       // Ψ = Λ⁻¹Ψ  :107
+    // Ψ = Λ⁻ᵀΦ (PFFCalculator.jl:97), ldiv!(Ψ, fdm, Ψ) (:99), Ψ = Λ⁻¹Ψ (:107) and the partials of S_f = Φ·Ψ (:109) in the kernels of the solve:
+    // cg_init reads Φ through Λ⁻ᵀ, cg_finish writes Λ⁻¹x into the scratch vector that then becomes Ψ (CgArgs::lam)
+    if (int rc = cg_dev(c, c->vecs[psi], nullptr, true, tol, maxiter, use_precond, iters, eps, c->vecs[phi], c->scr[0])) return rc;
     std::swap(c->scr[0], c->vecs[psi]);
-    launch_dot(c->stream, c->vecs[phi], c->vecs[psi], c->part_c, c->d_dot_out, g.Lt, g.N, g.nsys, c->Tc, c->nchunk);           // S_f = Φ·Ψ  :109
+    launch_dot_final(c->stream, c->part_c, c->d_dot_out, g.nsys, c->nchunk);
     if (want_force) if (int rc = force_device(c, psi)) return rc;                                                               // :146-155
     return 0;
 }

@@ -336,6 +336,12 @@ __global__ void dot_final_kernel(const double2 *__restrict__ partial, double2 *_
     if (threadIdx.x == 0) out[blockIdx.x] = t;
 }
 
+// second half of launch_dot alone: the per-chunk partials were written by another kernel (cg_finish with the fused Λ⁻¹ and Φ·Ψ)
+void launch_dot_final(hipStream_t st, const double2 *partial, double2 *out, int nsys, int nchunk)
+{
+    hipLaunchKernelGGL(dot_final_kernel, dim3(nsys), dim3(64), 0, st, partial, out, nchunk);
+}
+
 void launch_dot(hipStream_t st, const double2 *a, const double2 *b, double2 *partial, double2 *out, int Lt, int N, int nsys, int Tc, int nchunk)
 {
     hipLaunchKernelGGL(dot_partial_kernel, dim3(nchunk * nsys), dim3(kThreads), 0, st, a, b, partial, Lt, N, nsys, Tc, nchunk);
@@ -415,7 +421,16 @@ __global__ void __launch_bounds__(kThreads) cg_init_kernel(CgArgs a)
     for (int idx = threadIdx.x; idx < nk * a.N; idx += blockDim.x) {
         const int k = idx / a.N, i = idx - k * a.N, l = l0 + k;
         const size_t off = (size_t)l * sstride + base + i;
-        const double2 bv = cmul(a.b[off], a.th[l]);
+        double2 bsrc;
+        if (a.lam) {  // b = Λ⁻ᵀΦ: (Λ⁻ᵀv)[l] = v[l+1] / Λ[l+1] (src/holstein_shift_matrix.jl:129-153; the arithmetic of lambda_apply_kernel)
+            const int lp = (l + 1 == a.Lt) ? 0 : l + 1;
+            const double f = a.lam[((size_t)(sys / a.nrhs) * a.Lt + lp) * a.N + i];
+            const double2 v = a.phi[(size_t)lp * sstride + base + i];
+            bsrc = make_double2(v.x / f, v.y / f);
+        } else {
+            bsrc = a.b[off];
+        }
+        const double2 bv = cmul(bsrc, a.th[l]);
         double2 rv;
         if (X_IS_B) {
             rv = bv;
@@ -533,6 +548,27 @@ __global__ void __launch_bounds__(kThreads) cg_update_p_kernel(CgArgs a)
 __global__ void __launch_bounds__(kThreads) cg_finish_kernel(CgArgs a)
 {
     CG_PROLOGUE
+    if (a.lam) {
+        // Ψ[l] = (Λ⁻¹ x)[l] = x[l-1] / Λ[l] with x = Θᴴ x̃ (src/holstein_shift_matrix.jl:74-98, PFFCalculator.jl:107), out of place, and the
+        // partial of Φ·Ψ (:109) over this chunk: the operations and the summation order of cg_finish + lambda_apply + dot_partial
+        double2 acc = make_double2(0.0, 0.0);
+        for (int idx = threadIdx.x; idx < nk * a.N; idx += blockDim.x) {
+            const int k = idx / a.N, i = idx - k * a.N, l = l0 + k;
+            const int lm = (l == 0) ? a.Lt - 1 : l - 1;
+            const size_t off = (size_t)l * sstride + base + i;
+            const double2 t = a.th[lm];
+            const double2 xv = cmul(a.x[(size_t)lm * sstride + base + i], make_double2(t.x, -t.y));
+            const double f = a.lam[((size_t)(sys / a.nrhs) * a.Lt + l) * a.N + i];
+            const double2 y = make_double2(xv.x / f, xv.y / f);
+            a.x_out[off] = y;
+            const double2 p = a.phi[off];
+            acc.x += p.x * y.x + p.y * y.y;
+            acc.y += p.x * y.y - p.y * y.x;
+        }
+        const double2 tsum = block_sum_bcast(acc, red);
+        if (threadIdx.x == 0) a.part_dot[pidx] = tsum;
+        return;
+    }
     for (int idx = threadIdx.x; idx < nk * a.N; idx += blockDim.x) {
         const int k = idx / a.N, i = idx - k * a.N, l = l0 + k;
         const size_t off = (size_t)l * sstride + base + i;

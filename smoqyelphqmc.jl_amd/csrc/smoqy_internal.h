@@ -200,6 +200,7 @@ void launch_fields_from_path_integral_c(hipStream_t st, const double *V, const d
 void launch_lambda_update(hipStream_t st, double *Lam, int Lt, int N, const double *x, int Nph, double dtau, int ncoup, const int *c2p, const int *c2s, const double *alpha, const double *alpha3, const int *phsym, const int *site_first, const int *site_next, int Lt1);
 void launch_lambda_apply(hipStream_t st, int op, double2 *out, const double2 *in, const double *Lam, int Lt, int N, int nsys, int nrhs, int wslot_override);
 void launch_dot(hipStream_t st, const double2 *a, const double2 *b, double2 *partial, double2 *out, int Lt, int N, int nsys, int Tc, int nchunk);
+void launch_dot_final(hipStream_t st, const double2 *partial, double2 *out, int nsys, int nchunk);
 void launch_fft_twiddle(hipStream_t st, double2 *v, const double2 *tw, int Lt, int N, int nsys, int inverse);
 void launch_make_twiddle(hipStream_t st, double2 *tw, int Lt, double scale);
 void launch_tau_means(hipStream_t st, const KpmGeom &kg, const double *expV, const double *ch, const double *sh, double *dbar, double *cbar, double *sbar, int Lt, int N, int Nh, int w0, int nw, const double *shi = nullptr,
@@ -231,6 +232,14 @@ struct CgArgs {
     int maxiter;
     int use_precond;
     int nrz, rz_stride;
+    // The solve of calculate_fermionic_action! (src/PFFCalculator.jl:97-109) with its Λ applies folded into the first and the last kernel
+    // (round 3): when `lam` is set, cg_init forms the right-hand side b = Λ⁻ᵀΦ on the fly from Φ (`phi`; :97) instead of reading a prepared b,
+    // and cg_finish writes Ψ = Λ⁻¹ x (:107) into `x_out` together with the per-chunk partials of Φ·Ψ (:109) into `part_dot` — the arithmetic
+    // and the summation order of the three separate kernels they replace, seven vector passes fewer per solve.
+    const double *lam;     // [w][Lt][N]
+    const double2 *phi;
+    double2 *x_out;
+    double2 *part_dot;     // [nsys][nchunk]
 };
 void launch_cg_init(hipStream_t s, const CgArgs &a, bool x_is_b);
 void launch_cg_start(hipStream_t s, const CgArgs &a);
