@@ -215,6 +215,28 @@ def test_time_extents_with_large_prime_factors_fall_back_to_rocfft(Lt, is_sym):
     assert relerr(x[:, :, 0], xo) < 1e-8
 
 
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_iterate_after_every_iteration_count(use_graph):
+    """The x update of the fused CG iteration lives one kernel later than the r update (the inverse τ-FFT kernel applies x += αp): cut
+    the solve off after 1 … 7 iterations (unreachable tolerance) and compare the iterate with the oracle's after the same number of
+    iterations — eager launches and the four-iteration captured graph (whose replays run past maxiter as early-exit workgroups)."""
+    N, Lt_ = 24, 12
+    h, o, nt, colors = make(lat.chain_neighbor_table(N), Lt_, N, True, seed=13, nrhs=2, vscale=0.5)
+    v = rand(Lt_, N, 2, 14)
+    rv = np.random.default_rng(15).standard_normal(N)
+    P = orc.OracleKPM(o[0])
+    P.update(rv)
+    h.call("smoqy_precond_update", 0, L.ptr(rv))
+    h.call("smoqy_cg_use_graph", use_graph)
+    for maxiter in range(1, 8):
+        x, it, eps = solve(h, v, 1e-30, maxiter, 1)
+        assert list(it) == [maxiter, maxiter]
+        for s_ in range(2):
+            xo, ito, _ = o[0].cg_solve(v[:, :, s_], precond=P, tol=1e-30, maxiter=maxiter)
+            assert ito == maxiter
+            assert relerr(x[:, :, s_], xo) < 1e-11, (maxiter, s_)
+
+
 def _oversubscribed_solve(concurrent):
     """16 walkers x 10 right-hand sides at L = 16, Lτ = 128: 160 systems x 64 site tiles = 10 240 workgroups per τ-FFT launch, far
     beyond what is co-resident (256 CUs), optionally with a long-running kernel queue on a second stream competing for the CUs."""
