@@ -76,6 +76,9 @@ def parse():
     ap.add_argument("--proc-scan", default="1,2,4,6", help="process counts of procs_per_gpu_scan (the pool admits at most 6 GPU processes per card)")
     ap.add_argument("--thread-scan", default="1,2,4,8,16", help="thread counts of threads_per_gpu_scan")
     ap.add_argument("--team-scan", default="8,16,32", help="member counts of team_threads_scan")
+    ap.add_argument("--member-worker", default="", help=argparse.SUPPRESS)  # child process of team_procs_scan: "<info json>|<w>|<sweeps>", never touches the GPU
+    ap.add_argument("--team-procs", default="16,32,4x32", help="points of team_procs_scan: K member PROCESSES on one served team, or TxK (T teams)")
+    ap.add_argument("--team-multi", default="4x32", help="TxK points of team_threads_scan: T teams of K native member threads side by side")
     ap.add_argument("--no-proc-scan", action="store_true", help="skip procs_per_gpu_scan, threads_per_gpu_scan and team_threads_scan")
     ap.add_argument("--roofline-only", action="store_true", help="run only the isolated roofline leg (for a rocprofv3 pass whose kernel average must match roofline.avg_launch_us)")
     ap.add_argument("--batch-scan", action="store_true", help="try tau chunks 1..4 at every point of the batch scan (the default scan uses the heuristic chunk)")
@@ -316,6 +319,9 @@ def team_scan(args, counts, dev, walker0):
     (host-driven HMC: x uploaded, force downloaded every step) driven by one caller through the batched entry points."""
     from concurrent.futures import ThreadPoolExecutor
 
+    import numpy as np
+
+    from smoqyelphqmc_amd import _lib as L
     from smoqyelphqmc_amd.walkers import WalkerBatch, WalkerTeam
 
     out = []
@@ -327,6 +333,14 @@ def team_scan(args, counts, dev, walker0):
             list(pool.map(lambda m: [m.sweep() for _ in range(args.scan_sweeps)], team.members))
             span = time.perf_counter() - t0
         iters = sum(m.iters_sum for m in team.members) / max(sum(m.solves for m in team.members), 1)
+        # the same member sweep from K native threads (no interpreter lock): smoqy_team_bench_sweeps
+        b = team.batch
+        x0 = np.ascontiguousarray(np.stack([np.asarray(b.xs_force[w]) for w in range(K)]))
+        secs, so, itn = L.C.c_double(0.0), L.C.c_long(0), L.C.c_long(0)
+        team.call("smoqy_team_bench_sweeps", L.ptr(x0), int(b.Nph), L.C.c_double(b.drift), int(b.Nt), L.C.c_double(b.tol), L.C.c_double(b.tol_force), int(b.maxiter), 1,
+                  int(args.scan_sweeps), 4242 + walker0, L.C.byref(secs), L.C.byref(so), L.C.byref(itn))
+        native = K * args.scan_sweeps / secs.value
+        native_iters = itn.value / max(so.value, 1)
         team.close()
         ob = WalkerBatch(args.workload, nwalkers=K, walker0=walker0 + 3000, device=dev, device_efa=False)
         ob.sweep()
@@ -338,7 +352,89 @@ def team_scan(args, counts, dev, walker0):
         span_b = time.perf_counter() - t1
         ob.h.close()
         out.append({"threads": K, "walkers_per_thread": 1, "handles": 1, "sweeps_per_s": K * args.scan_sweeps / span, "avg_cg_iters": iters,
+                    "native_threads_sweeps_per_s": native, "native_avg_cg_iters": native_iters,
                     "one_caller_batched_sweeps_per_s": K * args.scan_sweeps / span_b, "sweeps_each": args.scan_sweeps})
+    # several teams side by side (one handle and stream each), native member threads only: T x K per-walker control flows on one GPU
+    for spec in [q for q in getattr(args, "team_multi", "").split(",") if q]:
+        T, K = (int(v) for v in spec.split("x"))
+        teams = [WalkerTeam(args.workload, K, walker0=walker0 + 5000 + 64 * q, device=dev) for q in range(T)]
+
+        def native_run(team, warm, sweeps):
+            b = team.batch
+            x0 = np.ascontiguousarray(np.stack([np.asarray(b.xs_force[w]) for w in range(K)]))
+            secs, so, itn = L.C.c_double(0.0), L.C.c_long(0), L.C.c_long(0)
+            team.call("smoqy_team_bench_sweeps", L.ptr(x0), int(b.Nph), L.C.c_double(b.drift), int(b.Nt), L.C.c_double(b.tol), L.C.c_double(b.tol_force), int(b.maxiter), warm,
+                      sweeps, 777 + walker0, L.C.byref(secs), L.C.byref(so), L.C.byref(itn))
+            return itn.value, so.value
+
+        with ThreadPoolExecutor(T) as pool:
+            list(pool.map(lambda tm: native_run(tm, 0, 1), teams))            # warm-up, untimed
+            t0 = time.perf_counter()
+            res = list(pool.map(lambda tm: native_run(tm, 0, args.scan_sweeps), teams))
+            span = time.perf_counter() - t0
+        for tm in teams:
+            tm.close()
+        out.append({"teams": T, "threads": T * K, "walkers_per_thread": 1, "handles": T, "native_threads_sweeps_per_s": T * K * args.scan_sweeps / span,
+                    "native_avg_cg_iters": sum(r[0] for r in res) / max(sum(r[1] for r in res), 1), "sweeps_each": args.scan_sweeps})
+    return out
+
+
+def member_worker(spec):
+    """Child process of team_procs_scan: ONE rank of the reference's one-walker-per-rank model (tutorials/holstein_honeycomb_mpi.jl:60-72),
+    joined to a team that the parent process serves (smoqy_team_serve).  No GPU, no handle: the per-walker sweep against its own walker,
+    its own rng, every library call through shared memory.  One warm-up sweep, then the timed ones."""
+    from smoqyelphqmc_amd.walkers import RemoteMember
+
+    info, w, sweeps = spec.rsplit("|", 2)
+    m = RemoteMember(json.loads(info), int(w), seed=4711, wait_seconds=120.0)
+    m.sweep()
+    m.solves = m.iters_sum = 0
+    t0 = time.time()
+    for _ in range(int(sweeps)):
+        m.sweep()
+    t1 = time.time()
+    print(json.dumps({"start": t0, "end": t1, "solves": m.solves, "iters": m.iters_sum}), flush=True)
+    m.close()
+
+
+def team_procs_scan(args, points, dev, walker0):
+    """The reference's execution model made to scale on one GPU: K member PROCESSES (ranks), each driving its own walker only, joined
+    through shared memory to ONE batched handle that this process owns and serves (TxK: T served teams side by side, one handle and
+    stream each).  Aggregate sweeps/s = members * sweeps / (last end - first start)."""
+    import subprocess
+
+    from smoqyelphqmc_amd.walkers import WalkerTeam
+
+    out = []
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    for spec in points:
+        T, K = (int(v) for v in spec.split("x")) if "x" in spec else (1, int(spec))
+        rec = {"teams": T, "procs": T * K, "walkers_per_proc": 1, "handles": T}
+        teams, procs = [], []
+        try:
+            for q in range(T):
+                tm = WalkerTeam(args.workload, K, walker0=walker0 + 7000 + 64 * q, device=dev)
+                teams.append(tm)
+                info = tm.serve(f"/smoqy-bench-{os.getpid()}-{q}")
+                procs += [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--member-worker", json.dumps(info) + f"|{w}|{args.scan_sweeps}"],
+                                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True) for w in range(K)]
+            res = []
+            for pr in procs:
+                o, e = pr.communicate(timeout=600)
+                if pr.returncode != 0:
+                    raise RuntimeError((e or "")[-300:])
+                res.append(json.loads(o.strip().splitlines()[-1]))
+            span = max(r["end"] for r in res) - min(r["start"] for r in res)
+            rec.update({"sweeps_per_s": T * K * args.scan_sweeps / span, "avg_cg_iters": sum(r["iters"] for r in res) / max(sum(r["solves"] for r in res), 1), "sweeps_each": args.scan_sweeps})
+        except Exception as ex:  # noqa: BLE001 — a failed point is reported, never substituted
+            rec["error"] = str(ex)[:300]
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+        finally:
+            for tm in teams:
+                tm.close()
+        out.append(rec)
     return out
 
 
@@ -507,6 +603,9 @@ def main():
     if args.cpu_worker >= 0:  # CPU-only child of cpu_baseline(): never touches the GPU
         print(json.dumps(cpu_sample(args.workload, args.cpu_tol, args.cpu_nt, walker=args.cpu_worker)))
         return
+    if args.member_worker:  # CPU-only child of team_procs_scan
+        member_worker(args.member_worker)
+        return
     if args.rank_worker >= 0:  # GPU child of procs_per_gpu_scan
         rank_worker(args)
         return
@@ -642,10 +741,19 @@ def main():
                 try:
                     extra["team_threads_scan"] = {"model": "K host threads, each driving ONE walker with the reference's per-walker update sequence, through a walker team "
                                                            "(smoqy_team_*: the members' calls rendezvous in the library and run as one batched call on one handle); "
-                                                           "host-driven HMC (x uploaded, force downloaded every step), so compare with one_caller_batched, not with `value`",
+                                                           "host-driven HMC (x uploaded, force downloaded every step), so compare with one_caller_batched, not with `value`; "
+                                                           "native_threads: the same member sweep from K std::threads inside the library (smoqy_team_bench_sweeps) — "
+                                                           "what a caller without an interpreter lock gets",
                                                   "points": team_scan(args, [int(k) for k in args.team_scan.split(",") if k], dev, mine.start)}
                 except Exception as ex:  # noqa: BLE001
                     extra["team_threads_scan"] = {"error": str(ex)[:400]}
+                try:
+                    extra["team_procs_scan"] = {"model": "K member PROCESSES ('MPI ranks', tutorials/holstein_honeycomb_mpi.jl:60-72), each driving ONE walker with the per-walker update "
+                                                         "sequence and no GPU access of its own, joined through shared memory (smoqy_team_serve / smoqy_member_*) to one batched handle "
+                                                         "per team in this process; host-driven HMC as in team_threads_scan; compare with procs_per_gpu_scan",
+                                                "points": team_procs_scan(args, [q for q in args.team_procs.split(",") if q], dev, mine.start)}
+                except Exception as ex:  # noqa: BLE001
+                    extra["team_procs_scan"] = {"error": str(ex)[:400]}
         # the CPU baseline is a rank-0, N = 1 measurement (it would only hold the other ranks at the final barrier)
         cpu = None if (args.no_cpu_baseline or args.roofline_only or args.timed_only or world > 1) else cpu_baseline(args.workload, batch.tol, batch.Nt)
         # the whole sweep against the roofline: algorithmic bytes of one preconditioned CG iteration per walker as SURVEY.md §8(d)

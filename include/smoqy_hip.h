@@ -70,6 +70,9 @@ int smoqy_sync(smoqy_ctx *ctx);
 /* optional: page-locked host memory for arrays that are handed to the library repeatedly */
 int smoqy_host_alloc(smoqy_ctx *ctx, void **ptr, size_t bytes);
 int smoqy_host_free(smoqy_ctx *ctx, void *ptr);
+/* page-lock memory the caller already owns (a Julia array, a shared-memory segment) / undo it */
+int smoqy_host_register(smoqy_ctx *ctx, void *ptr, size_t bytes);
+int smoqy_host_unregister(smoqy_ctx *ctx, void *ptr);
 /* size(fdm) (src/FermionDetMatrix.jl:243): dims = {Ltau, N, Nh, ncolors, nwalkers, nrhs} */
 int smoqy_dims(const smoqy_ctx *ctx, int dims[6]);
 
@@ -374,7 +377,38 @@ int smoqy_team_sample_phi(smoqy_team *team, int w, const void *R, double *RdotR)
  * start vector (KPMPreconditioner.jl:634; needed when use_precond != 0).  Out: S_f, (iters, eps) of the solve, ∂S_f/∂x (Nph x Ltau, stored). */
 int smoqy_team_pff_step(smoqy_team *team, int w, const double *x, const double *randvec, double tol, int maxiter, int use_precond, double *Sf, int *iters, double *eps, double *dSdx);
 
+/* Teams across processes — the reference's walkers are MPI ranks (processes): the rank that owns the GPU handle publishes its team in a
+ * POSIX shared-memory segment `name` ("/something"); every rank of the node, the serving one included, joins with smoqy_member_attach and
+ * makes the same two calls as a team member.  A member needs no GPU and no handle: it copies its arrays into the segment (page-locked in
+ * the serving process) and sleeps until a server thread in the serving process has run the round for all K members.  x0 (optional): the
+ * K members' initial phonon fields, Nph x Ltau each, which smoqy_member_fields hands to the members.  While a team is published its
+ * in-process entry points (smoqy_team_sample_phi / _pff_step) are closed.  smoqy_team_unserve (also run by smoqy_team_destroy) wakes every
+ * waiting member with code 10 and removes the segment. */
+int smoqy_team_serve(smoqy_team *team, const char *name, const double *x0);
+int smoqy_team_unserve(smoqy_team *team);
+typedef struct smoqy_member smoqy_member;
+/* waits up to wait_seconds for the segment to appear (the ranks of a job start together); w = this rank's walker index in the team */
+int smoqy_member_attach(smoqy_member **out, const char *name, int w, double wait_seconds);
+int smoqy_member_detach(smoqy_member *member);
+const char *smoqy_member_last_error(const smoqy_member *member);
+/* dims[0..3] = Ltau, N, K, Nph */
+int smoqy_member_dims(const smoqy_member *member, int *dims);
+/* the phonon fields the serving handle last received for this walker (x0 of smoqy_team_serve before the first step) */
+int smoqy_member_fields(const smoqy_member *member, double *x);
+/* smoqy_team_sample_phi / smoqy_team_pff_step for this member */
+int smoqy_member_sample_phi(smoqy_member *member, const void *R, double *RdotR);
+int smoqy_member_pff_step(smoqy_member *member, const double *x, const double *randvec, double tol, int maxiter, int use_precond, double *Sf, int *iters, double *eps, double *dSdx);
+
 /* ---- measurement aids (bench.py) -------------------------------------------------------- */
+
+/* K native member threads (K = the team's size) each run `warmup_sweeps` untimed and `nsweeps` timed sweeps of the reference tutorial's
+ * per-walker update sequence (tutorials/holstein_honeycomb.jl:611-684: two local-move-like updates, an HMC trajectory of Nt force
+ * evaluations, the closing action) through smoqy_team_sample_phi / smoqy_team_pff_step, drawing their own normal deviates: the number a
+ * caller WITHOUT an interpreter lock gets from a team.  x0: the K members' phonon fields (Nph x Ltau each, member-major); the first
+ * `nfree` modes of every slice are moved by the synthetic drift of bench.py's sweep and restored.  Out: wall seconds of the timed part,
+ * solves and CG iterations summed over the members. */
+int smoqy_team_bench_sweeps(smoqy_team *team, const double *x0, int nfree, double drift, int Nt, double tol, double tol_force, int maxiter, int warmup_sweeps, int nsweeps,
+                            unsigned long seed, double *seconds, long *solves, long *iters);
 
 /* HIP events on the handle's stream */
 int smoqy_timer_start(smoqy_ctx *ctx);

@@ -51,6 +51,8 @@ SIGNATURES = {
     "smoqy_sync": [_p],
     "smoqy_host_alloc": [_p, C.POINTER(_p), C.c_size_t],
     "smoqy_host_free": [_p, _p],
+    "smoqy_host_register": [_p, _p, C.c_size_t],
+    "smoqy_host_unregister": [_p, _p],
     "smoqy_dims": [_p, _pi],
     "smoqy_set_tau_chunk": [_p, _i],
     "smoqy_get_tau_chunk": [_p, _pi],
@@ -74,6 +76,15 @@ SIGNATURES = {
     "smoqy_team_vectors": [_p, _pi, _pi],
     "smoqy_team_sample_phi": [_p, _i, _p, _pd],
     "smoqy_team_pff_step": [_p, _i, _p, _p, _d, _i, _i, _pd, _pi, _pd, _p],
+    "smoqy_team_serve": [_p, C.c_char_p, _p],
+    "smoqy_team_unserve": [_p],
+    "smoqy_member_attach": [C.POINTER(_p), C.c_char_p, _i, _d],
+    "smoqy_member_detach": [_p],
+    "smoqy_member_dims": [_p, _pi],
+    "smoqy_member_fields": [_p, _p],
+    "smoqy_member_sample_phi": [_p, _p, _pd],
+    "smoqy_member_pff_step": [_p, _p, _p, _d, _i, _i, _pd, _pi, _pd, _p],
+    "smoqy_team_bench_sweeps": [_p, _p, _i, _d, _i, _d, _d, _i, _i, _i, C.c_ulong, _pd, C.POINTER(C.c_long), C.POINTER(C.c_long)],
     "smoqy_matvec": [_p, _i, _p, _p, _i, _i],
     "smoqy_checkerboard_v": [_p, _i, _i, _i, _i, _i],
     "smoqy_checkerboard": [_p, _p, _i, _i, _i, _i, _i, _i],
@@ -158,6 +169,8 @@ def load():
     lib.smoqy_last_error.restype = C.c_char_p
     lib.smoqy_team_last_error.argtypes = [_p]
     lib.smoqy_team_last_error.restype = C.c_char_p
+    lib.smoqy_member_last_error.argtypes = [_p]
+    lib.smoqy_member_last_error.restype = C.c_char_p
     _lib = lib
     return lib
 

@@ -819,6 +819,23 @@ int smoqy_host_free(smoqy_ctx *c, void *ptr)
     return 0;
 }
 
+// page-lock memory the caller already owns (a Julia array, a shared-memory segment): same effect as smoqy_host_alloc for transfers from it
+int smoqy_host_register(smoqy_ctx *c, void *ptr, size_t bytes)
+{
+    CHECK_CTX(c);
+    if (!ptr || bytes == 0) FAIL(c, 1, "smoqy_host_register: null pointer or zero size");
+    HIPCHK(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return 0;
+}
+
+int smoqy_host_unregister(smoqy_ctx *c, void *ptr)
+{
+    CHECK_CTX(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipHostUnregister(ptr));
+    return 0;
+}
+
 int smoqy_sync(smoqy_ctx *c)
 {
     CHECK_CTX(c);

@@ -8,11 +8,23 @@
 // and call the team entry points with their own walker index; a call blocks until all K members have made the same call, the last one
 // to arrive executes the batched library call for everybody, and each member returns with its own results.  Built on the public C ABI
 // only; no kernel knows about teams.
+#include <atomic>
 #include <chrono>
+#include <cmath>
+#include <cstdint>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
+
+#include <errno.h>
+#include <fcntl.h>
+#include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 #include <vector>
 
 #include "../../include/smoqy_hip.h"
@@ -29,6 +41,8 @@ struct Slot {
     int rc = 0;
 };
 }  // namespace
+
+struct Served;
 
 struct smoqy_team {
     smoqy_ctx *c = nullptr;
@@ -47,6 +61,7 @@ struct smoqy_team {
     std::vector<double> Sf, eps, dot;
     std::vector<int> iters;
     std::string err;
+    struct Served *served = nullptr;  // published for members of other processes (smoqy_team_serve)
 };
 
 static std::string g_team_error;
@@ -55,9 +70,12 @@ extern "C" {
 
 const char *smoqy_team_last_error(const smoqy_team *t) { return t ? t->err.c_str() : g_team_error.c_str(); }
 
+int smoqy_team_unserve(smoqy_team *t);
+
 int smoqy_team_destroy(smoqy_team *t)
 {
     if (!t) return 0;
+    smoqy_team_unserve(t);
     if (t->c) {
         if (t->h_R) smoqy_host_free(t->c, t->h_R);
         if (t->h_x) smoqy_host_free(t->c, t->h_x);
@@ -124,15 +142,15 @@ int smoqy_team_vectors(const smoqy_team *t, int *phi, int *psi)
 
 }  // extern "C"
 
+static int rendezvous_locked(smoqy_team *t, int w, int op, const Slot &args);
+
 // the batched call of one round, run by the last member to arrive (all the others are blocked in rendezvous)
 static int run_round(smoqy_team *t)
 {
     smoqy_ctx *c = t->c;
     const int K = t->K;
-    const size_t nR = (size_t)t->Lt * t->N * 16, nx = (size_t)t->Nph * t->Lt;
     if (t->op == OP_SAMPLE) {
         // sample_pseudofermion_fields! (src/PFFCalculator.jl:56-76): Φ = Λᵀ Mᵀ R, |R|² per member
-        for (int w = 0; w < K; ++w) std::memcpy((char *)t->h_R + (size_t)w * nR, t->slot[w].R, nR);
         if (int rc = smoqy_vec_upload(c, t->phi, t->h_R, 0, K)) return rc;
         if (int rc = smoqy_vec_dot(c, t->phi, t->phi, t->dot.data())) return rc;
         if (int rc = smoqy_matvec_v(c, SMOQY_OP_MT, t->phi, t->phi)) return rc;                // lmul_Mt! (:71)
@@ -146,10 +164,9 @@ static int run_round(smoqy_team *t)
     bool any_x = false, any_force = false, all_rv = true;
     for (int w = 0; w < K; ++w) {
         const Slot &s = t->slot[w];
-        if (s.x) { std::memcpy(t->h_x + (size_t)w * nx, s.x, nx * sizeof(double)); t->x_seen[w] = 1; any_x = true; }
+        if (s.x) { t->x_seen[w] = 1; any_x = true; }
         if (s.dSdx) any_force = true;
-        if (s.rv) std::memcpy(t->h_rv + (size_t)w * t->N, s.rv, (size_t)t->N * sizeof(double));
-        else all_rv = false;
+        if (!s.rv) all_rv = false;
         if (s.tol != t->slot[0].tol || s.maxiter != t->slot[0].maxiter || s.use_precond != t->slot[0].use_precond) {
             t->err = "smoqy_team_pff_step: the members of a round must pass the same tol / maxiter / use_precond";
             return 1;
@@ -170,16 +187,29 @@ static int run_round(smoqy_team *t)
         if (s.Sf) *s.Sf = t->Sf[w];
         if (s.iters) *s.iters = t->iters[w];
         if (s.eps) *s.eps = t->eps[w];
-        if (s.dSdx) std::memcpy(s.dSdx, t->h_dS + (size_t)w * nx, nx * sizeof(double));
     }
     return 0;
 }
 
-// deposit member w's arguments, wait for the others; the last arrival runs the round
+// deposit member w's arguments, wait for the others; the last arrival runs the round.  Every member copies its OWN arrays into / out of
+// its part of the page-locked staging buffers outside the lock (K copies in parallel instead of K in a row inside the round): a member's
+// part is its own between its return from one round and its arrival in the next, and no round starts before every member has arrived.
 static int rendezvous(smoqy_team *t, int w, int op, const Slot &args)
 {
     if (!t) return 1;
     if (w < 0 || w >= t->K) { t->err = "team member index out of range"; return 1; }
+    if (t->served) { t->err = "this team is published (smoqy_team_serve): its members call smoqy_member_*"; return 1; }
+    const size_t nR = (size_t)t->Lt * t->N * 16, nx = (size_t)t->Nph * t->Lt;
+    if (args.R) std::memcpy((char *)t->h_R + (size_t)w * nR, args.R, nR);
+    if (args.x) std::memcpy(t->h_x + (size_t)w * nx, args.x, nx * sizeof(double));
+    if (args.rv) std::memcpy(t->h_rv + (size_t)w * t->N, args.rv, (size_t)t->N * sizeof(double));
+    const int rc = rendezvous_locked(t, w, op, args);
+    if (rc == 0 && args.dSdx) std::memcpy(args.dSdx, t->h_dS + (size_t)w * nx, nx * sizeof(double));
+    return rc;
+}
+
+static int rendezvous_locked(smoqy_team *t, int w, int op, const Slot &args)
+{
     std::unique_lock<std::mutex> lk(t->m);
     if (t->arrived > 0 && t->op != op) { t->err = "team members made different calls in the same round"; return 8; }
     t->op = op;
@@ -221,6 +251,411 @@ int smoqy_team_pff_step(smoqy_team *t, int w, const double *x, const double *ran
     s.x = x; s.rv = randvec; s.tol = tol; s.maxiter = maxiter; s.use_precond = use_precond ? 1 : 0;
     s.Sf = Sf; s.iters = iters; s.eps = eps; s.dSdx = dSdx;
     return rendezvous(t, w, OP_PFF, s);
+}
+
+
+}  // extern "C"
+
+// ---- teams across processes ---------------------------------------------------------------------------------------------------------
+// The reference's walkers are MPI ranks: processes, not threads.  smoqy_team_serve publishes a team in a POSIX shared-memory segment;
+// a rank of the same node joins with smoqy_member_attach (no GPU, no handle on its side) and makes the same two calls.  A member copies its
+// arrays into its part of the segment's staging area (page-locked in the serving process, so the batched upload reads it directly),
+// deposits its scalars and sleeps on a process-shared condition variable; a server thread in the process that owns the handle runs the
+// round once all K members have arrived — the same run_round as the in-process team, its slots pointing into the segment.
+namespace {
+constexpr uint64_t kShmMagic = 0x534d4f5159544d31ull;  // "SMOQYTM1"
+struct ShmMember {
+    int has_x, has_rv, want_force, maxiter, use_precond, iters, rc, attached;
+    double tol, Sf, eps, RdotR;
+};
+struct ShmHeader {
+    uint64_t magic;
+    int K, Lt, N, Nph;
+    int op, arrived, shutdown, rc;
+    unsigned long gen;
+    double timeout_s;
+    size_t off_members, off_R, off_x, off_rv, off_dS, total;
+    pthread_mutex_t m;
+    pthread_cond_t cv_arrive, cv_done;
+    char err[256];
+};
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+int shm_lock(ShmHeader *h)
+{
+    const int e = pthread_mutex_lock(&h->m);
+    if (e == EOWNERDEAD) { pthread_mutex_consistent(&h->m); return 0; }  // a member died inside the lock: the state it guards is plain counters
+    return e;
+}
+timespec deadline_after(double seconds)
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    const double t = ts.tv_sec + ts.tv_nsec * 1e-9 + seconds;
+    ts.tv_sec = (time_t)t;
+    ts.tv_nsec = (long)((t - (double)ts.tv_sec) * 1e9);
+    return ts;
+}
+}  // namespace
+
+struct Served {
+    std::string name;
+    ShmHeader *h = nullptr;
+    std::thread server;
+    void *own_R = nullptr;
+    double *own_x = nullptr, *own_rv = nullptr, *own_dS = nullptr;  // the team's private staging, put back by unserve
+    bool registered = false;
+};
+
+struct smoqy_member {
+    ShmHeader *h = nullptr;
+    int w = -1;
+    std::string err;
+};
+
+static std::string g_member_error;
+
+static void serve_loop(smoqy_team *t)
+{
+    ShmHeader *h = t->served->h;
+    ShmMember *mem = (ShmMember *)((char *)h + h->off_members);
+    shm_lock(h);
+    for (;;) {
+        while (!h->shutdown && h->arrived < h->K) pthread_cond_wait(&h->cv_arrive, &h->m);
+        if (h->shutdown) break;
+        t->op = h->op;
+        for (int w = 0; w < t->K; ++w) {
+            ShmMember &q = mem[w];
+            Slot s;
+            // run_round reads the array pointers as flags only (the data already sits in the staging area, which IS the segment)
+            s.R = h->op == OP_SAMPLE ? (const void *)h : nullptr;
+            s.x = q.has_x ? (const double *)h : nullptr;
+            s.rv = q.has_rv ? (const double *)h : nullptr;
+            s.dSdx = q.want_force ? (double *)h : nullptr;
+            s.tol = q.tol; s.maxiter = q.maxiter; s.use_precond = q.use_precond;
+            s.Sf = &q.Sf; s.iters = &q.iters; s.eps = &q.eps; s.RdotR = &q.RdotR;
+            t->slot[w] = s;
+        }
+        pthread_mutex_unlock(&h->m);
+        const int rc = run_round(t);  // every member is asleep on cv_done
+        shm_lock(h);
+        for (int w = 0; w < t->K; ++w) mem[w].rc = rc;
+        h->rc = rc;
+        snprintf(h->err, sizeof(h->err), "%s", rc ? t->err.c_str() : "");
+        h->arrived = 0;
+        h->op = OP_NONE;
+        t->op = OP_NONE;
+        ++h->gen;
+        pthread_cond_broadcast(&h->cv_done);
+    }
+    pthread_mutex_unlock(&h->m);
+}
+
+extern "C" {
+
+int smoqy_team_serve(smoqy_team *t, const char *name, const double *x0)
+{
+    if (!t || !name || name[0] != '/') { g_team_error = "smoqy_team_serve: null team or a name that does not start with '/'"; return 1; }
+    if (t->served) { t->err = "smoqy_team_serve: this team is already published"; return 1; }
+    const size_t nR = (size_t)t->Lt * t->N * 16, nx = (size_t)std::max(t->Nph, 1) * t->Lt * sizeof(double);
+    ShmHeader lay{};
+    lay.off_members = align_up(sizeof(ShmHeader), 64);
+    lay.off_R = align_up(lay.off_members + sizeof(ShmMember) * (size_t)t->K, 4096);
+    lay.off_x = align_up(lay.off_R + nR * t->K, 4096);
+    lay.off_rv = align_up(lay.off_x + nx * t->K, 4096);
+    lay.off_dS = align_up(lay.off_rv + (size_t)t->N * t->K * sizeof(double), 4096);
+    lay.total = align_up(lay.off_dS + nx * t->K, 4096);
+    shm_unlink(name);  // a stale segment of a crashed job
+    const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) { t->err = std::string("smoqy_team_serve: shm_open failed for ") + name; return 2; }
+    if (ftruncate(fd, (off_t)lay.total) != 0) { close(fd); shm_unlink(name); t->err = "smoqy_team_serve: ftruncate failed (is /dev/shm large enough?)"; return 2; }
+    void *p = mmap(nullptr, lay.total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { shm_unlink(name); t->err = "smoqy_team_serve: mmap failed"; return 2; }
+    ShmHeader *h = (ShmHeader *)p;
+    std::memset(h, 0, lay.off_R);
+    h->K = t->K; h->Lt = t->Lt; h->N = t->N; h->Nph = t->Nph;
+    h->timeout_s = t->timeout_s;
+    h->off_members = lay.off_members; h->off_R = lay.off_R; h->off_x = lay.off_x; h->off_rv = lay.off_rv; h->off_dS = lay.off_dS; h->total = lay.total;
+    pthread_mutexattr_t ma;
+    pthread_mutexattr_init(&ma);
+    pthread_mutexattr_setpshared(&ma, PTHREAD_PROCESS_SHARED);
+    pthread_mutexattr_setrobust(&ma, PTHREAD_MUTEX_ROBUST);
+    pthread_mutex_init(&h->m, &ma);
+    pthread_mutexattr_destroy(&ma);
+    pthread_condattr_t ca;
+    pthread_condattr_init(&ca);
+    pthread_condattr_setpshared(&ca, PTHREAD_PROCESS_SHARED);
+    pthread_condattr_setclock(&ca, CLOCK_MONOTONIC);
+    pthread_cond_init(&h->cv_arrive, &ca);
+    pthread_cond_init(&h->cv_done, &ca);
+    pthread_condattr_destroy(&ca);
+    Served *sv = new Served();
+    sv->name = name; sv->h = h;
+    sv->own_R = t->h_R; sv->own_x = t->h_x; sv->own_rv = t->h_rv; sv->own_dS = t->h_dS;
+    char *base = (char *)p;
+    // the staging area of the team now IS the segment; page-lock it where the driver allows (transfers work either way)
+    sv->registered = smoqy_host_register(t->c, base + h->off_R, h->total - h->off_R) == 0;
+    t->h_R = base + h->off_R; t->h_x = (double *)(base + h->off_x); t->h_rv = (double *)(base + h->off_rv); t->h_dS = (double *)(base + h->off_dS);
+    std::memcpy(t->h_x, x0 ? (const void *)x0 : (const void *)sv->own_x, nx * t->K);
+    t->served = sv;
+    sv->server = std::thread(serve_loop, t);
+    __atomic_store_n(&h->magic, kShmMagic, __ATOMIC_RELEASE);  // members wait for this
+    return 0;
+}
+
+int smoqy_team_unserve(smoqy_team *t)
+{
+    if (!t || !t->served) return 0;
+    Served *sv = t->served;
+    ShmHeader *h = sv->h;
+    shm_lock(h);
+    h->shutdown = 1;
+    snprintf(h->err, sizeof(h->err), "the team was withdrawn by its serving process");
+    for (int w = 0; w < h->K; ++w) ((ShmMember *)((char *)h + h->off_members))[w].rc = 10;
+    ++h->gen;
+    pthread_cond_broadcast(&h->cv_arrive);
+    pthread_cond_broadcast(&h->cv_done);
+    pthread_mutex_unlock(&h->m);
+    if (sv->server.joinable()) sv->server.join();
+    if (sv->registered) smoqy_host_unregister(t->c, (char *)h + h->off_R);
+    t->h_R = sv->own_R; t->h_x = sv->own_x; t->h_rv = sv->own_rv; t->h_dS = sv->own_dS;
+    shm_unlink(sv->name.c_str());
+    munmap(h, h->total);
+    delete sv;
+    t->served = nullptr;
+    return 0;
+}
+
+const char *smoqy_member_last_error(const smoqy_member *m) { return m ? m->err.c_str() : g_member_error.c_str(); }
+
+int smoqy_member_attach(smoqy_member **out, const char *name, int w, double wait_seconds)
+{
+    if (!out || !name) { g_member_error = "smoqy_member_attach: null argument"; return 1; }
+    *out = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto waited = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    ShmHeader *h = nullptr;
+    for (;;) {  // the ranks of a job start together: the serving rank may not have published yet
+        const int fd = shm_open(name, O_RDWR, 0600);
+        if (fd >= 0) {
+            struct stat st;
+            if (fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(ShmHeader)) {
+                void *p = mmap(nullptr, (size_t)st.st_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                if (p != MAP_FAILED) {
+                    ShmHeader *q = (ShmHeader *)p;
+                    if (__atomic_load_n(&q->magic, __ATOMIC_ACQUIRE) == kShmMagic && q->total == (size_t)st.st_size) { h = q; close(fd); break; }
+                    munmap(p, (size_t)st.st_size);
+                }
+            }
+            close(fd);
+        }
+        if (waited() >= wait_seconds) { g_member_error = std::string("smoqy_member_attach: no team published as ") + name; return 9; }
+        usleep(2000);
+    }
+    if (w < 0 || w >= h->K) { g_member_error = "smoqy_member_attach: member index outside the team"; munmap(h, h->total); return 1; }
+    ShmMember *mem = (ShmMember *)((char *)h + h->off_members);
+    shm_lock(h);
+    const bool taken = mem[w].attached != 0;
+    if (!taken) mem[w].attached = 1;
+    pthread_mutex_unlock(&h->m);
+    if (taken) { g_member_error = "smoqy_member_attach: this member index is already attached"; munmap(h, h->total); return 1; }
+    smoqy_member *m = new smoqy_member();
+    m->h = h; m->w = w;
+    *out = m;
+    return 0;
+}
+
+int smoqy_member_detach(smoqy_member *m)
+{
+    if (!m) return 0;
+    if (m->h) {
+        ShmMember *mem = (ShmMember *)((char *)m->h + m->h->off_members);
+        shm_lock(m->h);
+        mem[m->w].attached = 0;
+        pthread_mutex_unlock(&m->h->m);
+        munmap(m->h, m->h->total);
+    }
+    delete m;
+    return 0;
+}
+
+int smoqy_member_dims(const smoqy_member *m, int *dims)
+{
+    if (!m || !dims) return 1;
+    dims[0] = m->h->Lt; dims[1] = m->h->N; dims[2] = m->h->K; dims[3] = m->h->Nph;
+    return 0;
+}
+
+int smoqy_member_fields(const smoqy_member *m, double *x)
+{
+    if (!m || !x) return 1;
+    const size_t nx = (size_t)std::max(m->h->Nph, 1) * m->h->Lt;
+    std::memcpy(x, (const char *)m->h + m->h->off_x + (size_t)m->w * nx * sizeof(double), nx * sizeof(double));
+    return 0;
+}
+
+}  // extern "C"
+
+static int member_round(smoqy_member *m, int op, const void *R, const double *x, const double *rv, double tol, int maxiter, int use_precond, double *Sf, int *iters, double *eps, double *dSdx, double *RdotR)
+{
+    if (!m || !m->h) return 1;
+    ShmHeader *h = m->h;
+    const int w = m->w;
+    char *base = (char *)h;
+    const size_t nR = (size_t)h->Lt * h->N * 16, nx = (size_t)std::max(h->Nph, 1) * h->Lt * sizeof(double);
+    if (R) std::memcpy(base + h->off_R + (size_t)w * nR, R, nR);
+    if (x) std::memcpy(base + h->off_x + (size_t)w * nx, x, nx);
+    if (rv) std::memcpy(base + h->off_rv + (size_t)w * h->N * sizeof(double), rv, (size_t)h->N * sizeof(double));
+    ShmMember &q = ((ShmMember *)(base + h->off_members))[w];
+    shm_lock(h);
+    if (h->shutdown) { m->err = h->err; pthread_mutex_unlock(&h->m); return 10; }
+    if (h->arrived > 0 && h->op != op) { m->err = "team members made different calls in the same round"; pthread_mutex_unlock(&h->m); return 8; }
+    h->op = op;
+    q.has_x = x != nullptr; q.has_rv = rv != nullptr; q.want_force = dSdx != nullptr;
+    q.tol = tol; q.maxiter = maxiter; q.use_precond = use_precond;
+    const unsigned long my_gen = h->gen;
+    if (++h->arrived == h->K) pthread_cond_signal(&h->cv_arrive);
+    const timespec dl = deadline_after(h->timeout_s);
+    int rc = 0;
+    while (h->gen == my_gen) {
+        const int e = pthread_cond_timedwait(&h->cv_done, &h->m, &dl);
+        if (e == EOWNERDEAD) pthread_mutex_consistent(&h->m);
+        if (e == ETIMEDOUT && h->gen == my_gen) {
+            --h->arrived;
+            m->err = "team rendezvous timed out: not every member made the call";
+            pthread_mutex_unlock(&h->m);
+            return 9;
+        }
+    }
+    rc = q.rc;
+    if (rc) m->err = h->err;
+    const double sf = q.Sf, ep = q.eps, rr = q.RdotR;
+    const int it = q.iters;
+    pthread_mutex_unlock(&h->m);
+    if (rc == 0) {
+        if (Sf) *Sf = sf;
+        if (iters) *iters = it;
+        if (eps) *eps = ep;
+        if (RdotR) *RdotR = rr;
+        if (dSdx) std::memcpy(dSdx, base + h->off_dS + (size_t)w * nx, nx);
+    }
+    return rc;
+}
+
+extern "C" {
+
+int smoqy_member_sample_phi(smoqy_member *m, const void *R, double *RdotR)
+{
+    if (!R) return 1;
+    return member_round(m, OP_SAMPLE, R, nullptr, nullptr, 0.0, 0, 0, nullptr, nullptr, nullptr, nullptr, RdotR);
+}
+
+int smoqy_member_pff_step(smoqy_member *m, const double *x, const double *randvec, double tol, int maxiter, int use_precond, double *Sf, int *iters, double *eps, double *dSdx)
+{
+    return member_round(m, OP_PFF, nullptr, x, randvec, tol, maxiter, use_precond ? 1 : 0, Sf, iters, eps, dSdx, nullptr);
+}
+
+}  // extern "C"
+
+extern "C" {
+
+// ---- measurement: K native member threads ----------------------------------------------------------------------------------------
+// What a caller without an interpreter lock gets from a team: K std::threads, each running the per-walker sweep of the reference's
+// tutorial (tutorials/holstein_honeycomb.jl:611-684: two local-move-like updates, then an HMC trajectory of Nt force evaluations and the
+// closing action) against ITS OWN walker through smoqy_team_sample_phi / smoqy_team_pff_step, with its own random stream (xoshiro256++
+// and Box-Muller: the randn! calls of src/PFFCalculator.jl:67 and src/KPMPreconditioner.jl:634 are part of a member's host work).  The
+// phonon-field moves are the synthetic drift of bench.py's sweep (x += drift·π, restored afterwards), as in walkers.TeamMember.sweep.
+namespace {
+struct Xo {
+    uint64_t s[4];
+    explicit Xo(uint64_t seed) { for (auto &v : s) { seed += 0x9E3779B97F4A7C15ull; uint64_t z = seed; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; v = z ^ (z >> 31); } }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next() { const uint64_t r = rotl(s[0] + s[3], 23) + s[0], t = s[1] << 17; s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45); return r; }
+    double uni() { return ((next() >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+    void normal(double *out, size_t n, double scale)
+    {
+        for (size_t i = 0; i < n; i += 2) {
+            const double r = std::sqrt(-2.0 * std::log(uni())) * scale, a = 6.283185307179586 * uni();
+            out[i] = r * std::cos(a);
+            if (i + 1 < n) out[i + 1] = r * std::sin(a);
+        }
+    }
+};
+struct Member {
+    std::vector<double> x, pi, rv, dS, R;
+    Xo rng{0};
+    long solves = 0, iters = 0;
+    int rc = 0;
+};
+}  // namespace
+
+int smoqy_team_bench_sweeps(smoqy_team *t, const double *x0, int nfree, double drift, int Nt, double tol, double tol_force, int maxiter, int warmup_sweeps, int nsweeps, unsigned long seed,
+                            double *seconds, long *solves, long *iters)
+{
+    if (!t || !x0 || nfree < 0 || nfree > t->Nph || Nt < 1 || nsweeps < 1 || !seconds) return 1;
+    const int K = t->K, Lt = t->Lt, N = t->N, Nph = t->Nph;
+    const size_t nx = (size_t)Nph * Lt;
+    std::vector<Member> mem((size_t)K);
+    for (int w = 0; w < K; ++w) {
+        Member &m = mem[w];
+        m.x.assign(x0 + (size_t)w * nx, x0 + (size_t)(w + 1) * nx);
+        m.pi.resize((size_t)Lt * nfree); m.rv.resize((size_t)N); m.dS.resize(nx); m.R.resize(2 * (size_t)Lt * N);
+        m.rng = Xo(seed + 7919ull * (uint64_t)w);
+    }
+    auto shift = [&](Member &m, double f) {  // x[:, :nfree] += f·π
+        for (int l = 0; l < Lt; ++l)
+            for (int j = 0; j < nfree; ++j) m.x[(size_t)l * Nph + j] += f * m.pi[(size_t)l * nfree + j];
+    };
+    auto step = [&](Member &m, int w, double tl, bool force) {
+        m.rng.normal(m.rv.data(), m.rv.size(), 1.0);
+        double sf = 0, eps = 0;
+        int it = 0;
+        const int rc = smoqy_team_pff_step(t, w, m.x.data(), m.rv.data(), tl, maxiter, 1, &sf, &it, &eps, force ? m.dS.data() : nullptr);
+        m.solves += 1; m.iters += it;
+        return rc;
+    };
+    auto sample = [&](Member &m, int w) {
+        m.rng.normal(m.R.data(), m.R.size(), std::sqrt(0.5));
+        double rr = 0;
+        return smoqy_team_sample_phi(t, w, m.R.data(), &rr);
+    };
+    auto sweep = [&](Member &m, int w) {
+        for (int rep = 0; rep < 2; ++rep) {
+            if (int rc = sample(m, w)) return rc;
+            m.rng.normal(m.pi.data(), m.pi.size(), 1.0);
+            shift(m, drift);
+            if (int rc = step(m, w, tol, false)) return rc;
+            shift(m, -drift);
+        }
+        if (int rc = sample(m, w)) return rc;
+        m.rng.normal(m.pi.data(), m.pi.size(), 1.0);
+        for (int q = 0; q < Nt; ++q) {
+            if (int rc = step(m, w, tol_force, true)) return rc;
+            shift(m, drift / Nt);
+        }
+        if (int rc = step(m, w, tol, false)) return rc;
+        shift(m, -drift);
+        return 0;
+    };
+    auto run = [&](int count) {
+        std::vector<std::thread> th;
+        for (int w = 0; w < K; ++w)
+            th.emplace_back([&, w] {
+                for (int q = 0; q < count && mem[w].rc == 0; ++q) mem[w].rc = sweep(mem[w], w);
+            });
+        for (auto &x : th) x.join();
+    };
+    if (warmup_sweeps > 0) run(warmup_sweeps);
+    for (auto &m : mem) { m.solves = 0; m.iters = 0; }
+    const auto t0 = std::chrono::steady_clock::now();
+    run(nsweeps);
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    long so = 0, itn = 0;
+    int rc = 0;
+    for (auto &m : mem) { so += m.solves; itn += m.iters; if (m.rc) rc = m.rc; }
+    if (solves) *solves = so;
+    if (iters) *iters = itn;
+    return rc;
 }
 
 }  // extern "C"

@@ -406,6 +406,17 @@ class WalkerTeam:
         if rc:
             raise L.SmoqyError(f"{name} failed ({rc}): " + (self.lib.smoqy_team_last_error(self._t) or b"").decode())
 
+    def serve(self, name: str):
+        """Publish the team for members of other processes (smoqy_team_serve): ranks join with ``RemoteMember(name, w)``.  The members'
+        initial phonon fields are the batch's."""
+        b = self.batch
+        x0 = np.ascontiguousarray(np.stack([np.asarray(b.xs_force[w]) for w in range(b.nw)]))
+        self.call("smoqy_team_serve", name.encode(), L.ptr(x0))
+        return {"name": name, "tol": b.tol, "tol_force": b.tol_force, "maxiter": b.maxiter, "Nt": b.Nt, "drift": b.drift, "free": b.Nph}
+
+    def unserve(self):
+        self.call("smoqy_team_unserve")
+
     def close(self):
         if self._t:
             self.lib.smoqy_team_destroy(self._t)
@@ -429,19 +440,25 @@ class TeamMember:
         self.tol, self.tol_force, self.maxiter, self.Nt, self.drift = b.tol, b.tol_force, b.maxiter, b.Nt, b.drift
         self.solves = self.iters_sum = 0
 
+    def _sample_call(self, R, rr):
+        self.team.call("smoqy_team_sample_phi", self.w, R, rr)
+
+    def _step_call(self, *a):
+        self.team.call("smoqy_team_pff_step", self.w, *a)
+
     def sample_pseudofermion_fields(self):
         flat = self.R.reshape(-1, order="F").view(np.float64)
         self.rng.standard_normal(out=flat)                    # randn!(rng, Φ), src/PFFCalculator.jl:67
         flat *= np.sqrt(0.5)
         rr = C.c_double(0.0)
-        self.team.call("smoqy_team_sample_phi", self.w, L.ptr(self.R), C.byref(rr))
+        self._sample_call(L.ptr(self.R), C.byref(rr))
         return rr.value
 
     def pff_step(self, tol, moved, want_force):
         rv = self.rng.standard_normal(self.N)                 # randn!(rng, v), KPMPreconditioner.jl:634
         sf, eps, it = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
-        self.team.call("smoqy_team_pff_step", self.w, L.ptr(self.x) if moved else None, L.ptr(rv), C.c_double(tol), int(self.maxiter), 1, C.byref(sf), C.byref(it), C.byref(eps),
-                       L.ptr(self.dSdx) if want_force else None)
+        self._step_call(L.ptr(self.x) if moved else None, L.ptr(rv), C.c_double(tol), int(self.maxiter), 1, C.byref(sf), C.byref(it), C.byref(eps),
+                        L.ptr(self.dSdx) if want_force else None)
         self.solves += 1
         self.iters_sum += it.value
         return sf.value, it.value, eps.value
@@ -464,3 +481,44 @@ class TeamMember:
         last = self.pff_step(self.tol, moved=True, want_force=False)
         self.x[:, : self.free] -= self.drift * pi
         return last
+
+
+class RemoteMember(TeamMember):
+    """A member of a team published by ANOTHER process (``WalkerTeam.serve``): what one MPI rank of the reference becomes when the ranks
+    of a node share a GPU through one serving rank.  Needs no GPU and no handle — only the library (for the shared-memory rendezvous) and
+    the run parameters the serving rank announces (``info``: the dict ``serve`` returned, sent over whatever channel the job has)."""
+
+    def __init__(self, info: dict, w: int, seed: int = 0, wait_seconds: float = 60.0):
+        self.lib = L.load()
+        self._m = C.c_void_p()
+        rc = self.lib.smoqy_member_attach(C.byref(self._m), info["name"].encode(), int(w), C.c_double(wait_seconds))
+        if rc:
+            raise L.SmoqyError(f"smoqy_member_attach failed ({rc}): " + (self.lib.smoqy_member_last_error(None) or b"").decode())
+        d = (C.c_int * 4)()
+        self.lib.smoqy_member_dims(self._m, d)
+        self.team, self.w = None, w
+        self.Lt, self.N, self.K, self.Nph = d[0], d[1], d[2], d[3]
+        self.rng = np.random.default_rng([seed, w])
+        self.x = np.zeros((self.Lt, max(self.Nph, 1)))
+        self.lib.smoqy_member_fields(self._m, L.ptr(self.x))
+        self.free = int(info["free"])
+        self.R = np.empty((self.Lt, self.N), dtype=np.complex128, order="F")
+        self.dSdx = np.zeros((self.Lt, self.Nph))
+        self.tol, self.tol_force, self.maxiter, self.Nt, self.drift = info["tol"], info["tol_force"], info["maxiter"], info["Nt"], info["drift"]
+        self.solves = self.iters_sum = 0
+
+    def _call(self, name, *a):
+        rc = getattr(self.lib, name)(self._m, *a)
+        if rc:
+            raise L.SmoqyError(f"{name} failed ({rc}): " + (self.lib.smoqy_member_last_error(self._m) or b"").decode())
+
+    def _sample_call(self, R, rr):
+        self._call("smoqy_member_sample_phi", R, rr)
+
+    def _step_call(self, *a):
+        self._call("smoqy_member_pff_step", *a)
+
+    def close(self):
+        if self._m:
+            self.lib.smoqy_member_detach(self._m)
+            self._m = C.c_void_p()

@@ -25,7 +25,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in smoqy_hip.h but not exported"
     # and the Python binding covers the same set
-    assert set(names) == set(L.SIGNATURES) | {"smoqy_last_error", "smoqy_team_last_error"}  # the two that return a string
+    assert set(names) == set(L.SIGNATURES) | {"smoqy_last_error", "smoqy_team_last_error", "smoqy_member_last_error"}  # the three that return a string
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -71,3 +71,11 @@ def test_header_and_c_example_compile_as_plain_c(tmp_path):
     subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_demo.c"), "-L" + lib_dir, "-lsmoqy_hip", "-lm",
                     "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(out)], check=True)
     assert out.exists()
+
+
+def test_member_attach_fails_cleanly_without_a_team():
+    """the member side of a cross-process team needs no GPU: joining a team nobody serves times out with code 9 and a message"""
+    lib = L.load()
+    m = C.c_void_p()
+    assert lib.smoqy_member_attach(C.byref(m), b"/smoqy-no-such-team", 0, C.c_double(0.05)) == 9
+    assert b"no team published" in lib.smoqy_member_last_error(None)

@@ -87,3 +87,72 @@ def test_team_sweeps_and_errors():
         rr = list(pool.map(lambda m: m.sample_pseudofermion_fields(), team.members))
     assert all(r > 0 for r in rr)
     team.close()
+
+
+def test_native_member_threads_run_the_member_sweep():
+    """smoqy_team_bench_sweeps (measurement aid of bench.py's team scan): K std::threads inside the library run the member sweep through the
+    team entry points.  Its counts are fixed by the sweep's shape — 3 + Nt solves per member and sweep — and the solves converge in the
+    iteration range the Python members see on the same lattice."""
+    K = 3
+    team = WalkerTeam("holstein_honeycomb_L4_Ltau40", K)
+    b = team.batch
+    x0 = np.ascontiguousarray(np.stack([np.asarray(b.xs_force[w]) for w in range(K)]))
+    secs, so, itn = C.c_double(0.0), C.c_long(0), C.c_long(0)
+    team.call("smoqy_team_bench_sweeps", L.ptr(x0), int(b.Nph), C.c_double(b.drift), int(b.Nt), C.c_double(b.tol), C.c_double(b.tol_force), int(b.maxiter), 1, 2, 99,
+              C.byref(secs), C.byref(so), C.byref(itn))
+    assert so.value == K * 2 * (3 + b.Nt) and secs.value > 0
+    native = itn.value / so.value
+    with ThreadPoolExecutor(K) as pool:
+        list(pool.map(lambda m: m.sweep(), team.members))
+    py = sum(m.iters_sum for m in team.members) / sum(m.solves for m in team.members)
+    assert abs(native - py) <= 0.25 * py + 2, (native, py)
+    with pytest.raises(L.SmoqyError):
+        team.call("smoqy_team_bench_sweeps", L.ptr(x0), int(b.Nph_force) + 1, C.c_double(b.drift), int(b.Nt), C.c_double(b.tol), C.c_double(b.tol_force), int(b.maxiter), 0, 1, 99,
+                  C.byref(secs), C.byref(so), C.byref(itn))
+    team.close()
+
+
+def test_members_in_other_processes_equal_the_batched_calls(tmp_path):
+    """smoqy_team_serve / smoqy_member_*: the members are separate PROCESSES (the reference's MPI ranks) that never touch the GPU; each
+    joins the published team through shared memory, sends its own arrays and must receive exactly what one caller gets from the batched
+    entry points for the same inputs."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    name, K, seed = "holstein_honeycomb_L4_Ltau40", 3, 20261004
+    team = WalkerTeam(name, K)
+    ref = WalkerBatch(name, nwalkers=K, device_efa=False)
+    info = dict(team.serve(f"/smoqy-test-{os.getpid()}"), seed=seed)
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_team_member_child.py")
+    procs = [subprocess.Popen([sys.executable, child, json.dumps(info), str(w), "parity", str(tmp_path / f"m{w}.npz")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for w in range(K)]
+    for p in procs:
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err[-2000:]
+    # an in-process call is refused while the team is published
+    with pytest.raises(L.SmoqyError):
+        team.call("smoqy_team_sample_phi", 0, L.ptr(np.zeros((ref.Lt, ref.N), dtype=np.complex128, order="F")), C.byref(C.c_double(0.0)))
+    team.unserve()
+    Lt, N, Nph = ref.Lt, ref.N, ref.Nph_force
+    Rs = np.empty((Lt, N, K), dtype=np.complex128, order="F")
+    xs = np.array(ref.xs_force, copy=True)
+    rvs = np.empty((K, N))
+    for w in range(K):
+        g = np.random.default_rng([seed, w])
+        Rs[:, :, w] = (g.standard_normal((Lt, N)) + 1j * g.standard_normal((Lt, N))) * np.sqrt(0.5)
+        xs[w, :, : ref.Nph] += 0.05 * g.standard_normal((Lt, ref.Nph))
+        rvs[w] = g.standard_normal(N)
+    ref.h.vec_upload(ref.phi, Rs)
+    rr_ref = ref.h.vec_dot(ref.phi, ref.phi).real
+    ref.h.call("smoqy_matvec_v", L.OP_MT, ref.phi, ref.phi)
+    ref.h.call("smoqy_lambda_apply_v", L.LAMBDA_MULT, ref.phi, ref.phi)
+    sf, it, ep = np.zeros(K), np.zeros(K, dtype=np.int32), np.zeros(K)
+    dS = np.zeros((K, Lt, Nph))
+    ref.h.call("smoqy_pff_step_v", ref.phi, ref.u, L.ptr(xs), L.ptr(rvs), C.c_double(1e-10), 10000, 1, L.ptr(sf), L.ptr(it), L.ptr(ep), L.ptr(dS))
+    for w in range(K):
+        r = np.load(tmp_path / f"m{w}.npz")
+        assert float(r["rr"]) == rr_ref[w] and float(r["sf"]) == sf[w] and int(r["it"]) == it[w] and float(r["eps"]) == ep[w]
+        assert np.array_equal(r["dS"], dS[w])
+    team.close()
+
