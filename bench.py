@@ -765,7 +765,9 @@ def main():
         avg_iters = sum(b.stats.iters_sum for b in batches) / max(sum(b.stats.solves for b in batches), 1)
         sweep_gbs = value * batch.solves_per_sweep * avg_iters * it_bytes / 1e9
         extra["sweep_roofline"] = {"algorithmic_bytes_per_cg_iteration_per_walker": it_bytes, "achieved": sweep_gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS * world,
-                                   "frac": sweep_gbs / (HBM_PEAK_GBS * world),
+                                   "frac": sweep_gbs / (HBM_PEAK_GBS * world), "physical": sweep_gbs <= HBM_PEAK_GBS * world,
+                                   "achieved_is": "algorithmic bytes of the REFERENCE's pass structure (SURVEY.md §8(d): 20S + 2F per CG iteration and walker) x iterations per second; "
+                                                  "not a bandwidth the device sustains — the physical reading of the whole step is cg_iteration_traffic",
                                    "note": "CG iterations only (the solves are >85 % of the sweep); the fused kernels move 12 vectors per iteration where this count assumes 20S + 2F"}
         # real bytes: one CG iteration of a 16-system batch moves `it_traffic` bytes beyond L2 (committed PMC pass); iterations per second
         # come from this run
