@@ -325,24 +325,26 @@ def team_scan(args, counts, dev, walker0):
     from smoqyelphqmc_amd.walkers import WalkerBatch, WalkerTeam
 
     out = []
+    dev_hmc = getattr(args, "hmc", "device") == "device"  # the members' hmc_update! with the trajectory on the device (smoqy_team_hmc_update) or host-driven, step by step
+    member_sweep = (lambda m: m.sweep_device_hmc()) if dev_hmc else (lambda m: m.sweep())
     for K in counts:
-        team = WalkerTeam(args.workload, K, walker0=walker0 + 3000, device=dev)
+        team = WalkerTeam(args.workload, K, walker0=walker0 + 3000, device=dev, device_efa=dev_hmc)
         with ThreadPoolExecutor(K) as pool:
-            list(pool.map(lambda m: m.sweep(), team.members))
+            list(pool.map(member_sweep, team.members))
             t0 = time.perf_counter()
-            list(pool.map(lambda m: [m.sweep() for _ in range(args.scan_sweeps)], team.members))
+            list(pool.map(lambda m: [member_sweep(m) for _ in range(args.scan_sweeps)], team.members))
             span = time.perf_counter() - t0
         iters = sum(m.iters_sum for m in team.members) / max(sum(m.solves for m in team.members), 1)
         # the same member sweep from K native threads (no interpreter lock): smoqy_team_bench_sweeps
         b = team.batch
         x0 = np.ascontiguousarray(np.stack([np.asarray(b.xs_force[w]) for w in range(K)]))
         secs, so, itn = L.C.c_double(0.0), L.C.c_long(0), L.C.c_long(0)
-        team.call("smoqy_team_bench_sweeps", L.ptr(x0), int(b.Nph), L.C.c_double(b.drift), int(b.Nt), L.C.c_double(b.tol), L.C.c_double(b.tol_force), int(b.maxiter), 1,
+        team.call("smoqy_team_bench_sweeps", L.ptr(x0), int(b.Nph), L.C.c_double(b.drift), int(b.Nt), L.C.c_double(b.tol), L.C.c_double(b.tol_force), int(b.maxiter), int(dev_hmc), 1,
                   int(args.scan_sweeps), 4242 + walker0, L.C.byref(secs), L.C.byref(so), L.C.byref(itn))
         native = K * args.scan_sweeps / secs.value
         native_iters = itn.value / max(so.value, 1)
         team.close()
-        ob = WalkerBatch(args.workload, nwalkers=K, walker0=walker0 + 3000, device=dev, device_efa=False)
+        ob = WalkerBatch(args.workload, nwalkers=K, walker0=walker0 + 3000, device=dev, device_efa=dev_hmc)
         ob.sweep()
         ob.h.call("smoqy_sync")
         t1 = time.perf_counter()
@@ -351,19 +353,19 @@ def team_scan(args, counts, dev, walker0):
         ob.h.call("smoqy_sync")
         span_b = time.perf_counter() - t1
         ob.h.close()
-        out.append({"threads": K, "walkers_per_thread": 1, "handles": 1, "sweeps_per_s": K * args.scan_sweeps / span, "avg_cg_iters": iters,
+        out.append({"threads": K, "walkers_per_thread": 1, "handles": 1, "hmc": "device" if dev_hmc else "host", "sweeps_per_s": K * args.scan_sweeps / span, "avg_cg_iters": iters,
                     "native_threads_sweeps_per_s": native, "native_avg_cg_iters": native_iters,
                     "one_caller_batched_sweeps_per_s": K * args.scan_sweeps / span_b, "sweeps_each": args.scan_sweeps})
     # several teams side by side (one handle and stream each), native member threads only: T x K per-walker control flows on one GPU
     for spec in [q for q in getattr(args, "team_multi", "").split(",") if q]:
         T, K = (int(v) for v in spec.split("x"))
-        teams = [WalkerTeam(args.workload, K, walker0=walker0 + 5000 + 64 * q, device=dev) for q in range(T)]
+        teams = [WalkerTeam(args.workload, K, walker0=walker0 + 5000 + 64 * q, device=dev, device_efa=dev_hmc) for q in range(T)]
 
         def native_run(team, warm, sweeps):
             b = team.batch
             x0 = np.ascontiguousarray(np.stack([np.asarray(b.xs_force[w]) for w in range(K)]))
             secs, so, itn = L.C.c_double(0.0), L.C.c_long(0), L.C.c_long(0)
-            team.call("smoqy_team_bench_sweeps", L.ptr(x0), int(b.Nph), L.C.c_double(b.drift), int(b.Nt), L.C.c_double(b.tol), L.C.c_double(b.tol_force), int(b.maxiter), warm,
+            team.call("smoqy_team_bench_sweeps", L.ptr(x0), int(b.Nph), L.C.c_double(b.drift), int(b.Nt), L.C.c_double(b.tol), L.C.c_double(b.tol_force), int(b.maxiter), int(dev_hmc), warm,
                       sweeps, 777 + walker0, L.C.byref(secs), L.C.byref(so), L.C.byref(itn))
             return itn.value, so.value
 
@@ -374,7 +376,7 @@ def team_scan(args, counts, dev, walker0):
             span = time.perf_counter() - t0
         for tm in teams:
             tm.close()
-        out.append({"teams": T, "threads": T * K, "walkers_per_thread": 1, "handles": T, "native_threads_sweeps_per_s": T * K * args.scan_sweeps / span,
+        out.append({"teams": T, "threads": T * K, "walkers_per_thread": 1, "handles": T, "hmc": "device" if dev_hmc else "host", "native_threads_sweeps_per_s": T * K * args.scan_sweeps / span,
                     "native_avg_cg_iters": sum(r[0] for r in res) / max(sum(r[1] for r in res), 1), "sweeps_each": args.scan_sweeps})
     return out
 
@@ -386,12 +388,14 @@ def member_worker(spec):
     from smoqyelphqmc_amd.walkers import RemoteMember
 
     info, w, sweeps = spec.rsplit("|", 2)
-    m = RemoteMember(json.loads(info), int(w), seed=4711, wait_seconds=120.0)
-    m.sweep()
+    info = json.loads(info)
+    m = RemoteMember(info, int(w), seed=4711, wait_seconds=120.0)
+    sweep = m.sweep_device_hmc if info.get("device_efa") else m.sweep
+    sweep()
     m.solves = m.iters_sum = 0
     t0 = time.time()
     for _ in range(int(sweeps)):
-        m.sweep()
+        sweep()
     t1 = time.time()
     print(json.dumps({"start": t0, "end": t1, "solves": m.solves, "iters": m.iters_sum}), flush=True)
     m.close()
@@ -409,11 +413,12 @@ def team_procs_scan(args, points, dev, walker0):
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     for spec in points:
         T, K = (int(v) for v in spec.split("x")) if "x" in spec else (1, int(spec))
-        rec = {"teams": T, "procs": T * K, "walkers_per_proc": 1, "handles": T}
+        dev_hmc = getattr(args, "hmc", "device") == "device"
+        rec = {"teams": T, "procs": T * K, "walkers_per_proc": 1, "handles": T, "hmc": "device" if dev_hmc else "host"}
         teams, procs = [], []
         try:
             for q in range(T):
-                tm = WalkerTeam(args.workload, K, walker0=walker0 + 7000 + 64 * q, device=dev)
+                tm = WalkerTeam(args.workload, K, walker0=walker0 + 7000 + 64 * q, device=dev, device_efa=dev_hmc)
                 teams.append(tm)
                 info = tm.serve(f"/smoqy-bench-{os.getpid()}-{q}")
                 procs += [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--member-worker", json.dumps(info) + f"|{w}|{args.scan_sweeps}"],
@@ -741,7 +746,7 @@ def main():
                 try:
                     extra["team_threads_scan"] = {"model": "K host threads, each driving ONE walker with the reference's per-walker update sequence, through a walker team "
                                                            "(smoqy_team_*: the members' calls rendezvous in the library and run as one batched call on one handle); "
-                                                           "host-driven HMC (x uploaded, force downloaded every step), so compare with one_caller_batched, not with `value`; "
+                                                           "each point says whether the members' hmc_update! ran its trajectory on the device (smoqy_team_hmc_update, the bench's own mode) or host-driven, step by step (--hmc host); "
                                                            "native_threads: the same member sweep from K std::threads inside the library (smoqy_team_bench_sweeps) — "
                                                            "what a caller without an interpreter lock gets",
                                                   "points": team_scan(args, [int(k) for k in args.team_scan.split(",") if k], dev, mine.start)}
@@ -750,7 +755,7 @@ def main():
                 try:
                     extra["team_procs_scan"] = {"model": "K member PROCESSES ('MPI ranks', tutorials/holstein_honeycomb_mpi.jl:60-72), each driving ONE walker with the per-walker update "
                                                          "sequence and no GPU access of its own, joined through shared memory (smoqy_team_serve / smoqy_member_*) to one batched handle "
-                                                         "per team in this process; host-driven HMC as in team_threads_scan; compare with procs_per_gpu_scan",
+                                                         "per team in this process; HMC mode as in team_threads_scan; compare with procs_per_gpu_scan",
                                                 "points": team_procs_scan(args, [q for q in args.team_procs.split(",") if q], dev, mine.start)}
                 except Exception as ex:  # noqa: BLE001
                     extra["team_procs_scan"] = {"error": str(ex)[:400]}

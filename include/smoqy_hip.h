@@ -292,6 +292,9 @@ int smoqy_efa_energies(smoqy_ctx *ctx, double *K, double *Sb);
 int smoqy_efa_evolve(smoqy_ctx *ctx, double dt, double kick_dt, int refresh_fields);
 /* restore = 0: copyto!(x0, x) (:130);  restore = 1: the reject branch — copyto!(x, x0) and update! (:263-275) */
 int smoqy_efa_checkpoint(smoqy_ctx *ctx, int restore);
+/* the reject branch for some walkers of the batch only: restore[w] != 0 puts walker w back to its checkpoint (every replica takes its own
+ * Metropolis decision, :252-275), the others keep the fields the trajectory left */
+int smoqy_efa_restore_walkers(smoqy_ctx *ctx, const int *restore);
 /* the trajectory of hmc_update! between the momentum refresh and the final action (src/EFAPFFHMCUpdater.jl:148-206) in ONE call:
  * evolve(Δt/2), update!; Nt times { calculate_derivative_fermionic_action! at tol_force; p -= Δt ∂S_f/∂x; evolve(Δt, last step Δt/2);
  * update! }.  Φ in vector phi, Ψ left in psi.  randvecs: N x nwalkers x Nt Lanczos start vectors (the rng stays on the host); Sf, iters,
@@ -377,6 +380,19 @@ int smoqy_team_sample_phi(smoqy_team *team, int w, const void *R, double *RdotR)
  * start vector (KPMPreconditioner.jl:634; needed when use_precond != 0).  Out: S_f, (iters, eps) of the solve, ∂S_f/∂x (Nph x Ltau, stored). */
 int smoqy_team_pff_step(smoqy_team *team, int w, const double *x, const double *randvec, double tol, int maxiter, int use_precond, double *Sf, int *iters, double *eps, double *dSdx);
 
+/* hmc_update! (src/EFAPFFHMCUpdater.jl:102-276) of member w with the whole trajectory on the device (the team's handle needs
+ * smoqy_efa_config): fields from x (NULL = unchanged), Φ = Λᵀ Mᵀ R (:133), copyto!(x0, x) (:130), momenta from the member's Nph x Ltau unit
+ * normal deviates P (:142), the leapfrog of Nt steps (smoqy_hmc_trajectory_v, :148-206), the final action at `tol` (:217).  randvecs: N x (Nt+1)
+ * Lanczos start vectors (one per force evaluation and one for the final action; Nt <= 64).  Out: H0 = {S_f, S_b, K} before the trajectory,
+ * H1 = the same after it, x_new = the proposed fields (Nph x Ltau; may be NULL), *iters = CG iterations of all Nt + 1 solves.  The member
+ * then takes its Metropolis decision (:247-260) and MUST report it with smoqy_team_hmc_finish before any other team call: accept != 0
+ * keeps the proposed fields on the device, 0 restores this walker's checkpoint (:263-275).  All members of a round pass the same Nt, dt,
+ * tolerances and maxiter.  A failing solve restores every member's fields and returns non-zero to everybody (the catch block, :176-187);
+ * no finish call follows then. */
+int smoqy_team_hmc_update(smoqy_team *team, int w, const double *x, const void *R, const double *P, const double *randvecs, int Nt, double dt, double tol_force, double tol, int maxiter,
+                          double *H0, double *H1, double *x_new, int *iters);
+int smoqy_team_hmc_finish(smoqy_team *team, int w, int accept);
+
 /* Teams across processes — the reference's walkers are MPI ranks (processes): the rank that owns the GPU handle publishes its team in a
  * POSIX shared-memory segment `name` ("/something"); every rank of the node, the serving one included, joins with smoqy_member_attach and
  * makes the same two calls as a team member.  A member needs no GPU and no handle: it copies its arrays into the segment (page-locked in
@@ -398,6 +414,10 @@ int smoqy_member_fields(const smoqy_member *member, double *x);
 /* smoqy_team_sample_phi / smoqy_team_pff_step for this member */
 int smoqy_member_sample_phi(smoqy_member *member, const void *R, double *RdotR);
 int smoqy_member_pff_step(smoqy_member *member, const double *x, const double *randvec, double tol, int maxiter, int use_precond, double *Sf, int *iters, double *eps, double *dSdx);
+/* smoqy_team_hmc_update / smoqy_team_hmc_finish for this member */
+int smoqy_member_hmc_update(smoqy_member *member, const double *x, const void *R, const double *P, const double *randvecs, int Nt, double dt, double tol_force, double tol, int maxiter,
+                            double *H0, double *H1, double *x_new, int *iters);
+int smoqy_member_hmc_finish(smoqy_member *member, int accept);
 
 /* ---- measurement aids (bench.py) -------------------------------------------------------- */
 
@@ -405,10 +425,11 @@ int smoqy_member_pff_step(smoqy_member *member, const double *x, const double *r
  * per-walker update sequence (tutorials/holstein_honeycomb.jl:611-684: two local-move-like updates, an HMC trajectory of Nt force
  * evaluations, the closing action) through smoqy_team_sample_phi / smoqy_team_pff_step, drawing their own normal deviates: the number a
  * caller WITHOUT an interpreter lock gets from a team.  x0: the K members' phonon fields (Nph x Ltau each, member-major); the first
- * `nfree` modes of every slice are moved by the synthetic drift of bench.py's sweep and restored.  Out: wall seconds of the timed part,
- * solves and CG iterations summed over the members. */
-int smoqy_team_bench_sweeps(smoqy_team *team, const double *x0, int nfree, double drift, int Nt, double tol, double tol_force, int maxiter, int warmup_sweeps, int nsweeps,
-                            unsigned long seed, double *seconds, long *solves, long *iters);
+ * `nfree` modes of every slice are moved by the synthetic drift of bench.py's sweep and restored.  device_hmc != 0: the HMC part is
+ * smoqy_team_hmc_update (trajectory on the device, Δt = π/(2 Nt), always rejected) instead of Nt host-driven force steps.  Out: wall
+ * seconds of the timed part, solves and CG iterations summed over the members. */
+int smoqy_team_bench_sweeps(smoqy_team *team, const double *x0, int nfree, double drift, int Nt, double tol, double tol_force, int maxiter, int device_hmc, int warmup_sweeps,
+                            int nsweeps, unsigned long seed, double *seconds, long *solves, long *iters);
 
 /* HIP events on the handle's stream */
 int smoqy_timer_start(smoqy_ctx *ctx);

@@ -84,7 +84,11 @@ SIGNATURES = {
     "smoqy_member_fields": [_p, _p],
     "smoqy_member_sample_phi": [_p, _p, _pd],
     "smoqy_member_pff_step": [_p, _p, _p, _d, _i, _i, _pd, _pi, _pd, _p],
-    "smoqy_team_bench_sweeps": [_p, _p, _i, _d, _i, _d, _d, _i, _i, _i, C.c_ulong, _pd, C.POINTER(C.c_long), C.POINTER(C.c_long)],
+    "smoqy_team_hmc_update": [_p, _i, _p, _p, _p, _p, _i, _d, _d, _d, _i, _p, _p, _p, _pi],
+    "smoqy_team_hmc_finish": [_p, _i, _i],
+    "smoqy_member_hmc_update": [_p, _p, _p, _p, _p, _i, _d, _d, _d, _i, _p, _p, _p, _pi],
+    "smoqy_member_hmc_finish": [_p, _i],
+    "smoqy_team_bench_sweeps": [_p, _p, _i, _d, _i, _d, _d, _i, _i, _i, _i, C.c_ulong, _pd, C.POINTER(C.c_long), C.POINTER(C.c_long)],
     "smoqy_matvec": [_p, _i, _p, _p, _i, _i],
     "smoqy_checkerboard_v": [_p, _i, _i, _i, _i, _i],
     "smoqy_checkerboard": [_p, _p, _i, _i, _i, _i, _i, _i],
@@ -133,6 +137,7 @@ SIGNATURES = {
     "smoqy_efa_energies": [_p, _p, _p],
     "smoqy_efa_evolve": [_p, _d, _d, _i],
     "smoqy_efa_checkpoint": [_p, _i],
+    "smoqy_efa_restore_walkers": [_p, _p],
     "smoqy_hmc_trajectory_v": [_p, _i, _i, _i, _d, _d, _i, _i, _p, _p, _p, _p],
     "smoqy_copy_fields": [_p, _i, _p, _i],
     "smoqy_ge_config": [_p, _i, _i, _p],

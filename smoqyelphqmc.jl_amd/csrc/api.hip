@@ -2553,6 +2553,26 @@ int smoqy_efa_checkpoint(smoqy_ctx *c, int restore)
     return 0;
 }
 
+// the reject branch (:263-275) for SOME walkers of the batch: restore[w] != 0 puts walker w's x back to its checkpoint, the others keep
+// the fields the trajectory left (each replica takes its own Metropolis decision)
+int smoqy_efa_restore_walkers(smoqy_ctx *c, const int *restore)
+{
+    CHECK_CTX(c);
+    CHECK_EFA(c);
+    if (!restore) FAIL(c, 1, "restore is NULL");
+    const size_t slab = (size_t)c->g.Lt * c->force.Nph;
+    bool any = false;
+    for (int w = 0; w < c->g.nw; ++w)
+        if (restore[w] && slab) {
+            HIPCHK(c, hipMemcpyAsync(c->force.d_x + (size_t)w * slab, c->force.d_x0 + (size_t)w * slab, slab * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            any = true;
+        }
+    if (any)
+        if (int rc = refresh_from_device_x(c)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int smoqy_hmc_trajectory_v(smoqy_ctx *c, int phi, int psi, int Nt, double dt, double tol_force, int maxiter, int use_precond, const double *randvecs, double *Sf, int *iters, double *eps)
 {
     CHECK_CTX(c);

@@ -30,7 +30,8 @@
 #include "../../include/smoqy_hip.h"
 
 namespace {
-enum { OP_NONE = 0, OP_SAMPLE = 1, OP_PFF = 2 };
+enum { OP_NONE = 0, OP_SAMPLE = 1, OP_PFF = 2, OP_HMC = 3, OP_FINISH = 4 };
+constexpr int kMaxNt = 64;  // leapfrog steps a team's staging is sized for (smoqy_team_hmc_update)
 struct Slot {
     const void *R = nullptr;
     const double *x = nullptr, *rv = nullptr;
@@ -38,8 +39,36 @@ struct Slot {
     int maxiter = 0, use_precond = 0;
     double *Sf = nullptr, *eps = nullptr, *dSdx = nullptr, *RdotR = nullptr;
     int *iters = nullptr;
+    // OP_HMC: momentum deviates, N x (Nt + 1) Lanczos start vectors, trajectory parameters, {S_f, S_b, K} before / after, proposed fields
+    const double *P = nullptr, *rvs = nullptr;
+    int Nt = 0;
+    double dt = 0, tol_force = 0;
+    double *H0 = nullptr, *H1 = nullptr, *x_new = nullptr;
+    int accept = 0;  // OP_FINISH
     int rc = 0;
 };
+// where a member's arrays are staged for the batched call: the team's own page-locked buffers, or the shared-memory segment
+struct Stage {
+    char *R = nullptr;
+    double *x = nullptr, *rv = nullptr, *dS = nullptr, *P = nullptr, *rvs = nullptr;
+};
+// a member copies its OWN inputs in before the rendezvous and its own outputs out after it (K copies in parallel, outside any lock)
+void stage_in(const Stage &g, int K, int Lt, int N, int Nph, int w, const Slot &a)
+{
+    const size_t nR = (size_t)Lt * N * 16, nx = (size_t)(Nph > 0 ? Nph : 1) * Lt;
+    if (a.R) std::memcpy(g.R + (size_t)w * nR, a.R, nR);
+    if (a.x) std::memcpy(g.x + (size_t)w * nx, a.x, nx * sizeof(double));
+    if (a.rv) std::memcpy(g.rv + (size_t)w * N, a.rv, (size_t)N * sizeof(double));
+    if (a.P) std::memcpy(g.P + (size_t)w * nx, a.P, nx * sizeof(double));
+    if (a.rvs && a.Nt >= 1 && a.Nt <= kMaxNt)  // the batched trajectory wants N x K x Nt: step-major, member w's vector of step t at (t K + w) N
+        for (int t = 0; t <= a.Nt; ++t) std::memcpy(g.rvs + ((size_t)t * K + w) * N, a.rvs + (size_t)t * N, (size_t)N * sizeof(double));
+}
+void stage_out(const Stage &g, int Lt, int Nph, int w, const Slot &a)
+{
+    const size_t nx = (size_t)(Nph > 0 ? Nph : 1) * Lt;
+    if (a.dSdx) std::memcpy(a.dSdx, g.dS + (size_t)w * nx, nx * sizeof(double));
+    if (a.x_new) std::memcpy(a.x_new, g.dS + (size_t)w * nx, nx * sizeof(double));  // OP_HMC returns the proposed fields through the force staging
+}
 }  // namespace
 
 struct Served;
@@ -55,10 +84,14 @@ struct smoqy_team {
     double timeout_s = 600.0;
     std::vector<Slot> slot;
     std::vector<char> x_seen;  // member w has supplied its phonon fields at least once (later NULLs mean "unchanged")
+    bool hmc_pending = false;  // an hmc_update round is waiting for the members' accept / reject decisions
     // page-locked staging in the batched layouts of the C ABI
     void *h_R = nullptr;                                     // Ltau x N x K complex128
     double *h_x = nullptr, *h_rv = nullptr, *h_dS = nullptr;  // Nph x Ltau x K, N x K, Nph x Ltau x K
-    std::vector<double> Sf, eps, dot;
+    double *h_P = nullptr, *h_rvs = nullptr;                  // Nph x Ltau x K, N x K x (kMaxNt + 1)
+    Stage stage() const { Stage g; g.R = (char *)h_R; g.x = h_x; g.rv = h_rv; g.dS = h_dS; g.P = h_P; g.rvs = h_rvs; return g; }
+    std::vector<double> Sf, eps, dot, e0, e1;
+    std::vector<int> flags;
     std::vector<int> iters;
     std::string err;
     struct Served *served = nullptr;  // published for members of other processes (smoqy_team_serve)
@@ -81,6 +114,8 @@ int smoqy_team_destroy(smoqy_team *t)
         if (t->h_x) smoqy_host_free(t->c, t->h_x);
         if (t->h_rv) smoqy_host_free(t->c, t->h_rv);
         if (t->h_dS) smoqy_host_free(t->c, t->h_dS);
+        if (t->h_P) smoqy_host_free(t->c, t->h_P);
+        if (t->h_rvs) smoqy_host_free(t->c, t->h_rvs);
         if (t->phi >= 0) smoqy_vec_free(t->c, t->phi);
         if (t->psi >= 0) smoqy_vec_free(t->c, t->psi);
     }
@@ -100,11 +135,14 @@ int smoqy_team_create(smoqy_team **out, smoqy_ctx *ctx, int Nph)
     t->slot.resize((size_t)t->K);
     t->x_seen.assign((size_t)t->K, 0);
     t->Sf.resize((size_t)t->K); t->eps.resize((size_t)t->K); t->iters.resize((size_t)t->K); t->dot.resize(2 * (size_t)t->K);
+    t->e0.resize((size_t)t->K); t->e1.resize((size_t)t->K); t->flags.resize((size_t)t->K);
     const size_t nR = (size_t)t->Lt * t->N * t->K * 16, nx = (size_t)std::max(Nph, 1) * t->Lt * t->K * sizeof(double);
     int rc = smoqy_host_alloc(ctx, &t->h_R, nR);
     if (!rc) rc = smoqy_host_alloc(ctx, (void **)&t->h_x, nx);
     if (!rc) rc = smoqy_host_alloc(ctx, (void **)&t->h_dS, nx);
     if (!rc) rc = smoqy_host_alloc(ctx, (void **)&t->h_rv, (size_t)t->N * t->K * sizeof(double));
+    if (!rc) rc = smoqy_host_alloc(ctx, (void **)&t->h_P, nx);
+    if (!rc) rc = smoqy_host_alloc(ctx, (void **)&t->h_rvs, (size_t)t->N * t->K * (kMaxNt + 1) * sizeof(double));
     if (!rc) rc = smoqy_vec_alloc(ctx, &t->phi);
     if (!rc) rc = smoqy_vec_alloc(ctx, &t->psi);
     if (rc) {
@@ -149,6 +187,7 @@ static int run_round(smoqy_team *t)
 {
     smoqy_ctx *c = t->c;
     const int K = t->K;
+    if (t->op == OP_SAMPLE && t->hmc_pending) { t->err = "the members owe their decisions first: smoqy_team_hmc_finish must follow smoqy_team_hmc_update"; return 1; }
     if (t->op == OP_SAMPLE) {
         // sample_pseudofermion_fields! (src/PFFCalculator.jl:56-76): Φ = Λᵀ Mᵀ R, |R|² per member
         if (int rc = smoqy_vec_upload(c, t->phi, t->h_R, 0, K)) return rc;
@@ -157,6 +196,74 @@ static int run_round(smoqy_team *t)
         if (int rc = smoqy_lambda_apply_v(c, SMOQY_LAMBDA_MULT, t->phi, t->phi)) return rc;    // mul_Λᵀ! (:73)
         for (int w = 0; w < K; ++w)
             if (t->slot[w].RdotR) *t->slot[w].RdotR = t->dot[2 * (size_t)w];
+        return 0;
+    }
+    if (t->op == OP_FINISH) {
+        // each member's Metropolis decision (src/EFAPFFHMCUpdater.jl:252-275): the rejecting ones get their checkpointed fields back
+        if (!t->hmc_pending) { t->err = "smoqy_team_hmc_finish without a preceding smoqy_team_hmc_update"; return 1; }
+        const size_t nx = (size_t)(t->Nph > 0 ? t->Nph : 1) * t->Lt;
+        for (int w = 0; w < K; ++w) {
+            t->flags[w] = t->slot[w].accept ? 0 : 1;
+            // the staged copy of an accepting member's fields follows the device (a later batched upload sends the staging of ALL members)
+            if (t->slot[w].accept) std::memcpy(t->h_x + (size_t)w * nx, t->h_dS + (size_t)w * nx, nx * sizeof(double));
+        }
+        t->hmc_pending = false;
+        if (int rc = smoqy_efa_restore_walkers(c, t->flags.data())) { t->err = smoqy_last_error(c); return rc; }
+        return 0;
+    }
+    if (t->hmc_pending) { t->err = "the members owe their decisions first: smoqy_team_hmc_finish must follow smoqy_team_hmc_update"; return 1; }
+    if (t->op == OP_HMC) {
+        // hmc_update! (src/EFAPFFHMCUpdater.jl:102-276) of all K members with the trajectory on the device: fields from the members' x,
+        // Φ = Λᵀ Mᵀ R (:133), copyto!(x0, x) (:130), momenta from the members' deviates (:142), S_b (:136), the leapfrog (:148-206) in one
+        // library call, the final action at `tol` (:217), K and S_b afterwards (:238-244), the proposed fields back to the members
+        const Slot &s0 = t->slot[0];
+        bool any_x = false;
+        for (int w = 0; w < K; ++w) {
+            const Slot &s = t->slot[w];
+            if (s.x) { t->x_seen[w] = 1; any_x = true; }
+            if (!s.R || !s.P || !s.rvs) { t->err = "smoqy_team_hmc_update: R, P and randvecs are needed from every member"; return 1; }
+            if (s.Nt != s0.Nt || s.dt != s0.dt || s.tol != s0.tol || s.tol_force != s0.tol_force || s.maxiter != s0.maxiter) {
+                t->err = "smoqy_team_hmc_update: the members of a round must pass the same Nt / dt / tolerances / maxiter";
+                return 1;
+            }
+        }
+        if (s0.Nt < 1 || s0.Nt > kMaxNt) { t->err = "smoqy_team_hmc_update: Nt outside 1 … 64"; return 1; }
+        if (any_x)
+            for (int w = 0; w < K; ++w)
+                if (!t->x_seen[w]) { t->err = "smoqy_team_hmc_update: a member passed x = NULL before it ever supplied its phonon fields"; return 1; }
+        auto fail = [&](int rc) { t->err = smoqy_last_error(c); return rc; };
+        if (any_x) if (int rc = smoqy_efa_set_state(c, t->h_x, nullptr)) return fail(rc);
+        if (int rc = smoqy_vec_upload(c, t->phi, t->h_R, 0, K)) return fail(rc);
+        if (int rc = smoqy_vec_dot(c, t->phi, t->phi, t->dot.data())) return fail(rc);             // S_f at the start = |R|²
+        if (int rc = smoqy_matvec_v(c, SMOQY_OP_MT, t->phi, t->phi)) return fail(rc);
+        if (int rc = smoqy_lambda_apply_v(c, SMOQY_LAMBDA_MULT, t->phi, t->phi)) return fail(rc);
+        if (int rc = smoqy_efa_checkpoint(c, 0)) return fail(rc);
+        if (int rc = smoqy_efa_initialize_momentum(c, t->h_P, t->e0.data())) return fail(rc);       // K before
+        if (int rc = smoqy_efa_energies(c, nullptr, t->e1.data())) return fail(rc);                // S_b before
+        for (int w = 0; w < K; ++w)
+            if (double *H = t->slot[w].H0) { H[0] = t->dot[2 * (size_t)w]; H[1] = t->e1[w]; H[2] = t->e0[w]; }
+        std::vector<int> its((size_t)K * s0.Nt);
+        int rc = smoqy_hmc_trajectory_v(c, t->phi, t->psi, s0.Nt, s0.dt, s0.tol_force, s0.maxiter, 1, t->h_rvs, nullptr, its.data(), nullptr);
+        if (!rc) rc = smoqy_pff_step_v(c, t->phi, t->psi, nullptr, t->h_rvs + (size_t)s0.Nt * K * t->N, s0.tol, s0.maxiter, 1, t->Sf.data(), t->iters.data(), t->eps.data(), nullptr);
+        if (rc) {
+            // the reference's catch block (:176-187): the update is rejected for everybody, the fields go back to the checkpoint
+            t->err = smoqy_last_error(c);
+            (void)smoqy_efa_checkpoint(c, 1);
+            return rc;
+        }
+        if (int rc2 = smoqy_efa_energies(c, t->e0.data(), t->e1.data())) return fail(rc2);         // K, S_b after
+        if (int rc2 = smoqy_efa_get_state(c, t->h_dS, nullptr)) return fail(rc2);                  // the proposed fields, through the force staging
+        for (int w = 0; w < K; ++w) {
+            const Slot &s = t->slot[w];
+            if (s.H1) { s.H1[0] = t->Sf[w]; s.H1[1] = t->e1[w]; s.H1[2] = t->e0[w]; }
+            if (s.eps) *s.eps = t->eps[w];
+            if (s.iters) {
+                int sum = t->iters[w];
+                for (int q = 0; q < s0.Nt; ++q) sum += its[(size_t)q * K + w];
+                *s.iters = sum;
+            }
+        }
+        t->hmc_pending = true;
         return 0;
     }
     // calculate_fermionic_action! / calculate_derivative_fermionic_action! (src/PFFCalculator.jl:79-157) behind the field update of
@@ -199,12 +306,9 @@ static int rendezvous(smoqy_team *t, int w, int op, const Slot &args)
     if (!t) return 1;
     if (w < 0 || w >= t->K) { t->err = "team member index out of range"; return 1; }
     if (t->served) { t->err = "this team is published (smoqy_team_serve): its members call smoqy_member_*"; return 1; }
-    const size_t nR = (size_t)t->Lt * t->N * 16, nx = (size_t)t->Nph * t->Lt;
-    if (args.R) std::memcpy((char *)t->h_R + (size_t)w * nR, args.R, nR);
-    if (args.x) std::memcpy(t->h_x + (size_t)w * nx, args.x, nx * sizeof(double));
-    if (args.rv) std::memcpy(t->h_rv + (size_t)w * t->N, args.rv, (size_t)t->N * sizeof(double));
+    stage_in(t->stage(), t->K, t->Lt, t->N, t->Nph, w, args);
     const int rc = rendezvous_locked(t, w, op, args);
-    if (rc == 0 && args.dSdx) std::memcpy(args.dSdx, t->h_dS + (size_t)w * nx, nx * sizeof(double));
+    if (rc == 0) stage_out(t->stage(), t->Lt, t->Nph, w, args);
     return rc;
 }
 
@@ -253,6 +357,24 @@ int smoqy_team_pff_step(smoqy_team *t, int w, const double *x, const double *ran
     return rendezvous(t, w, OP_PFF, s);
 }
 
+int smoqy_team_hmc_update(smoqy_team *t, int w, const double *x, const void *R, const double *P, const double *randvecs, int Nt, double dt, double tol_force, double tol, int maxiter,
+                          double *H0, double *H1, double *x_new, int *iters)
+{
+    if (!R || !P || !randvecs) return 1;
+    if (Nt < 1 || Nt > kMaxNt) { if (t) t->err = "smoqy_team_hmc_update: Nt outside 1 … 64"; return 1; }
+    Slot s;
+    s.x = x; s.R = R; s.P = P; s.rvs = randvecs; s.Nt = Nt; s.dt = dt; s.tol_force = tol_force; s.tol = tol; s.maxiter = maxiter;
+    s.H0 = H0; s.H1 = H1; s.x_new = x_new; s.iters = iters;
+    return rendezvous(t, w, OP_HMC, s);
+}
+
+int smoqy_team_hmc_finish(smoqy_team *t, int w, int accept)
+{
+    Slot s;
+    s.accept = accept ? 1 : 0;
+    return rendezvous(t, w, OP_FINISH, s);
+}
+
 
 }  // extern "C"
 
@@ -263,10 +385,12 @@ int smoqy_team_pff_step(smoqy_team *t, int w, const double *x, const double *ran
 // deposits its scalars and sleeps on a process-shared condition variable; a server thread in the process that owns the handle runs the
 // round once all K members have arrived — the same run_round as the in-process team, its slots pointing into the segment.
 namespace {
-constexpr uint64_t kShmMagic = 0x534d4f5159544d31ull;  // "SMOQYTM1"
+constexpr uint64_t kShmMagic = 0x534d4f5159544d32ull;  // "SMOQYTM2"
 struct ShmMember {
     int has_x, has_rv, want_force, maxiter, use_precond, iters, rc, attached;
+    int has_R, has_P, has_rvs, want_xnew, Nt, accept;
     double tol, Sf, eps, RdotR;
+    double dt, tol_force, H0[3], H1[3];
 };
 struct ShmHeader {
     uint64_t magic;
@@ -274,7 +398,7 @@ struct ShmHeader {
     int op, arrived, shutdown, rc;
     unsigned long gen;
     double timeout_s;
-    size_t off_members, off_R, off_x, off_rv, off_dS, total;
+    size_t off_members, off_R, off_x, off_rv, off_dS, off_P, off_rvs, total;
     pthread_mutex_t m;
     pthread_cond_t cv_arrive, cv_done;
     char err[256];
@@ -302,7 +426,7 @@ struct Served {
     ShmHeader *h = nullptr;
     std::thread server;
     void *own_R = nullptr;
-    double *own_x = nullptr, *own_rv = nullptr, *own_dS = nullptr;  // the team's private staging, put back by unserve
+    double *own_x = nullptr, *own_rv = nullptr, *own_dS = nullptr, *own_P = nullptr, *own_rvs = nullptr;  // the team's private staging, put back by unserve
     bool registered = false;
 };
 
@@ -327,12 +451,16 @@ static void serve_loop(smoqy_team *t)
             ShmMember &q = mem[w];
             Slot s;
             // run_round reads the array pointers as flags only (the data already sits in the staging area, which IS the segment)
-            s.R = h->op == OP_SAMPLE ? (const void *)h : nullptr;
+            s.R = q.has_R ? (const void *)h : nullptr;
             s.x = q.has_x ? (const double *)h : nullptr;
             s.rv = q.has_rv ? (const double *)h : nullptr;
+            s.P = q.has_P ? (const double *)h : nullptr;
+            s.rvs = q.has_rvs ? (const double *)h : nullptr;
             s.dSdx = q.want_force ? (double *)h : nullptr;
+            s.x_new = q.want_xnew ? (double *)h : nullptr;
             s.tol = q.tol; s.maxiter = q.maxiter; s.use_precond = q.use_precond;
-            s.Sf = &q.Sf; s.iters = &q.iters; s.eps = &q.eps; s.RdotR = &q.RdotR;
+            s.Nt = q.Nt; s.dt = q.dt; s.tol_force = q.tol_force; s.accept = q.accept;
+            s.Sf = &q.Sf; s.iters = &q.iters; s.eps = &q.eps; s.RdotR = &q.RdotR; s.H0 = q.H0; s.H1 = q.H1;
             t->slot[w] = s;
         }
         pthread_mutex_unlock(&h->m);
@@ -363,7 +491,9 @@ int smoqy_team_serve(smoqy_team *t, const char *name, const double *x0)
     lay.off_x = align_up(lay.off_R + nR * t->K, 4096);
     lay.off_rv = align_up(lay.off_x + nx * t->K, 4096);
     lay.off_dS = align_up(lay.off_rv + (size_t)t->N * t->K * sizeof(double), 4096);
-    lay.total = align_up(lay.off_dS + nx * t->K, 4096);
+    lay.off_P = align_up(lay.off_dS + nx * t->K, 4096);
+    lay.off_rvs = align_up(lay.off_P + nx * t->K, 4096);
+    lay.total = align_up(lay.off_rvs + (size_t)t->N * t->K * (kMaxNt + 1) * sizeof(double), 4096);
     shm_unlink(name);  // a stale segment of a crashed job
     const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
     if (fd < 0) { t->err = std::string("smoqy_team_serve: shm_open failed for ") + name; return 2; }
@@ -375,7 +505,7 @@ int smoqy_team_serve(smoqy_team *t, const char *name, const double *x0)
     std::memset(h, 0, lay.off_R);
     h->K = t->K; h->Lt = t->Lt; h->N = t->N; h->Nph = t->Nph;
     h->timeout_s = t->timeout_s;
-    h->off_members = lay.off_members; h->off_R = lay.off_R; h->off_x = lay.off_x; h->off_rv = lay.off_rv; h->off_dS = lay.off_dS; h->total = lay.total;
+    h->off_members = lay.off_members; h->off_R = lay.off_R; h->off_x = lay.off_x; h->off_rv = lay.off_rv; h->off_dS = lay.off_dS; h->off_P = lay.off_P; h->off_rvs = lay.off_rvs; h->total = lay.total;
     pthread_mutexattr_t ma;
     pthread_mutexattr_init(&ma);
     pthread_mutexattr_setpshared(&ma, PTHREAD_PROCESS_SHARED);
@@ -391,11 +521,12 @@ int smoqy_team_serve(smoqy_team *t, const char *name, const double *x0)
     pthread_condattr_destroy(&ca);
     Served *sv = new Served();
     sv->name = name; sv->h = h;
-    sv->own_R = t->h_R; sv->own_x = t->h_x; sv->own_rv = t->h_rv; sv->own_dS = t->h_dS;
+    sv->own_R = t->h_R; sv->own_x = t->h_x; sv->own_rv = t->h_rv; sv->own_dS = t->h_dS; sv->own_P = t->h_P; sv->own_rvs = t->h_rvs;
     char *base = (char *)p;
     // the staging area of the team now IS the segment; page-lock it where the driver allows (transfers work either way)
     sv->registered = smoqy_host_register(t->c, base + h->off_R, h->total - h->off_R) == 0;
     t->h_R = base + h->off_R; t->h_x = (double *)(base + h->off_x); t->h_rv = (double *)(base + h->off_rv); t->h_dS = (double *)(base + h->off_dS);
+    t->h_P = (double *)(base + h->off_P); t->h_rvs = (double *)(base + h->off_rvs);
     std::memcpy(t->h_x, x0 ? (const void *)x0 : (const void *)sv->own_x, nx * t->K);
     t->served = sv;
     sv->server = std::thread(serve_loop, t);
@@ -418,7 +549,7 @@ int smoqy_team_unserve(smoqy_team *t)
     pthread_mutex_unlock(&h->m);
     if (sv->server.joinable()) sv->server.join();
     if (sv->registered) smoqy_host_unregister(t->c, (char *)h + h->off_R);
-    t->h_R = sv->own_R; t->h_x = sv->own_x; t->h_rv = sv->own_rv; t->h_dS = sv->own_dS;
+    t->h_R = sv->own_R; t->h_x = sv->own_x; t->h_rv = sv->own_rv; t->h_dS = sv->own_dS; t->h_P = sv->own_P; t->h_rvs = sv->own_rvs;
     shm_unlink(sv->name.c_str());
     munmap(h, h->total);
     delete sv;
@@ -496,27 +627,28 @@ int smoqy_member_fields(const smoqy_member *m, double *x)
 
 }  // extern "C"
 
-static int member_round(smoqy_member *m, int op, const void *R, const double *x, const double *rv, double tol, int maxiter, int use_precond, double *Sf, int *iters, double *eps, double *dSdx, double *RdotR)
+static int member_round(smoqy_member *m, int op, const Slot &a)
 {
     if (!m || !m->h) return 1;
     ShmHeader *h = m->h;
     const int w = m->w;
     char *base = (char *)h;
-    const size_t nR = (size_t)h->Lt * h->N * 16, nx = (size_t)std::max(h->Nph, 1) * h->Lt * sizeof(double);
-    if (R) std::memcpy(base + h->off_R + (size_t)w * nR, R, nR);
-    if (x) std::memcpy(base + h->off_x + (size_t)w * nx, x, nx);
-    if (rv) std::memcpy(base + h->off_rv + (size_t)w * h->N * sizeof(double), rv, (size_t)h->N * sizeof(double));
+    Stage g;
+    g.R = base + h->off_R; g.x = (double *)(base + h->off_x); g.rv = (double *)(base + h->off_rv); g.dS = (double *)(base + h->off_dS);
+    g.P = (double *)(base + h->off_P); g.rvs = (double *)(base + h->off_rvs);
+    stage_in(g, h->K, h->Lt, h->N, h->Nph, w, a);
     ShmMember &q = ((ShmMember *)(base + h->off_members))[w];
     shm_lock(h);
     if (h->shutdown) { m->err = h->err; pthread_mutex_unlock(&h->m); return 10; }
     if (h->arrived > 0 && h->op != op) { m->err = "team members made different calls in the same round"; pthread_mutex_unlock(&h->m); return 8; }
     h->op = op;
-    q.has_x = x != nullptr; q.has_rv = rv != nullptr; q.want_force = dSdx != nullptr;
-    q.tol = tol; q.maxiter = maxiter; q.use_precond = use_precond;
+    q.has_R = a.R != nullptr; q.has_x = a.x != nullptr; q.has_rv = a.rv != nullptr; q.has_P = a.P != nullptr; q.has_rvs = a.rvs != nullptr;
+    q.want_force = a.dSdx != nullptr; q.want_xnew = a.x_new != nullptr;
+    q.tol = a.tol; q.maxiter = a.maxiter; q.use_precond = a.use_precond;
+    q.Nt = a.Nt; q.dt = a.dt; q.tol_force = a.tol_force; q.accept = a.accept;
     const unsigned long my_gen = h->gen;
     if (++h->arrived == h->K) pthread_cond_signal(&h->cv_arrive);
     const timespec dl = deadline_after(h->timeout_s);
-    int rc = 0;
     while (h->gen == my_gen) {
         const int e = pthread_cond_timedwait(&h->cv_done, &h->m, &dl);
         if (e == EOWNERDEAD) pthread_mutex_consistent(&h->m);
@@ -527,17 +659,18 @@ static int member_round(smoqy_member *m, int op, const void *R, const double *x,
             return 9;
         }
     }
-    rc = q.rc;
+    const int rc = q.rc;
     if (rc) m->err = h->err;
-    const double sf = q.Sf, ep = q.eps, rr = q.RdotR;
-    const int it = q.iters;
+    const ShmMember r = q;  // this member's results, copied under the lock
     pthread_mutex_unlock(&h->m);
     if (rc == 0) {
-        if (Sf) *Sf = sf;
-        if (iters) *iters = it;
-        if (eps) *eps = ep;
-        if (RdotR) *RdotR = rr;
-        if (dSdx) std::memcpy(dSdx, base + h->off_dS + (size_t)w * nx, nx);
+        if (a.Sf) *a.Sf = r.Sf;
+        if (a.iters) *a.iters = r.iters;
+        if (a.eps) *a.eps = r.eps;
+        if (a.RdotR) *a.RdotR = r.RdotR;
+        if (a.H0) std::memcpy(a.H0, r.H0, sizeof(r.H0));
+        if (a.H1) std::memcpy(a.H1, r.H1, sizeof(r.H1));
+        stage_out(g, h->Lt, h->Nph, w, a);
     }
     return rc;
 }
@@ -547,12 +680,35 @@ extern "C" {
 int smoqy_member_sample_phi(smoqy_member *m, const void *R, double *RdotR)
 {
     if (!R) return 1;
-    return member_round(m, OP_SAMPLE, R, nullptr, nullptr, 0.0, 0, 0, nullptr, nullptr, nullptr, nullptr, RdotR);
+    Slot s;
+    s.R = R; s.RdotR = RdotR;
+    return member_round(m, OP_SAMPLE, s);
 }
 
 int smoqy_member_pff_step(smoqy_member *m, const double *x, const double *randvec, double tol, int maxiter, int use_precond, double *Sf, int *iters, double *eps, double *dSdx)
 {
-    return member_round(m, OP_PFF, nullptr, x, randvec, tol, maxiter, use_precond ? 1 : 0, Sf, iters, eps, dSdx, nullptr);
+    Slot s;
+    s.x = x; s.rv = randvec; s.tol = tol; s.maxiter = maxiter; s.use_precond = use_precond ? 1 : 0;
+    s.Sf = Sf; s.iters = iters; s.eps = eps; s.dSdx = dSdx;
+    return member_round(m, OP_PFF, s);
+}
+
+int smoqy_member_hmc_update(smoqy_member *m, const double *x, const void *R, const double *P, const double *randvecs, int Nt, double dt, double tol_force, double tol, int maxiter,
+                            double *H0, double *H1, double *x_new, int *iters)
+{
+    if (!R || !P || !randvecs) return 1;
+    if (Nt < 1 || Nt > kMaxNt) { if (m) m->err = "smoqy_member_hmc_update: Nt outside 1 … 64"; return 1; }
+    Slot s;
+    s.x = x; s.R = R; s.P = P; s.rvs = randvecs; s.Nt = Nt; s.dt = dt; s.tol_force = tol_force; s.tol = tol; s.maxiter = maxiter;
+    s.H0 = H0; s.H1 = H1; s.x_new = x_new; s.iters = iters;
+    return member_round(m, OP_HMC, s);
+}
+
+int smoqy_member_hmc_finish(smoqy_member *m, int accept)
+{
+    Slot s;
+    s.accept = accept ? 1 : 0;
+    return member_round(m, OP_FINISH, s);
 }
 
 }  // extern "C"
@@ -582,17 +738,17 @@ struct Xo {
     }
 };
 struct Member {
-    std::vector<double> x, pi, rv, dS, R;
+    std::vector<double> x, pi, rv, dS, R, P, rvs;
     Xo rng{0};
     long solves = 0, iters = 0;
     int rc = 0;
 };
 }  // namespace
 
-int smoqy_team_bench_sweeps(smoqy_team *t, const double *x0, int nfree, double drift, int Nt, double tol, double tol_force, int maxiter, int warmup_sweeps, int nsweeps, unsigned long seed,
-                            double *seconds, long *solves, long *iters)
+int smoqy_team_bench_sweeps(smoqy_team *t, const double *x0, int nfree, double drift, int Nt, double tol, double tol_force, int maxiter, int device_hmc, int warmup_sweeps, int nsweeps,
+                            unsigned long seed, double *seconds, long *solves, long *iters)
 {
-    if (!t || !x0 || nfree < 0 || nfree > t->Nph || Nt < 1 || nsweeps < 1 || !seconds) return 1;
+    if (!t || !x0 || nfree < 0 || nfree > t->Nph || Nt < 1 || nsweeps < 1 || !seconds || (device_hmc && Nt > kMaxNt)) return 1;
     const int K = t->K, Lt = t->Lt, N = t->N, Nph = t->Nph;
     const size_t nx = (size_t)Nph * Lt;
     std::vector<Member> mem((size_t)K);
@@ -600,6 +756,7 @@ int smoqy_team_bench_sweeps(smoqy_team *t, const double *x0, int nfree, double d
         Member &m = mem[w];
         m.x.assign(x0 + (size_t)w * nx, x0 + (size_t)(w + 1) * nx);
         m.pi.resize((size_t)Lt * nfree); m.rv.resize((size_t)N); m.dS.resize(nx); m.R.resize(2 * (size_t)Lt * N);
+        if (device_hmc) { m.P.resize(nx); m.rvs.resize((size_t)N * (Nt + 1)); }
         m.rng = Xo(seed + 7919ull * (uint64_t)w);
     }
     auto shift = [&](Member &m, double f) {  // x[:, :nfree] += f·π
@@ -626,6 +783,18 @@ int smoqy_team_bench_sweeps(smoqy_team *t, const double *x0, int nfree, double d
             shift(m, drift);
             if (int rc = step(m, w, tol, false)) return rc;
             shift(m, -drift);
+        }
+        if (device_hmc) {
+            // hmc_update! with the trajectory on the device (smoqy_team_hmc_update), Δt = π/(2 Nt) (tutorials/holstein_honeycomb.jl:542);
+            // always rejected, as bench.py's sweep does
+            m.rng.normal(m.R.data(), m.R.size(), std::sqrt(0.5));
+            m.rng.normal(m.P.data(), m.P.size(), 1.0);
+            m.rng.normal(m.rvs.data(), m.rvs.size(), 1.0);
+            double H0[3], H1[3];
+            int it = 0;
+            if (int rc = smoqy_team_hmc_update(t, w, m.x.data(), m.R.data(), m.P.data(), m.rvs.data(), Nt, 1.5707963267948966 / Nt, tol_force, tol, maxiter, H0, H1, nullptr, &it)) return rc;
+            m.solves += Nt + 1; m.iters += it;
+            return smoqy_team_hmc_finish(t, w, 0);
         }
         if (int rc = sample(m, w)) return rc;
         m.rng.normal(m.pi.data(), m.pi.size(), 1.0);

@@ -390,8 +390,10 @@ class WalkerTeam:
     hands out ``members[w]``; ``member.sweep()`` is the host-driven sweep of ``WalkerBatch.sweep`` (device_efa = False) for ONE walker.
     """
 
-    def __init__(self, workload: str, nwalkers: int, walker0: int = 0, device: int = -1, **kw):
-        self.batch = WalkerBatch(workload, nwalkers=nwalkers, walker0=walker0, device=device, device_efa=False, host_threads=1, **kw)
+    def __init__(self, workload: str, nwalkers: int, walker0: int = 0, device: int = -1, device_efa: bool = False, **kw):
+        # device_efa: configure the exact-Fourier-acceleration state on the handle so that members can call hmc_update (the whole
+        # trajectory of a member's hmc_update! on the device)
+        self.batch = WalkerBatch(workload, nwalkers=nwalkers, walker0=walker0, device=device, device_efa=device_efa, host_threads=1, **kw)
         b = self.batch
         self._t = C.c_void_p()
         lib = L.load()
@@ -412,7 +414,7 @@ class WalkerTeam:
         b = self.batch
         x0 = np.ascontiguousarray(np.stack([np.asarray(b.xs_force[w]) for w in range(b.nw)]))
         self.call("smoqy_team_serve", name.encode(), L.ptr(x0))
-        return {"name": name, "tol": b.tol, "tol_force": b.tol_force, "maxiter": b.maxiter, "Nt": b.Nt, "drift": b.drift, "free": b.Nph}
+        return {"name": name, "tol": b.tol, "tol_force": b.tol_force, "maxiter": b.maxiter, "Nt": b.Nt, "drift": b.drift, "free": b.Nph, "device_efa": bool(b.device_efa)}
 
     def unserve(self):
         self.call("smoqy_team_unserve")
@@ -445,6 +447,50 @@ class TeamMember:
 
     def _step_call(self, *a):
         self.team.call("smoqy_team_pff_step", self.w, *a)
+
+    def _hmc_call(self, *a):
+        self.team.call("smoqy_team_hmc_update", self.w, *a)
+
+    def _finish_call(self, accept):
+        self.team.call("smoqy_team_hmc_finish", self.w, int(accept))
+
+    def hmc_update(self, dt=None, send_x=True):
+        """hmc_update! (src/EFAPFFHMCUpdater.jl:102-276) for this walker with the trajectory on the device: the member draws what the
+        reference draws from its rng (Φ deviates :133, momenta :142, one Lanczos start vector per solve), the library runs the leapfrog for
+        all members at once.  Returns (ΔH, x_new); the caller decides and reports with ``hmc_finish(accept)``."""
+        dt = np.pi / (2 * self.Nt) if dt is None else float(dt)          # tutorials/holstein_honeycomb.jl:542
+        flat = self.R.reshape(-1, order="F").view(np.float64)
+        self.rng.standard_normal(out=flat)
+        flat *= np.sqrt(0.5)
+        P = self.rng.standard_normal((self.Lt, max(self.Nph, 1)))
+        rvs = self.rng.standard_normal((self.Nt + 1, self.N))
+        H0, H1 = np.zeros(3), np.zeros(3)
+        x_new = np.empty_like(self.x)
+        it = C.c_int(0)
+        self._hmc_call(L.ptr(self.x) if send_x else None, L.ptr(self.R), L.ptr(P), L.ptr(rvs), int(self.Nt), C.c_double(dt), C.c_double(self.tol_force), C.c_double(self.tol), int(self.maxiter),
+                       L.ptr(H0), L.ptr(H1), L.ptr(x_new), C.byref(it))
+        self.solves += self.Nt + 1
+        self.iters_sum += it.value
+        self.H0, self.H1 = H0, H1
+        return float(H1.sum() - H0.sum()), x_new
+
+    def hmc_finish(self, accept, x_new=None):
+        self._finish_call(accept)
+        if accept and x_new is not None:
+            self.x[...] = x_new
+
+    def sweep_device_hmc(self):
+        """the sweep of ``WalkerBatch.sweep`` with device_efa = True for ONE walker: two local-move-like updates, then hmc_update! with the
+        trajectory on the device, always rejected (bench.py's convention: the field distribution stays the one SURVEY.md §8(d) defines)"""
+        for _ in range(2):
+            self.sample_pseudofermion_fields()
+            pi = self.rng.standard_normal((self.Lt, self.free))
+            self.x[:, : self.free] += self.drift * pi
+            self.pff_step(self.tol, moved=True, want_force=False)
+            self.x[:, : self.free] -= self.drift * pi
+        dH, _ = self.hmc_update()
+        self.hmc_finish(False)
+        return dH
 
     def sample_pseudofermion_fields(self):
         flat = self.R.reshape(-1, order="F").view(np.float64)
@@ -517,6 +563,12 @@ class RemoteMember(TeamMember):
 
     def _step_call(self, *a):
         self._call("smoqy_member_pff_step", *a)
+
+    def _hmc_call(self, *a):
+        self._call("smoqy_member_hmc_update", *a)
+
+    def _finish_call(self, accept):
+        self._call("smoqy_member_hmc_finish", int(accept))
 
     def close(self):
         if self._m:

@@ -1,5 +1,5 @@
 """Child process of tests/test_gpu_team.py: ONE rank of the reference's one-walker-per-rank model, joining a team another process serves.
-It never touches the GPU.  argv: info-json, walker index, mode ("parity" out.npz | "sweeps" n)."""
+It never touches the GPU.  argv: info-json, walker index, mode ("parity" out.npz | "hmc" out.npz | "sweeps" n)."""
 import ctypes as C
 import json
 import os
@@ -25,6 +25,13 @@ if mode == "parity":
     d = np.zeros((m.Lt, m.Nph))
     m._step_call(L.ptr(x), L.ptr(rv), C.c_double(1e-10), 10000, 1, C.byref(s), C.byref(i), C.byref(e), L.ptr(d))
     np.savez(sys.argv[4], rr=rr.value, sf=s.value, it=i.value, eps=e.value, dS=d)
+elif mode == "hmc":
+    from smoqyelphqmc_amd import lattice as lat  # noqa: E402
+
+    m.rng = np.random.Generator(np.random.PCG64(lat.SEED0 + 7919 * w + 1))  # walker w's stream, as WalkerBatch seeds it
+    dH, x_new = m.hmc_update()
+    m.hmc_finish(w % 2 == 0, x_new)
+    np.savez(sys.argv[4], dH=dH, x_new=x_new)
 else:
     for _ in range(int(sys.argv[4])):
         m.sweep()

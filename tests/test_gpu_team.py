@@ -98,7 +98,7 @@ def test_native_member_threads_run_the_member_sweep():
     b = team.batch
     x0 = np.ascontiguousarray(np.stack([np.asarray(b.xs_force[w]) for w in range(K)]))
     secs, so, itn = C.c_double(0.0), C.c_long(0), C.c_long(0)
-    team.call("smoqy_team_bench_sweeps", L.ptr(x0), int(b.Nph), C.c_double(b.drift), int(b.Nt), C.c_double(b.tol), C.c_double(b.tol_force), int(b.maxiter), 1, 2, 99,
+    team.call("smoqy_team_bench_sweeps", L.ptr(x0), int(b.Nph), C.c_double(b.drift), int(b.Nt), C.c_double(b.tol), C.c_double(b.tol_force), int(b.maxiter), 0, 1, 2, 99,
               C.byref(secs), C.byref(so), C.byref(itn))
     assert so.value == K * 2 * (3 + b.Nt) and secs.value > 0
     native = itn.value / so.value
@@ -107,7 +107,7 @@ def test_native_member_threads_run_the_member_sweep():
     py = sum(m.iters_sum for m in team.members) / sum(m.solves for m in team.members)
     assert abs(native - py) <= 0.25 * py + 2, (native, py)
     with pytest.raises(L.SmoqyError):
-        team.call("smoqy_team_bench_sweeps", L.ptr(x0), int(b.Nph_force) + 1, C.c_double(b.drift), int(b.Nt), C.c_double(b.tol), C.c_double(b.tol_force), int(b.maxiter), 0, 1, 99,
+        team.call("smoqy_team_bench_sweeps", L.ptr(x0), int(b.Nph_force) + 1, C.c_double(b.drift), int(b.Nt), C.c_double(b.tol), C.c_double(b.tol_force), int(b.maxiter), 0, 0, 1, 99,
                   C.byref(secs), C.byref(so), C.byref(itn))
     team.close()
 
@@ -156,3 +156,78 @@ def test_members_in_other_processes_equal_the_batched_calls(tmp_path):
         assert np.array_equal(r["dS"], dS[w])
     team.close()
 
+
+
+def _reference_trajectory(name, K):
+    """one caller, batched entry points, the same per-walker random streams as the members: (ΔH, proposed fields, original fields)"""
+    ref = WalkerBatch(name, nwalkers=K, device_efa=True)
+    x_before = np.array(ref.xs_force, copy=True)
+    dH, _ = ref.hmc_trajectory_device()
+    x_prop = np.zeros_like(x_before)
+    ref.h.call("smoqy_efa_get_state", L.ptr(x_prop), None)
+    ref.h.close()
+    return dH, x_prop, x_before
+
+
+@pytest.mark.parametrize("name,K", [("holstein_honeycomb_L4_Ltau40", 4), ("bssh_chain_L256_Ltau200_alpha0p2", 3)])
+def test_team_hmc_update_equals_the_batched_trajectory(name, K):
+    """smoqy_team_hmc_update / smoqy_team_hmc_finish: every member's hmc_update! (src/EFAPFFHMCUpdater.jl:102-276) runs its trajectory on the
+    device, all members in one batched call; ΔH and the proposed fields must be those of one caller driving the batched entry points with
+    the same random streams, and each member's own accept / reject decision must leave its walker — and only its walker — accordingly."""
+    dH_ref, x_prop, x_before = _reference_trajectory(name, K)
+    team = WalkerTeam(name, K, device_efa=True)
+    out = [None] * K
+
+    def member(w):
+        m = team.members[w]
+        threading.Event().wait(0.01 * ((w * 5) % K))
+        dH, x_new = m.hmc_update()
+        m.hmc_finish(w % 2 == 0, x_new)
+        out[w] = (dH, x_new)
+
+    with ThreadPoolExecutor(K) as pool:
+        list(pool.map(member, range(K)))
+    x_dev = np.zeros_like(x_before)
+    team.batch.h.call("smoqy_efa_get_state", L.ptr(x_dev), None)
+    for w in range(K):
+        assert out[w][0] == dH_ref[w]                       # same kernels on the same batch: bit for bit
+        assert np.array_equal(out[w][1], x_prop[w])
+        assert np.array_equal(x_dev[w], x_prop[w] if w % 2 == 0 else x_before[w])
+        assert np.array_equal(team.members[w].x, x_dev[w])
+    # the calls must come in pairs
+    with pytest.raises(L.SmoqyError):
+        with ThreadPoolExecutor(K) as pool:
+            list(pool.map(lambda w: team.members[w].hmc_finish(True), range(K)))
+    # a following per-step round without x sees the fields the decisions left
+    with ThreadPoolExecutor(K) as pool:
+        list(pool.map(lambda w: team.members[w].sample_pseudofermion_fields(), range(K)))
+        res = list(pool.map(lambda w: team.members[w].pff_step(1e-10, moved=False, want_force=False), range(K)))
+    assert all(np.isfinite(r[0]) and r[2] < 1e-10 for r in res)
+    team.close()
+
+
+def test_hmc_update_of_members_in_other_processes(tmp_path):
+    """the same through smoqy_team_serve / smoqy_member_hmc_update: the members are processes without GPU access"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    name, K = "holstein_honeycomb_L4_Ltau40", 3
+    dH_ref, x_prop, x_before = _reference_trajectory(name, K)
+    team = WalkerTeam(name, K, device_efa=True)
+    info = dict(team.serve(f"/smoqy-test-hmc-{os.getpid()}"), seed=0)
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_team_member_child.py")
+    procs = [subprocess.Popen([sys.executable, child, json.dumps(info), str(w), "hmc", str(tmp_path / f"h{w}.npz")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for w in range(K)]
+    for p in procs:
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err[-2000:]
+    team.unserve()
+    x_dev = np.zeros_like(x_before)
+    team.batch.h.call("smoqy_efa_get_state", L.ptr(x_dev), None)
+    for w in range(K):
+        r = np.load(tmp_path / f"h{w}.npz")
+        assert float(r["dH"]) == dH_ref[w]
+        assert np.array_equal(r["x_new"], x_prop[w])
+        assert np.array_equal(x_dev[w], x_prop[w] if w % 2 == 0 else x_before[w])
+    team.close()

@@ -1,4 +1,4 @@
-"""team_threads_scan of bench.py alone (Python member threads, native member threads, one caller): python tools/team_scan.py [K,K,...] [sweeps] [TxK,...]"""
+"""(SMOQY_TEAM_HMC=host for the step-by-step HMC of the members) team_threads_scan of bench.py alone (Python member threads, native member threads, one caller): python tools/team_scan.py [K,K,...] [sweeps] [TxK,...]"""
 import argparse
 import json
 import os
@@ -8,6 +8,6 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import bench  # noqa: E402
 
 counts = [int(k) for k in (sys.argv[1] if len(sys.argv) > 1 else "8,16,32").split(",")]
-args = argparse.Namespace(workload="holstein_honeycomb_L16_Ltau128", scan_sweeps=int(sys.argv[2]) if len(sys.argv) > 2 else 4, team_multi=sys.argv[3] if len(sys.argv) > 3 else "")
+args = argparse.Namespace(workload="holstein_honeycomb_L16_Ltau128", hmc=os.environ.get("SMOQY_TEAM_HMC", "device"), scan_sweeps=int(sys.argv[2]) if len(sys.argv) > 2 else 4, team_multi=sys.argv[3] if len(sys.argv) > 3 else "")
 for p in bench.team_scan(args, counts, 0, 0):
     print(json.dumps(p), flush=True)
