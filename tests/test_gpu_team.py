@@ -231,3 +231,66 @@ def test_hmc_update_of_members_in_other_processes(tmp_path):
         assert np.array_equal(r["x_new"], x_prop[w])
         assert np.array_equal(x_dev[w], x_prop[w] if w % 2 == 0 else x_before[w])
     team.close()
+
+
+def test_team_error_paths_leave_the_team_usable():
+    """a member that never arrives (code 9 after the team's time-out), members that make different calls in one round (code 8), a published
+    team that is withdrawn while a member waits (code 10): every waiting member gets an error instead of hanging, and the team works
+    afterwards"""
+    import os
+
+    from smoqyelphqmc_amd.walkers import RemoteMember
+
+    K = 2
+    team = WalkerTeam("holstein_honeycomb_L4_Ltau40", K)
+    b = team.batch
+    R = np.asfortranarray(np.random.default_rng(1).standard_normal((b.Lt, b.N)) + 0j)
+    rr = C.c_double(0.0)
+    team.call("smoqy_team_set_timeout", C.c_double(0.3))
+    lib = team.lib
+    # (9) the other member never comes
+    assert lib.smoqy_team_sample_phi(team._t, 0, L.ptr(R), C.byref(rr)) == 9
+    assert b"timed out" in lib.smoqy_team_last_error(team._t)
+    # (8) different calls in one round: the late caller is refused, the early one completes when its partner makes the right call
+    team.call("smoqy_team_set_timeout", C.c_double(20.0))
+    res = {}
+
+    def early():
+        res["early"] = lib.smoqy_team_sample_phi(team._t, 0, L.ptr(R), C.byref(rr))
+
+    th = threading.Thread(target=early)
+    th.start()
+    threading.Event().wait(0.2)
+    sf, ep, it = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
+    rv = np.random.default_rng(2).standard_normal(b.N)
+    x = np.ascontiguousarray(b.xs_force[1])
+    assert lib.smoqy_team_pff_step(team._t, 1, L.ptr(x), L.ptr(rv), C.c_double(1e-8), 1000, 1, C.byref(sf), C.byref(it), C.byref(ep), None) == 8
+    rr1 = C.c_double(0.0)
+    assert lib.smoqy_team_sample_phi(team._t, 1, L.ptr(R), C.byref(rr1)) == 0
+    th.join(30)
+    assert res["early"] == 0 and rr.value == rr1.value > 0
+    # (10) a published team withdrawn under a waiting member
+    info = team.serve(f"/smoqy-test-err-{os.getpid()}")
+    m0 = RemoteMember(info, 0)
+    with pytest.raises(L.SmoqyError):  # index 0 is taken
+        RemoteMember(info, 0, wait_seconds=1.0)
+
+    def waiting():
+        try:
+            m0.sample_pseudofermion_fields()
+            res["remote"] = 0
+        except L.SmoqyError as e:
+            res["remote"] = str(e)
+
+    th = threading.Thread(target=waiting)
+    th.start()
+    threading.Event().wait(0.3)
+    team.unserve()
+    th.join(30)
+    assert "(10)" in res["remote"] and "withdrawn" in res["remote"]
+    m0.close()
+    # the in-process entry points work again
+    with ThreadPoolExecutor(K) as pool:
+        rrs = list(pool.map(lambda w: team.members[w].sample_pseudofermion_fields(), range(K)))
+    assert all(v > 0 for v in rrs)
+    team.close()
