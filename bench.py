@@ -557,6 +557,9 @@ def roofline_record(args, batch, per, S, dev, insitu, extra, L, np):
         "systems_per_launch": per,
         "tau_chunk": tc.value,
         "concurrent_streams": S,
+        "solves_in_flight": int(args.solve_concurrency) if args.solve_concurrency else S,
+        "shared_device": "the sampled launches run while the kernels of up to solves_in_flight - 1 other CG solves share the GPU, so their duration is a shared-device figure: it grows "
+                         "with the gate (22 us at 3 solves in flight, 29 us at 4) while sweeps/s rises; the kernel alone is `isolated`, the whole step in real bytes is cg_iteration_traffic",
         "in_timed_region": None if not timed_s else {
             "device_clock_avg_us": insitu["device_us"], "event_pair_avg_us": insitu["event_us"], "launches_sampled": insitu["device_n"],
             "note": "every 16th full-batch MtM launch of the CG loops while all streams run; the device clock spans first workgroup start -> last workgroup end "
