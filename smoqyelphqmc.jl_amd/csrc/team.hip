@@ -304,8 +304,11 @@ static int run_round(smoqy_team *t)
 static int rendezvous(smoqy_team *t, int w, int op, const Slot &args)
 {
     if (!t) return 1;
-    if (w < 0 || w >= t->K) { t->err = "team member index out of range"; return 1; }
-    if (t->served) { t->err = "this team is published (smoqy_team_serve): its members call smoqy_member_*"; return 1; }
+    if (w < 0 || w >= t->K || t->served) {
+        std::lock_guard<std::mutex> lk(t->m);  // the error string is shared by the members
+        t->err = t->served ? "this team is published (smoqy_team_serve): its members call smoqy_member_*" : "team member index out of range";
+        return 1;
+    }
     stage_in(t->stage(), t->K, t->Lt, t->N, t->Nph, w, args);
     const int rc = rendezvous_locked(t, w, op, args);
     if (rc == 0) stage_out(t->stage(), t->Lt, t->Nph, w, args);
