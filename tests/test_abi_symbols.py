@@ -71,6 +71,11 @@ def test_header_and_c_example_compile_as_plain_c(tmp_path):
     subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_demo.c"), "-L" + lib_dir, "-lsmoqy_hip", "-lm",
                     "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(out)], check=True)
     assert out.exists()
+    # the member rank of a served walker team (no GPU, no handle): examples/team_member_demo.c
+    out2 = tmp_path / "team_member_demo"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "team_member_demo.c"), "-L" + lib_dir, "-lsmoqy_hip", "-lm",
+                    "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(out2)], check=True)
+    assert out2.exists()
 
 
 def test_member_attach_fails_cleanly_without_a_team():

@@ -33,3 +33,19 @@ def test_python_tutorial_example_runs():
     tail = r.stdout.strip().splitlines()[-1]
     total = float(tail.split("sum = ")[1].split(",")[0])
     assert abs(total - 1.0) < 1e-12
+
+
+def test_ranks_in_plain_c_join_a_served_team():
+    """examples/walker_team_ranks.py: this process serves a walker team, K separately built plain-C programs (examples/team_member_demo.c,
+    no GPU access) each drive one walker through smoqy_member_*: every rank reports its solves, and all ranks of a round see the same
+    number of CG iterations only if their walkers happen to agree — what must agree is the count of solves, 2 + Nt + 1 per sweep."""
+    import json
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "walker_team_ranks.py"), "holstein_honeycomb_L4_Ltau40", "3", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    recs = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
+    assert sorted(q["walker"] for q in recs) == [0, 1, 2]
+    for q in recs:
+        assert q["solves"] == 2 * (2 + 24 + 1) and q["cg_iterations"] > q["solves"] and abs(q["last_dH"]) < 50.0
+    assert "sweeps/s on one GPU" in r.stdout
