@@ -21,6 +21,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <pthread.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
@@ -589,8 +590,10 @@ int smoqy_member_attach(smoqy_member **out, const char *name, int w, double wait
     if (w < 0 || w >= h->K) { g_member_error = "smoqy_member_attach: member index outside the team"; munmap(h, h->total); return 1; }
     ShmMember *mem = (ShmMember *)((char *)h + h->off_members);
     shm_lock(h);
-    const bool taken = mem[w].attached != 0;
-    if (!taken) mem[w].attached = 1;
+    // `attached` holds the pid of the rank that owns the index; a rank that died without detaching (kill(pid, 0) says ESRCH) is replaced
+    const int owner = mem[w].attached;
+    const bool taken = owner != 0 && !(kill((pid_t)owner, 0) != 0 && errno == ESRCH);
+    if (!taken) mem[w].attached = (int)getpid();
     pthread_mutex_unlock(&h->m);
     if (taken) { g_member_error = "smoqy_member_attach: this member index is already attached"; munmap(h, h->total); return 1; }
     smoqy_member *m = new smoqy_member();

@@ -294,3 +294,56 @@ def test_team_error_paths_leave_the_team_usable():
         rrs = list(pool.map(lambda w: team.members[w].sample_pseudofermion_fields(), range(K)))
     assert all(v > 0 for v in rrs)
     team.close()
+
+
+def test_a_rank_that_dies_does_not_wedge_the_others(tmp_path):
+    """a member PROCESS is killed while it waits in a round (an MPI rank that crashes): the surviving member gets the rendezvous time-out
+    (code 9) instead of hanging, the dead rank's index can be attached again, and the next complete round works"""
+    import json
+    import os
+    import signal
+    import subprocess
+    import sys
+    import time
+
+    from smoqyelphqmc_amd.walkers import RemoteMember
+
+    K = 2
+    team = WalkerTeam("holstein_honeycomb_L4_Ltau40", K)
+    team.call("smoqy_team_set_timeout", C.c_double(1.5))
+    info = dict(team.serve(f"/smoqy-test-kill-{os.getpid()}"), seed=3)
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_team_member_child.py")
+    # rank 1 joins and blocks in its first call (rank 0 has not called yet) ... and is killed there
+    p = subprocess.Popen([sys.executable, child, json.dumps(info), "1", "sweeps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(2.0)
+    p.send_signal(signal.SIGKILL)
+    p.wait(timeout=30)
+    m0 = RemoteMember(info, 0)
+    # if the dead rank had already arrived in its round, that round completes with its last deposit (otherwise it times out like the next) ...
+    try:
+        assert m0.sample_pseudofermion_fields() > 0
+    except L.SmoqyError as first:
+        assert "(9)" in str(first)
+    # ... and the next one cannot: the survivor gets the time-out, it does not hang
+    t0 = time.perf_counter()
+    with pytest.raises(L.SmoqyError) as e:
+        m0.pff_step(1e-8, moved=True, want_force=False)
+    assert "(9)" in str(e.value) and time.perf_counter() - t0 < 10.0
+    # a restarted rank takes the dead one's index over (its pid is gone), and complete rounds work again
+    m1 = RemoteMember(info, 1)
+    res = {}
+
+    def other():
+        res["rr1"] = m1.sample_pseudofermion_fields()
+        res["s1"] = m1.pff_step(1e-8, moved=True, want_force=False)
+
+    th = threading.Thread(target=other)
+    th.start()
+    rr0 = m0.sample_pseudofermion_fields()
+    s0 = m0.pff_step(1e-8, moved=True, want_force=False)
+    th.join(60)
+    assert rr0 > 0 and res["rr1"] > 0 and s0[2] < 1e-8 and res["s1"][2] < 1e-8
+    m0.close()
+    m1.close()
+    team.unserve()
+    team.close()
