@@ -459,6 +459,78 @@ def team_procs_scan(args, points, dev, walker0):
     return out
 
 
+def iteration_kernels(args, dev, walker0, L, np):
+    """All four kernels of the fused CG iteration against the roofline, measured live inside real solves: 16 walkers on one stream, one part
+    (full-batch launches), HIP events in front of each launch of up to 512 iterations of one sweep (smoqy_cg_iteration_timing).  Bytes: the
+    least each fused kernel can move (every array it reads or writes counted once; S = one state vector, F = the field arrays) and the
+    committed PMC traffic of the same kernels (profiles/r*_pmc_iteration.json)."""
+    from smoqyelphqmc_amd.walkers import WalkerBatch
+
+    nw = 16
+    ob = WalkerBatch(args.workload, nwalkers=nw, walker0=walker0, device=dev, device_efa=args.hmc == "device", cg_split=1)
+    ob.sweep()
+    ob.h.call("smoqy_cg_iteration_timing", 512)
+    ob.sweep()
+    us = (L.C.c_double * 4)()
+    n = L.C.c_int(0)
+    ob.h.call("smoqy_cg_iteration_timing_read", us, L.C.byref(n))
+    Sb = 16.0 * ob.Lt * ob.N * nw
+    Fb = (8.0 * ob.Lt * ob.N + 16.0 * ob.Lt * ob.Nh) * nw
+    ob.h.close()
+    _, per_kernel, src = committed_iteration_traffic(args.workload)
+    per_kernel = per_kernel or {}
+
+    def traffic(prefix):
+        hits = [v for k, v in per_kernel.items() if k.startswith(prefix)]
+        return hits[0] if hits else None
+
+    rows = [("fused MtM (fdm_stream_kernel)", us[0], 2 * Sb + Fb, traffic("fdm_")),
+            ("forward tau-FFT + r update (tfft_kernel<2>)", us[1], 3 * Sb, traffic("tfft_kernel<2")),
+            ("Chebyshev apply (cheb_own_kernel)", us[2], 2 * Sb, traffic("cheb_")),
+            ("inverse tau-FFT + x, p updates (tfft_kernel<3>)", us[3], 5 * Sb, traffic("tfft_kernel<3"))]
+    prof, prof_src = committed_solo_durations(args.workload)
+    out = []
+    for (name, t_us, least, tr), key in zip(rows, ("fdm_", "tfft_kernel<2", "cheb_", "tfft_kernel<3")):
+        t_s = t_us * 1e-6
+        p_us = next((v for k, v in prof.items() if k.startswith(key)), None)
+        out.append({"kernel": name, "us": t_us, "least_bytes": least, "frac_least": (least / t_s / 1e9 / HBM_PEAK_GBS) if t_s else None,
+                    "traffic_bytes": tr, "frac_traffic": (tr / t_s / 1e9 / HBM_PEAK_GBS) if (tr and t_s) else None,
+                    "rocprof_us": p_us, "frac_least_rocprof": (least / (p_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if p_us else None})
+    tot = sum(r[1] for r in rows)
+    return {"systems_per_launch": nw, "iterations_sampled": n.value, "us_per_iteration": tot,
+            "timing": "us: HIP events in front of each of the four dependent launches inside real solves, one stream, one part — event to event, i.e. the kernel plus the hand-over to "
+                      "the next launch, which the event commands themselves lengthen by about 3 us per launch; rocprof_us: rocprofv3's per-dispatch average of the same kernels in the "
+                      "same one-stream run (committed file, not measured by this run)",
+            "rocprof_source": prof_src,
+            "traffic_source": src, "traffic_measured_live": False, "peak_GBs": HBM_PEAK_GBS,
+            "note": "at 16 systems the working set (5 vectors, 84 MB) sits in the Infinity Cache: these are not HBM figures; frac_least = least bytes the fused kernel can move / time / 8 TB/s",
+            "kernels": out}
+
+
+def committed_solo_durations(workload):
+    """rocprofv3 per-dispatch averages (us) of the iteration's kernels in the newest committed one-stream, 16-walker profile
+    (profiles/r*_solo_kernel_stats_hc16.txt).  Headline lattice only."""
+    import glob
+    if workload != "holstein_honeycomb_L16_Ltau128":
+        return {}, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_solo_kernel_stats_hc16.txt")), reverse=True):
+        out = {}
+        try:
+            for line in open(path):
+                if not line.startswith("void smoqy::"):
+                    continue
+                name = line.replace("void ", "").replace("smoqy::", "").replace("(anonymous namespace)::", "")
+                head = name.split("(")[0]
+                nums = [c for c in line.split() if c.replace(".", "", 1).isdigit()]
+                if len(nums) >= 6:
+                    out[head] = float(nums[-4])  # calls total_ms avg_us min_us max_us pct
+        except OSError:
+            continue
+        if out:
+            return out, "profiles/" + os.path.basename(path)
+    return {}, None
+
+
 def committed_iteration_traffic(workload):
     """HBM-side bytes of ONE CG iteration at 16 systems per launch (all four kernels), from the newest committed rocprofv3 PMC pass
     (profiles/r*_pmc_iteration.json; FETCH_SIZE x 2 + WRITE_SIZE per kernel, medians over a sweep).  Headline lattice only."""
@@ -754,6 +826,10 @@ def main():
                 one_stream.append({"walkers_per_gpu": nw1, "streams": 1, "sweeps_per_s": nw1 * 1e3 / ms_one, "ms_per_sweep": ms_one})
             extra["single_walker"] = dict(one_stream[0], note="one walker on one stream: the launch-latency regime (4 dependent launches per CG iteration)")
             extra["one_stream"] = one_stream
+            try:
+                extra["iteration_kernels"] = iteration_kernels(args, dev, mine.start, L, np)
+            except Exception as ex:  # noqa: BLE001 — reported, never fatal to the bench line
+                extra["iteration_kernels"] = {"error": str(ex)[:400]}
             if proc_scan is not None:
                 extra["procs_per_gpu_scan"] = {"model": "K processes ('MPI ranks', tutorials/holstein_honeycomb_mpi.jl:60-72), one single-walker handle each, sharing cuda:0; "
                                                         "started together after a warm-up sweep; K <= 6 (the GPU pool's process guard)", "points": proc_scan}

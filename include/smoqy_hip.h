@@ -443,6 +443,11 @@ int smoqy_matvec_timing_read(smoqy_ctx *ctx, double *avg_us, int *samples);
  * interval rocprofv3 --kernel-trace reports for a dispatch (an event pair on a busy stream also holds the gap to the previous
  * launch).  Call before smoqy_matvec_timing_read, which ends the sampling. */
 int smoqy_matvec_timing_read_device(smoqy_ctx *ctx, double *avg_us, int *samples);
+/* per-kernel durations of the fused CG iteration inside real solves: the next `iterations` full-batch iterations on the handle's stream get
+ * an event in front of each of their four launches and one behind the last; _read returns us[0..3] = mean event-to-event time of the fused
+ * MᵀM, the forward τ-FFT (with the r update), the Chebyshev apply and the inverse τ-FFT (with the x / p updates), and ends the sampling */
+int smoqy_cg_iteration_timing(smoqy_ctx *ctx, int iterations);
+int smoqy_cg_iteration_timing_read(smoqy_ctx *ctx, double *us, int *iterations);
 /* device stream-copy ceiling: `reps` device-to-device copies of `bytes` bytes by a plain 16-byte-per-lane copy
  * kernel between two HIP events; each copy moves 2 * bytes.  Buffers are allocated and freed inside the call. */
 int smoqy_bench_copy(smoqy_ctx *ctx, size_t bytes, int reps, double *ms);

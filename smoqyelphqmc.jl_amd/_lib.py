@@ -148,6 +148,8 @@ SIGNATURES = {
     "smoqy_timer_stop": [_p, _pd],
     "smoqy_matvec_timing": [_p, _i, _i],
     "smoqy_matvec_timing_read": [_p, _pd, _pi],
+    "smoqy_cg_iteration_timing": [_p, _i],
+    "smoqy_cg_iteration_timing_read": [_p, _p, _pi],
     "smoqy_matvec_timing_read_device": [_p, _pd, _pi],
     "smoqy_bench_copy": [_p, C.c_size_t, _i, _pd],
     "smoqy_bench_matvec": [_p, _i, _i, _i, _i, _pd],

@@ -197,6 +197,11 @@ struct smoqy_ctx {
         unsigned long long *d_stamp = nullptr;  // [cap][wgs][2] start / end of every workgroup of each sampled launch (FdmArgs::stamp)
         int stamp_cap = 0, stamp_wgs = 0;
     } mvt;
+    // event brackets around the four launches of fused CG iterations (smoqy_cg_iteration_timing): 5 events per sampled iteration
+    struct IterTiming {
+        int want = 0, used = 0;
+        std::vector<hipEvent_t> ev;
+    } itt;
 
     size_t vec_elems() const { return (size_t)g.nsys * g.Lt * g.N; }
 };
@@ -433,6 +438,7 @@ int smoqy_destroy(smoqy_ctx *c)
                     (void *)c->force.d_m, (void *)c->force.d_part, (void *)c->force.d_fm})
         if (q) (void)hipFree(q);
     for (auto &e : c->mvt.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : c->itt.ev) (void)hipEventDestroy(e);
     if (c->mvt.d_stamp) (void)hipFree(c->mvt.d_stamp);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1808,7 +1814,12 @@ static int auto_parts(const smoqy_ctx *c) { return c->g.nsys >= 8 ? 2 : 1; }  //
 // the fused form of one CG iteration for systems [sys0, sys0 + count) on stream st: four launches
 static int cg_iteration_fused(smoqy_ctx *c, const CgArgs &a, hipStream_t st, int sys0, int count)
 {
+    // smoqy_cg_iteration_timing: full-batch iterations on the handle's own stream get an event in front of each launch and one behind the last
+    auto &IT = c->itt;
+    hipEvent_t *tev = (IT.used < IT.want && st == c->stream && count == c->g.nsys && !c->use_graph) ? &IT.ev[(size_t)5 * IT.used] : nullptr;
+    if (tev) (void)hipEventRecord(tev[0], st);
     if (int rc = matvec_dev(c, SMOQY_OP_MTM, c->cg_z, c->cg_p, c->part_pz, c->d_st, sys0, count, true, st)) return rc;  // z = A p, partial p·Ap (:219)
+    if (tev) (void)hipEventRecord(tev[1], st);
     // the tau-FFT kernels absorb the BLAS-1 updates (kernels_tfft.hip).  In this form a.r holds the residual in FREQUENCY space (r̂):
     // the forward kernel updates it with α·FFT(Ap), the Chebyshev kernel reads it and writes ẑ into v (out of place), the inverse
     // kernel turns ẑ into z and updates x and p.
@@ -1820,13 +1831,16 @@ static int cg_iteration_fused(smoqy_ctx *c, const CgArgs &a, hipStream_t st, int
     t.part_rr = a.part_rr; t.nrr = t.ntile; t.rr_stride = c->pstride;
     t.st = a.st;
     launch_tfft(st, 2, t);                      // :219-226: α, r̂ -= α FFT(Ap), |r|²
+    if (tev) (void)hipEventRecord(tev[2], st);
     KpmArgs k = kpm_args(c, c->cg_r, c->d_st);
     k.sys_first = sys0; k.sys_count = count;
     k.vout = c->cg_z;  // ẑ reuses the buffer of A p, which the forward kernel has consumed (one vector less in the cache-resident working set)
     k.part_rz = c->part_rz;
     launch_cheb(st, k, c->kg);                  // :237 in frequency space, partial r·z by Parseval
+    if (tev) (void)hipEventRecord(tev[3], st);
     t.src = a.v;
     launch_tfft(st, 3, t);                      // inverse FFT + x += α p + :229-245
+    if (tev) { (void)hipEventRecord(tev[4], st); ++IT.used; }
     return check_launch(c, "cg iteration");
 }
 
@@ -2903,6 +2917,45 @@ int smoqy_matvec_timing_read(smoqy_ctx *c, double *avg_us, int *samples)
     if (samples) *samples = T.used;
     T.every = 0;
     T.seen = T.used = 0;
+    return 0;
+}
+
+// per-kernel durations of the fused CG iteration inside real solves: the next `iterations` full-batch iterations on the handle's stream get an
+// event in front of each of their four launches (MᵀM, forward τ-FFT, Chebyshev, inverse τ-FFT) and one behind the last
+int smoqy_cg_iteration_timing(smoqy_ctx *c, int iterations)
+{
+    CHECK_CTX(c);
+    if (iterations < 0 || iterations > 4096) FAIL(c, 1, "invalid number of iterations");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto &IT = c->itt;
+    while (IT.ev.size() < (size_t)5 * iterations) {
+        hipEvent_t e = nullptr;
+        HIPCHK(c, hipEventCreate(&e));
+        IT.ev.push_back(e);
+    }
+    IT.want = iterations;
+    IT.used = 0;
+    return 0;
+}
+
+// us[0..3] = mean event-to-event time of the four launches over the sampled iterations (dependent launches on one stream: the kernel plus
+// the hand-over to the next one); ends the sampling
+int smoqy_cg_iteration_timing_read(smoqy_ctx *c, double *us, int *iterations)
+{
+    CHECK_CTX(c);
+    if (!us) FAIL(c, 1, "us is NULL");
+    auto &IT = c->itt;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double sum[4] = {0, 0, 0, 0};
+    for (int k = 0; k < IT.used; ++k)
+        for (int q = 0; q < 4; ++q) {
+            float f = 0;
+            HIPCHK(c, hipEventElapsedTime(&f, IT.ev[(size_t)5 * k + q], IT.ev[(size_t)5 * k + q + 1]));
+            sum[q] += f;
+        }
+    for (int q = 0; q < 4; ++q) us[q] = IT.used ? 1e3 * sum[q] / IT.used : 0.0;
+    if (iterations) *iterations = IT.used;
+    IT.want = IT.used = 0;
     return 0;
 }
 

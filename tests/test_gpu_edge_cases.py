@@ -549,3 +549,22 @@ def test_speculative_solve_restarts_when_the_preconditioner_grows():
     assert abs(itA - ito) <= 1 and relerr(np.asarray(xA).reshape(Lt, N, order="F"), xo) < 1e-8
     hA.close()
     hB.close()
+
+
+def test_cg_iteration_timing_brackets_the_four_launches():
+    """smoqy_cg_iteration_timing (bench.py's iteration_kernels): the next n full-batch fused iterations get an event in front of each of their
+    four launches; the read returns four positive means, the number of iterations sampled, and ends the sampling"""
+    from smoqyelphqmc_amd.walkers import WalkerBatch
+
+    b = WalkerBatch("holstein_honeycomb_L4_Ltau40", nwalkers=2, cg_split=1)
+    b.sweep()
+    b.h.call("smoqy_cg_iteration_timing", 8)
+    b.sweep()
+    us = (C.c_double * 4)()
+    n = C.c_int(0)
+    b.h.call("smoqy_cg_iteration_timing_read", us, C.byref(n))
+    assert n.value == 8 and all(0.5 < v < 500.0 for v in us)
+    b.sweep()
+    b.h.call("smoqy_cg_iteration_timing_read", us, C.byref(n))
+    assert n.value == 0
+    b.h.close()
