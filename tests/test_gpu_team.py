@@ -158,15 +158,20 @@ def test_members_in_other_processes_equal_the_batched_calls(tmp_path):
 
 
 
-def _reference_trajectory(name, K):
-    """one caller, batched entry points, the same per-walker random streams as the members: (ΔH, proposed fields, original fields)"""
+def _reference_trajectory(name, K, second=False):
+    """one caller, batched entry points, the same per-walker random streams as the members: (ΔH, proposed fields, original fields[, ΔH of
+    a second trajectory after the even walkers accepted and the odd ones rejected])"""
     ref = WalkerBatch(name, nwalkers=K, device_efa=True)
     x_before = np.array(ref.xs_force, copy=True)
     dH, _ = ref.hmc_trajectory_device()
     x_prop = np.zeros_like(x_before)
     ref.h.call("smoqy_efa_get_state", L.ptr(x_prop), None)
+    dH2 = None
+    if second:
+        ref.h.call("smoqy_efa_restore_walkers", L.ptr(np.array([w % 2 for w in range(K)], dtype=np.int32)))
+        dH2 = np.array(ref.hmc_trajectory_device()[0], copy=True)
     ref.h.close()
-    return dH, x_prop, x_before
+    return (np.array(dH, copy=True), x_prop, x_before) + ((dH2,) if second else ())
 
 
 @pytest.mark.parametrize("name,K", [("holstein_honeycomb_L4_Ltau40", 4), ("bssh_chain_L256_Ltau200_alpha0p2", 3)])
@@ -174,9 +179,10 @@ def test_team_hmc_update_equals_the_batched_trajectory(name, K):
     """smoqy_team_hmc_update / smoqy_team_hmc_finish: every member's hmc_update! (src/EFAPFFHMCUpdater.jl:102-276) runs its trajectory on the
     device, all members in one batched call; ΔH and the proposed fields must be those of one caller driving the batched entry points with
     the same random streams, and each member's own accept / reject decision must leave its walker — and only its walker — accordingly."""
-    dH_ref, x_prop, x_before = _reference_trajectory(name, K)
+    dH_ref, x_prop, x_before, dH2_ref = _reference_trajectory(name, K, second=True)
     team = WalkerTeam(name, K, device_efa=True)
     out = [None] * K
+    out2 = [None] * K
 
     def member(w):
         m = team.members[w]
@@ -198,6 +204,17 @@ def test_team_hmc_update_equals_the_batched_trajectory(name, K):
     with pytest.raises(L.SmoqyError):
         with ThreadPoolExecutor(K) as pool:
             list(pool.map(lambda w: team.members[w].hmc_finish(True), range(K)))
+
+    # a second update WITHOUT sending x: every walker continues from where its own decision left it on the device
+    def member2(w):
+        m = team.members[w]
+        dH, x_new = m.hmc_update(send_x=False)
+        m.hmc_finish(False)
+        out2[w] = dH
+
+    with ThreadPoolExecutor(K) as pool:
+        list(pool.map(member2, range(K)))
+    assert all(out2[w] == dH2_ref[w] for w in range(K))
     # a following per-step round without x sees the fields the decisions left
     with ThreadPoolExecutor(K) as pool:
         list(pool.map(lambda w: team.members[w].sample_pseudofermion_fields(), range(K)))
