@@ -62,6 +62,9 @@ enum { SMOQY_OP_M = 0, SMOQY_OP_MT = 1, SMOQY_OP_MTM = 2, SMOQY_OP_MMT = 3 };
 int smoqy_create(smoqy_ctx **out, int Ltau, int N, int Nh, int ncolors, const int64_t *neighbor_table,
                  const int64_t *color_ranges, int is_sym, int is_complex_T, int nwalkers, int nrhs, int device_id);
 int smoqy_destroy(smoqy_ctx *ctx);
+/* a second handle on the same lattice, propagator form, device and preconditioner configuration with `nrhs` right-hand sides per walker
+ * (the GreensEstimator's follower handle: Nrv systems per walker, its fields copied over with smoqy_copy_fields) */
+int smoqy_clone(smoqy_ctx **out, const smoqy_ctx *src, int nrhs);
 /* text of the last error on this handle (or of the last failed smoqy_create when ctx == NULL) */
 const char *smoqy_last_error(const smoqy_ctx *ctx);
 /* adopt a caller-owned hipStream_t (pass NULL to return to the handle's own stream) */
@@ -393,6 +396,17 @@ int smoqy_team_hmc_update(smoqy_team *team, int w, const double *x, const void *
                           double *H0, double *H1, double *x_new, int *iters);
 int smoqy_team_hmc_finish(smoqy_team *team, int w, int accept);
 
+/* GreensEstimator for team members (src/Measurements/GreensEstimator.jl): smoqy_team_ge_config — once, before smoqy_team_serve — clones the
+ * team's handle with Nrv right-hand sides per walker (smoqy_clone) and configures the contractions (smoqy_ge_config: n_orbitals, D, L).
+ * smoqy_team_ge_update = update_greens_estimator! (:125-175) of member w: R = the member's Ltau x N x Nrv unit-modulus random vectors
+ * (randn!, R ./= abs.(R), :141-142), randvec = the Lanczos start vector of update_preconditioner! (:150); the follower handle takes every
+ * walker's current fields and solves all K·Nrv systems in ONE batched CG; *iters = iterations summed over the member's Nrv solves, *eps = its
+ * largest residual.  smoqy_team_ge_measure_GD0 = measure_GΔ0! (:179-233) for orbitals (a, b), 1-based, the same for all members of a round:
+ * out = the member's (Ltau+1) x L... complex array. */
+int smoqy_team_ge_config(smoqy_team *team, int Nrv, int n_orbitals, int D, const int64_t *L);
+int smoqy_team_ge_update(smoqy_team *team, int w, const void *R, const double *randvec, double tol, int maxiter, int *iters, double *eps);
+int smoqy_team_ge_measure_GD0(smoqy_team *team, int w, int a, int b, void *out);
+
 /* Teams across processes — the reference's walkers are MPI ranks (processes): the rank that owns the GPU handle publishes its team in a
  * POSIX shared-memory segment `name` ("/something"); every rank of the node, the serving one included, joins with smoqy_member_attach and
  * makes the same two calls as a team member.  A member needs no GPU and no handle: it copies its arrays into the segment (page-locked in
@@ -418,6 +432,11 @@ int smoqy_member_pff_step(smoqy_member *member, const double *x, const double *r
 int smoqy_member_hmc_update(smoqy_member *member, const double *x, const void *R, const double *P, const double *randvecs, int Nt, double dt, double tol_force, double tol, int maxiter,
                             double *H0, double *H1, double *x_new, int *iters);
 int smoqy_member_hmc_finish(smoqy_member *member, int accept);
+/* smoqy_team_ge_update / smoqy_team_ge_measure_GD0 for this member; _ge_dims: Nrv and the bytes of one member's G(Δ,0) array (0 / 0 if the
+ * serving rank did not configure a GreensEstimator) */
+int smoqy_member_ge_dims(const smoqy_member *member, int *Nrv, size_t *g_bytes);
+int smoqy_member_ge_update(smoqy_member *member, const void *R, const double *randvec, double tol, int maxiter, int *iters, double *eps);
+int smoqy_member_ge_measure_GD0(smoqy_member *member, int a, int b, void *out);
 
 /* ---- measurement aids (bench.py) -------------------------------------------------------- */
 

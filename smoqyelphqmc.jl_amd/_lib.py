@@ -47,6 +47,7 @@ _pd = C.POINTER(C.c_double)
 SIGNATURES = {
     "smoqy_create": [C.POINTER(_p), _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i],
     "smoqy_destroy": [_p],
+    "smoqy_clone": [C.POINTER(_p), _p, _i],
     "smoqy_set_stream": [_p, _p],
     "smoqy_sync": [_p],
     "smoqy_host_alloc": [_p, C.POINTER(_p), C.c_size_t],
@@ -88,6 +89,12 @@ SIGNATURES = {
     "smoqy_team_hmc_finish": [_p, _i, _i],
     "smoqy_member_hmc_update": [_p, _p, _p, _p, _p, _i, _d, _d, _d, _i, _p, _p, _p, _pi],
     "smoqy_member_hmc_finish": [_p, _i],
+    "smoqy_team_ge_config": [_p, _i, _i, _i, _p],
+    "smoqy_team_ge_update": [_p, _i, _p, _p, _d, _i, _pi, _pd],
+    "smoqy_team_ge_measure_GD0": [_p, _i, _i, _i, _p],
+    "smoqy_member_ge_dims": [_p, _pi, C.POINTER(C.c_size_t)],
+    "smoqy_member_ge_update": [_p, _p, _p, _d, _i, _pi, _pd],
+    "smoqy_member_ge_measure_GD0": [_p, _i, _i, _p],
     "smoqy_team_bench_sweeps": [_p, _p, _i, _d, _i, _d, _d, _i, _i, _i, _i, C.c_ulong, _pd, C.POINTER(C.c_long), C.POINTER(C.c_long)],
     "smoqy_matvec": [_p, _i, _p, _p, _i, _i],
     "smoqy_checkerboard_v": [_p, _i, _i, _i, _i, _i],

@@ -202,6 +202,7 @@ struct smoqy_ctx {
         int want = 0, used = 0;
         std::vector<hipEvent_t> ev;
     } itt;
+    std::vector<int64_t> in_nt, in_cr;  // the neighbour table and colour ranges the handle was created from (smoqy_clone)
 
     size_t vec_elems() const { return (size_t)g.nsys * g.Lt * g.N; }
 };
@@ -793,8 +794,22 @@ int smoqy_create(smoqy_ctx **out, int Ltau, int N, int Nh, int ncolors, const in
         smoqy_destroy(c);
         return rc;
     }
+    if (Nh > 0) {
+        c->in_nt.assign(neighbor_table, neighbor_table + 2 * (size_t)Nh);
+        c->in_cr.assign(color_ranges, color_ranges + 2 * (size_t)ncolors);
+    }
     *out = c;
     return 0;
+}
+
+// a second handle on the same lattice, propagator form, device and preconditioner configuration with `nrhs` right-hand sides per walker
+// (e.g. the GreensEstimator's follower handle: Nrv systems per walker, fields copied over with smoqy_copy_fields)
+int smoqy_clone(smoqy_ctx **out, const smoqy_ctx *src, int nrhs)
+{
+    if (!out || !src || nrhs < 1) { g_create_error = "smoqy_clone: null handle or nrhs < 1"; return 1; }
+    const Geometry &g = src->g;
+    if (int rc = smoqy_create(out, g.Lt, g.N, g.Nh, g.ncol, src->in_nt.data(), src->in_cr.data(), g.is_sym, g.is_cplx, g.nw, nrhs, src->device)) return rc;
+    return smoqy_precond_config(*out, src->rbuf, src->nlanczos, src->a1, src->a2);
 }
 
 int smoqy_set_stream(smoqy_ctx *c, void *s)

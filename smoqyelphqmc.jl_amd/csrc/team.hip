@@ -31,7 +31,7 @@
 #include "../../include/smoqy_hip.h"
 
 namespace {
-enum { OP_NONE = 0, OP_SAMPLE = 1, OP_PFF = 2, OP_HMC = 3, OP_FINISH = 4 };
+enum { OP_NONE = 0, OP_SAMPLE = 1, OP_PFF = 2, OP_HMC = 3, OP_FINISH = 4, OP_GE_UPDATE = 5, OP_GE_GD0 = 6 };
 constexpr int kMaxNt = 64;  // leapfrog steps a team's staging is sized for (smoqy_team_hmc_update)
 struct Slot {
     const void *R = nullptr;
@@ -46,12 +46,19 @@ struct Slot {
     double dt = 0, tol_force = 0;
     double *H0 = nullptr, *H1 = nullptr, *x_new = nullptr;
     int accept = 0;  // OP_FINISH
+    // GreensEstimator: Nrv random vectors (Ltau x N x Nrv, OP_GE_UPDATE); orbitals and the member's G(Δ,0) array (OP_GE_GD0)
+    const void *Rrv = nullptr;
+    void *G = nullptr;
+    int orb_a = 0, orb_b = 0;
     int rc = 0;
 };
 // where a member's arrays are staged for the batched call: the team's own page-locked buffers, or the shared-memory segment
 struct Stage {
     char *R = nullptr;
     double *x = nullptr, *rv = nullptr, *dS = nullptr, *P = nullptr, *rvs = nullptr;
+    char *GR = nullptr, *G = nullptr;  // GreensEstimator: the members' random vectors (Nrv per member) and their G(Δ,0) arrays
+    int Nrv = 0;
+    size_t gbytes = 0;                 // bytes of one member's G(Δ,0)
 };
 // a member copies its OWN inputs in before the rendezvous and its own outputs out after it (K copies in parallel, outside any lock)
 void stage_in(const Stage &g, int K, int Lt, int N, int Nph, int w, const Slot &a)
@@ -61,6 +68,7 @@ void stage_in(const Stage &g, int K, int Lt, int N, int Nph, int w, const Slot &
     if (a.x) std::memcpy(g.x + (size_t)w * nx, a.x, nx * sizeof(double));
     if (a.rv) std::memcpy(g.rv + (size_t)w * N, a.rv, (size_t)N * sizeof(double));
     if (a.P) std::memcpy(g.P + (size_t)w * nx, a.P, nx * sizeof(double));
+    if (a.Rrv && g.GR) std::memcpy(g.GR + (size_t)w * nR * g.Nrv, a.Rrv, nR * g.Nrv);
     if (a.rvs && a.Nt >= 1 && a.Nt <= kMaxNt)  // the batched trajectory wants N x K x Nt: step-major, member w's vector of step t at (t K + w) N
         for (int t = 0; t <= a.Nt; ++t) std::memcpy(g.rvs + ((size_t)t * K + w) * N, a.rvs + (size_t)t * N, (size_t)N * sizeof(double));
 }
@@ -69,6 +77,7 @@ void stage_out(const Stage &g, int Lt, int Nph, int w, const Slot &a)
     const size_t nx = (size_t)(Nph > 0 ? Nph : 1) * Lt;
     if (a.dSdx) std::memcpy(a.dSdx, g.dS + (size_t)w * nx, nx * sizeof(double));
     if (a.x_new) std::memcpy(a.x_new, g.dS + (size_t)w * nx, nx * sizeof(double));  // OP_HMC returns the proposed fields through the force staging
+    if (a.G && g.G) std::memcpy(a.G, g.G + (size_t)w * g.gbytes, g.gbytes);
 }
 }  // namespace
 
@@ -90,7 +99,20 @@ struct smoqy_team {
     void *h_R = nullptr;                                     // Ltau x N x K complex128
     double *h_x = nullptr, *h_rv = nullptr, *h_dS = nullptr;  // Nph x Ltau x K, N x K, Nph x Ltau x K
     double *h_P = nullptr, *h_rvs = nullptr;                  // Nph x Ltau x K, N x K x (kMaxNt + 1)
-    Stage stage() const { Stage g; g.R = (char *)h_R; g.x = h_x; g.rv = h_rv; g.dS = h_dS; g.P = h_P; g.rvs = h_rvs; return g; }
+    // GreensEstimator (smoqy_team_ge_config): follower handle with Nrv systems per walker, its vectors R / GR / MᵀR, staging
+    smoqy_ctx *ge = nullptr;
+    int ge_Nrv = 0, ge_r = -1, ge_gr = -1, ge_mtr = -1;
+    size_t ge_gbytes = 0;
+    char *h_GR = nullptr, *h_G = nullptr;
+    std::vector<int> ge_it;
+    std::vector<double> ge_eps;
+    Stage stage() const
+    {
+        Stage g;
+        g.R = (char *)h_R; g.x = h_x; g.rv = h_rv; g.dS = h_dS; g.P = h_P; g.rvs = h_rvs;
+        g.GR = h_GR; g.G = h_G; g.Nrv = ge_Nrv; g.gbytes = ge_gbytes;
+        return g;
+    }
     std::vector<double> Sf, eps, dot, e0, e1;
     std::vector<int> flags;
     std::vector<int> iters;
@@ -117,6 +139,9 @@ int smoqy_team_destroy(smoqy_team *t)
         if (t->h_dS) smoqy_host_free(t->c, t->h_dS);
         if (t->h_P) smoqy_host_free(t->c, t->h_P);
         if (t->h_rvs) smoqy_host_free(t->c, t->h_rvs);
+        if (t->h_GR) smoqy_host_free(t->c, t->h_GR);
+        if (t->h_G) smoqy_host_free(t->c, t->h_G);
+        if (t->ge) smoqy_destroy(t->ge);
         if (t->phi >= 0) smoqy_vec_free(t->c, t->phi);
         if (t->psi >= 0) smoqy_vec_free(t->c, t->psi);
     }
@@ -197,6 +222,40 @@ static int run_round(smoqy_team *t)
         if (int rc = smoqy_lambda_apply_v(c, SMOQY_LAMBDA_MULT, t->phi, t->phi)) return rc;    // mul_Λᵀ! (:73)
         for (int w = 0; w < K; ++w)
             if (t->slot[w].RdotR) *t->slot[w].RdotR = t->dot[2 * (size_t)w];
+        return 0;
+    }
+    if (t->op == OP_GE_UPDATE || t->op == OP_GE_GD0) {
+        if (!t->ge) { t->err = "smoqy_team_ge_*: call smoqy_team_ge_config first"; return 1; }
+        if (t->hmc_pending) { t->err = "the members owe their decisions first: smoqy_team_hmc_finish must follow smoqy_team_hmc_update"; return 1; }
+        auto fail = [&](int rc) { t->err = smoqy_last_error(t->ge); return rc; };
+        const Slot &s0 = t->slot[0];
+        if (t->op == OP_GE_UPDATE) {
+            // update_greens_estimator! (src/Measurements/GreensEstimator.jl:125-175) of all K members: the follower handle takes the walkers'
+            // current fields, update_preconditioner! (:150), MᵀR (:157), K·Nrv solves in ONE batched CG (:159-165)
+            for (int w = 0; w < K; ++w) {
+                const Slot &s = t->slot[w];
+                if (!s.Rrv || !s.rv) { t->err = "smoqy_team_ge_update: random vectors and a Lanczos start vector are needed from every member"; return 1; }
+                if (s.tol != s0.tol || s.maxiter != s0.maxiter) { t->err = "smoqy_team_ge_update: the members of a round must pass the same tol / maxiter"; return 1; }
+                if (int rc = smoqy_copy_fields(t->ge, w, c, w)) return fail(rc);
+            }
+            if (int rc = smoqy_precond_update_all(t->ge, t->h_rv)) return fail(rc);
+            if (int rc = smoqy_vec_upload(t->ge, t->ge_r, t->h_GR, 0, K * t->ge_Nrv)) return fail(rc);
+            if (int rc = smoqy_matvec_v(t->ge, SMOQY_OP_MT, t->ge_mtr, t->ge_r)) return fail(rc);
+            if (int rc = smoqy_cg_solve_v(t->ge, t->ge_gr, t->ge_mtr, s0.tol, s0.maxiter, 1, t->ge_it.data(), t->ge_eps.data())) return fail(rc);
+            for (int w = 0; w < K; ++w) {
+                const Slot &s = t->slot[w];
+                int sum = 0;
+                double worst = 0.0;
+                for (int j = 0; j < t->ge_Nrv; ++j) { sum += t->ge_it[(size_t)w * t->ge_Nrv + j]; worst = std::max(worst, t->ge_eps[(size_t)w * t->ge_Nrv + j]); }
+                if (s.iters) *s.iters = sum;
+                if (s.eps) *s.eps = worst;
+            }
+            return 0;
+        }
+        // measure_GΔ0! (:179-233) for the orbital pair all members ask for: one batched contraction, each member takes its own array
+        for (int w = 0; w < K; ++w)
+            if (t->slot[w].orb_a != s0.orb_a || t->slot[w].orb_b != s0.orb_b) { t->err = "smoqy_team_ge_measure_GD0: the members of a round must ask for the same orbital pair"; return 1; }
+        if (int rc = smoqy_ge_measure_GD0(t->ge, t->ge_gr, t->ge_r, s0.orb_a, s0.orb_b, t->h_G)) return fail(rc);
         return 0;
     }
     if (t->op == OP_FINISH) {
@@ -379,6 +438,52 @@ int smoqy_team_hmc_finish(smoqy_team *t, int w, int accept)
     return rendezvous(t, w, OP_FINISH, s);
 }
 
+int smoqy_team_ge_config(smoqy_team *t, int Nrv, int n_orbitals, int D, const int64_t *Ldims)
+{
+    if (!t || Nrv < 1 || n_orbitals < 1 || D < 1 || !Ldims) return 1;
+    std::lock_guard<std::mutex> lk(t->m);
+    if (t->served) { t->err = "smoqy_team_ge_config: configure the GreensEstimator before smoqy_team_serve"; return 1; }
+    if (t->ge) { t->err = "smoqy_team_ge_config: already configured"; return 1; }
+    size_t Nc = 1;
+    for (int d = 0; d < D; ++d) Nc *= (size_t)(Ldims[d] > 0 ? Ldims[d] : 0);
+    smoqy_ctx *ge = nullptr;
+    if (int rc = smoqy_clone(&ge, t->c, Nrv)) { t->err = std::string("smoqy_team_ge_config: ") + smoqy_last_error(nullptr); return rc; }
+    int rc = smoqy_ge_config(ge, n_orbitals, D, Ldims);
+    int v[3] = {-1, -1, -1};
+    for (int q = 0; q < 3 && !rc; ++q) rc = smoqy_vec_alloc(ge, &v[q]);
+    const size_t nR = (size_t)t->Lt * t->N * 16, gbytes = ((size_t)t->Lt + 1) * Nc * 16;
+    void *gr = nullptr, *g = nullptr;
+    if (!rc) rc = smoqy_host_alloc(t->c, &gr, nR * Nrv * t->K);
+    if (!rc) rc = smoqy_host_alloc(t->c, &g, gbytes * t->K);
+    if (rc) {
+        t->err = std::string("smoqy_team_ge_config: ") + smoqy_last_error(ge);
+        if (gr) smoqy_host_free(t->c, gr);
+        if (g) smoqy_host_free(t->c, g);
+        smoqy_destroy(ge);
+        return rc;
+    }
+    t->ge = ge; t->ge_Nrv = Nrv; t->ge_r = v[0]; t->ge_gr = v[1]; t->ge_mtr = v[2]; t->ge_gbytes = gbytes;
+    t->h_GR = (char *)gr; t->h_G = (char *)g;
+    t->ge_it.resize((size_t)t->K * Nrv); t->ge_eps.resize((size_t)t->K * Nrv);
+    return 0;
+}
+
+int smoqy_team_ge_update(smoqy_team *t, int w, const void *R, const double *randvec, double tol, int maxiter, int *iters, double *eps)
+{
+    if (!R || !randvec) return 1;
+    Slot s;
+    s.Rrv = R; s.rv = randvec; s.tol = tol; s.maxiter = maxiter; s.iters = iters; s.eps = eps;
+    return rendezvous(t, w, OP_GE_UPDATE, s);
+}
+
+int smoqy_team_ge_measure_GD0(smoqy_team *t, int w, int a, int b, void *out)
+{
+    if (!out) return 1;
+    Slot s;
+    s.orb_a = a; s.orb_b = b; s.G = out;
+    return rendezvous(t, w, OP_GE_GD0, s);
+}
+
 
 }  // extern "C"
 
@@ -389,10 +494,11 @@ int smoqy_team_hmc_finish(smoqy_team *t, int w, int accept)
 // deposits its scalars and sleeps on a process-shared condition variable; a server thread in the process that owns the handle runs the
 // round once all K members have arrived — the same run_round as the in-process team, its slots pointing into the segment.
 namespace {
-constexpr uint64_t kShmMagic = 0x534d4f5159544d32ull;  // "SMOQYTM2"
+constexpr uint64_t kShmMagic = 0x534d4f5159544d33ull;  // "SMOQYTM3"
 struct ShmMember {
     int has_x, has_rv, want_force, maxiter, use_precond, iters, rc, attached;
     int has_R, has_P, has_rvs, want_xnew, Nt, accept;
+    int has_Rrv, want_G, orb_a, orb_b;
     double tol, Sf, eps, RdotR;
     double dt, tol_force, H0[3], H1[3];
 };
@@ -402,7 +508,9 @@ struct ShmHeader {
     int op, arrived, shutdown, rc;
     unsigned long gen;
     double timeout_s;
-    size_t off_members, off_R, off_x, off_rv, off_dS, off_P, off_rvs, total;
+    size_t off_members, off_R, off_x, off_rv, off_dS, off_P, off_rvs, off_GR, off_G, total;
+    int ge_Nrv, ge_pad;
+    size_t ge_gbytes;
     pthread_mutex_t m;
     pthread_cond_t cv_arrive, cv_done;
     char err[256];
@@ -431,6 +539,7 @@ struct Served {
     std::thread server;
     void *own_R = nullptr;
     double *own_x = nullptr, *own_rv = nullptr, *own_dS = nullptr, *own_P = nullptr, *own_rvs = nullptr;  // the team's private staging, put back by unserve
+    char *own_GR = nullptr, *own_G = nullptr;
     bool registered = false;
 };
 
@@ -462,6 +571,9 @@ static void serve_loop(smoqy_team *t)
             s.rvs = q.has_rvs ? (const double *)h : nullptr;
             s.dSdx = q.want_force ? (double *)h : nullptr;
             s.x_new = q.want_xnew ? (double *)h : nullptr;
+            s.Rrv = q.has_Rrv ? (const void *)h : nullptr;
+            s.G = q.want_G ? (void *)h : nullptr;
+            s.orb_a = q.orb_a; s.orb_b = q.orb_b;
             s.tol = q.tol; s.maxiter = q.maxiter; s.use_precond = q.use_precond;
             s.Nt = q.Nt; s.dt = q.dt; s.tol_force = q.tol_force; s.accept = q.accept;
             s.Sf = &q.Sf; s.iters = &q.iters; s.eps = &q.eps; s.RdotR = &q.RdotR; s.H0 = q.H0; s.H1 = q.H1;
@@ -497,7 +609,9 @@ int smoqy_team_serve(smoqy_team *t, const char *name, const double *x0)
     lay.off_dS = align_up(lay.off_rv + (size_t)t->N * t->K * sizeof(double), 4096);
     lay.off_P = align_up(lay.off_dS + nx * t->K, 4096);
     lay.off_rvs = align_up(lay.off_P + nx * t->K, 4096);
-    lay.total = align_up(lay.off_rvs + (size_t)t->N * t->K * (kMaxNt + 1) * sizeof(double), 4096);
+    lay.off_GR = align_up(lay.off_rvs + (size_t)t->N * t->K * (kMaxNt + 1) * sizeof(double), 4096);
+    lay.off_G = align_up(lay.off_GR + nR * t->ge_Nrv * t->K, 4096);  // both empty without smoqy_team_ge_config
+    lay.total = align_up(lay.off_G + t->ge_gbytes * t->K, 4096);
     shm_unlink(name);  // a stale segment of a crashed job
     const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
     if (fd < 0) { t->err = std::string("smoqy_team_serve: shm_open failed for ") + name; return 2; }
@@ -509,7 +623,8 @@ int smoqy_team_serve(smoqy_team *t, const char *name, const double *x0)
     std::memset(h, 0, lay.off_R);
     h->K = t->K; h->Lt = t->Lt; h->N = t->N; h->Nph = t->Nph;
     h->timeout_s = t->timeout_s;
-    h->off_members = lay.off_members; h->off_R = lay.off_R; h->off_x = lay.off_x; h->off_rv = lay.off_rv; h->off_dS = lay.off_dS; h->off_P = lay.off_P; h->off_rvs = lay.off_rvs; h->total = lay.total;
+    h->off_members = lay.off_members; h->off_R = lay.off_R; h->off_x = lay.off_x; h->off_rv = lay.off_rv; h->off_dS = lay.off_dS; h->off_P = lay.off_P; h->off_rvs = lay.off_rvs; h->off_GR = lay.off_GR; h->off_G = lay.off_G; h->total = lay.total;
+    h->ge_Nrv = t->ge_Nrv; h->ge_gbytes = t->ge_gbytes;
     pthread_mutexattr_t ma;
     pthread_mutexattr_init(&ma);
     pthread_mutexattr_setpshared(&ma, PTHREAD_PROCESS_SHARED);
@@ -525,12 +640,13 @@ int smoqy_team_serve(smoqy_team *t, const char *name, const double *x0)
     pthread_condattr_destroy(&ca);
     Served *sv = new Served();
     sv->name = name; sv->h = h;
-    sv->own_R = t->h_R; sv->own_x = t->h_x; sv->own_rv = t->h_rv; sv->own_dS = t->h_dS; sv->own_P = t->h_P; sv->own_rvs = t->h_rvs;
+    sv->own_R = t->h_R; sv->own_x = t->h_x; sv->own_rv = t->h_rv; sv->own_dS = t->h_dS; sv->own_P = t->h_P; sv->own_rvs = t->h_rvs; sv->own_GR = t->h_GR; sv->own_G = t->h_G;
     char *base = (char *)p;
     // the staging area of the team now IS the segment; page-lock it where the driver allows (transfers work either way)
     sv->registered = smoqy_host_register(t->c, base + h->off_R, h->total - h->off_R) == 0;
     t->h_R = base + h->off_R; t->h_x = (double *)(base + h->off_x); t->h_rv = (double *)(base + h->off_rv); t->h_dS = (double *)(base + h->off_dS);
     t->h_P = (double *)(base + h->off_P); t->h_rvs = (double *)(base + h->off_rvs);
+    if (t->ge) { t->h_GR = base + h->off_GR; t->h_G = base + h->off_G; }
     std::memcpy(t->h_x, x0 ? (const void *)x0 : (const void *)sv->own_x, nx * t->K);
     t->served = sv;
     sv->server = std::thread(serve_loop, t);
@@ -553,7 +669,7 @@ int smoqy_team_unserve(smoqy_team *t)
     pthread_mutex_unlock(&h->m);
     if (sv->server.joinable()) sv->server.join();
     if (sv->registered) smoqy_host_unregister(t->c, (char *)h + h->off_R);
-    t->h_R = sv->own_R; t->h_x = sv->own_x; t->h_rv = sv->own_rv; t->h_dS = sv->own_dS; t->h_P = sv->own_P; t->h_rvs = sv->own_rvs;
+    t->h_R = sv->own_R; t->h_x = sv->own_x; t->h_rv = sv->own_rv; t->h_dS = sv->own_dS; t->h_P = sv->own_P; t->h_rvs = sv->own_rvs; t->h_GR = sv->own_GR; t->h_G = sv->own_G;
     shm_unlink(sv->name.c_str());
     munmap(h, h->total);
     delete sv;
@@ -642,6 +758,7 @@ static int member_round(smoqy_member *m, int op, const Slot &a)
     Stage g;
     g.R = base + h->off_R; g.x = (double *)(base + h->off_x); g.rv = (double *)(base + h->off_rv); g.dS = (double *)(base + h->off_dS);
     g.P = (double *)(base + h->off_P); g.rvs = (double *)(base + h->off_rvs);
+    if (h->ge_Nrv > 0) { g.GR = base + h->off_GR; g.G = base + h->off_G; g.Nrv = h->ge_Nrv; g.gbytes = h->ge_gbytes; }
     stage_in(g, h->K, h->Lt, h->N, h->Nph, w, a);
     ShmMember &q = ((ShmMember *)(base + h->off_members))[w];
     shm_lock(h);
@@ -650,6 +767,7 @@ static int member_round(smoqy_member *m, int op, const Slot &a)
     h->op = op;
     q.has_R = a.R != nullptr; q.has_x = a.x != nullptr; q.has_rv = a.rv != nullptr; q.has_P = a.P != nullptr; q.has_rvs = a.rvs != nullptr;
     q.want_force = a.dSdx != nullptr; q.want_xnew = a.x_new != nullptr;
+    q.has_Rrv = a.Rrv != nullptr; q.want_G = a.G != nullptr; q.orb_a = a.orb_a; q.orb_b = a.orb_b;
     q.tol = a.tol; q.maxiter = a.maxiter; q.use_precond = a.use_precond;
     q.Nt = a.Nt; q.dt = a.dt; q.tol_force = a.tol_force; q.accept = a.accept;
     const unsigned long my_gen = h->gen;
@@ -715,6 +833,30 @@ int smoqy_member_hmc_finish(smoqy_member *m, int accept)
     Slot s;
     s.accept = accept ? 1 : 0;
     return member_round(m, OP_FINISH, s);
+}
+
+int smoqy_member_ge_dims(const smoqy_member *m, int *Nrv, size_t *g_bytes)
+{
+    if (!m || !m->h) return 1;
+    if (Nrv) *Nrv = m->h->ge_Nrv;
+    if (g_bytes) *g_bytes = m->h->ge_gbytes;
+    return 0;
+}
+
+int smoqy_member_ge_update(smoqy_member *m, const void *R, const double *randvec, double tol, int maxiter, int *iters, double *eps)
+{
+    if (!R || !randvec) return 1;
+    Slot s;
+    s.Rrv = R; s.rv = randvec; s.tol = tol; s.maxiter = maxiter; s.iters = iters; s.eps = eps;
+    return member_round(m, OP_GE_UPDATE, s);
+}
+
+int smoqy_member_ge_measure_GD0(smoqy_member *m, int a, int b, void *out)
+{
+    if (!out) return 1;
+    Slot s;
+    s.orb_a = a; s.orb_b = b; s.G = out;
+    return member_round(m, OP_GE_GD0, s);
 }
 
 }  // extern "C"

@@ -408,13 +408,30 @@ class WalkerTeam:
         if rc:
             raise L.SmoqyError(f"{name} failed ({rc}): " + (self.lib.smoqy_team_last_error(self._t) or b"").decode())
 
+    def ge_config(self, Nrv: int = 10):
+        """GreensEstimator for the members (smoqy_team_ge_config): a follower handle with Nrv right-hand sides per walker; call before
+        ``serve``.  Lattice geometry as in ``WalkerBatch.measure_greens``."""
+        b = self.batch
+        meta = b.models[0].meta
+        if "L" not in meta:
+            raise ValueError("no lattice geometry recorded for this workload")
+        Lc = int(meta["L"])
+        n_orb = 2 if b.models[0].name.startswith("holstein_honeycomb") else 1
+        Ls = (Lc, Lc) if n_orb * Lc * Lc == b.N else (Lc,)
+        self.call("smoqy_team_ge_config", int(Nrv), n_orb, len(Ls), L.ptr(np.asarray(Ls, dtype=np.int64)))
+        self.ge = {"Nrv": int(Nrv), "Ls": list(Ls)}
+        for m in self.members:
+            m.ge = self.ge
+        return self.ge
+
     def serve(self, name: str):
         """Publish the team for members of other processes (smoqy_team_serve): ranks join with ``RemoteMember(name, w)``.  The members'
         initial phonon fields are the batch's."""
         b = self.batch
         x0 = np.ascontiguousarray(np.stack([np.asarray(b.xs_force[w]) for w in range(b.nw)]))
         self.call("smoqy_team_serve", name.encode(), L.ptr(x0))
-        return {"name": name, "tol": b.tol, "tol_force": b.tol_force, "maxiter": b.maxiter, "Nt": b.Nt, "drift": b.drift, "free": b.Nph, "device_efa": bool(b.device_efa)}
+        return {"name": name, "tol": b.tol, "tol_force": b.tol_force, "maxiter": b.maxiter, "Nt": b.Nt, "drift": b.drift, "free": b.Nph, "device_efa": bool(b.device_efa),
+                "ge": getattr(self, "ge", None)}
 
     def unserve(self):
         self.call("smoqy_team_unserve")
@@ -453,6 +470,33 @@ class TeamMember:
 
     def _finish_call(self, accept):
         self.team.call("smoqy_team_hmc_finish", self.w, int(accept))
+
+    def _ge_update_call(self, *a):
+        self.team.call("smoqy_team_ge_update", self.w, *a)
+
+    def _ge_gd0_call(self, *a):
+        self.team.call("smoqy_team_ge_measure_GD0", self.w, *a)
+
+    def measure_greens(self, orbitals=(1, 1), tol=None):
+        """update_greens_estimator! + measure_GΔ0! (src/Measurements/GreensEstimator.jl:125-233) for this walker: the member draws its Nrv
+        unit-modulus random vectors (:141-142) and the Lanczos start vector; all members' K·Nrv systems advance in one batched CG.  Returns
+        (G(Δ,0) of shape (Lτ+1, L...), iterations summed over the Nrv solves)."""
+        ge = getattr(self, "ge", None)
+        if not ge:
+            raise RuntimeError("the team has no GreensEstimator (WalkerTeam.ge_config before serve)")
+        Nrv, Ls = ge["Nrv"], tuple(ge["Ls"])
+        R = np.empty((self.Lt, self.N, Nrv), dtype=np.complex128, order="F")
+        flat = R.reshape(-1, order="F").view(np.float64)
+        self.rng.standard_normal(out=flat)
+        np.divide(R, np.abs(R), out=R)
+        rv = self.rng.standard_normal(self.N)
+        it, ep = C.c_int(0), C.c_double(0.0)
+        self._ge_update_call(L.ptr(R), L.ptr(rv), C.c_double(self.tol if tol is None else tol), int(self.maxiter), C.byref(it), C.byref(ep))
+        out = np.zeros((*reversed(Ls), self.Lt + 1), dtype=np.complex128)   # C order == (Lτ+1) x L... column-major
+        self._ge_gd0_call(int(orbitals[0]), int(orbitals[1]), L.ptr(out))
+        self.solves += Nrv
+        self.iters_sum += it.value
+        return np.transpose(out, tuple(range(out.ndim - 1, -1, -1))), it.value
 
     def hmc_update(self, dt=None, send_x=True):
         """hmc_update! (src/EFAPFFHMCUpdater.jl:102-276) for this walker with the trajectory on the device: the member draws what the
@@ -552,6 +596,7 @@ class RemoteMember(TeamMember):
         self.dSdx = np.zeros((self.Lt, self.Nph))
         self.tol, self.tol_force, self.maxiter, self.Nt, self.drift = info["tol"], info["tol_force"], info["maxiter"], info["Nt"], info["drift"]
         self.solves = self.iters_sum = 0
+        self.ge = info.get("ge")
 
     def _call(self, name, *a):
         rc = getattr(self.lib, name)(self._m, *a)
@@ -569,6 +614,12 @@ class RemoteMember(TeamMember):
 
     def _finish_call(self, accept):
         self._call("smoqy_member_hmc_finish", int(accept))
+
+    def _ge_update_call(self, *a):
+        self._call("smoqy_member_ge_update", *a)
+
+    def _ge_gd0_call(self, *a):
+        self._call("smoqy_member_ge_measure_GD0", *a)
 
     def close(self):
         if self._m:

@@ -1,5 +1,5 @@
 """Child process of tests/test_gpu_team.py: ONE rank of the reference's one-walker-per-rank model, joining a team another process serves.
-It never touches the GPU.  argv: info-json, walker index, mode ("parity" out.npz | "hmc" out.npz | "sweeps" n)."""
+It never touches the GPU.  argv: info-json, walker index, mode ("parity" out.npz | "hmc" out.npz | "ge" out.npz | "sweeps" n)."""
 import ctypes as C
 import json
 import os
@@ -32,6 +32,12 @@ elif mode == "hmc":
     dH, x_new = m.hmc_update()
     m.hmc_finish(w % 2 == 0, x_new)
     np.savez(sys.argv[4], dH=dH, x_new=x_new)
+elif mode == "ge":
+    from smoqyelphqmc_amd import lattice as lat  # noqa: E402
+
+    m.rng = np.random.Generator(np.random.PCG64(lat.SEED0 + 7919 * w + 1))  # walker w's stream, as WalkerBatch seeds it
+    G, it = m.measure_greens(orbitals=(1, 2))
+    np.savez(sys.argv[4], G=G, it=it)
 else:
     for _ in range(int(sys.argv[4])):
         m.sweep()

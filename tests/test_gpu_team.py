@@ -364,3 +364,43 @@ def test_a_rank_that_dies_does_not_wedge_the_others(tmp_path):
     m1.close()
     team.unserve()
     team.close()
+
+
+def test_team_greens_estimator_equals_the_batched_measurement(tmp_path):
+    """smoqy_team_ge_update / smoqy_team_ge_measure_GD0 (and smoqy_member_*): each member's update_greens_estimator! + measure_GΔ0!
+    (src/Measurements/GreensEstimator.jl:125-233) — its own random vectors, all K·Nrv systems in one batched CG — must give the G(Δ,0) array
+    and the iteration counts of one caller driving the batched entry points (WalkerBatch.measure_greens) with the same random streams:
+    members as threads, then members as processes."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    name, K, Nrv = "holstein_honeycomb_L4_Ltau40", 3, 4
+    ref = WalkerBatch(name, nwalkers=K)
+    G_ref, it_ref = ref.measure_greens(Nrv, orbitals=(1, 2))
+    it_ref = it_ref.reshape(K, Nrv).sum(axis=1)
+    ref._ge[0].close()
+    ref.h.close()
+    # threads
+    team = WalkerTeam(name, K)
+    team.ge_config(Nrv)
+    with ThreadPoolExecutor(K) as pool:
+        res = list(pool.map(lambda m: m.measure_greens(orbitals=(1, 2)), team.members))
+    for w in range(K):
+        assert np.array_equal(res[w][0], G_ref[w]) and res[w][1] == it_ref[w]
+    team.close()
+    # processes
+    team = WalkerTeam(name, K)
+    team.ge_config(Nrv)
+    info = dict(team.serve(f"/smoqy-test-ge-{os.getpid()}"), seed=0)
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_team_member_child.py")
+    procs = [subprocess.Popen([sys.executable, child, json.dumps(info), str(w), "ge", str(tmp_path / f"g{w}.npz")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for w in range(K)]
+    for p in procs:
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err[-2000:]
+    team.close()
+    for w in range(K):
+        r = np.load(tmp_path / f"g{w}.npz")
+        assert np.array_equal(r["G"], G_ref[w]) and int(r["it"]) == it_ref[w]
+    # G(r = 0, τ = 0) + G(r = 0, τ = β) = 1 for equal orbitals is checked by tests/test_gpu_greens.py on the batched path this one equals
