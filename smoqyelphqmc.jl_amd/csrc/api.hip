@@ -614,6 +614,11 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
             HIPCHK(c, hipMalloc(&c->d_tpos, pos.size() * sizeof(int)));
             HIPCHK(c, hipMemcpy(c->d_tpos, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice));
             c->tf.pos = c->d_tpos;
+            // form of the own tau-FFT when nobody chose one (smoqy_tfft_form, SMOQY_TFFT_SLIM): in place from 32 systems per launch — at that
+            // size the launches are HBM bound and six workgroups per CU beat four (64 walkers on one stream: 253.7 -> 242.9 ms per sweep,
+            // 128: 491 -> 464), below it the two-image form's fewer passes win (16 walkers: DESIGN.md §4.3)
+            static const bool form_free = getenv("SMOQY_TFFT_SLIM") == nullptr;
+            if (form_free && c->tf.slim_ok && g.nsys >= 32) c->tf.slim = 1;
         }
     }
 
