@@ -12,3 +12,5 @@ SMOQY_EFA=1 bash tools/gap_probe.sh r03_1walker 1 && SMOQY_EFA=1 bash tools/gap_
 echo done
 # N > 1 control flow rehearsed on the one GPU: two ranks share cuda:0, gloo for the barrier and the MAX (no scaling claim)
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --rehearse-one-gpu --steps 3 --warmup 1 --walkers-per-gpu 64 --streams 4 > gpurun_out/r03_rehearse_2ranks.json 2> gpurun_out/r03_rehearse_2ranks.err; echo rehearse rc=$?; tail -c 600 gpurun_out/r03_rehearse_2ranks.json
+# walker-team scans on their own (more points than the bench record holds)
+timeout -k 10 500 python tools/team_procs_scan.py 16,32,64,2x32,4x32 4 > gpurun_out/r03_team_procs_devhmc.txt 2>&1; timeout -k 10 500 python tools/team_scan.py 16,32,64 4 2x32,4x32 > gpurun_out/r03_team_scan_devhmc.txt 2>&1; tail -2 gpurun_out/r03_team_procs_devhmc.txt | cut -c1-200
