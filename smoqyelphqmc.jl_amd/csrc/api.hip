@@ -1846,6 +1846,12 @@ static int cg_iteration_fused(smoqy_ctx *c, const CgArgs &a, hipStream_t st, int
     TfftArgs t = c->tf;
     t.sys_first = sys0; t.sys_count = count;
     t.x = a.x; t.r = a.r; t.p = a.p; t.z = a.z;
+    // x is touched by the inverse kernel only, once per iteration.  Where the in-place form is in use — several handles share the GPU, or the
+    // launch is HBM resident — the vectors of the solves in flight compete for the Infinity Cache, and x goes past it with nontemporal
+    // loads and stores so that p, A p, r̂ and ẑ (each written by one kernel and read by the next) keep their hits: +2.4 % in the
+    // eight-stream bench (four alternating pairs); a single small batch keeps x cached (one walker: 40.9 against 47.3 ms per sweep)
+    static const int xs_env = [] { const char *e = getenv("SMOQY_X_STREAM"); return e ? atoi(e) : -1; }();  // A/B switch
+    t.x_stream = xs_env < 0 ? t.slim : (xs_env != 0);
     t.part_rz = a.part_rz; t.nrz = a.nrz; t.rz_stride = a.rz_stride;
     t.part_pz = a.part_pz; t.npz = a.nchunk; t.pz_stride = a.nchunk;
     t.part_rr = a.part_rr; t.nrr = t.ntile; t.rr_stride = c->pstride;

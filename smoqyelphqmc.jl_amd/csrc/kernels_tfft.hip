@@ -297,6 +297,7 @@ enum { MODE_PLAIN_FWD = 0, MODE_PLAIN_INV = 1, MODE_FWD_CG = 2, MODE_INV_CG = 3 
 
 // SLIM: the in-place form (one LDS image, radix <= 7): about half the LDS and two thirds of the registers of the ping-pong form, so
 // more workgroups fit a CU when several CG pipelines share the chip
+typedef double v2d_t __attribute__((ext_vector_type(2)));
 template <int MODE, bool SLIM>
 __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
 {
@@ -454,7 +455,10 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
                     if (lu < Lt) {
                         const size_t off = (size_t)lu * sstride + base + sb;
                         pv[u] = a.p[off];
-                        xv[u] = a.x[off];
+                        if (a.x_stream) {  // x is touched by this kernel only, once per iteration: keep it out of the caches the other vectors live in
+                            const v2d_t t_ = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(a.x + off));
+                            xv[u] = make_double2(t_.x, t_.y);
+                        } else xv[u] = a.x[off];
                     }
                 }
 #pragma unroll
@@ -462,7 +466,9 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
                     const int lu = l + u * lstep;
                     if (lu < Lt) {
                         const size_t off = (size_t)lu * sstride + base + sb;
-                        a.x[off] = cadd(xv[u], cm(alpha, pv[u]));
+                        const double2 xn_ = cadd(xv[u], cm(alpha, pv[u]));
+                        if (a.x_stream) { v2d_t t_; t_.x = xn_.x; t_.y = xn_.y; __builtin_nontemporal_store(t_, reinterpret_cast<v2d_t *>(a.x + off)); }
+                        else a.x[off] = xn_;
                         if (!conv) a.p[off] = cadd(res[lu * SB + sb], cm(beta, pv[u]));
                     }
                 }
@@ -594,6 +600,7 @@ bool tfft_plan(int Lt, int N, TfftArgs &a)
     for (int R : spref)
         while (m % R == 0 && a.snfac < 16) { a.sfac[a.snfac++] = R; m /= R; }
     static const int slim_env = [] { const char *e = getenv("SMOQY_TFFT_SLIM"); return e ? atoi(e) : 0; }();
+    a.x_stream = 0;  // decided per launch (api.hip: cg_iteration_fused)
     a.slim_ok = (m == 1) ? 1 : 0;           // lengths 2^a 3^b 5^c only
     a.slim = (slim_env && a.slim_ok) ? 1 : 0;  // default form: SMOQY_TFFT_SLIM, else smoqy_tfft_form
     a.SB = 16;

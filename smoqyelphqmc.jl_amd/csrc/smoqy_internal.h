@@ -296,6 +296,7 @@ void launch_ge_finalize_gd0(hipStream_t st, const double2 *S, double2 *out, int 
 struct TfftArgs {
     int Lt, N, nsys, SB, ntile, nfac;
     int sys_first, sys_count;             // systems [sys_first, sys_first + sys_count) are processed; sys_count = 0 means all
+    int x_stream;                         // inverse CG mode: nontemporal loads / stores for x
     int fac[16];
     // in-place form (one LDS image): radix 2 / 3 / 4 / 5 factors `sfac` applied as decimation-in-frequency passes (forward) or, in reverse
     // order, decimation-in-time passes (inverse); element k of the spectrum sits at LDS row pos[k]
