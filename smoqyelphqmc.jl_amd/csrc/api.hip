@@ -1183,6 +1183,11 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
     // streaming MᵀM (fdm_stream_kernel): workgroups walk runs of slices with their loads two iterations ahead — for launches big enough that
     // the chunked kernel's load-wait-compute workgroups leave the memory system idle
     a.run_len = (op == SMOQY_OP_MTM && in != out) ? stream_run_length(c, count, cs_const) : 0;
+    {   // exp(-ΔτV) is read once per launch: where the vectors of several solves compete for the Infinity Cache (the in-place τ-FFT form is
+        // the sign of it, see cg_iteration_fused) it is loaded past the caches (+1.1 % in the eight-stream bench, four alternating pairs)
+        static const int nt_env = [] { const char *e = getenv("SMOQY_NT_FIELDS"); return e ? atoi(e) : -1; }();  // A/B switch
+        a.nt_fields = nt_env < 0 ? (c->tf_ok && c->tf.slim) : (nt_env != 0);
+    }
     if (a.run_len > 0 && fdm_stream_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_stream(st, a, c->ff, cs_const);
     else if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_own(st, op, a, c->ff);
     else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_fast(st, op, a, c->ff, c->g.is_sym != 0, cs_const);

@@ -667,8 +667,13 @@ __global__ void __launch_bounds__(LB) fdm_stream_kernel(FdmArgs a, FdmFast ff)
         if (CSV) {                                                                                                    \
             _Pragma("unroll") for (int c = 0; c < NC; ++c) cs_[c] = csf[(size_t)l_ * ff.ptotal + cidx[c]];           \
         }                                                                                                             \
-        di_ = expV[(size_t)l_ * N + s0.x];                                                                            \
-        dj_ = expV[(size_t)l_ * N + s0.y];                                                                            \
+        if (a.nt_fields) {                                                                                            \
+            di_ = __builtin_nontemporal_load(&expV[(size_t)l_ * N + s0.x]);                                           \
+            dj_ = __builtin_nontemporal_load(&expV[(size_t)l_ * N + s0.y]);                                           \
+        } else {                                                                                                      \
+            di_ = expV[(size_t)l_ * N + s0.x];                                                                        \
+            dj_ = expV[(size_t)l_ * N + s0.y];                                                                        \
+        }                                                                                                             \
     }
 #define ROTATE_FLD()                                                                                                  \
     {                                                                                                                 \

@@ -72,6 +72,7 @@ struct FdmArgs {
     // -> last end of the launch, the interval rocprofv3 reports, free of the inter-launch gap an event pair includes
     unsigned long long *stamp;
     int run_len;  // fdm_stream_kernel: output slices per workgroup (a multiple of Tc); 0 = not a streaming launch
+    int nt_fields;  // fdm_stream_kernel: nontemporal loads of exp(-ΔτV)
 };
 
 // stamps for FdmArgs::stamp
