@@ -1857,6 +1857,14 @@ static int cg_iteration_fused(smoqy_ctx *c, const CgArgs &a, hipStream_t st, int
     // eight-stream bench (four alternating pairs); a single small batch keeps x cached (one walker: 40.9 against 47.3 ms per sweep)
     static const int xs_env = [] { const char *e = getenv("SMOQY_X_STREAM"); return e ? atoi(e) : -1; }();  // A/B switch
     t.x_stream = xs_env < 0 ? t.slim : (xs_env != 0);
+    // Workgroups go to the eight XCDs round-robin, each XCD has its own 4 MiB L2.  When a launch covers a multiple of eight systems and an
+    // XCD's share of the iteration's vectors (p, A p / ẑ, r̂, x) is small enough to live there, the τ-FFT and Chebyshev kernels take the
+    // blockIdx -> system map the MᵀM kernels already use (XCD x works on the contiguous share [x·n/8, (x+1)·n/8) of the systems): what one
+    // kernel wrote is still in that XCD's L2 when the next one reads it.  8 walkers on one stream: 59.7 -> 54.3 ms per sweep, 16: 80.3 ->
+    // 79.3, 32: 135.1 -> 138.0 (off there), the eight-stream bench unchanged.
+    static const int xm_env = [] { const char *e = getenv("SMOQY_XCD_MAP"); return e ? atoi(e) : -1; }();  // A/B switch
+    const size_t xcd_share = (size_t)(count / 8) * 4 * c->g.Lt * c->g.N * sizeof(double2);
+    t.xcd_map = xm_env < 0 ? (count % 8 == 0 && xcd_share <= (size_t)8 << 20) : (xm_env != 0);
     t.part_rz = a.part_rz; t.nrz = a.nrz; t.rz_stride = a.rz_stride;
     t.part_pz = a.part_pz; t.npz = a.nchunk; t.pz_stride = a.nchunk;
     t.part_rr = a.part_rr; t.nrr = t.ntile; t.rr_stride = c->pstride;
@@ -1865,6 +1873,7 @@ static int cg_iteration_fused(smoqy_ctx *c, const CgArgs &a, hipStream_t st, int
     if (tev) (void)hipEventRecord(tev[2], st);
     KpmArgs k = kpm_args(c, c->cg_r, c->d_st);
     k.sys_first = sys0; k.sys_count = count;
+    k.xcd_map = t.xcd_map;
     k.vout = c->cg_z;  // ẑ reuses the buffer of A p, which the forward kernel has consumed (one vector less in the cache-resident working set)
     k.part_rz = c->part_rz;
     launch_cheb(st, k, c->kg);                  // :237 in frequency space, partial r·z by Parseval

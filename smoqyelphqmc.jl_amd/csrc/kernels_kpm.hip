@@ -695,7 +695,14 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
     __shared__ double red[17];
     const int N = k.N, Lt = k.Lt, Tn = blockDim.x, j = threadIdx.x;
     const int ncnt_ = k.sys_count > 0 ? k.sys_count : k.nsys;
-    const int sys = k.sys_first + blockIdx.x % ncnt_, slotid = blockIdx.x / ncnt_;
+    int sys = k.sys_first + blockIdx.x % ncnt_, slotid = blockIdx.x / ncnt_;
+    if (k.xcd_map && (ncnt_ & 7) == 0) {
+        // XCD x (workgroups go round-robin) takes the contiguous share [x·n/8, (x+1)·n/8) of the systems, as in the MᵀM and τ-FFT kernels;
+        // within an XCD the order stays slot-major (heaviest chains first)
+        const int per_ = ncnt_ >> 3, q_ = blockIdx.x >> 3;
+        sys = k.sys_first + (blockIdx.x & 7) * per_ + q_ % per_;
+        slotid = q_ / per_;
+    }
     const int heavy = min(k.heavy, Lt), heavy_slots = SPLIT ? 2 * heavy : heavy;
     const int w = sys / k.nrhs;
     const int Lo2 = (Lt + 1) / 2;

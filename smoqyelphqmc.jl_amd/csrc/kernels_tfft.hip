@@ -306,7 +306,11 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
     const int Lt = a.Lt, SB = a.SB, N = a.N;
     double2 *A = lds, *B = A + (size_t)Lt * SB, *WT = SLIM ? B : B + (size_t)Lt * SB;
     int *POS = reinterpret_cast<int *>(WT + Lt);  // SLIM only
-    const int tile = blockIdx.x % a.ntile, sys = a.sys_first + blockIdx.x / a.ntile;
+    // XCD-aware order (workgroups go to the eight XCDs round-robin): XCD x works on the same contiguous share of the systems as in the MᵀM
+    // and Chebyshev kernels, so that what one kernel wrote is still in that XCD's L2 when the next kernel of the iteration reads it
+    int bid_ = blockIdx.x;
+    if (a.xcd_map && (gridDim.x & 7) == 0) bid_ = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int tile = bid_ % a.ntile, sys = a.sys_first + bid_ / a.ntile;
     if (MODE == MODE_FWD_CG) {
         // `done` was written by an earlier launch (inverse kernel of the previous iteration or cg_start): safe to gate on.
         // Latch it into `stop` for the inverse kernel of THIS iteration, which must not look at `done` (it writes it).
@@ -601,6 +605,7 @@ bool tfft_plan(int Lt, int N, TfftArgs &a)
         while (m % R == 0 && a.snfac < 16) { a.sfac[a.snfac++] = R; m /= R; }
     static const int slim_env = [] { const char *e = getenv("SMOQY_TFFT_SLIM"); return e ? atoi(e) : 0; }();
     a.x_stream = 0;  // decided per launch (api.hip: cg_iteration_fused)
+    a.xcd_map = 0;   // decided per launch (api.hip: cg_iteration_fused)
     a.slim_ok = (m == 1) ? 1 : 0;           // lengths 2^a 3^b 5^c only
     a.slim = (slim_env && a.slim_ok) ? 1 : 0;  // default form: SMOQY_TFFT_SLIM, else smoqy_tfft_form
     a.SB = 16;

@@ -96,6 +96,7 @@ struct KpmArgs {
     const double *bounds;               // [w][2]
     const int *active;                  // [w]
     int nslot, maxorder;
+    int xcd_map;                        // cheb_own_kernel: keep a system's workgroups on one XCD (see tfft_kernel)
     double2 *v;                         // input, slice(=frequency)-major
     double2 *vout;                      // output; nullptr = in place
     double2 *scratch;                   // see FdmArgs::scratch
@@ -298,6 +299,7 @@ struct TfftArgs {
     int Lt, N, nsys, SB, ntile, nfac;
     int sys_first, sys_count;             // systems [sys_first, sys_first + sys_count) are processed; sys_count = 0 means all
     int x_stream;                         // inverse CG mode: nontemporal loads / stores for x
+    int xcd_map;                          // blockIdx -> (tile, system) map that keeps a system's workgroups on one XCD
     int fac[16];
     // in-place form (one LDS image): radix 2 / 3 / 4 / 5 factors `sfac` applied as decimation-in-frequency passes (forward) or, in reverse
     // order, decimation-in-time passes (inverse); element k of the spectrum sits at LDS row pos[k]
