@@ -1857,11 +1857,13 @@ static int cg_iteration_fused(smoqy_ctx *c, const CgArgs &a, hipStream_t st, int
     // eight-stream bench (four alternating pairs); a single small batch keeps x cached (one walker: 40.9 against 47.3 ms per sweep)
     static const int xs_env = [] { const char *e = getenv("SMOQY_X_STREAM"); return e ? atoi(e) : -1; }();  // A/B switch
     t.x_stream = xs_env < 0 ? t.slim : (xs_env != 0);
-    // Workgroups go to the eight XCDs round-robin, each XCD has its own 4 MiB L2.  When a launch covers a multiple of eight systems and an
-    // XCD's share of the iteration's vectors (p, A p / ẑ, r̂, x) is small enough to live there, the τ-FFT and Chebyshev kernels take the
-    // blockIdx -> system map the MᵀM kernels already use (XCD x works on the contiguous share [x·n/8, (x+1)·n/8) of the systems): what one
-    // kernel wrote is still in that XCD's L2 when the next one reads it.  8 walkers on one stream: 59.7 -> 54.3 ms per sweep, 16: 80.3 ->
-    // 79.3, 32: 135.1 -> 138.0 (off there), the eight-stream bench unchanged.
+    // Workgroups go to the eight XCDs round-robin.  When a launch covers a multiple of eight systems the τ-FFT and Chebyshev kernels take the
+    // blockIdx -> system map the MᵀM kernels already use (XCD x works on the contiguous share [x·n/8, (x+1)·n/8) of the systems), so that in
+    // every kernel of the iteration an XCD touches the same eighth of each vector.  Measured: 8 walkers on one stream 57.7 -> 54.2 ms per
+    // sweep, 16: 79.9 -> 79.3, bond-SSH chain 16 walkers 55.7 -> 46.5, 32 walkers of the headline lattice 135.1 -> 138.0 (hence the size
+    // rule), the eight-stream bench unchanged.  It is NOT inter-kernel L2 reuse: FETCH_SIZE per kernel is the same with either map
+    // (8 walkers: 16.5 / 16.3 MB for the forward τ-FFT) — the L2s do not keep lines across kernel boundaries; what shrinks is the address
+    // range an XCD walks per kernel (translation and fabric locality).
     static const int xm_env = [] { const char *e = getenv("SMOQY_XCD_MAP"); return e ? atoi(e) : -1; }();  // A/B switch
     const size_t xcd_share = (size_t)(count / 8) * 4 * c->g.Lt * c->g.N * sizeof(double2);
     t.xcd_map = xm_env < 0 ? (count % 8 == 0 && xcd_share <= (size_t)8 << 20) : (xm_env != 0);

@@ -307,7 +307,8 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
     double2 *A = lds, *B = A + (size_t)Lt * SB, *WT = SLIM ? B : B + (size_t)Lt * SB;
     int *POS = reinterpret_cast<int *>(WT + Lt);  // SLIM only
     // XCD-aware order (workgroups go to the eight XCDs round-robin): XCD x works on the same contiguous share of the systems as in the MᵀM
-    // and Chebyshev kernels, so that what one kernel wrote is still in that XCD's L2 when the next kernel of the iteration reads it
+    // and Chebyshev kernels — every kernel of the iteration then walks the same eighth of each vector on a given XCD (api.hip,
+    // cg_iteration_fused, for what that buys and what it does not)
     int bid_ = blockIdx.x;
     if (a.xcd_map && (gridDim.x & 7) == 0) bid_ = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int tile = bid_ % a.ntile, sys = a.sys_first + bid_ / a.ntile;

@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT
 for ctr in FETCH_SIZE WRITE_SIZE; do
   out=$GRAFT_REPO_ROOT/gpurun_out/pmci_$ctr
   rm -rf $out
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -o run -- python3 tools/one_stream.py 16 > gpurun_out/pmci_$ctr.log 2>&1 || exit 1
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -o run -- python3 tools/one_stream.py ${PMC_WALKERS:-16} ${PMC_WORKLOAD:-} > gpurun_out/pmci_$ctr.log 2>&1 || exit 1
 done
 python3 - <<'PY'
 import csv, glob, json, collections
