@@ -35,6 +35,11 @@ __device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_doub
 // multiply by -i (forward) or +i (inverse)
 __device__ __forceinline__ double2 mul_mi(double2 a, bool inv) { return inv ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x); }
 
+// every kernel of this file is launched with 256 lanes.  A compile-time constant, not blockDim.x: that is a 16-bit global load from the
+// dispatch packet, and inside the pass loops the compiler re-issued it in every pass with an s_waitcnt vmcnt(0) behind it — a memory round
+// trip per pass on the critical path, and a drain of whatever loads were meant to travel under the passes
+constexpr int kTfftThreads = 256;
+
 template <int R>
 __device__ __forceinline__ void dft(double2 (&v)[R], const double2 *__restrict__ wt, int Lt, bool inv)
 {
@@ -116,7 +121,7 @@ template <int R>
 __device__ __forceinline__ void stockham_pass(const double2 *__restrict__ in, double2 *__restrict__ out, const double2 *__restrict__ wt, int Lt, int SB, int Ns, bool inv)
 {
     const int stride = Lt / R, nb = stride * SB, tw_step = Lt / (Ns * R);
-    for (int idx = threadIdx.x; idx < nb; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < nb; idx += kTfftThreads) {
         const int j = idx / SB, sb = idx - j * SB;
         const int k = j % Ns;
         double2 v[R];
@@ -144,7 +149,7 @@ __device__ __forceinline__ double2 *stockham(double2 *A, double2 *B, const doubl
     int Ns = 1;
     double2 *src = A, *dst = B;
     for (int f = 0; f < a.nfac; ++f) {
-        const int R = a.fac[f];
+        const int R = (int)((a.fpack >> (4 * f)) & 15u);  // not a.fac[f]: a dynamically indexed kernel argument is a global load + wait in every pass
         switch (R) {
             case 2: stockham_pass<2>(src, dst, wt, a.Lt, a.SB, Ns, inv); break;
             case 3: stockham_pass<3>(src, dst, wt, a.Lt, a.SB, Ns, inv); break;
@@ -167,7 +172,7 @@ template <int R, bool DIT>
 __device__ __forceinline__ void inplace_pass(double2 *__restrict__ X, const double2 *__restrict__ wt, int Lt, int SB, int ncur, bool inv)
 {
     const int m = ncur / R, nb = (Lt / R) * SB, tws = Lt / ncur, stride = m * SB;
-    for (int idx = threadIdx.x; idx < nb; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < nb; idx += kTfftThreads) {
         const int jg = idx / SB, sb = idx - jg * SB;
         const int blk = jg / m, j = jg - blk * m;
         double2 *x = X + (size_t)(blk * ncur + j) * SB + sb;
@@ -213,8 +218,9 @@ __device__ __forceinline__ void inplace_forward(double2 *X, const double2 *wt, c
 {
     int ncur = a.Lt;
     for (int f = 0; f < a.snfac; ++f) {
-        inplace_one<false>(X, wt, a, a.sfac[f], ncur, false);
-        ncur /= a.sfac[f];
+        const int R = (int)((a.sfpack >> (4 * f)) & 15u);
+        inplace_one<false>(X, wt, a, R, ncur, false);
+        ncur /= R;
     }
 }
 
@@ -223,8 +229,9 @@ __device__ __forceinline__ void inplace_inverse(double2 *X, const double2 *wt, c
 {
     int ncur = 1;
     for (int f = a.snfac - 1; f >= 0; --f) {
-        ncur *= a.sfac[f];
-        inplace_one<true>(X, wt, a, a.sfac[f], ncur, true);
+        const int R = (int)((a.sfpack >> (4 * f)) & 15u);
+        ncur *= R;
+        inplace_one<true>(X, wt, a, R, ncur, true);
     }
 }
 
@@ -239,7 +246,7 @@ __device__ __forceinline__ double2 bsum(double2 v, double *red)
 {
     v.x = wsum_t(v.x);
     v.y = wsum_t(v.y);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = (blockDim.x + 63) >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = (kTfftThreads + 63) >> 6;
     __syncthreads();
     if (lane == 0) { red[2 * wave] = v.x; red[2 * wave + 1] = v.y; }
     __syncthreads();
@@ -258,7 +265,7 @@ __device__ __forceinline__ void bsum4(double2 &u, double2 &v, double *red)
 {
     u.x = wsum_t(u.x); u.y = wsum_t(u.y);
     v.x = wsum_t(v.x); v.y = wsum_t(v.y);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = (blockDim.x + 63) >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = (kTfftThreads + 63) >> 6;
     __syncthreads();
     if (lane == 0) { red[4 * wave] = u.x; red[4 * wave + 1] = u.y; red[4 * wave + 2] = v.x; red[4 * wave + 3] = v.y; }
     __syncthreads();
@@ -276,14 +283,14 @@ __device__ __forceinline__ void bsum4(double2 &u, double2 &v, double *red)
 __device__ __forceinline__ double2 reduce_c(const double2 *part, int n, double *red)
 {
     double2 t = make_double2(0.0, 0.0);
-    for (int c = threadIdx.x; c < n; c += blockDim.x) { t.x += part[c].x; t.y += part[c].y; }
+    for (int c = threadIdx.x; c < n; c += kTfftThreads) { t.x += part[c].x; t.y += part[c].y; }
     return bsum(t, red);
 }
 
 __device__ __forceinline__ double reduce_r(const double *part, int n, double *red)
 {
     double2 t = make_double2(0.0, 0.0);
-    for (int c = threadIdx.x; c < n; c += blockDim.x) t.x += part[c];
+    for (int c = threadIdx.x; c < n; c += kTfftThreads) t.x += part[c];
     return bsum(t, red).x;
 }
 
@@ -335,7 +342,7 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
     const int i0 = tile * SB, ns = min(SB, N - i0);
     const size_t sstride = (size_t)a.nsys * N;
     const size_t base = (size_t)sys * N + i0;
-    for (int q = threadIdx.x; q < Lt; q += blockDim.x) {
+    for (int q = threadIdx.x; q < Lt; q += kTfftThreads) {
         WT[q] = a.wtab[q];
         if (SLIM) POS[q] = a.pos[q];
     }
@@ -358,7 +365,7 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
     }
 
     // 256 % SB == 0, so a lane keeps one site column sb and walks slices l0, l0 + lstep, ...
-    const int sb = threadIdx.x % SB, l0 = threadIdx.x / SB, lstep = blockDim.x / SB;
+    const int sb = threadIdx.x % SB, l0 = threadIdx.x / SB, lstep = kTfftThreads / SB;
     const bool act = sb < ns;
     constexpr int U = 4;  // slices in flight per lane: all loads of a batch are issued before its first store
 
@@ -388,14 +395,14 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
 
     if (MODE == MODE_FWD_CG) {
         const double2 *prz = a.part_rz + (size_t)sys * a.rz_stride, *ppz = a.part_pz + (size_t)sys * a.pz_stride;
-        for (int c = threadIdx.x + blockDim.x; c < a.nrz; c += blockDim.x) { q1.x += prz[c].x; q1.y += prz[c].y; }
-        for (int c = threadIdx.x + blockDim.x; c < a.npz; c += blockDim.x) { q2.x += ppz[c].x; q2.y += ppz[c].y; }
+        for (int c = threadIdx.x + kTfftThreads; c < a.nrz; c += kTfftThreads) { q1.x += prz[c].x; q1.y += prz[c].y; }
+        for (int c = threadIdx.x + kTfftThreads; c < a.npz; c += kTfftThreads) { q2.x += ppz[c].x; q2.y += ppz[c].y; }
         bsum4(q1, q2, red);  // q1 = r·z, q2 = p·Ap
     } else if (MODE == MODE_INV_CG) {
         const double *prr = a.part_rr + (size_t)sys * a.rr_stride;
         const double2 *prz = a.part_rz + (size_t)sys * a.rz_stride;
-        for (int c = threadIdx.x + blockDim.x; c < a.nrr; c += blockDim.x) q1.x += prr[c];
-        for (int c = threadIdx.x + blockDim.x; c < a.nrz; c += blockDim.x) { q2.x += prz[c].x; q2.y += prz[c].y; }
+        for (int c = threadIdx.x + kTfftThreads; c < a.nrr; c += kTfftThreads) q1.x += prr[c];
+        for (int c = threadIdx.x + kTfftThreads; c < a.nrz; c += kTfftThreads) { q2.x += prz[c].x; q2.y += prz[c].y; }
         bsum4(q1, q2, red);  // q1.x = |r|², q2 = r·z
     }
 
@@ -487,7 +494,7 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
             else if (s.iters >= s.maxiter) s.done = 2;
         }
     } else {
-        for (int idx = threadIdx.x; idx < Lt * SB; idx += blockDim.x) {
+        for (int idx = threadIdx.x; idx < Lt * SB; idx += kTfftThreads) {
             const int l = idx / SB, sb = idx - l * SB;
             if (sb < ns) {
                 double2 x = res[row(l) * SB + sb];
@@ -515,8 +522,8 @@ __global__ void __launch_bounds__(256) efa_kernel(EfaArgs a, TfftArgs plan)
     const int tile = blockIdx.x % a.ntile, w = blockIdx.x / a.ntile;
     const int i0 = tile * SB, ns = min(SB, Nph - i0);
     const size_t wbase = (size_t)w * Lt * Nph;
-    for (int q = threadIdx.x; q < Lt; q += blockDim.x) WT[q] = a.wtab[q];
-    for (int idx = threadIdx.x; idx < Lt * SB; idx += blockDim.x) {
+    for (int q = threadIdx.x; q < Lt; q += kTfftThreads) WT[q] = a.wtab[q];
+    for (int idx = threadIdx.x; idx < Lt * SB; idx += kTfftThreads) {
         const int l = idx / SB, sb = idx - l * SB;
         double2 z = make_double2(0.0, 0.0);
         if (sb < ns) {
@@ -532,7 +539,7 @@ __global__ void __launch_bounds__(256) efa_kernel(EfaArgs a, TfftArgs plan)
     double2 *oth = (res == A) ? B : A;
     double accK = 0.0, accS = 0.0;
     const double iLt = 1.0 / (double)Lt;
-    for (int idx = threadIdx.x; idx < Lt * SB; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < Lt * SB; idx += kTfftThreads) {
         const int om = idx / SB, sb = idx - om * SB;
         double2 out = make_double2(0.0, 0.0);
         if (sb < ns) {
@@ -569,7 +576,7 @@ __global__ void __launch_bounds__(256) efa_kernel(EfaArgs a, TfftArgs plan)
     __syncthreads();
     if (a.mode != 2) {
         res = stockham(oth, res, WT, plan, true);
-        for (int idx = threadIdx.x; idx < Lt * SB; idx += blockDim.x) {
+        for (int idx = threadIdx.x; idx < Lt * SB; idx += kTfftThreads) {
             const int l = idx / SB, sb = idx - l * SB;
             if (sb < ns && (a.mode == 1 || a.finite_mass[i0 + sb] != 0)) {  // an infinite-mass mode is not touched at all (its momentum is set to zero when sampled)
                 const size_t off = wbase + (size_t)l * Nph + i0 + sb;
@@ -604,6 +611,10 @@ bool tfft_plan(int Lt, int N, TfftArgs &a)
     const int spref[] = {4, 2, 3, 5};
     for (int R : spref)
         while (m % R == 0 && a.snfac < 16) { a.sfac[a.snfac++] = R; m /= R; }
+    // the kernels read the radices from these 4-bit packs (scalar shifts), not from the arrays (a global load and a wait per pass)
+    a.fpack = a.sfpack = 0;
+    for (int f = 0; f < a.nfac; ++f) a.fpack |= (unsigned long long)a.fac[f] << (4 * f);
+    for (int f = 0; f < a.snfac; ++f) a.sfpack |= (unsigned long long)a.sfac[f] << (4 * f);
     static const int slim_env = [] { const char *e = getenv("SMOQY_TFFT_SLIM"); return e ? atoi(e) : 0; }();
     a.x_stream = 0;  // decided per launch (api.hip: cg_iteration_fused)
     a.xcd_map = 0;   // decided per launch (api.hip: cg_iteration_fused)
@@ -655,7 +666,7 @@ hipError_t configure_tfft_kernels(const char **what)
 
 void launch_tfft(hipStream_t st, int mode, const TfftArgs &a)
 {
-    const dim3 grid((unsigned)(a.ntile * (a.sys_count > 0 ? a.sys_count : a.nsys))), block(256);
+    const dim3 grid((unsigned)(a.ntile * (a.sys_count > 0 ? a.sys_count : a.nsys))), block(kTfftThreads);
     if (a.slim && a.pos) {
         const size_t lds = ((size_t)a.Lt * a.SB + a.Lt) * sizeof(double2) + (size_t)a.Lt * sizeof(int);
         switch (mode) {
@@ -680,9 +691,11 @@ void launch_efa(hipStream_t st, const EfaArgs &a)
     TfftArgs plan{};
     plan.Lt = a.Lt; plan.N = a.Nph; plan.nsys = a.nw; plan.SB = a.SB; plan.ntile = a.ntile; plan.nfac = a.nfac;
     for (int f = 0; f < 16; ++f) plan.fac[f] = a.fac[f];
+    plan.fpack = 0;
+    for (int f = 0; f < a.nfac; ++f) plan.fpack |= (unsigned long long)a.fac[f] << (4 * f);
     plan.wtab = a.wtab;
     const size_t lds = (2 * (size_t)a.Lt * a.SB + a.Lt) * sizeof(double2);
-    hipLaunchKernelGGL(efa_kernel, dim3((unsigned)(a.ntile * a.nw)), dim3(256), lds, st, a, plan);
+    hipLaunchKernelGGL(efa_kernel, dim3((unsigned)(a.ntile * a.nw)), dim3(kTfftThreads), lds, st, a, plan);
 }
 
 }  // namespace smoqy

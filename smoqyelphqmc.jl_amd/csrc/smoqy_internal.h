@@ -301,6 +301,7 @@ struct TfftArgs {
     int x_stream;                         // inverse CG mode: nontemporal loads / stores for x
     int xcd_map;                          // blockIdx -> (tile, system) map that keeps a system's workgroups on one XCD
     int fac[16];
+    unsigned long long fpack, sfpack;     // fac / sfac packed four bits per radix: what the kernels read
     // in-place form (one LDS image): radix 2 / 3 / 4 / 5 factors `sfac` applied as decimation-in-frequency passes (forward) or, in reverse
     // order, decimation-in-time passes (inverse); element k of the spectrum sits at LDS row pos[k]
     int slim, slim_ok, snfac;             // slim: in-place form selected; slim_ok: Lt = 2^a 3^b 5^c, the in-place form exists
