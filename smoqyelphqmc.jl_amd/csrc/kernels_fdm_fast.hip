@@ -617,7 +617,7 @@ __global__ void __launch_bounds__(LB) fdm_stream_kernel(FdmArgs a, FdmFast ff)
     if ((nblk & 7) == 0) bid = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
     const int run = bid % nrun, sys = a.sys_first + bid / nrun;
     stamp_begin(a.stamp);
-    if (a.cg && a.cg[sys].done) return;
+    const int sys_done = a.cg ? a.cg[sys].done : 0;  // acted on in the prologue, with the bond program and the first two slices already in flight
     const int w = sys / a.nrhs;
     const int la = run * R, lb = min(Lt, la + R);  // output slices [la, lb)
     const size_t sstride = (size_t)a.nsys * N;
@@ -770,6 +770,7 @@ __global__ void __launch_bounds__(LB) fdm_stream_kernel(FdmArgs a, FdmFast ff)
     double2 pfa0, pfa1, pfb0, pfb1;
     LOAD_SLICE(pfa0, pfa1, min(la + 2, lb))  // needed as slices up to lb (the last one only for its values at the own sites)
     LOAD_SLICE(pfb0, pfb1, min(la + 3, lb))
+    if (sys_done) return;  // workgroup-uniform; nothing has been stored yet
     LOAD_FLD(csn, dni, dnj, la + 2)
     LOAD_FLD(cs2, d2i, d2j, la)        // slot 2 of the prologue: B_la on v[la-1]
     LOAD_FLD(cs1, d1i, d1j, la + 1)    // slot 1: B_{la+1} on v[la]

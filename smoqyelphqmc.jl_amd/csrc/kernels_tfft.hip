@@ -319,25 +319,21 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
     int bid_ = blockIdx.x;
     if (a.xcd_map && (gridDim.x & 7) == 0) bid_ = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int tile = bid_ % a.ntile, sys = a.sys_first + bid_ / a.ntile;
+    int st_done = 0, st_stop = 0;
     if (MODE == MODE_FWD_CG) {
         // `done` was written by an earlier launch (inverse kernel of the previous iteration or cg_start): safe to gate on.
         // Latch it into `stop` for the inverse kernel of THIS iteration, which must not look at `done` (it writes it).
-        const int done = a.st[sys].done;
-        if (done) {
-            if (tile == 0 && threadIdx.x == 0) a.st[sys].stop = done;
-            return;
-        }
+        st_done = a.st[sys].done;  // acted on below, behind the first staging loads (one memory latency instead of two in a row)
     }
     // the recurrence scalars of this system, read with the stop flag (same cache line) instead of after the transform
     double st_normb2 = 1.0, st_tol = 0.0;
     double2 st_alpha = make_double2(0.0, 0.0), st_rho = make_double2(1.0, 0.0);
     if (MODE == MODE_INV_CG) {
         const CgState &s0 = a.st[sys];
-        const int stop = s0.stop;
+        st_stop = s0.stop;         // likewise
         st_normb2 = s0.normb2; st_tol = s0.tol;
         st_alpha = make_double2(s0.alpha_re, s0.alpha_im);
         st_rho = make_double2(s0.rho_re, s0.rho_im);
-        if (stop) return;
     }
     const int i0 = tile * SB, ns = min(SB, N - i0);
     const size_t sstride = (size_t)a.nsys * N;
@@ -379,6 +375,16 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
             for (int u = 0; u < U; ++u) {
                 const int lu = l + u * lstep;
                 t[u] = (act && lu < Lt) ? src[(size_t)lu * sstride + base + sb] : make_double2(0.0, 0.0);
+            }
+            if (l == l0) {
+                // the early exits (workgroup-uniform), with the tile's first loads already in flight.  `done` was written by an earlier launch
+                // (inverse kernel of the previous iteration or cg_start): safe to gate on; it is latched into `stop` for the inverse kernel of
+                // THIS iteration, which must not look at `done` (it writes it).
+                if (MODE == MODE_FWD_CG && st_done) {
+                    if (tile == 0 && threadIdx.x == 0) a.st[sys].stop = st_done;
+                    return;
+                }
+                if (MODE == MODE_INV_CG && st_stop) return;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
