@@ -338,12 +338,26 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
     const int i0 = tile * SB, ns = min(SB, N - i0);
     const size_t sstride = (size_t)a.nsys * N;
     const size_t base = (size_t)sys * N + i0;
-    for (int q = threadIdx.x; q < Lt; q += kTfftThreads) {
-        WT[q] = a.wtab[q];
-        if (SLIM) POS[q] = a.pos[q];
-    }
+    // One round of loads: the twiddle table and the row positions (first 256 entries: one per lane, into registers), the partial sums and
+    // the tile's first batch of slices are all requested before any of them is waited for; the LDS copies of the tables are written
+    // behind the staging loads (staging_tables below).  As first written (tables: load, wait, store; then the rest) every workgroup paid a
+    // full memory round trip before it asked for its data.
     constexpr bool INV = (MODE == MODE_PLAIN_INV || MODE == MODE_INV_CG);
-    if (SLIM && INV) __syncthreads();  // the staging below scatters through POS
+    const int tq_ = min((int)threadIdx.x, Lt - 1);
+    const double2 wt0_ = a.wtab[tq_];
+    int pos0_ = 0;
+    if (SLIM) pos0_ = a.pos[tq_];
+    auto staging_tables = [&]() {
+        if ((int)threadIdx.x < Lt) {
+            WT[threadIdx.x] = wt0_;
+            if (SLIM) POS[threadIdx.x] = pos0_;
+        }
+        for (int q = threadIdx.x + kTfftThreads; q < Lt; q += kTfftThreads) {  // Lτ > 256 only
+            WT[q] = a.wtab[q];
+            if (SLIM) POS[q] = a.pos[q];
+        }
+        if (SLIM && INV) __syncthreads();  // the staging stores scatter through POS
+    };
 
     // The scalars of the CG recurrence (α; the stop test and β) depend on the partial sums the previous kernels left, not on this
     // kernel's transform: their loads are issued here, in front of the staging loads, and reduced before the passes, so that their memory
@@ -351,13 +365,17 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
     double2 q1 = make_double2(0.0, 0.0), q2 = make_double2(0.0, 0.0);
     if (MODE == MODE_FWD_CG) {
         const double2 *prz = a.part_rz + (size_t)sys * a.rz_stride, *ppz = a.part_pz + (size_t)sys * a.pz_stride;
-        if ((int)threadIdx.x < a.nrz) q1 = prz[threadIdx.x];
-        if ((int)threadIdx.x < a.npz) q2 = ppz[threadIdx.x];
+        // unconditional, clamped (see the staging loads): lanes beyond the count drop their value
+        const double2 v1 = prz[min((int)threadIdx.x, a.nrz - 1)], v2 = ppz[min((int)threadIdx.x, a.npz - 1)];
+        if ((int)threadIdx.x < a.nrz) q1 = v1;
+        if ((int)threadIdx.x < a.npz) q2 = v2;
     } else if (MODE == MODE_INV_CG) {
         const double *prr = a.part_rr + (size_t)sys * a.rr_stride;
         const double2 *prz = a.part_rz + (size_t)sys * a.rz_stride;
-        if ((int)threadIdx.x < a.nrr) q1.x = prr[threadIdx.x];
-        if ((int)threadIdx.x < a.nrz) q2 = prz[threadIdx.x];
+        const double v1 = prr[min((int)threadIdx.x, a.nrr - 1)];
+        const double2 v2 = prz[min((int)threadIdx.x, a.nrz - 1)];
+        if ((int)threadIdx.x < a.nrr) q1.x = v1;
+        if ((int)threadIdx.x < a.nrz) q2 = v2;
     }
 
     // 256 % SB == 0, so a lane keeps one site column sb and walks slices l0, l0 + lstep, ...
@@ -369,33 +387,50 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
     // per lane in flight, and with a single wave of workgroups on the chip the kernel is then bound by memory latency, not bandwidth
     {
         const double2 *src = (MODE == MODE_FWD_CG) ? a.z : a.src;  // forward CG mode transforms A p
-        for (int l = l0; l < Lt; l += U * lstep) {
-            double2 t[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int lu = l + u * lstep;
-                t[u] = (act && lu < Lt) ? src[(size_t)lu * sstride + base + sb] : make_double2(0.0, 0.0);
-            }
-            if (l == l0) {
-                // the early exits (workgroup-uniform), with the tile's first loads already in flight.  `done` was written by an earlier launch
-                // (inverse kernel of the previous iteration or cg_start): safe to gate on; it is latched into `stop` for the inverse kernel of
-                // THIS iteration, which must not look at `done` (it writes it).
-                if (MODE == MODE_FWD_CG && st_done) {
-                    if (tile == 0 && threadIdx.x == 0) a.st[sys].stop = st_done;
-                    return;
-                }
-                if (MODE == MODE_INV_CG && st_stop) return;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int lu = l + u * lstep;
-                if (lu < Lt) {
-                    double2 x = t[u];
-                    if (MODE != MODE_FWD_CG && a.pre_tw && act) x = cm(x, a.pre_tw[lu]);
-                    A[((SLIM && INV) ? POS[lu] : lu) * SB + sb] = x;
-                }
-            }
+        // one batch: loads (unconditional, clamped addresses — a load inside a branch makes the compiler lose count of what is in flight
+        // and fall back to `s_waitcnt vmcnt(0)`, which here sat in front of the loads: a full round trip for the partial sums requested
+        // above before the tile's data were even asked for), then the LDS stores
+#define TFFT_STAGE_LOADS(l_)                                                                              \
+        double2 t0_, t1_, t2_, t3_;                                                                       \
+        {                                                                                                 \
+            const size_t col_ = base + (act ? sb : 0);                                                    \
+            t0_ = src[(size_t)min((l_), Lt - 1) * sstride + col_];                                        \
+            t1_ = src[(size_t)min((l_) + lstep, Lt - 1) * sstride + col_];                                \
+            t2_ = src[(size_t)min((l_) + 2 * lstep, Lt - 1) * sstride + col_];                            \
+            t3_ = src[(size_t)min((l_) + 3 * lstep, Lt - 1) * sstride + col_];                            \
         }
+#define TFFT_STAGE_STORE(t_, lu_)                                                                         \
+        if ((lu_) < Lt) {                                                                                 \
+            double2 x_ = act ? (t_) : make_double2(0.0, 0.0);                                             \
+            if (MODE != MODE_FWD_CG && a.pre_tw && act) x_ = cm(x_, a.pre_tw[(lu_)]);                     \
+            A[((SLIM && INV) ? POS[(lu_)] : (lu_)) * SB + sb] = x_;                                       \
+        }
+        static_assert(U == 4, "the staging macros are written for four slices in flight");
+        {   // first batch, straight-line: the table copies and the early exits sit between its loads and its stores
+            TFFT_STAGE_LOADS(l0)
+            staging_tables();
+            // the early exits (workgroup-uniform), with the tile's first loads already in flight.  `done` was written by an earlier launch
+            // (inverse kernel of the previous iteration or cg_start): safe to gate on; it is latched into `stop` for the inverse kernel of
+            // THIS iteration, which must not look at `done` (it writes it).
+            if (MODE == MODE_FWD_CG && st_done) {
+                if (tile == 0 && threadIdx.x == 0) a.st[sys].stop = st_done;
+                return;
+            }
+            if (MODE == MODE_INV_CG && st_stop) return;
+            TFFT_STAGE_STORE(t0_, l0)
+            TFFT_STAGE_STORE(t1_, l0 + lstep)
+            TFFT_STAGE_STORE(t2_, l0 + 2 * lstep)
+            TFFT_STAGE_STORE(t3_, l0 + 3 * lstep)
+        }
+        for (int l = l0 + U * lstep; l < Lt; l += U * lstep) {  // Lτ > U·lstep only
+            TFFT_STAGE_LOADS(l)
+            TFFT_STAGE_STORE(t0_, l)
+            TFFT_STAGE_STORE(t1_, l + lstep)
+            TFFT_STAGE_STORE(t2_, l + 2 * lstep)
+            TFFT_STAGE_STORE(t3_, l + 3 * lstep)
+        }
+#undef TFFT_STAGE_LOADS
+#undef TFFT_STAGE_STORE
         __syncthreads();
     }
 
