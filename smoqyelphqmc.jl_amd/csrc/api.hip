@@ -90,7 +90,7 @@ struct smoqy_ctx {
     size_t big_stride = 0;
     double2 *part_pz = nullptr, *part_rz = nullptr, *part_c = nullptr, *d_dot_out = nullptr;
     double *part_rr = nullptr, *part_bb = nullptr;
-    CgState *d_st = nullptr, *h_st = nullptr;
+    CgState *d_st = nullptr, *h_st = nullptr, *d_st_idle = nullptr;
     void *h_poll_dot = nullptr;  // pinned staging for per-system scalars (smoqy_pff_step_v)
     double2 *h_traj_dot = nullptr;  // pinned [Nt][nsys]: S_f of every step of a device trajectory, read once at its end
     size_t traj_cap = 0;
@@ -295,7 +295,7 @@ static FdmArgs fdm_args(smoqy_ctx *c, const double2 *in, double2 *out, double2 *
     a.Tc = c->Tc; a.nchunk = c->nchunk;
     a.bonds = c->d_bonds; a.col_off = c->d_col_off;
     a.expV = c->d_expV; a.ch = c->d_ch; a.sh = c->d_sh; a.shi = c->d_shi;
-    a.in = in; a.out = out; a.partial = partial; a.cg = cg;
+    a.in = in; a.out = out; a.partial = partial; a.cg = cg ? cg : c->d_st_idle;
     a.sys_first = sys0; a.sys_count = count;
     a.hop_re = 1.0; a.hop_im = 0.0; a.antiperiodic = 1;  // the reference operator
     a.scratch = c->d_big; a.scratch_stride = c->big_stride;
@@ -311,7 +311,7 @@ static KpmArgs kpm_args(smoqy_ctx *c, double2 *v, const CgState *cg)
     k.dbar = c->d_dbar; k.cbar = c->d_cbar; k.sbar = c->d_sbar; k.sbari = c->d_sbari;
     k.order = c->d_order; k.coefs = c->d_coefs; k.bounds = c->d_bounds; k.active = c->d_active;
     k.nslot = c->nslot; k.maxorder = c->maxorder;
-    k.v = v; k.cg = cg;
+    k.v = v; k.cg = cg ? cg : c->d_st_idle;
     k.part_rz = nullptr; k.rz_stride = 2 * g.Lt; k.scale = 1.0 / (double)g.Lt;  // two r·z slots per frequency: the component-split Chebyshev kernel fills both
     k.scratch = c->d_big; k.scratch_stride = c->big_stride;
     k.heavy = c->cheb_heavy; k.group = 8;  // light workgroups of cheb_own_kernel: eight single-term frequencies each
@@ -418,7 +418,7 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->plan_f_oop) rocfft_plan_destroy(c->plan_f_oop);
     if (c->fft_info) rocfft_execution_info_destroy(c->fft_info);
     void *ptrs[] = {c->d_bonds, c->d_col_off, c->d_expV, c->d_ch, c->d_sh, c->d_lam, c->d_stage, c->d_stage_real, c->d_stage_int, c->scr[0], c->scr[1], c->scr[2], c->cg_r, c->cg_p,
-                    c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->fft_work, c->d_tw, c->d_th, c->d_wtab, c->d_tpos, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
+                    c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->d_st_idle, c->fft_work, c->d_tw, c->d_th, c->d_wtab, c->d_tpos, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
                     c->d_rand, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_big, c->d_shi, c->d_sbari};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -558,6 +558,10 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     HIPCHK(c, hipMalloc(&c->d_dot_out, (size_t)g.nsys * sizeof(double2)));
     HIPCHK(c, hipMalloc(&c->d_st, (size_t)g.nsys * sizeof(CgState)));
     HIPCHK(c, hipMemset(c->d_st, 0, (size_t)g.nsys * sizeof(CgState)));
+    // an all-zero state ("nobody is done") for launches outside a CG loop: the kernels read the flag unconditionally — a load inside an
+    // `if (cg)` is waited for on the spot, in front of everything else the workgroup could have asked for
+    HIPCHK(c, hipMalloc(&c->d_st_idle, (size_t)g.nsys * sizeof(CgState)));
+    HIPCHK(c, hipMemset(c->d_st_idle, 0, (size_t)g.nsys * sizeof(CgState)));
     HIPCHK(c, hipHostMalloc(&c->h_st, (size_t)g.nsys * sizeof(CgState)));
     HIPCHK(c, hipHostMalloc(&c->h_poll_dot, (size_t)g.nsys * sizeof(double2)));
     choose_chunking(c);

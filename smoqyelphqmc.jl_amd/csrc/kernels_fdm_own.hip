@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(TMAX) fdm_own_kernel(FdmArgs a, FdmFast ff)
     if ((nblk & 7) == 0) bid = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
     const int chunk = bid % a.nchunk, sys = a.sys_first + bid / a.nchunk;
     stamp_begin(a.stamp);
-    const int sys_done = a.cg ? a.cg[sys].done : 0;  // acted on below, with the lane program's loads already in flight (one round trip less in front of the data)
+    const int sys_done = a.cg[sys].done;  // (a.cg is never null)  // acted on below, with the lane program's loads already in flight (one round trip less in front of the data)
     const int w = sys / a.nrhs;
     const int Lt = a.Lt, N = a.N, T = blockDim.x, T2 = 2 * T, j = threadIdx.x;
     const int l0 = chunk * a.Tc;
@@ -172,6 +172,7 @@ __global__ void __launch_bounds__(TMAX) fdm_own_kernel(FdmArgs a, FdmFast ff)
     }
     // hoppings that do not depend on τ are fetched once instead of once per slice
     const bool cs_varies = ff.cs_varies[w] != 0;
+    asm volatile("" ::: "memory");  // compiler fence: keeps the loads above on this side of the early return (no instruction, no wait)
     if (sys_done) return;  // workgroup-uniform
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) {

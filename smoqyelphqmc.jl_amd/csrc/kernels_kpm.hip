@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
     const int sys = k.sys_first + blockIdx.x % ncnt_, rank = blockIdx.x / ncnt_;
     const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);  // heaviest orders first
     const int w = sys / k.nrhs;
-    if (k.cg && k.cg[sys].done) return;
+    if (k.cg[sys].done) return;  // k.cg is never null (api.hip: an all-zero state outside CG loops)
     const double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
     double2 *vo = (k.vout ? k.vout : k.v) + ((size_t)om * k.nsys + sys) * N;
     double2 *prz = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride + om : nullptr;
@@ -713,7 +713,7 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
         // elements (a lane serves the sites j and j + Tn: N <= 2 Tn), then the stores and ONE reduction pass for all the Parseval sums.
         constexpr int GMAX = 8;
         const int r0 = heavy + (slotid - heavy_slots) * k.group, r1 = min(Lt, r0 + min(k.group, GMAX));
-        const bool sys_done = (k.cg ? k.cg[sys].done : 0) != 0;
+        const bool sys_done = k.cg[sys].done != 0;  // (k.cg is never null)
         const bool act = k.active[w] != 0;
         int omg[GMAX];
         double fg[GMAX];
@@ -790,7 +790,7 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
     // the expansion order, the spectral bounds and the lane program's table indices.  The workgroup with the longest chain sets the
     // duration of the launch and every serial round trip in front of the chain adds to it; as written naively (flag, return; active,
     // order, return; bounds; table; gathers) that was five.
-    const bool sys_done = (k.cg ? k.cg[sys].done : 0) != 0;
+    const bool sys_done = k.cg[sys].done != 0;  // (k.cg is never null)
     const bool act = k.active[w] != 0;
     const int n_raw = k.order[(size_t)w * k.nslot + slot];
     const double emin = k.bounds[2 * w], emax = k.bounds[2 * w + 1];
@@ -889,7 +889,7 @@ __global__ void __launch_bounds__(1024) cheb_own_asym_kernel(KpmArgs k, KpmGeom 
     const int Lo2 = (Lt + 1) / 2;
     if (k.half && om >= Lo2) return;
     // round 1 of loads (see cheb_own_kernel)
-    const bool sys_done = (k.cg ? k.cg[sys].done : 0) != 0;
+    const bool sys_done = k.cg[sys].done != 0;  // (k.cg is never null)
     const bool act = k.active[w] != 0;
     const int n_raw = k.order[(size_t)w * k.nslot + om], n2_raw = k.order[(size_t)w * k.nslot + omc];
     const double emin = k.bounds[2 * w], emax = k.bounds[2 * w + 1];
@@ -1131,7 +1131,7 @@ __global__ void __launch_bounds__(kThreads) cheb_generic_kernel(KpmArgs k)
     const int sys = k.sys_first + blockIdx.x % ncnt_, rank = blockIdx.x / ncnt_;
     const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);
     const int w = sys / k.nrhs;
-    if (k.cg && k.cg[sys].done) return;
+    if (k.cg[sys].done) return;  // k.cg is never null (api.hip: an all-zero state outside CG loops)
     if (k.half && om >= (Lt + 1) / 2) return;
     const double *dbar = k.dbar + (size_t)w * N, *cbar = k.cbar + (size_t)w * k.Nh, *sbar = k.sbar + (size_t)w * k.Nh;
     const double *sbari = k.sbari ? k.sbari + (size_t)w * k.Nh : nullptr;
