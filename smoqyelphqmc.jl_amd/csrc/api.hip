@@ -733,12 +733,19 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
                     if (b.y != b.x) slot[b.y] = T + j;
                 }
                 bool ok = g.ncol >= 3;
+                // ... and, stronger: are they the lane's neighbours in its row of 16 lanes, cyclically (mate of the first site one lane
+                // down, mate of the second one lane up, or the other way round)?  Then the exchange is two DPP row rotations — register
+                // moves, no LDS permute unit at all (wl0 = 2 / 3).  Honeycomb L = 16: the colour-0 bond is the one along the rows of 16 cells.
+                bool rot_dn = ok && nb == T && T % 16 == 0, rot_up = rot_dn;
                 for (int j = 0; j < nb && ok; ++j) {
                     const int2 b = pb[(size_t)poff[q_cheb] + j];
                     const int sx = slot[mate[0][b.x]], sy = slot[mate[0][b.y]];
                     ok = sx >= T && (sx - T) / 64 == j / 64 && sy < T && sy / 64 == j / 64;
+                    const int dn = (j & ~15) | ((j - 1) & 15), up = (j & ~15) | ((j + 1) & 15);
+                    rot_dn = rot_dn && ok && sx - T == dn && sy == up;
+                    rot_up = rot_up && ok && sx - T == up && sy == dn;
                 }
-                c->kg.wl0 = ok ? 1 : 0;
+                c->kg.wl0 = ok ? (rot_dn ? 2 : (rot_up ? 3 : 1)) : 0;
             }
             if (q_fdm == q_cheb) { c->d_own_f = c->d_own; c->ff.own_n = c->kg.own_n; }
             else if (int rc = build_own(q_fdm, &c->d_own_f, &c->ff.own_n)) return rc;

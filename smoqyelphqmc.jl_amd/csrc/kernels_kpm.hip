@@ -454,6 +454,27 @@ __device__ __forceinline__ double cmul(double2 c, double x) { return c.x * x; }
 __device__ __forceinline__ double2 cmul(double2 c, double2 x) { return cmulk(c, x); }
 __device__ __forceinline__ double shfl(double x, int lane) { return __shfl(x, lane, 64); }
 __device__ __forceinline__ double2 shfl(double2 x, int lane) { return make_double2(__shfl(x.x, lane, 64), __shfl(x.y, lane, 64)); }
+// rotation within rows of 16 lanes as a DPP modifier (a register move — no trip through the LDS permute unit as for ds_bpermute):
+// CTRL = 0x120 + n is row_ror:n, lane i takes the value of lane (i - n) mod 16 of its row
+template <int CTRL>
+__device__ __forceinline__ double row_rot(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double2 row_rot(double2 x) { return make_double2(row_rot<CTRL>(x.x), row_rot<CTRL>(x.y)); }
+// the two colour-0 mates of a lane under KpmGeom::wl0 = WL0: 1 — any lanes of the wavefront (ds_bpermute); 2 / 3 — the neighbours in the
+// lane's row of 16, cyclically (mate of the first site one lane down and of the second one lane up, or the other way round)
+template <int WL0, class T>
+__device__ __forceinline__ void wl_mates(T ax, T ay, int wl_x, int wl_y, T &mx, T &my)
+{
+    if constexpr (WL0 == 2) { mx = row_rot<0x121>(ay); my = row_rot<0x12F>(ax); }
+    else if constexpr (WL0 == 3) { mx = row_rot<0x12F>(ay); my = row_rot<0x121>(ax); }
+    else { mx = shfl(ay, wl_x); my = shfl(ax, wl_y); }
+}
 __device__ __forceinline__ double ld(const double2 *v, int i, int comp, double) { return comp ? v[i].y : v[i].x; }
 __device__ __forceinline__ double2 ld(const double2 *v, int i, int, double2) { return v[i]; }
 __device__ __forceinline__ void st(double2 *v, int i, int comp, double x) { if (comp) v[i].y = x; else v[i].x = x; }
@@ -566,7 +587,7 @@ __device__ __forceinline__ void own_load_prog(OwnProg<NCOL> &P, const OwnIdx<NCO
 
 // (ax, ay) <- B̄ (ax, ay) for the Sym propagator in its plain form B̄ = C_{L-1} … C_1 (C_0 D̄ C_0) C_1 … C_{L-1} (no basis change: what
 // Lanczos needs, KPMPreconditioner.jl:625-639) on the lane's own two sites; all lanes of the workgroup call it together
-template <int NCOL, class T, bool WL0 = false>
+template <int NCOL, class T, int WL0 = 0>
 __device__ __forceinline__ void own_bbar_apply(const OwnProg<NCOL> &P, T &ax, T &ay, T *Wb0, T *Wb1, int &buf)
 {
     using namespace ownk;
@@ -574,7 +595,8 @@ __device__ __forceinline__ void own_bbar_apply(const OwnProg<NCOL> &P, T &ax, T 
 #pragma unroll
     for (int c = NCOL - 1; c >= 1; --c) OWN_STAGE(c)
     if constexpr (WL0 && Q != 0) {  // the colour-0 mates sit in this wavefront (KpmGeom::wl0): shuffles instead of an LDS exchange
-        const T mx_ = shfl(ay, (P.px[0] - (int)blockDim.x) & 63), my_ = shfl(ax, P.py[0] & 63);
+        T mx_, my_;
+        wl_mates<WL0>(ax, ay, (P.px[0] - (int)blockDim.x) & 63, P.py[0] & 63, mx_, my_);
         T x_ = lin(P.cx[0].x, ax, P.cx[0].y, mx_), xm_ = lin(P.cx[0].x, mx_, P.cx[0].y, ax);
         T y_ = lin(P.cy[0].x, ay, P.cy[0].y, my_), ym_ = lin(P.cy[0].x, my_, P.cy[0].y, ay);
         x_ = scl(P.dx, x_);
@@ -596,7 +618,7 @@ __device__ __forceinline__ void own_bbar_apply(const OwnProg<NCOL> &P, T &ax, T 
 // the first site in some lane's second slot and vice versa (KpmGeom::wl0; honeycomb L = 16: the colour-0 partner is the neighbouring cell
 // of the same row of 16).  The centre exchange of a Chebyshev step then needs no LDS image and no barrier: two wave shuffles
 // (ds_bpermute) bring the mates.  Same values, same arithmetic: bit-identical to the LDS form.
-template <int NCOL, class T, bool WL0 = false>
+template <int NCOL, class T, int WL0 = 0>
 __device__ __forceinline__ void own_chain(const OwnProg<NCOL> &P, T &ax, T &ay, T *Wb0, T *Wb1, int &buf, const double2 *CF, int n, double avg, double imag_)
 {
     using namespace ownk;
@@ -626,8 +648,7 @@ __device__ __forceinline__ void own_chain(const OwnProg<NCOL> &P, T &ax, T &ay, 
         } else {       // one exchange; the mate's value after C₁ and D̄ is recomputed here (same bond, its own d̄)
             T mx, my;
             if constexpr (WL0) {
-                mx = shfl(ay, wl_x);
-                my = shfl(ax, wl_y);
+                wl_mates<WL0>(ax, ay, wl_x, wl_y, mx, my);
             } else {
                 OWN_EXCHANGE(0, mx, my)
             }
@@ -685,7 +706,7 @@ __device__ __forceinline__ void own_chain(const OwnProg<NCOL> &P, T &ax, T &ay, 
 // light frequency costs ≈ 2 µs of a workgroup slot for 16 KB of traffic — the round trips in front of the work — and with a workgroup per
 // frequency and component the Chebyshev kernel held more wave-slot time than any other kernel of the iteration (SQ_WAVE_CYCLES 35.4 M
 // against 31.9 M for MᵀM, profiles/r02_pmc_lds_iteration.txt), which is what the multi-stream bench is bound by.
-template <int NCOL, bool SPLIT, bool WL0 = false>
+template <int NCOL, bool SPLIT, int WL0 = 0>
 __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
 {
     static_assert(NCOL >= 2, "single-colour decompositions use cheb_fast_kernel");
@@ -1204,12 +1225,17 @@ void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
             const size_t olds = (split ? sizeof(double) : sizeof(double2)) * 4 * (size_t)kg.threads + sizeof(double2) * (size_t)k.maxorder;
             const dim3 ogrid((unsigned)(((split ? 2 : 1) * kk.heavy + nlight) * ncnt));
             static const int env_wl = [] { const char *e = getenv("SMOQY_CHEB_WL0"); return (e && e[0] == '0') ? 0 : 1; }();  // A/B switch, default on
-            const bool wl0 = kg.wl0 && k.ncol >= 3 && env_wl;
+            // wave-local colour-0 exchange: 0 off, 1 ds_bpermute, 2 / 3 DPP row rotations (KpmGeom::wl0; SMOQY_CHEB_WL0=0 / 1 caps it)
+            static const int env_wl_cap = [] { const char *e = getenv("SMOQY_CHEB_WL0"); return e ? atoi(e) : 3; }();
+            int wl0 = (k.ncol >= 3 && env_wl) ? kg.wl0 : 0;
+            if (wl0 > 1 && (env_wl_cap == 1 || !split)) wl0 = 1;  // the DPP forms are instantiated for the component-split kernel only
 #define OWN_LAUNCH(C_)                                                                                          \
     {                                                                                                           \
-        if (split && wl0) hipLaunchKernelGGL((cheb_own_kernel<C_, true, true>), ogrid, block, olds, st, kk, kg); \
+        if (split && wl0 == 2) hipLaunchKernelGGL((cheb_own_kernel<C_, true, 2>), ogrid, block, olds, st, kk, kg); \
+        else if (split && wl0 == 3) hipLaunchKernelGGL((cheb_own_kernel<C_, true, 3>), ogrid, block, olds, st, kk, kg); \
+        else if (split && wl0) hipLaunchKernelGGL((cheb_own_kernel<C_, true, 1>), ogrid, block, olds, st, kk, kg); \
         else if (split) hipLaunchKernelGGL((cheb_own_kernel<C_, true>), ogrid, block, olds, st, kk, kg);         \
-        else if (wl0) hipLaunchKernelGGL((cheb_own_kernel<C_, false, true>), ogrid, block, olds, st, kk, kg);    \
+        else if (wl0) hipLaunchKernelGGL((cheb_own_kernel<C_, false, 1>), ogrid, block, olds, st, kk, kg);       \
         else hipLaunchKernelGGL((cheb_own_kernel<C_, false>), ogrid, block, olds, st, kk, kg);                   \
     }
             switch (k.ncol) {
@@ -1494,7 +1520,7 @@ __global__ void __launch_bounds__(1024) lanczos_kernel(KpmArgs k, KpmGeom kg, in
 // B̄ is applied through the lane program of cheb_own_kernel (three exchanges per apply on the honeycomb lattice instead of five LDS
 // read-modify-write stages) and each of the two inner products of a step costs one barrier (wave sums ping-pong between two LDS rows).
 // Arithmetic per site is that of lanczos_kernel; the inner products add the sites in lane order instead of LDS-position order.
-template <int NCOL, bool WL0>
+template <int NCOL, int WL0>
 __global__ void __launch_bounds__(1024) lanczos_own_kernel(KpmArgs k, KpmGeom kg, int w0, const double *__restrict__ randvec, int nsteps, double *alpha, double *beta, PreUpd u)
 {
     using namespace ownk;
@@ -1556,22 +1582,25 @@ hipError_t configure_kpm_kernels(const char **what)
     SMOQY_SET_LDS((lanczos_kernel<0, false>), 160 * 1024 - 256);
     SMOQY_SET_LDS((lanczos_kernel<2, false>), 160 * 1024 - 256);
     SMOQY_SET_LDS(kpm_expansions_kernel, 160 * 1024 - 256);
-    SMOQY_SET_LDS((lanczos_own_kernel<2, false>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
-    SMOQY_SET_LDS((lanczos_own_kernel<2, true>), 160 * 1024 - 1024);
-    SMOQY_SET_LDS((lanczos_own_kernel<3, false>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
-    SMOQY_SET_LDS((lanczos_own_kernel<3, true>), 160 * 1024 - 1024);
-    SMOQY_SET_LDS((lanczos_own_kernel<4, false>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
-    SMOQY_SET_LDS((lanczos_own_kernel<4, true>), 160 * 1024 - 1024);
-    SMOQY_SET_LDS((lanczos_own_kernel<5, false>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
-    SMOQY_SET_LDS((lanczos_own_kernel<5, true>), 160 * 1024 - 1024);
-    SMOQY_SET_LDS((lanczos_own_kernel<6, false>), 160 * 1024 - 1024);  // 320 bytes of static LDS besides
-    SMOQY_SET_LDS((lanczos_own_kernel<6, true>), 160 * 1024 - 1024);
+#define SMOQY_LANCZOS_OWN_LDS(C_)                                         \
+    SMOQY_SET_LDS((lanczos_own_kernel<C_, 0>), 160 * 1024 - 1024); /* 320 bytes of static LDS besides */ \
+    SMOQY_SET_LDS((lanczos_own_kernel<C_, 1>), 160 * 1024 - 1024);         \
+    SMOQY_SET_LDS((lanczos_own_kernel<C_, 2>), 160 * 1024 - 1024);         \
+    SMOQY_SET_LDS((lanczos_own_kernel<C_, 3>), 160 * 1024 - 1024);
+    SMOQY_LANCZOS_OWN_LDS(2)
+    SMOQY_LANCZOS_OWN_LDS(3)
+    SMOQY_LANCZOS_OWN_LDS(4)
+    SMOQY_LANCZOS_OWN_LDS(5)
+    SMOQY_LANCZOS_OWN_LDS(6)
+#undef SMOQY_LANCZOS_OWN_LDS
     // owner-computes Chebyshev kernels: four images of `threads` values + the coefficient tables pass 64 KB at 1024 threads (complex values)
 #define SMOQY_OWN_LDS(C_)                                                  \
     SMOQY_SET_LDS((cheb_own_kernel<C_, false>), 160 * 1024 - 256);         \
     SMOQY_SET_LDS((cheb_own_kernel<C_, true>), 160 * 1024 - 256);          \
-    SMOQY_SET_LDS((cheb_own_kernel<C_, false, true>), 160 * 1024 - 256);   \
-    SMOQY_SET_LDS((cheb_own_kernel<C_, true, true>), 160 * 1024 - 256);    \
+    SMOQY_SET_LDS((cheb_own_kernel<C_, false, 1>), 160 * 1024 - 256);      \
+    SMOQY_SET_LDS((cheb_own_kernel<C_, true, 1>), 160 * 1024 - 256);       \
+    SMOQY_SET_LDS((cheb_own_kernel<C_, true, 2>), 160 * 1024 - 256);       \
+    SMOQY_SET_LDS((cheb_own_kernel<C_, true, 3>), 160 * 1024 - 256);       \
     SMOQY_SET_LDS((cheb_own_asym_kernel<C_>), 160 * 1024 - 256);
     SMOQY_OWN_LDS(2) SMOQY_OWN_LDS(3) SMOQY_OWN_LDS(4) SMOQY_OWN_LDS(5) SMOQY_OWN_LDS(6)
 #undef SMOQY_OWN_LDS
@@ -1584,11 +1613,13 @@ void launch_lanczos(hipStream_t st, const KpmArgs &k, const KpmGeom &kg, int w0,
     const int threads = kg.fast ? kg.threads : kThreads;
     if (kg.fast && !use_BtB && k.ncol >= 2 && k.ncol <= kMaxColours && kg.own && cheb_own_enabled() && k.sbari == nullptr) {
         const size_t olds = sizeof(double) * (4 * (size_t)kg.threads + 2 * (size_t)nsteps);
-        const bool wl0 = kg.wl0 && k.ncol >= 3;
+        const int wl0 = k.ncol >= 3 ? kg.wl0 : 0;
 #define LANCZOS_OWN(C_)                                                                                                                         \
     {                                                                                                                                           \
-        if (wl0) hipLaunchKernelGGL((lanczos_own_kernel<C_, true>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u);  \
-        else hipLaunchKernelGGL((lanczos_own_kernel<C_, false>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u);     \
+        if (wl0 == 2) hipLaunchKernelGGL((lanczos_own_kernel<C_, 2>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u);  \
+        else if (wl0 == 3) hipLaunchKernelGGL((lanczos_own_kernel<C_, 3>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u);  \
+        else if (wl0) hipLaunchKernelGGL((lanczos_own_kernel<C_, 1>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u);  \
+        else hipLaunchKernelGGL((lanczos_own_kernel<C_, 0>), dim3(nw), dim3(threads), olds, st, k, kg, w0, randvec, nsteps, alpha, beta, u);     \
     }
         switch (k.ncol) {
             case 2: LANCZOS_OWN(2); break;
