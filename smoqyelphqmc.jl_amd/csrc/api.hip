@@ -747,6 +747,9 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
                 }
                 c->kg.wl0 = ok ? (rot_dn ? 2 : (rot_up ? 3 : 1)) : 0;
             }
+            // the MᵀM kernel for small launches shares the lane layout when it owns the same colour: the DPP form of the colour-0 exchange too
+            static const bool wl_env_off = [] { const char *e = getenv("SMOQY_CHEB_WL0"); return e && (e[0] == '0' || e[0] == '1'); }();
+            c->ff.wl0 = (q_fdm == q_cheb && c->kg.wl0 >= 2 && !wl_env_off) ? c->kg.wl0 : 0;
             if (q_fdm == q_cheb) { c->d_own_f = c->d_own; c->ff.own_n = c->kg.own_n; }
             else if (int rc = build_own(q_fdm, &c->d_own_f, &c->ff.own_n)) return rc;
             c->ff.own = c->d_own_f;

@@ -34,6 +34,18 @@ __device__ __forceinline__ double2 hopcomb_o(double2 v, double2 u, bool wrap, bo
     return make_double2(v.x - (pr * u.x - pi * u.y), v.y - (pr * u.y + pi * u.x));
 }
 
+// rotation within rows of 16 lanes as a DPP modifier (see kernels_kpm.hip, row_rot): CTRL = 0x120 + n is row_ror:n
+template <int CTRL>
+__device__ __forceinline__ double2 row_rot_o(double2 x)
+{
+    int a0 = __double2loint(x.x), a1 = __double2hiint(x.x), b0 = __double2loint(x.y), b1 = __double2hiint(x.y);
+    a0 = __builtin_amdgcn_update_dpp(0, a0, CTRL, 0xf, 0xf, false);
+    a1 = __builtin_amdgcn_update_dpp(0, a1, CTRL, 0xf, 0xf, false);
+    b0 = __builtin_amdgcn_update_dpp(0, b0, CTRL, 0xf, 0xf, false);
+    b1 = __builtin_amdgcn_update_dpp(0, b1, CTRL, 0xf, 0xf, false);
+    return make_double2(__hiloint2double(a1, a0), __hiloint2double(b1, b0));
+}
+
 template <int NCOL, int KM>
 struct OwnLane {
     int ox, oy;                   // LDS slots of the two own sites (equal for a self bond)
@@ -45,7 +57,7 @@ struct OwnLane {
 
 // (ux, uy)[k] <- B (ux, uy)[k] for k < nk, fields of register slice k + SH
 template <int NCOL, int KM, int SH>
-__device__ __forceinline__ void propagate_own(const OwnLane<NCOL, KM> &ln, double2 (&ux)[KM], double2 (&uy)[KM], int nk, double2 *W0, double2 *W1, int &buf, int T2)
+__device__ __forceinline__ void propagate_own(const OwnLane<NCOL, KM> &ln, double2 (&ux)[KM], double2 (&uy)[KM], int nk, double2 *W0, double2 *W1, int &buf, int T2, int wl0)
 {
     constexpr int Q = NCOL >= 2 ? 1 : 0;
 #define FDM_OWN_EXCHANGE(c_, mx_, my_)                                              \
@@ -95,7 +107,15 @@ __device__ __forceinline__ void propagate_own(const OwnLane<NCOL, KM> &ln, doubl
             }
     } else {          // one exchange; the mate's value after C₁ and D is recomputed (same bond, its own exp(-ΔτV))
         double2 mx[KM], my[KM];
-        FDM_OWN_EXCHANGE(0, mx, my)
+        if (wl0 == 2) {         // the mates are the lane's row neighbours (FdmFast::wl0): two DPP row rotations, no LDS image, no barrier
+#pragma unroll
+            for (int k = 0; k < KM - SH; ++k) { mx[k] = row_rot_o<0x121>(uy[k]); my[k] = row_rot_o<0x12F>(ux[k]); }
+        } else if (wl0 == 3) {
+#pragma unroll
+            for (int k = 0; k < KM - SH; ++k) { mx[k] = row_rot_o<0x12F>(uy[k]); my[k] = row_rot_o<0x121>(ux[k]); }
+        } else {
+            FDM_OWN_EXCHANGE(0, mx, my)
+        }
 #pragma unroll
         for (int k = 0; k < KM - SH; ++k)
             if (k < nk) {
@@ -229,7 +249,7 @@ __global__ void __launch_bounds__(TMAX) fdm_own_kernel(FdmArgs a, FdmFast ff)
 
     int buf = 0;
     double2 acc = make_double2(0.0, 0.0);
-    propagate_own<NCOL, KM, 0>(ln, ux, uy, K1, W0, W1, buf, T2);
+    propagate_own<NCOL, KM, 0>(ln, ux, uy, K1, W0, W1, buf, T2, ff.wl0);
     if (!FUSED) {
         // M:  out[l] = v[l] ∓ B_l v[l-1]  (+ on the first slice);  Mᵀ: out[l] = v[l] ∓ B_{l+1} v[l+1]  (+ on the last)
 #pragma unroll
@@ -270,8 +290,8 @@ __global__ void __launch_bounds__(TMAX) fdm_own_kernel(FdmArgs a, FdmFast ff)
             ux[k] = (ks < KM) ? yx[ks < KM ? ks : 0] : make_double2(0.0, 0.0);
             uy[k] = (ks < KM) ? yy[ks < KM ? ks : 0] : make_double2(0.0, 0.0);
         }
-        if (OP == SMOQY_OP_MTM) propagate_own<NCOL, KM, 1>(ln, ux, uy, nk, W0, W1, buf, T2);
-        else propagate_own<NCOL, KM, 0>(ln, ux, uy, nk, W0, W1, buf, T2);
+        if (OP == SMOQY_OP_MTM) propagate_own<NCOL, KM, 1>(ln, ux, uy, nk, W0, W1, buf, T2, ff.wl0);
+        else propagate_own<NCOL, KM, 0>(ln, ux, uy, nk, W0, W1, buf, T2, ff.wl0);
 #pragma unroll
         for (int k = 0; k < KM - 1; ++k) {
             if (k < nk && ln.on) {

@@ -164,6 +164,7 @@ struct FdmFast {
     const int *own;      // owner-computes tables (layout as KpmGeom::own) for owned colour 1 (0 when there is one colour)
     int own_n;
     int full;            // every colour is a perfect matching: `threads` two-site bonds per padded list, N = 2·threads (fdm_stream_kernel<…, FULL>)
+    int wl0;             // fdm_own_kernel: the colour-0 mates are the lane's neighbours in its row of 16 lanes (2 / 3 as KpmGeom::wl0, else 0)
 };
 
 // ---- launchers (defined in the .hip files) -----------------------------------------------
