@@ -14,10 +14,15 @@ ev = ev[len(ev) // 2:]  # steady state
 
 
 def short(n):
-    for key in ("cheb_own", "cheb_fast", "cheb_generic", "tfft_kernel<2>", "tfft_kernel<3>", "tfft_kernel<0>", "tfft_kernel<1>", "fdm_own", "fdm_fast", "fdm_kernel", "lanczos", "copyBuffer", "fillBuffer"):
+    # template arguments differ from build to build ("tfft_kernel<2, false>", "cheb_own_kernel<3, true, 3>"): classify by the stem and, for
+    # the tau-FFT, its mode
+    for mode in "0123":
+        if f"tfft_kernel<{mode}," in n:
+            return f"tfft_kernel<{mode}>"
+    for key in ("cheb_own", "cheb_fast", "cheb_generic", "fdm_stream", "fdm_own", "fdm_fast", "fdm_kernel", "lanczos", "copyBuffer", "fillBuffer"):
         if key in n:
             return key
-    return n.split("(")[0][-28:]
+    return n.replace("void ", "").replace("smoqy::", "").replace("(anonymous namespace)::", "").split("(")[0][-28:]
 
 
 gaps, durs = collections.defaultdict(list), collections.defaultdict(list)
@@ -28,7 +33,7 @@ print(f"{'pair':48s} {'count':>7s} {'median gap us':>14s} {'mean':>8s} {'p90':>8
 for k, g in sorted(gaps.items(), key=lambda kv: -len(kv[1]))[:14]:
     g.sort()
     print(f"{k[0] + ' -> ' + k[1]:48s} {len(g):7d} {g[len(g) // 2] / 1e3:14.2f} {sum(g) / len(g) / 1e3:8.2f} {g[int(.9 * len(g))] / 1e3:8.2f}")
-loop = ["fdm_own", "tfft_kernel<2>", "cheb_own", "tfft_kernel<3>"]
+loop = ["fdm_stream" if durs.get("fdm_stream") else "fdm_own", "tfft_kernel<2>", "cheb_own", "tfft_kernel<3>"]
 tot_k = sum(sorted(durs[k])[len(durs[k]) // 2] for k in loop if durs[k]) / 1e3
 tot_g = sum(sorted(gaps[(a, b)])[len(gaps[(a, b)]) // 2] for a, b in zip(loop, loop[1:] + loop[:1]) if gaps[(a, b)]) / 1e3
 print(f"one iteration (medians): kernels {tot_k:.1f} us + boundaries {tot_g:.1f} us = {tot_k + tot_g:.1f} us")
