@@ -40,3 +40,7 @@ print(f"one iteration (medians): kernels {tot_k:.1f} us + boundaries {tot_g:.1f}
 span = ev[-1][1] - ev[0][0]
 busy = sum(e - s for s, e, _ in ev)
 print(f"window {span / 1e6:.2f} ms, kernels busy {busy / 1e6:.2f} ms ({100 * busy / span:.1f} %)")
+# the tail of the iteration-closing boundary: how many of its gaps are not back to back, and what they add up to
+g = sorted(gaps[(loop[3], loop[0])])
+big = [x for x in g if x > 2000]
+print(f"{loop[3]} -> {loop[0]}: {len(g)} boundaries, {len(big)} above 2 us adding up to {sum(big) / 1e6:.2f} ms (largest {max(g) / 1e3:.1f} us)" if g else "")
