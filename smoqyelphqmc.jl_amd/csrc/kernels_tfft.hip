@@ -305,9 +305,33 @@ enum { MODE_PLAIN_FWD = 0, MODE_PLAIN_INV = 1, MODE_FWD_CG = 2, MODE_INV_CG = 3 
 // SLIM: the in-place form (one LDS image, radix <= 7): about half the LDS and two thirds of the registers of the ping-pong form, so
 // more workgroups fit a CU when several CG pipelines share the chip
 typedef double v2d_t __attribute__((ext_vector_type(2)));
-template <int MODE, bool SLIM>
+// ---- register-blocked form of the two-image transform (EDGE): Lτ = 4 · M · 4 with M = 4 or 8 and a tile of exactly 4 slices per lane
+// (Lτ · SB = 1024).  A lane's four staged slices n1 + (Lτ/4)·n2 are the inputs of one radix-4 butterfly of a decimation-in-frequency first
+// stage, and its four epilogue slices l0 + (Lτ/4)·u are the outputs of one radix-4 butterfly of a decimation-in-time last stage.  Both are
+// done in registers, so the LDS sees ONE pass (radix M) instead of three:
+//   X[k2 + 4 k1] = Σ_n1 W_Lτ^{n1 k2} [Σ_n2 x[n1 + (Lτ/4) n2] (∓i)^{n2 k2}] W_{Lτ/4}^{n1 k1},     n1 = 4a + b,  k1 = k' + M u:
+//   y_k2[n1] (staging)  ->  Z_{k2,b}[k'] = Σ_a y_k2[4a + b] W_M^{a k'} (LDS pass)  ->  X[l0 + (Lτ/4) u] = Σ_b (∓i)^{bu} W_Lτ^{4 b k'} Z_{k2,b}[k'],
+// k2 = l0 mod 4, k' = l0 div 4.  Same arithmetic as the three Stockham passes up to the order of the additions.
+template <int M>
+__device__ __forceinline__ void edge_middle(const double2 *__restrict__ in, double2 *__restrict__ out, int SB, bool inv)
+{
+    // work item = (b, k2, sb): the M values y_k2[4a + b] -> Z_{k2,b}[k'],  in[(n1·4 + k2)·SB + sb],  out[((k'·4 + b)·4 + k2)·SB + sb]
+    for (int w = threadIdx.x; w < 16 * SB; w += kTfftThreads) {
+        const int sb = w % SB, k2 = (w / SB) & 3, b = w / (4 * SB);
+        double2 v[M];
+#pragma unroll
+        for (int a_ = 0; a_ < M; ++a_) v[a_] = in[(size_t)((4 * a_ + b) * 4 + k2) * SB + sb];
+        dft<M>(v, nullptr, 0, inv);
+#pragma unroll
+        for (int kp = 0; kp < M; ++kp) out[(size_t)((kp * 4 + b) * 4 + k2) * SB + sb] = v[kp];
+    }
+    __syncthreads();
+}
+
+template <int MODE, bool SLIM, bool EDGE = false>
 __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
 {
+    static_assert(!(SLIM && EDGE), "the register-blocked edges belong to the two-image form");
     extern __shared__ double2 lds[];
     __shared__ double red[36];
     const int Lt = a.Lt, SB = a.SB, N = a.N;
@@ -408,6 +432,8 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
         static_assert(U == 4, "the staging macros are written for four slices in flight");
         {   // first batch, straight-line: the table copies and the early exits sit between its loads and its stores
             TFFT_STAGE_LOADS(l0)
+            double2 ew1 = make_double2(1.0, 0.0), ew2 = ew1, ew3 = ew1;  // EDGE: W^{n1 k2}, n1 = l0
+            if (EDGE) { ew1 = a.wtab[l0]; ew2 = a.wtab[2 * l0]; ew3 = a.wtab[3 * l0]; }
             staging_tables();
             // the early exits (workgroup-uniform), with the tile's first loads already in flight.  `done` was written by an earlier launch
             // (inverse kernel of the previous iteration or cg_start): safe to gate on; it is latched into `stop` for the inverse kernel of
@@ -417,10 +443,26 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
                 return;
             }
             if (MODE == MODE_INV_CG && st_stop) return;
+            if (EDGE) {
+                // first stage in registers: radix-4 butterfly over the lane's four slices, twiddles W^{n1 k2}, y_k2[n1] to A[(n1·4 + k2)·SB + sb]
+                double2 v4[4] = {t0_, t1_, t2_, t3_};
+                if (!act) v4[0] = v4[1] = v4[2] = v4[3] = make_double2(0.0, 0.0);
+                if (MODE != MODE_FWD_CG && a.pre_tw && act) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v4[u] = cm(v4[u], a.pre_tw[l0 + u * lstep]);
+                }
+                dft<4>(v4, nullptr, 0, INV);
+                if (INV) { ew1.y = -ew1.y; ew2.y = -ew2.y; ew3.y = -ew3.y; }
+                A[(size_t)(l0 * 4 + 0) * SB + sb] = v4[0];
+                A[(size_t)(l0 * 4 + 1) * SB + sb] = cm(v4[1], ew1);
+                A[(size_t)(l0 * 4 + 2) * SB + sb] = cm(v4[2], ew2);
+                A[(size_t)(l0 * 4 + 3) * SB + sb] = cm(v4[3], ew3);
+            } else {
             TFFT_STAGE_STORE(t0_, l0)
             TFFT_STAGE_STORE(t1_, l0 + lstep)
             TFFT_STAGE_STORE(t2_, l0 + 2 * lstep)
             TFFT_STAGE_STORE(t3_, l0 + 3 * lstep)
+            }
         }
         for (int l = l0 + U * lstep; l < Lt; l += U * lstep) {  // Lτ > U·lstep only
             TFFT_STAGE_LOADS(l)
@@ -447,8 +489,25 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
         bsum4(q1, q2, red);  // q1.x = |r|², q2 = r·z
     }
 
-    const double2 *res;
-    if (SLIM) {
+    const double2 *res = A;
+    double2 eo[4];  // EDGE: the lane's four outputs X[l0 + lstep·u]
+    if (EDGE) {
+        if (a.edge == 8) edge_middle<8>(A, B, SB, INV);
+        else edge_middle<4>(A, B, SB, INV);
+        // last stage in registers: Z_{k2,b}[k'] for b = 0..3, twiddles W^{4 b k'}, radix-4 butterfly
+        const int k2 = l0 & 3, kp = l0 >> 2;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            double2 z = B[(size_t)((kp * 4 + b) * 4 + k2) * SB + sb];
+            if (b > 0) {
+                double2 w = WT[4 * b * kp];
+                if (INV) w.y = -w.y;
+                z = cm(z, w);
+            }
+            eo[b] = z;
+        }
+        dft<4>(eo, nullptr, 0, INV);
+    } else if (SLIM) {
         if (INV) inplace_inverse(A, WT, a);
         else inplace_forward(A, WT, a);
         res = A;
@@ -457,6 +516,7 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
     }
     // LDS row of output element l
     auto row = [&](int l) { return (SLIM && !INV) ? POS[l] : l; };
+    (void)eo;
 
     if (MODE == MODE_FWD_CG) {
         // ConjugateGradient.jl:219-226 in frequency space: α = (r·z)/(p·Ap), r̂ -= α·FFT(Ap), |r|² = Σ|r̂|²/Lτ
@@ -475,7 +535,7 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
                 for (int u = 0; u < U; ++u) {
                     const int lu = l + u * lstep;
                     if (lu < Lt) {
-                        const double2 rn = csub(rv[u], cm(alpha, res[row(lu) * SB + sb]));
+                        const double2 rn = csub(rv[u], cm(alpha, EDGE ? eo[u] : res[row(lu) * SB + sb]));
                         a.r[(size_t)lu * sstride + base + sb] = rn;
                         acc += rn.x * rn.x + rn.y * rn.y;
                     }
@@ -522,7 +582,7 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
                         const double2 xn_ = cadd(xv[u], cm(alpha, pv[u]));
                         if (a.x_stream) { v2d_t t_; t_.x = xn_.x; t_.y = xn_.y; __builtin_nontemporal_store(t_, reinterpret_cast<v2d_t *>(a.x + off)); }
                         else a.x[off] = xn_;
-                        if (!conv) a.p[off] = cadd(res[lu * SB + sb], cm(beta, pv[u]));
+                        if (!conv) a.p[off] = cadd(EDGE ? eo[u] : res[lu * SB + sb], cm(beta, pv[u]));
                     }
                 }
             }
@@ -533,6 +593,17 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
             s.iters += 1;
             if (conv) s.done = 1;
             else if (s.iters >= s.maxiter) s.done = 2;
+        }
+    } else if (EDGE) {
+        // plain modes: the lane's four outputs sit in registers (same (slice, site) map as the loop below: idx = l·SB + sb, l = l0 + lstep·u)
+        if (act) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int l = l0 + u * lstep;
+                double2 x = eo[u];
+                if (a.post_tw) { const double2 w = a.post_tw[l]; x = cm(x, make_double2(w.x, -w.y)); }
+                a.dst[(size_t)l * sstride + base + sb] = x;
+            }
         }
     } else {
         for (int idx = threadIdx.x; idx < Lt * SB; idx += kTfftThreads) {
@@ -671,6 +742,9 @@ bool tfft_plan(int Lt, int N, TfftArgs &a)
     while (a.SB > 4 && (2 * (size_t)Lt * a.SB + Lt) * sizeof(double2) > lds_cap) a.SB /= 2;
     if ((2 * (size_t)Lt * a.SB + Lt) * sizeof(double2) > 150 * 1024) return false;
     a.ntile = (N + a.SB - 1) / a.SB;
+    // register-blocked two-image form (tfft_kernel<…, EDGE>): Lτ = 64 or 128 with exactly four slices per lane; SMOQY_TFFT_EDGE=0 switches it off
+    static const int edge_env = [] { const char *e = getenv("SMOQY_TFFT_EDGE"); return (e && e[0] == '0') ? 0 : 1; }();
+    a.edge = (edge_env && (Lt == 64 || Lt == 128) && Lt * a.SB == 4 * kTfftThreads) ? Lt / 16 : 0;
     return true;
 }
 
@@ -697,6 +771,10 @@ hipError_t configure_tfft_kernels(const char **what)
     SMOQY_SET_LDS((tfft_kernel<1, false>), 160 * 1024 - 512);
     SMOQY_SET_LDS((tfft_kernel<2, false>), 160 * 1024 - 512);
     SMOQY_SET_LDS((tfft_kernel<3, false>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((tfft_kernel<0, false, true>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((tfft_kernel<1, false, true>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((tfft_kernel<2, false, true>), 160 * 1024 - 512);
+    SMOQY_SET_LDS((tfft_kernel<3, false, true>), 160 * 1024 - 512);
     SMOQY_SET_LDS((tfft_kernel<0, true>), 160 * 1024 - 512);
     SMOQY_SET_LDS((tfft_kernel<1, true>), 160 * 1024 - 512);
     SMOQY_SET_LDS((tfft_kernel<2, true>), 160 * 1024 - 512);
@@ -719,6 +797,15 @@ void launch_tfft(hipStream_t st, int mode, const TfftArgs &a)
         return;
     }
     const size_t lds = (2 * (size_t)a.Lt * a.SB + a.Lt) * sizeof(double2);
+    if (a.edge) {
+        switch (mode) {
+            case 0: hipLaunchKernelGGL((tfft_kernel<0, false, true>), grid, block, lds, st, a); break;
+            case 1: hipLaunchKernelGGL((tfft_kernel<1, false, true>), grid, block, lds, st, a); break;
+            case 2: hipLaunchKernelGGL((tfft_kernel<2, false, true>), grid, block, lds, st, a); break;
+            default: hipLaunchKernelGGL((tfft_kernel<3, false, true>), grid, block, lds, st, a); break;
+        }
+        return;
+    }
     switch (mode) {
         case 0: hipLaunchKernelGGL((tfft_kernel<0, false>), grid, block, lds, st, a); break;
         case 1: hipLaunchKernelGGL((tfft_kernel<1, false>), grid, block, lds, st, a); break;
