@@ -308,34 +308,36 @@ typedef double v2d_t __attribute__((ext_vector_type(2)));
 // ---- register-blocked form of the two-image transform (EDGE): Lτ = 4 · M · 4 with M = 4 or 8 and a tile of exactly 4 slices per lane
 // (Lτ · SB = 1024).  A lane's four staged slices n1 + (Lτ/4)·n2 are the inputs of one radix-4 butterfly of a decimation-in-frequency first
 // stage, and its four epilogue slices l0 + (Lτ/4)·u are the outputs of one radix-4 butterfly of a decimation-in-time last stage.  Both are
-// done in registers, so the LDS sees ONE pass (radix M) instead of three:
+// done in registers, so the LDS sees ONE pass (radix M, in place: one image) instead of three (two-image form) or four (in-place form):
 //   X[k2 + 4 k1] = Σ_n1 W_Lτ^{n1 k2} [Σ_n2 x[n1 + (Lτ/4) n2] (∓i)^{n2 k2}] W_{Lτ/4}^{n1 k1},     n1 = 4a + b,  k1 = k' + M u:
 //   y_k2[n1] (staging)  ->  Z_{k2,b}[k'] = Σ_a y_k2[4a + b] W_M^{a k'} (LDS pass)  ->  X[l0 + (Lτ/4) u] = Σ_b (∓i)^{bu} W_Lτ^{4 b k'} Z_{k2,b}[k'],
 // k2 = l0 mod 4, k' = l0 div 4.  Same arithmetic as the three Stockham passes up to the order of the additions.
 template <int M>
-__device__ __forceinline__ void edge_middle(const double2 *__restrict__ in, double2 *__restrict__ out, int SB, bool inv)
+__device__ __forceinline__ void edge_middle(double2 *X, int SB, bool inv)
 {
-    // work item = (b, k2, sb): the M values y_k2[4a + b] -> Z_{k2,b}[k'],  in[(n1·4 + k2)·SB + sb],  out[((k'·4 + b)·4 + k2)·SB + sb]
+    // work item = (b, k2, sb): the M values y_k2[4a + b] at X[((4a + b)·4 + k2)·SB + sb] -> Z_{k2,b}[k'] at X[((4k' + b)·4 + k2)·SB + sb]:
+    // a butterfly writes the M rows it read, so the pass is in place and the form needs ONE LDS image
     for (int w = threadIdx.x; w < 16 * SB; w += kTfftThreads) {
         const int sb = w % SB, k2 = (w / SB) & 3, b = w / (4 * SB);
+        double2 *x = X + (size_t)(b * 4 + k2) * SB + sb;
         double2 v[M];
 #pragma unroll
-        for (int a_ = 0; a_ < M; ++a_) v[a_] = in[(size_t)((4 * a_ + b) * 4 + k2) * SB + sb];
+        for (int a_ = 0; a_ < M; ++a_) v[a_] = x[(size_t)a_ * 16 * SB];
         dft<M>(v, nullptr, 0, inv);
 #pragma unroll
-        for (int kp = 0; kp < M; ++kp) out[(size_t)((kp * 4 + b) * 4 + k2) * SB + sb] = v[kp];
+        for (int kp = 0; kp < M; ++kp) x[(size_t)kp * 16 * SB] = v[kp];
     }
     __syncthreads();
 }
 
 template <int MODE, bool SLIM, bool EDGE = false>
-__global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
+__global__ void __launch_bounds__(256, (SLIM || EDGE) ? 6 : 1) tfft_kernel(TfftArgs a)
 {
-    static_assert(!(SLIM && EDGE), "the register-blocked edges belong to the two-image form");
+    static_assert(!(SLIM && EDGE), "the register-blocked form replaces both pass schedules");
     extern __shared__ double2 lds[];
     __shared__ double red[36];
     const int Lt = a.Lt, SB = a.SB, N = a.N;
-    double2 *A = lds, *B = A + (size_t)Lt * SB, *WT = SLIM ? B : B + (size_t)Lt * SB;
+    double2 *A = lds, *B = A + (size_t)Lt * SB, *WT = (SLIM || EDGE) ? B : B + (size_t)Lt * SB;  // one image in the in-place and register-blocked forms
     int *POS = reinterpret_cast<int *>(WT + Lt);  // SLIM only
     // XCD-aware order (workgroups go to the eight XCDs round-robin): XCD x works on the same contiguous share of the systems as in the MᵀM
     // and Chebyshev kernels — every kernel of the iteration then walks the same eighth of each vector on a given XCD (api.hip,
@@ -492,13 +494,13 @@ __global__ void __launch_bounds__(256, SLIM ? 6 : 1) tfft_kernel(TfftArgs a)
     const double2 *res = A;
     double2 eo[4];  // EDGE: the lane's four outputs X[l0 + lstep·u]
     if (EDGE) {
-        if (a.edge == 8) edge_middle<8>(A, B, SB, INV);
-        else edge_middle<4>(A, B, SB, INV);
+        if (a.edge == 8) edge_middle<8>(A, SB, INV);
+        else edge_middle<4>(A, SB, INV);
         // last stage in registers: Z_{k2,b}[k'] for b = 0..3, twiddles W^{4 b k'}, radix-4 butterfly
         const int k2 = l0 & 3, kp = l0 >> 2;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            double2 z = B[(size_t)((kp * 4 + b) * 4 + k2) * SB + sb];
+            double2 z = A[(size_t)((kp * 4 + b) * 4 + k2) * SB + sb];
             if (b > 0) {
                 double2 w = WT[4 * b * kp];
                 if (INV) w.y = -w.y;
@@ -786,6 +788,16 @@ hipError_t configure_tfft_kernels(const char **what)
 void launch_tfft(hipStream_t st, int mode, const TfftArgs &a)
 {
     const dim3 grid((unsigned)(a.ntile * (a.sys_count > 0 ? a.sys_count : a.nsys))), block(kTfftThreads);
+    if (a.edge) {  // register-blocked form (Lτ = 64, 128): one image, one pass — stands in for both the two-image and the in-place request
+        const size_t lds = ((size_t)a.Lt * a.SB + a.Lt) * sizeof(double2);
+        switch (mode) {
+            case 0: hipLaunchKernelGGL((tfft_kernel<0, false, true>), grid, block, lds, st, a); break;
+            case 1: hipLaunchKernelGGL((tfft_kernel<1, false, true>), grid, block, lds, st, a); break;
+            case 2: hipLaunchKernelGGL((tfft_kernel<2, false, true>), grid, block, lds, st, a); break;
+            default: hipLaunchKernelGGL((tfft_kernel<3, false, true>), grid, block, lds, st, a); break;
+        }
+        return;
+    }
     if (a.slim && a.pos) {
         const size_t lds = ((size_t)a.Lt * a.SB + a.Lt) * sizeof(double2) + (size_t)a.Lt * sizeof(int);
         switch (mode) {
@@ -797,15 +809,6 @@ void launch_tfft(hipStream_t st, int mode, const TfftArgs &a)
         return;
     }
     const size_t lds = (2 * (size_t)a.Lt * a.SB + a.Lt) * sizeof(double2);
-    if (a.edge) {
-        switch (mode) {
-            case 0: hipLaunchKernelGGL((tfft_kernel<0, false, true>), grid, block, lds, st, a); break;
-            case 1: hipLaunchKernelGGL((tfft_kernel<1, false, true>), grid, block, lds, st, a); break;
-            case 2: hipLaunchKernelGGL((tfft_kernel<2, false, true>), grid, block, lds, st, a); break;
-            default: hipLaunchKernelGGL((tfft_kernel<3, false, true>), grid, block, lds, st, a); break;
-        }
-        return;
-    }
     switch (mode) {
         case 0: hipLaunchKernelGGL((tfft_kernel<0, false>), grid, block, lds, st, a); break;
         case 1: hipLaunchKernelGGL((tfft_kernel<1, false>), grid, block, lds, st, a); break;

@@ -33,7 +33,8 @@ def test_bench_shape_with_the_round_2_twins_of_the_round_3_kernels(wl0):
     colour-0 mates sit inside a wavefront: the headline lattice).  Their round-2 forms — the chunked MᵀM kernel and the LDS exchange — stay
     selectable (SMOQY_FDM_STREAM=0, SMOQY_CHEB_WL0=0) and are re-run here at the benchmarked shape of the headline lattice against the
     oracle, same tolerances."""
-    env = dict(os.environ, SMOQY_FDM_STREAM="0", SMOQY_CHEB_WL0=wl0)
+    # SMOQY_TFFT_EDGE=0: the Stockham / in-place pass schedules instead of the register-blocked τ-FFT that Lτ = 128 now takes
+    env = dict(os.environ, SMOQY_FDM_STREAM="0", SMOQY_CHEB_WL0=wl0, SMOQY_TFFT_EDGE="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_bench_shape.py"), "-m", "gpu", "-x", "-q", "-k", "honeycomb and 16sys and not switched_off"],
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
