@@ -379,7 +379,8 @@ int fdm_own_enabled()
 // 54.8 vs 60.3 µs at 64).  Hence the batch limit.
 bool fdm_own_supported(const FdmArgs &a, const FdmFast &ff, bool sym)
 {
-    return sym && ff.enabled && ff.own && fdm_own_enabled() && a.sys_count <= 8 && a.ncol >= 1 && a.ncol <= kFdmColours && a.Tc + 1 <= 3 &&
+    static const int own_max = [] { const char *e = getenv("SMOQY_FDM_OWN_MAX"); return e ? atoi(e) : 8; }();  // experiment knob: systems per launch up to which this kernel is chosen
+    return sym && ff.enabled && ff.own && fdm_own_enabled() && a.sys_count <= own_max && a.ncol >= 1 && a.ncol <= kFdmColours && a.Tc + 1 <= 3 &&
            sizeof(double2) * 2 * (size_t)(a.Tc + 1 <= 2 ? 2 : 3) * 2 * (size_t)ff.threads <= 64 * 1024;
 }
 
