@@ -1202,7 +1202,8 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
         static const int nt_env = [] { const char *e = getenv("SMOQY_NT_FIELDS"); return e ? atoi(e) : -1; }();  // A/B switch
         a.nt_fields = nt_env < 0 ? (c->tf_ok && c->tf.slim) : (nt_env != 0);
     }
-    if (a.run_len > 0 && fdm_stream_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_stream(st, a, c->ff, cs_const);
+    if (a.run_len > 0 && fdm_own_stream_supported(a, c->ff, c->g.is_sym != 0, cs_const)) launch_fdm_own_stream(st, a, c->ff);
+    else if (a.run_len > 0 && fdm_stream_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_stream(st, a, c->ff, cs_const);
     else if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_own(st, op, a, c->ff);
     else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_fast(st, op, a, c->ff, c->g.is_sym != 0, cs_const);
     else launch_fdm(st, op, c->g.is_sym != 0, a, c->d_big ? 0 : fdm_lds_bytes(op, c->g.N, c->Tc));

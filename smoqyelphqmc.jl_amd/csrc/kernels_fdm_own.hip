@@ -56,7 +56,8 @@ struct OwnLane {
 };
 
 // (ux, uy)[k] <- B (ux, uy)[k] for k < nk, fields of register slice k + SH
-template <int NCOL, int KM, int SH>
+// CS1 = 0: one (cosh, sinh) pair per colour for every slot (τ-independent hoppings: only csx / csy[c][0] are set and read)
+template <int NCOL, int KM, int SH, int CS1 = 1>
 __device__ __forceinline__ void propagate_own(const OwnLane<NCOL, KM> &ln, double2 (&ux)[KM], double2 (&uy)[KM], int nk, double2 *W0, double2 *W1, int &buf, int T2, int wl0)
 {
     constexpr int Q = NCOL >= 2 ? 1 : 0;
@@ -80,7 +81,7 @@ __device__ __forceinline__ void propagate_own(const OwnLane<NCOL, KM> &ln, doubl
     {                                                                                                       \
         if ((c_) == Q) {                                                                                    \
             _Pragma("unroll") for (int k = 0; k < KM - SH; ++k) if (k < nk) {                               \
-                const double c = ln.csx[Q][k + SH].x, s = ln.csx[Q][k + SH].y;                              \
+                const double c = ln.csx[Q][(k + SH) * CS1].x, s = ln.csx[Q][(k + SH) * CS1].y;                              \
                 const double2 t = lino(c, ux[k], s, uy[k]);                                                 \
                 uy[k] = lino(c, uy[k], s, ux[k]);                                                           \
                 ux[k] = t;                                                                                  \
@@ -89,8 +90,8 @@ __device__ __forceinline__ void propagate_own(const OwnLane<NCOL, KM> &ln, doubl
             double2 mx[KM], my[KM];                                                                         \
             FDM_OWN_EXCHANGE(c_, mx, my)                                                                    \
             _Pragma("unroll") for (int k = 0; k < KM - SH; ++k) if (k < nk) {                               \
-                ux[k] = lino(ln.csx[c_][k + SH].x, ux[k], ln.csx[c_][k + SH].y, mx[k]);                     \
-                uy[k] = lino(ln.csy[c_][k + SH].x, uy[k], ln.csy[c_][k + SH].y, my[k]);                     \
+                ux[k] = lino(ln.csx[c_][(k + SH) * CS1].x, ux[k], ln.csx[c_][(k + SH) * CS1].y, mx[k]);                     \
+                uy[k] = lino(ln.csy[c_][(k + SH) * CS1].x, uy[k], ln.csy[c_][(k + SH) * CS1].y, my[k]);                     \
             }                                                                                               \
         }                                                                                                   \
     }
@@ -100,7 +101,7 @@ __device__ __forceinline__ void propagate_own(const OwnLane<NCOL, KM> &ln, doubl
 #pragma unroll
         for (int k = 0; k < KM - SH; ++k)
             if (k < nk) {
-                const double c = ln.csx[0][k + SH].x, s = ln.csx[0][k + SH].y;
+                const double c = ln.csx[0][(k + SH) * CS1].x, s = ln.csx[0][(k + SH) * CS1].y;
                 const double2 x = sclo(ln.dx[k + SH], lino(c, ux[k], s, uy[k])), y = sclo(ln.dy[k + SH], lino(c, uy[k], s, ux[k]));
                 ux[k] = lino(c, x, s, y);
                 uy[k] = lino(c, y, s, x);
@@ -120,12 +121,12 @@ __device__ __forceinline__ void propagate_own(const OwnLane<NCOL, KM> &ln, doubl
         for (int k = 0; k < KM - SH; ++k)
             if (k < nk) {
                 {
-                    const double c = ln.csx[0][k + SH].x, s = ln.csx[0][k + SH].y;
+                    const double c = ln.csx[0][(k + SH) * CS1].x, s = ln.csx[0][(k + SH) * CS1].y;
                     const double2 x = sclo(ln.dx[k + SH], lino(c, ux[k], s, mx[k])), xm = sclo(ln.dmx[k + SH], lino(c, mx[k], s, ux[k]));
                     ux[k] = lino(c, x, s, xm);
                 }
                 {
-                    const double c = ln.csy[0][k + SH].x, s = ln.csy[0][k + SH].y;
+                    const double c = ln.csy[0][(k + SH) * CS1].x, s = ln.csy[0][(k + SH) * CS1].y;
                     const double2 y = sclo(ln.dy[k + SH], lino(c, uy[k], s, my[k])), ym = sclo(ln.dmy[k + SH], lino(c, my[k], s, uy[k]));
                     uy[k] = lino(c, y, s, ym);
                 }
@@ -330,6 +331,156 @@ __global__ void __launch_bounds__(TMAX) fdm_own_kernel(FdmArgs a, FdmFast ff)
     stamp_end(a.stamp);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Streaming MᵀM on the owner-computes lane program (τ-independent hoppings: one (cosh, sinh) pair per colour).  Workgroup = (run of R output
+// slices [la, lb), system), as in fdm_stream_kernel (kernels_fdm_fast.hip) — the same recurrences
+//     P1(m):  y[m] = v[m] − h B_m v[m−1]          P2(m):  out[m−1] = y[m−1] − h̄ B_m y[m],      p·Ap = Σ |y|²,
+// iteration j doing P1(j+1) and P2(j) as the two slots of ONE propagate — but the slices never enter LDS: lane t keeps v and y at the two
+// sites of its colour-1 bond in registers (loaded straight from global memory, two slices ahead), a B apply is propagate_own — colour 1 in
+// registers, colour 0 as DPP row rotations where FdmFast::wl0 allows, the other colours one LDS exchange each — i.e. TWO barriers per
+// iteration on the honeycomb lattice where fdm_stream_kernel has five.  That kernel spends half its time in its stage chain at every launch
+// size; this is the same pipeline with the shorter chain.
+template <int NCOL, int TMAX>
+__global__ void __launch_bounds__(TMAX) fdm_own_stream_kernel(FdmArgs a, FdmFast ff)
+{
+    extern __shared__ double2 U[];
+    __shared__ double red[34];
+    constexpr int KM = 2;
+    const int Lt = a.Lt, N = a.N, T = blockDim.x, T2 = 2 * T, j = threadIdx.x;
+    const int R = a.run_len, nrun = (Lt + R - 1) / R;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    if ((nblk & 7) == 0) bid = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);  // XCD x: a contiguous share of the systems
+    const int run = bid % nrun, sys = a.sys_first + bid / nrun;
+    stamp_begin(a.stamp);
+    const int sys_done = a.cg[sys].done;  // (a.cg is never null) acted on below, behind the first loads
+    const int w = sys / a.nrhs;
+    const int la = run * R, lb = min(Lt, la + R);
+    const size_t sstride = (size_t)a.nsys * N;
+    const double2 *in = a.in + (size_t)sys * N;
+    double2 *out = a.out + (size_t)sys * N;
+    const double *expV = a.expV + (size_t)w * Lt * N;
+    const double2 *csf = ff.csf + (size_t)w * Lt * ff.ptotal;
+    double2 *W0 = U, *W1 = U + (size_t)KM * T2;
+
+    // ---- the lane's program (clamped, unconditional loads: lanes beyond own_n compute on copies of lane 0's data and store nothing) ----
+    OwnLane<NCOL, KM> ln;
+    ln.on = j < ff.own_n;
+    const int jc = ln.on ? j : 0;
+    const int *own = ff.own;
+    const int sx = own[jc], sy = own[T + jc], m0x = own[2 * T + jc], m0y = own[3 * T + jc];
+    ln.ox = j; ln.oy = (sy != sx) ? T + j : j;
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+        ln.px[c] = own[(4 + 4 * c + 0) * T + jc];
+        ln.py[c] = own[(4 + 4 * c + 1) * T + jc];
+        const int bx = own[(4 + 4 * c + 2) * T + jc], by = own[(4 + 4 * c + 3) * T + jc];
+        const double2 cx = csf[bx], cy = csf[by];  // slice 0 of the packed table: the hoppings do not depend on τ
+        ln.csx[c][0] = cx;  // one pair per colour for both slots (propagate_own<…, CS1 = 0>)
+        ln.csy[c][0] = cy;
+    }
+    if (!ln.on) { ln.px[0] = ln.py[0] = j; }
+    // one slice at the lane's sites / exp(-ΔτV) of one slice at the lane's sites and their colour-0 mates (all unconditional)
+#define OS_LOAD_V(vx_, vy_, m_)                                      \
+    {                                                                \
+        const double2 *row_ = in + (size_t)wrapo((m_), Lt) * sstride; \
+        vx_ = row_[sx];                                              \
+        vy_ = row_[sy];                                              \
+    }
+#define OS_LOAD_F(d0_, d1_, d2_, d3_, m_)                            \
+    {                                                                \
+        const double *e_ = expV + (size_t)wrapo((m_), Lt) * N;       \
+        d0_ = e_[sx]; d1_ = e_[sy]; d2_ = e_[m0x]; d3_ = e_[m0y];    \
+    }
+    // what the loop waits for first goes out first: the two prefetched slices, then the fields of slice la+2, then the prologue's own data
+    double2 pax, pay, pbx, pby;
+    OS_LOAD_V(pax, pay, min(la + 2, lb))
+    OS_LOAD_V(pbx, pby, min(la + 3, lb))
+    asm volatile("" ::: "memory");  // keeps the loads above on this side of the early return
+    if (sys_done) return;           // workgroup-uniform; nothing stored yet
+    double fn0, fn1, fn2, fn3;      // fields of the slice after the two in use
+    OS_LOAD_F(fn0, fn1, fn2, fn3, min(la + 2, lb))
+    double f10, f11, f12, f13, f20, f21, f22, f23;  // slot 1: B_{m+1}, slot 2: B_m
+    OS_LOAD_F(f20, f21, f22, f23, la)
+    OS_LOAD_F(f10, f11, f12, f13, la + 1)
+    double2 vmx, vmy, v0x, v0y, v1x, v1y;
+    OS_LOAD_V(vmx, vmy, la - 1)
+    OS_LOAD_V(v0x, v0y, la)
+    OS_LOAD_V(v1x, v1y, la + 1)
+    int buf = 0;
+    double accr = 0.0;
+    double2 ux[KM], uy[KM];
+#define OS_SET_FIELDS()                                                          \
+    {                                                                            \
+        ln.dx[0] = f10; ln.dy[0] = f11; ln.dmx[0] = f12; ln.dmy[0] = f13;        \
+        ln.dx[1] = f20; ln.dy[1] = f21; ln.dmx[1] = f22; ln.dmy[1] = f23;        \
+    }
+    // ---- prologue: B_{la+1} v[la] (slot 1) and B_la v[la−1] (slot 2) together -> y[la], y[la+1] ----
+    OS_SET_FIELDS()
+    ux[0] = v0x; uy[0] = v0y; ux[1] = vmx; uy[1] = vmy;
+    propagate_own<NCOL, KM, 0, 0>(ln, ux, uy, 2, W0, W1, buf, T2, ff.wl0);
+    double2 yprev_x = hopcomb_o(v0x, ux[1], wrapo(la, Lt) == 0, false, a), yprev_y = hopcomb_o(v0y, uy[1], wrapo(la, Lt) == 0, false, a);          // y[la]
+    double2 ycur_x = hopcomb_o(v1x, ux[0], wrapo(la + 1, Lt) == 0, false, a), ycur_y = hopcomb_o(v1y, uy[0], wrapo(la + 1, Lt) == 0, false, a);    // y[la+1]
+    double2 vcur_x = v1x, vcur_y = v1y;  // v[la+1]
+    const bool two = sy != sx;
+    if (ln.on) accr += yprev_x.x * yprev_x.x + yprev_x.y * yprev_x.y + (two ? yprev_y.x * yprev_y.x + yprev_y.y * yprev_y.y : 0.0);
+    f20 = f10; f21 = f11; f22 = f12; f23 = f13;   // slot 2 of the first iteration: fields of slice la+1
+    f10 = fn0; f11 = fn1; f12 = fn2; f13 = fn3;   // slot 1: fields of slice la+2
+    // ---- steady state: iteration jj does P1(jj+1) (its result is unused at jj = lb) and P2(jj); written out twice per trip so that the two
+    // prefetch register sets alternate without a copy of a register that is still in flight ----
+#define OS_ITER(px_, py_, jj_)                                                                                        \
+    {                                                                                                                 \
+        const int jj = (jj_);                                                                                         \
+        OS_LOAD_F(fn0, fn1, fn2, fn3, min(jj + 2, lb))                                                                \
+        const double2 vnx = px_, vny = py_;  /* v[jj+1], requested two iterations ago */                              \
+        OS_LOAD_V(px_, py_, min(jj + 3, lb))                                                                          \
+        OS_SET_FIELDS()                                                                                               \
+        ux[0] = vcur_x; uy[0] = vcur_y; ux[1] = ycur_x; uy[1] = ycur_y;                                               \
+        propagate_own<NCOL, KM, 0, 0>(ln, ux, uy, 2, W0, W1, buf, T2, ff.wl0);                                           \
+        if (ln.on) { /* out[jj−1] = y[jj−1] − h̄ B_jj y[jj] */                                                          \
+            const bool wrap = (jj - 1) == Lt - 1;                                                                     \
+            double2 *row = out + (size_t)(jj - 1) * sstride;                                                          \
+            row[sx] = hopcomb_o(yprev_x, ux[1], wrap, true, a);                                                       \
+            if (two) row[sy] = hopcomb_o(yprev_y, uy[1], wrap, true, a);                                              \
+        }                                                                                                             \
+        yprev_x = ycur_x; yprev_y = ycur_y;                                                                           \
+        if (jj < lb) {                                                                                                \
+            if (ln.on) accr += yprev_x.x * yprev_x.x + yprev_x.y * yprev_x.y + (two ? yprev_y.x * yprev_y.x + yprev_y.y * yprev_y.y : 0.0); \
+            ycur_x = hopcomb_o(vnx, ux[0], wrapo(jj + 1, Lt) == 0, false, a);                                         \
+            ycur_y = hopcomb_o(vny, uy[0], wrapo(jj + 1, Lt) == 0, false, a);                                         \
+            vcur_x = vnx; vcur_y = vny;                                                                               \
+            f20 = f10; f21 = f11; f22 = f12; f23 = f13;                                                               \
+            f10 = fn0; f11 = fn1; f12 = fn2; f13 = fn3;                                                               \
+        }                                                                                                             \
+    }
+    int jj0 = la + 1;
+    for (; jj0 + 1 <= lb; jj0 += 2) {
+        OS_ITER(pax, pay, jj0)
+        OS_ITER(pbx, pby, jj0 + 1)
+    }
+    if (jj0 <= lb) OS_ITER(pax, pay, jj0)
+#undef OS_ITER
+#undef OS_SET_FIELDS
+#undef OS_LOAD_F
+#undef OS_LOAD_V
+    if (a.partial) {
+        for (int off = 32; off > 0; off >>= 1) accr += __shfl_down(accr, off, 64);
+        const int wave = j >> 6, lane = j & 63, nwave = (T + 63) >> 6;
+        __syncthreads();  // the LDS images are done with
+        if (lane == 0) red[wave] = accr;
+        __syncthreads();
+        if (j == 0) {
+            double s = 0.0;
+            for (int q = 0; q < nwave; ++q) s += red[q];
+            // the consumers reduce a.nchunk partials per system: the run's sum goes to its first chunk, its other chunks are zero
+            const int c0 = la / a.Tc, c1 = (lb + a.Tc - 1) / a.Tc;
+            a.partial[(size_t)sys * a.nchunk + c0] = make_double2(s, 0.0);
+            for (int c = c0 + 1; c < c1; ++c) a.partial[(size_t)sys * a.nchunk + c] = make_double2(0.0, 0.0);
+        }
+    }
+    stamp_end(a.stamp);
+}
+
 template <int NCOL, int KM>
 void launch_own(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff)
 {
@@ -382,6 +533,29 @@ bool fdm_own_supported(const FdmArgs &a, const FdmFast &ff, bool sym)
     static const int own_max = [] { const char *e = getenv("SMOQY_FDM_OWN_MAX"); return e ? atoi(e) : 8; }();  // experiment knob: systems per launch up to which this kernel is chosen
     return sym && ff.enabled && ff.own && fdm_own_enabled() && a.sys_count <= own_max && a.ncol >= 1 && a.ncol <= kFdmColours && a.Tc + 1 <= 3 &&
            sizeof(double2) * 2 * (size_t)(a.Tc + 1 <= 2 ? 2 : 3) * 2 * (size_t)ff.threads <= 64 * 1024;
+}
+
+// streaming MᵀM on the lane program: τ-independent hoppings (the caller passes cs_const), Sym, 256-lane lattices, R >= 2
+bool fdm_own_stream_supported(const FdmArgs &a, const FdmFast &ff, bool sym, bool cs_const)
+{
+    // opt-in (SMOQY_FDM_OWNSTREAM=1): 13.6 / 37.1 / 76.3 us against fdm_stream_kernel's 15.0 / 42.0 / 81.2 at 16 / 64 / 128 systems alone on the
+    // device, a 2 % shorter sweep for one stream of 16 walkers — and nothing in the bench, where four streams share the device and its 152 VGPRs
+    // (three waves per SIMD) cost what the shorter stage chain gains
+    static const int on = [] { const char *e = getenv("SMOQY_FDM_OWNSTREAM"); return (e && e[0] == '1') ? 1 : 0; }();
+    return on && sym && cs_const && ff.enabled && ff.own && ff.threads <= 256 && a.ncol >= 2 && a.ncol <= kFdmColours && a.run_len >= 2 && a.run_len % a.Tc == 0 &&
+           a.Lt >= 4 && a.shi == nullptr;
+}
+
+void launch_fdm_own_stream(hipStream_t st, const FdmArgs &a, const FdmFast &ff)
+{
+    const int nrun = (a.Lt + a.run_len - 1) / a.run_len;
+    const dim3 grid((unsigned)(nrun * a.sys_count)), block((unsigned)ff.threads);
+    const size_t lds = sizeof(double2) * 2 * 2 * 2 * (size_t)ff.threads;  // two images of KM = 2 slots x 2T values
+    switch (a.ncol) {
+        case 2: hipLaunchKernelGGL((fdm_own_stream_kernel<2, 256>), grid, block, lds, st, a, ff); break;
+        case 3: hipLaunchKernelGGL((fdm_own_stream_kernel<3, 256>), grid, block, lds, st, a, ff); break;
+        default: hipLaunchKernelGGL((fdm_own_stream_kernel<4, 256>), grid, block, lds, st, a, ff); break;
+    }
 }
 
 void launch_fdm_own(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff)

@@ -180,6 +180,8 @@ hipError_t configure_kpm_kernels(const char **what);
         hipError_t _e = hipFuncSetAttribute((const void *)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));                   \
         if (_e != hipSuccess && first == hipSuccess) { first = _e; *what = #fn; }                                                       \
     } while (0)
+bool fdm_own_stream_supported(const FdmArgs &a, const FdmFast &ff, bool sym, bool cs_const);
+void launch_fdm_own_stream(hipStream_t st, const FdmArgs &a, const FdmFast &ff);
 bool fdm_fast_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
 // cs_const: the caller has shown, on the host, that the hoppings of every walker of this launch do not depend on τ (Sym form only)
 void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff, bool sym = true, bool cs_const = false);
