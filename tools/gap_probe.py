@@ -33,6 +33,9 @@ print(f"{'pair':48s} {'count':>7s} {'median gap us':>14s} {'mean':>8s} {'p90':>8
 for k, g in sorted(gaps.items(), key=lambda kv: -len(kv[1]))[:14]:
     g.sort()
     print(f"{k[0] + ' -> ' + k[1]:48s} {len(g):7d} {g[len(g) // 2] / 1e3:14.2f} {sum(g) / len(g) / 1e3:8.2f} {g[int(.9 * len(g))] / 1e3:8.2f}")
+print("\nwhere the idle time of the window is (pairs by summed gap):")
+for k, g in sorted(gaps.items(), key=lambda kv: -sum(kv[1]))[:8]:
+    print(f"{k[0] + ' -> ' + k[1]:48s} {len(g):7d} {sum(g) / 1e6:11.2f} ms")
 loop = ["fdm_stream" if durs.get("fdm_stream") else "fdm_own", "tfft_kernel<2>", "cheb_own", "tfft_kernel<3>"]
 tot_k = sum(sorted(durs[k])[len(durs[k]) // 2] for k in loop if durs[k]) / 1e3
 tot_g = sum(sorted(gaps[(a, b)])[len(gaps[(a, b)]) // 2] for a, b in zip(loop, loop[1:] + loop[:1]) if gaps[(a, b)]) / 1e3
