@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--hmc", choices=["device", "host"], default="device",
                     help="device: the EFA leapfrog of the HMC trajectory runs on the GPU (x, p and the force never leave it; smoqy_hmc_trajectory_v); "
                          "host: round-1 form, a synthetic drift on the host with x uploaded and the force downloaded every step")
+    ap.add_argument("--no-prefetch", action="store_true", help="draw every sweep's random numbers when they are needed instead of one sweep ahead on the host-thread pool (WalkerBatch(prefetch_randoms=...)); same numbers either way")
     ap.add_argument("--tau-chunk", type=int, default=0)
     ap.add_argument("--check-every", type=int, default=0)
     ap.add_argument("--matvec-reps", type=int, default=400)
@@ -751,7 +752,7 @@ def main():
     cores_rank = max(1, available_cores() // world)
     rng_threads = max(1, min(max(2, 16 // S), cores_rank // S))
     batches = [WalkerBatch(args.workload, nwalkers=per, walker0=mine.start + s * per, device=dev, check_every=args.check_every or None, tau_chunk=args.tau_chunk or None,
-                           host_threads=rng_threads, measure_nrv=args.measure_nrv, device_efa=args.hmc == "device", cg_split=args.cg_split,
+                           host_threads=rng_threads, measure_nrv=args.measure_nrv, device_efa=args.hmc == "device", cg_split=args.cg_split, prefetch_randoms=not args.no_prefetch,
                            tfft_in_place=(S > 1 and _only_factors(lat_Lt, (2, 3))) if args.tfft_form == "auto" else args.tfft_form == "in-place") for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
     batch = batches[0]
     if args.solve_concurrency > 0:
@@ -814,7 +815,7 @@ def main():
         if world == 1 and not args.roofline_only and not args.timed_only:
             one_stream = []
             for nw1 in (1, 8, 16):
-                ob = WalkerBatch(args.workload, nwalkers=nw1, walker0=mine.start, device=dev, device_efa=args.hmc == "device")
+                ob = WalkerBatch(args.workload, nwalkers=nw1, walker0=mine.start, device=dev, device_efa=args.hmc == "device", prefetch_randoms=not args.no_prefetch)
                 ob.sweep()
                 ob.h.call("smoqy_sync")
                 t1 = time.perf_counter()
@@ -905,6 +906,7 @@ def main():
                 "tfft_form": ("in-place" if _in_place_tfft_exists(batch.Lt) else "two-image (in-place requested; Ltau has a factor 7)") if batch.tfft_in_place else "two-image",
                 "hmc": ("EFA leapfrog on the device, Nt = %d steps of dt = pi/(2 Nt), trajectory always rejected (x restored) so the field distribution stays the one SURVEY.md 8(d) defines" % batch.Nt)
                 if args.hmc == "device" else "synthetic host-side drift (round-1 form)",
+                "random_numbers": "one PCG64 generator per walker on the host" + ("" if args.no_prefetch else ", drawn one sweep ahead by the batch's host-thread pool while the device runs the current sweep (inside the timed region; same numbers as drawn on demand)"),
                 "parallelism": f"walker-parallel, {world} rank(s) x {wpg} walkers ({S} lock-step batches of {per}), no collective",
             },
             "roofline": roofline,

@@ -268,6 +268,8 @@ class Handle:
 
     def close(self):
         if getattr(self, "_h", None):
+            for cb in getattr(self, "before_close", []):  # owners of host threads that write into this handle's page-locked buffers wait for them here
+                cb()
             for p in getattr(self, "_pinned", []):
                 self.lib.smoqy_host_free(self._h, p)
             self._pinned = []

@@ -48,7 +48,8 @@ class WalkerBatch:
 
     def __init__(self, workload: str, nwalkers: int = 1, walker0: int = 0, is_sym: bool = True, device: int = -1, tol: float = 1e-10, maxiter: int = 10_000, Nt: int = 24,
                  drift: float = 0.02, check_every: int | None = None, tau_chunk: int | None = None, smooth: bool = False, host_threads: int = 8, device_update: bool = True, measure_nrv: int = 0,
-                 device_efa: bool = False, omega: float = 1.0, mass: float = 1.0, cg_split: int | None = None, tfft_in_place: bool | None = None):
+                 device_efa: bool = False, omega: float = 1.0, mass: float = 1.0, cg_split: int | None = None, tfft_in_place: bool | None = None,
+                 prefetch_randoms: bool = False):
         self.models = [lat.CONFIGS[workload](walker=walker0 + w, smooth=smooth) for w in range(nwalkers)]
         m0 = self.models[0]
         self.workload = workload
@@ -108,6 +109,13 @@ class WalkerBatch:
         # x, p and the force stay on the GPU for the whole trajectory.  Off by default: the host-side drift stays the tested default.
         self.device_efa = bool(device_efa)
         self.dH = None
+        # prefetch_randoms: the random numbers of sweep n + 1 are drawn by the host-thread pool while the device runs sweep n (each walker's
+        # generator is asked for the same arrays in the same order as without it, so the Markov chain is the same one); device_efa sweeps only
+        self.prefetch_randoms = bool(prefetch_randoms) and self.device_efa and not self.measure_nrv
+        self._draws = None          # the sweep's pre-drawn arrays while sweep() runs, else None: every draw site asks its generator
+        self._draws_next = None     # (arrays, futures) being filled for the next sweep
+        self._draw_sets = None
+        self.h.before_close = [self._drain_draws]  # a fill task must not outlive the page-locked arrays it writes
         if self.device_efa:
             if not device_update:
                 raise ValueError("device_efa needs device_update=True")
@@ -143,10 +151,68 @@ class WalkerBatch:
                 self.xs_force[:, :, : self.Nph] = self.xs
             self.h.call("smoqy_force_set_phonons", L.ptr(self.xs_force))  # Holstein models share the Λ upload instead
 
+    def _start_vectors(self):
+        """randn!(rng, v) at KPMPreconditioner.jl:634, one start vector per walker."""
+        d = self._draws
+        if d is not None:
+            d.i_rv += 1
+            return d.rv[d.i_rv - 1]
+        return np.ascontiguousarray(np.stack([g.standard_normal(self.N) for g in self.rng]))
+
     def update_preconditioner(self):
-        # randn!(rng, v) at KPMPreconditioner.jl:634, one start vector per walker
-        rv = np.ascontiguousarray(np.stack([g.standard_normal(self.N) for g in self.rng]))
-        self.h.call("smoqy_precond_update_all", L.ptr(rv))
+        self.h.call("smoqy_precond_update_all", L.ptr(self._start_vectors()))
+
+    # ---- random numbers one sweep ahead (prefetch_randoms) ---------------------------------------------
+    class _Draws:
+        """What one device_efa sweep asks the walkers' generators for, in the order it asks."""
+
+        def __init__(self, b):
+            self.R = [b.h.pinned_empty((b.Lt, b.N, b.nw), dtype=np.complex128, order="F") for _ in range(3)]   # sample_pseudofermion_fields x 3
+            self.dx = [np.empty((b.nw, b.Lt, b.Nph)) for _ in range(2)]                                        # momenta of the two global moves, times the drift
+            self.rv = [np.empty((b.nw, b.N)) for _ in range(3)]                                                # start vectors of the three action solves
+            self.efa_R = b.h.pinned_empty((b.nw, b.Lt, b.Nph_force))                                           # momentum refresh of hmc_update!
+            self.efa_rv = b.h.pinned_empty((b.Nt, b.nw, b.N))                                                  # start vectors of the trajectory's force solves
+            self.i_R = self.i_dx = self.i_rv = 0
+
+    def _fill_draws(self, d, w):
+        g = self.rng[w]
+
+        def cn(R):  # randn!(rng, Φ) for ComplexF64, as in sample_pseudofermion_fields
+            flat = R[:, :, w].reshape(-1, order="F").view(np.float64)
+            g.standard_normal(out=flat)
+            flat *= np.sqrt(0.5)
+
+        for i in range(2):  # the two global moves of sweep(): Φ, momentum, start vector of the action solve
+            cn(d.R[i])
+            g.standard_normal(out=d.dx[i][w])
+            d.dx[i][w] *= self.drift
+            g.standard_normal(out=d.rv[i][w])
+        cn(d.R[2])          # hmc_trajectory_device: Φ, momentum refresh, the force solves' start vectors, the final action's
+        g.standard_normal(out=d.efa_R[w].reshape(-1))
+        for t in range(self.Nt):
+            g.standard_normal(out=d.efa_rv[t, w])
+        g.standard_normal(out=d.rv[2][w])
+
+    def _submit_draws(self):
+        if self._draw_sets is None:
+            self._draw_sets = [WalkerBatch._Draws(self), WalkerBatch._Draws(self)]
+        d = self._draw_sets[0] if self._draws is not self._draw_sets[0] else self._draw_sets[1]
+        d.i_R = d.i_dx = d.i_rv = 0
+        self._draws_next = (d, [self.pool.submit(self._fill_draws, d, w) for w in range(self.nw)])
+
+    def _drain_draws(self):
+        if self._draws_next is not None:
+            for f in self._draws_next[1]:
+                f.result()
+
+    def _take_draws(self):
+        if self._draws_next is None:
+            self._submit_draws()
+        d, futures = self._draws_next
+        for f in futures:
+            f.result()
+        self._draws_next = None
+        return d
 
     def _randn_all(self, shape):
         """One standard-normal array per walker from that walker's generator (host threads)."""
@@ -155,15 +221,20 @@ class WalkerBatch:
     # ---- PFFCalculator on the device ---------------------------------------------------------------
     def sample_pseudofermion_fields(self):
         """Φ = Λᵀ Mᵀ R with R ~ CN(0,1) drawn on the host; returns |R|² per walker."""
-        R = self._R
+        d = self._draws
+        if d is not None:
+            R = d.R[d.i_R]
+            d.i_R += 1
+        else:
+            R = self._R
 
-        def fill(w):
-            # randn!(rng, Φ) for ComplexF64: (re, im) pairs in memory order, each of variance 1/2
-            flat = R[:, :, w].reshape(-1, order="F").view(np.float64)
-            self.rng[w].standard_normal(out=flat)
-            flat *= np.sqrt(0.5)
+            def fill(w):
+                # randn!(rng, Φ) for ComplexF64: (re, im) pairs in memory order, each of variance 1/2
+                flat = R[:, :, w].reshape(-1, order="F").view(np.float64)
+                self.rng[w].standard_normal(out=flat)
+                flat *= np.sqrt(0.5)
 
-        list(self.pool.map(fill, range(self.nw)))
+            list(self.pool.map(fill, range(self.nw)))
         self.h.vec_upload(self.phi, R)
         sf = self.h.vec_dot(self.phi, self.phi).real
         self.h.call("smoqy_matvec_v", L.OP_MT, self.phi, self.phi)          # lmul_Mt!  (:71)
@@ -206,7 +277,7 @@ class WalkerBatch:
             raise RuntimeError("pff_step needs the device-side update! (device_update=True)")
         if moved and self.xs_force is not self.xs:
             self.xs_force[:, :, : self.Nph] = self.xs
-        rv = np.ascontiguousarray(np.stack([g.standard_normal(self.N) for g in self.rng])) if use_precond else None  # randn!(rng, v), KPMPreconditioner.jl:634
+        rv = self._start_vectors() if use_precond else None  # randn!(rng, v), KPMPreconditioner.jl:634
         sf = np.zeros(self.nw)
         iters = np.zeros(self.nw, dtype=np.int32)
         eps = np.zeros(self.nw)
@@ -291,15 +362,18 @@ class WalkerBatch:
         dt = np.pi / (2 * self.Nt) if dt is None else float(dt)          # tutorials/holstein_honeycomb.jl:542
         sf0 = self.sample_pseudofermion_fields()                          # :133
         self.h.call("smoqy_efa_checkpoint", 0)                            # copyto!(x0, x), :130
-        R = self._efa_R
-        list(self.pool.map(lambda w: self.rng[w].standard_normal(out=R[w].reshape(-1)), range(self.nw)))
+        d = self._draws
+        R = self._efa_R if d is None else d.efa_R
+        if d is None:
+            list(self.pool.map(lambda w: self.rng[w].standard_normal(out=R[w].reshape(-1)), range(self.nw)))
         K0 = np.zeros(self.nw)
         self.h.call("smoqy_efa_initialize_momentum", L.ptr(R), L.ptr(K0))  # :142
         _, Sb0 = self.efa_energies()                                      # bosonic action, :136
-        rv = self._efa_rv
-        for t in range(self.Nt):
-            for w in range(self.nw):
-                self.rng[w].standard_normal(out=rv[t, w])                 # randn!(rng, v) of each update_preconditioner!, KPMPreconditioner.jl:634
+        rv = self._efa_rv if d is None else d.efa_rv
+        if d is None:
+            for t in range(self.Nt):
+                for w in range(self.nw):
+                    self.rng[w].standard_normal(out=rv[t, w])             # randn!(rng, v) of each update_preconditioner!, KPMPreconditioner.jl:634
         sf = np.zeros((self.Nt, self.nw))
         iters = np.zeros((self.Nt, self.nw), dtype=np.int32)
         eps = np.zeros((self.Nt, self.nw))
@@ -333,11 +407,30 @@ class WalkerBatch:
 
     # ---- one synthetic sweep -------------------------------------------------------------------------
     def sweep(self):
+        if self.prefetch_randoms:
+            self._draws = self._take_draws()   # drawn while the previous sweep ran (now, for the first one)
+            self._submit_draws()               # the next sweep's, under this sweep's device work
+            try:
+                return self._sweep()
+            finally:
+                self._draws = None
+        return self._sweep()
+
+    def _sweep(self):
         last = None
+        d = self._draws
         # reflection-like and swap-like global moves: sample Φ, move the fields, one action solve
         # (src/reflection_update.jl:69-114, src/swap_update.jl)
         for _ in range(2):
             self.sample_pseudofermion_fields()
+            if d is not None:
+                dx = d.dx[d.i_dx]              # momentum × drift, formed by the thread that drew it
+                d.i_dx += 1
+                self.drift_by(dx)
+                last = self.calculate_fermionic_action(self.tol)
+                np.subtract(self.xs, dx, out=self.xs)  # x + (−drift·π) of the branch below, bit for bit
+                self.refresh_fields()
+                continue
             pis = self._momentum()
             self.drift_fields(pis, self.drift)
             last = self.calculate_fermionic_action(self.tol)

@@ -141,3 +141,24 @@ def test_leapfrog_energy_error_scales_with_the_square_of_the_step(name, is_sym):
         b.h.close()
     ratio = dHs[0] / dHs[1]
     assert np.all(dHs[1] < dHs[0]) and np.all(ratio > 2.5) and np.all(ratio < 6.5), (dHs, ratio)
+
+
+def test_sweeps_with_the_random_numbers_drawn_one_sweep_ahead_are_the_same_sweeps():
+    """WalkerBatch(prefetch_randoms=True) lets the host-thread pool draw sweep n + 1's random numbers while the device runs sweep n: every
+    walker's generator is asked for the same arrays in the same order, so actions, ΔH, iteration counts and fields are those of the plain
+    sweep, bit for bit — and a handle closed with a fill task still pending waits for it."""
+    name, nw = "holstein_honeycomb_L4_Ltau40", 3
+    a = WalkerBatch(name, nwalkers=nw, device_efa=True, Nt=4, host_threads=2)
+    b = WalkerBatch(name, nwalkers=nw, device_efa=True, Nt=4, host_threads=2, prefetch_randoms=True)
+    assert b.prefetch_randoms
+    for _ in range(3):
+        la, lb = a.sweep(), b.sweep()
+        np.testing.assert_array_equal(la[0], lb[0])
+        np.testing.assert_array_equal(la[1], lb[1])
+        np.testing.assert_array_equal(a.dH, b.dH)
+        np.testing.assert_array_equal(a.xs, b.xs)
+    assert a.stats.iters_sum == b.stats.iters_sum and a.stats.solves == b.stats.solves
+    assert b._draws is None and b._draws_next is not None  # the fourth sweep's numbers are being drawn
+    b.h.close()                                            # waits for them before the page-locked arrays go
+    assert all(f.done() for f in b._draws_next[1])
+    a.h.close()

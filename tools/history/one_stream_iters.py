@@ -5,7 +5,7 @@ from smoqyelphqmc_amd.walkers import WalkerBatch
 nw = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 wl = sys.argv[2] if len(sys.argv) > 2 else "holstein_honeycomb_L16_Ltau128"
 ns = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-b = WalkerBatch(wl, nwalkers=nw, is_sym=True, cg_split=int(os.environ.get("SMOQY_SPLIT", "0")), device_efa=os.environ.get("SMOQY_EFA", "1") == "1")
+b = WalkerBatch(wl, nwalkers=nw, is_sym=True, cg_split=int(os.environ.get("SMOQY_SPLIT", "0")), device_efa=os.environ.get("SMOQY_EFA", "1") == "1", prefetch_randoms=os.environ.get("SMOQY_PREFETCH", "1") == "1")
 b.sweep(); b.sweep()
 out = []
 for _ in range(ns):
