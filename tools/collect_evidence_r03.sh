@@ -8,7 +8,7 @@ bash tools/profile_bench.sh r03 && echo prof ok
 bash tools/profile_roofline.sh r03 && echo roof ok
 bash tools/solo_profile.sh r03_hc16 16 && bash tools/solo_profile.sh r03_hc16_w1 1 && bash tools/solo_profile.sh r03_ossh 16 ossh_square_L12_Ltau100 && bash tools/solo_profile.sh r03_bssh 16 bssh_chain_L256_Ltau200 && bash tools/solo_profile.sh r03_hc8 16 holstein_honeycomb_L8_Ltau80
 SMOQY_CHEB_WL0=0 bash tools/solo_profile.sh r03_hc16_wl0off 16 && SMOQY_CHEB_WL0=0 bash tools/solo_profile.sh r03_hc16_w1_wl0off 1
-SMOQY_EFA=1 bash tools/gap_probe.sh r03_1walker 1 && SMOQY_EFA=1 bash tools/gap_probe.sh r03_16walkers 16
+SMOQY_EFA=1 SMOQY_PREFETCH=1 bash tools/gap_probe.sh r03_1walker 1 && SMOQY_EFA=1 SMOQY_PREFETCH=1 bash tools/gap_probe.sh r03_16walkers 16
 echo done
 # N > 1 control flow rehearsed on the one GPU: two ranks share cuda:0, gloo for the barrier and the MAX (no scaling claim)
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --rehearse-one-gpu --steps 3 --warmup 1 --walkers-per-gpu 64 --streams 4 > gpurun_out/r03_rehearse_2ranks.json 2> gpurun_out/r03_rehearse_2ranks.err; echo rehearse rc=$?; tail -c 600 gpurun_out/r03_rehearse_2ranks.json
