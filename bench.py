@@ -346,6 +346,11 @@ def team_scan(args, counts, dev, walker0):
     member_sweep = (lambda m: m.sweep_device_hmc()) if dev_hmc else (lambda m: m.sweep())
     for K in counts:
         team = WalkerTeam(args.workload, K, walker0=walker0 + 3000, device=dev, device_efa=dev_hmc)
+        draw_pool = None
+        if dev_hmc and not getattr(args, "no_prefetch", False):
+            draw_pool = ThreadPoolExecutor(min(K, 16))  # the members' random numbers, one sweep ahead (as the lock-step batches draw theirs)
+            for m in team.members:
+                m.prefetch_randoms(draw_pool)
         with ThreadPoolExecutor(K) as pool:
             list(pool.map(member_sweep, team.members))
             t0 = time.perf_counter()
@@ -360,6 +365,8 @@ def team_scan(args, counts, dev, walker0):
                   int(args.scan_sweeps), 4242 + walker0, L.C.byref(secs), L.C.byref(so), L.C.byref(itn))
         native = K * args.scan_sweeps / secs.value
         native_iters = itn.value / max(so.value, 1)
+        if draw_pool is not None:
+            draw_pool.shutdown(wait=True)
         team.close()
         ob = WalkerBatch(args.workload, nwalkers=K, walker0=walker0 + 3000, device=dev, device_efa=dev_hmc)
         ob.sweep()
@@ -408,6 +415,10 @@ def member_worker(spec):
     info = json.loads(info)
     m = RemoteMember(info, int(w), seed=4711, wait_seconds=120.0)
     sweep = m.sweep_device_hmc if info.get("device_efa") else m.sweep
+    if info.get("device_efa") and info.get("prefetch", True):
+        from concurrent.futures import ThreadPoolExecutor
+
+        m.prefetch_randoms(ThreadPoolExecutor(1))  # the rank draws its next sweep's random numbers on a thread of its own while it waits in the rendezvous
     sweep()
     m.solves = m.iters_sum = 0
     t0 = time.time()
@@ -438,6 +449,7 @@ def team_procs_scan(args, points, dev, walker0):
                 tm = WalkerTeam(args.workload, K, walker0=walker0 + 7000 + 64 * q, device=dev, device_efa=dev_hmc)
                 teams.append(tm)
                 info = tm.serve(f"/smoqy-bench-{os.getpid()}-{q}")
+                info["prefetch"] = not getattr(args, "no_prefetch", False)
                 procs += [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--member-worker", json.dumps(info) + f"|{w}|{args.scan_sweeps}"],
                                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True) for w in range(K)]
             res = []

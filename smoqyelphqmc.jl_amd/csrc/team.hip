@@ -885,11 +885,24 @@ struct Xo {
         }
     }
 };
+// what one sweep of a member asks its generator for, in the order it asks: drawn by the member's producer thread one sweep ahead, so that
+// a member's randn! calls run while the device works on the team's current call instead of between two calls (the lock-step batches of
+// bench.py do the same: WalkerBatch(prefetch_randoms)); the stream of numbers is the one the member would draw on demand
+struct Draws {
+    std::vector<double> R[3], pi[3], P, rvs;
+    std::vector<std::vector<double>> rv;
+};
 struct Member {
-    std::vector<double> x, pi, rv, dS, R, P, rvs;
+    std::vector<double> x, dS;
     Xo rng{0};
     long solves = 0, iters = 0;
     int rc = 0;
+    // two draw sets: the producer fills set (n & 1) for sweep n as soon as sweep n - 2 has released it
+    Draws d[2];
+    std::mutex mu;
+    std::condition_variable cv;
+    long produced = 0, consumed = 0;
+    bool stop = false;
 };
 }  // namespace
 
@@ -899,69 +912,124 @@ int smoqy_team_bench_sweeps(smoqy_team *t, const double *x0, int nfree, double d
     if (!t || !x0 || nfree < 0 || nfree > t->Nph || Nt < 1 || nsweeps < 1 || !seconds || (device_hmc && Nt > kMaxNt)) return 1;
     const int K = t->K, Lt = t->Lt, N = t->N, Nph = t->Nph;
     const size_t nx = (size_t)Nph * Lt;
+    const int nrv = device_hmc ? 2 : 2 + Nt + 1, npi = device_hmc ? 2 : 3;  // start vectors / momenta a sweep draws one at a time
     std::vector<Member> mem((size_t)K);
     for (int w = 0; w < K; ++w) {
         Member &m = mem[w];
         m.x.assign(x0 + (size_t)w * nx, x0 + (size_t)(w + 1) * nx);
-        m.pi.resize((size_t)Lt * nfree); m.rv.resize((size_t)N); m.dS.resize(nx); m.R.resize(2 * (size_t)Lt * N);
-        if (device_hmc) { m.P.resize(nx); m.rvs.resize((size_t)N * (Nt + 1)); }
+        m.dS.resize(nx);
+        for (Draws &d : m.d) {
+            for (auto &R : d.R) R.resize(2 * (size_t)Lt * N);
+            for (int q = 0; q < npi; ++q) d.pi[q].resize((size_t)Lt * nfree);
+            d.rv.assign((size_t)nrv, std::vector<double>((size_t)N));
+            if (device_hmc) { d.P.resize(nx); d.rvs.resize((size_t)N * (Nt + 1)); }
+        }
         m.rng = Xo(seed + 7919ull * (uint64_t)w);
     }
-    auto shift = [&](Member &m, double f) {  // x[:, :nfree] += f·π
-        for (int l = 0; l < Lt; ++l)
-            for (int j = 0; j < nfree; ++j) m.x[(size_t)l * Nph + j] += f * m.pi[(size_t)l * nfree + j];
+    // the member's random stream, in the order of the sweep below
+    auto draw = [&](Member &m, Draws &d) {
+        const double h = std::sqrt(0.5);
+        for (int rep = 0; rep < 2; ++rep) {
+            m.rng.normal(d.R[rep].data(), d.R[rep].size(), h);        // randn!(rng, Φ), src/PFFCalculator.jl:67
+            m.rng.normal(d.pi[rep].data(), d.pi[rep].size(), 1.0);
+            m.rng.normal(d.rv[rep].data(), d.rv[rep].size(), 1.0);    // randn!(rng, v), src/KPMPreconditioner.jl:634
+        }
+        m.rng.normal(d.R[2].data(), d.R[2].size(), h);
+        if (device_hmc) {
+            m.rng.normal(d.P.data(), d.P.size(), 1.0);
+            m.rng.normal(d.rvs.data(), d.rvs.size(), 1.0);
+        } else {
+            m.rng.normal(d.pi[2].data(), d.pi[2].size(), 1.0);
+            for (int q = 2; q < nrv; ++q) m.rng.normal(d.rv[q].data(), d.rv[q].size(), 1.0);
+        }
     };
-    auto step = [&](Member &m, int w, double tl, bool force) {
-        m.rng.normal(m.rv.data(), m.rv.size(), 1.0);
+    auto shift = [&](Member &m, const std::vector<double> &pi, double f) {  // x[:, :nfree] += f·π
+        for (int l = 0; l < Lt; ++l)
+            for (int j = 0; j < nfree; ++j) m.x[(size_t)l * Nph + j] += f * pi[(size_t)l * nfree + j];
+    };
+    auto step = [&](Member &m, int w, const std::vector<double> &rv, double tl, bool force) {
         double sf = 0, eps = 0;
         int it = 0;
-        const int rc = smoqy_team_pff_step(t, w, m.x.data(), m.rv.data(), tl, maxiter, 1, &sf, &it, &eps, force ? m.dS.data() : nullptr);
+        const int rc = smoqy_team_pff_step(t, w, m.x.data(), rv.data(), tl, maxiter, 1, &sf, &it, &eps, force ? m.dS.data() : nullptr);
         m.solves += 1; m.iters += it;
         return rc;
     };
-    auto sample = [&](Member &m, int w) {
-        m.rng.normal(m.R.data(), m.R.size(), std::sqrt(0.5));
+    auto sample = [&](int w, const std::vector<double> &R) {
         double rr = 0;
-        return smoqy_team_sample_phi(t, w, m.R.data(), &rr);
+        return smoqy_team_sample_phi(t, w, R.data(), &rr);
     };
-    auto sweep = [&](Member &m, int w) {
+    auto sweep = [&](Member &m, int w, Draws &d) {
         for (int rep = 0; rep < 2; ++rep) {
-            if (int rc = sample(m, w)) return rc;
-            m.rng.normal(m.pi.data(), m.pi.size(), 1.0);
-            shift(m, drift);
-            if (int rc = step(m, w, tol, false)) return rc;
-            shift(m, -drift);
+            if (int rc = sample(w, d.R[rep])) return rc;
+            shift(m, d.pi[rep], drift);
+            if (int rc = step(m, w, d.rv[rep], tol, false)) return rc;
+            shift(m, d.pi[rep], -drift);
         }
         if (device_hmc) {
             // hmc_update! with the trajectory on the device (smoqy_team_hmc_update), Δt = π/(2 Nt) (tutorials/holstein_honeycomb.jl:542);
             // always rejected, as bench.py's sweep does
-            m.rng.normal(m.R.data(), m.R.size(), std::sqrt(0.5));
-            m.rng.normal(m.P.data(), m.P.size(), 1.0);
-            m.rng.normal(m.rvs.data(), m.rvs.size(), 1.0);
             double H0[3], H1[3];
             int it = 0;
-            if (int rc = smoqy_team_hmc_update(t, w, m.x.data(), m.R.data(), m.P.data(), m.rvs.data(), Nt, 1.5707963267948966 / Nt, tol_force, tol, maxiter, H0, H1, nullptr, &it)) return rc;
+            if (int rc = smoqy_team_hmc_update(t, w, m.x.data(), d.R[2].data(), d.P.data(), d.rvs.data(), Nt, 1.5707963267948966 / Nt, tol_force, tol, maxiter, H0, H1, nullptr, &it)) return rc;
             m.solves += Nt + 1; m.iters += it;
             return smoqy_team_hmc_finish(t, w, 0);
         }
-        if (int rc = sample(m, w)) return rc;
-        m.rng.normal(m.pi.data(), m.pi.size(), 1.0);
+        if (int rc = sample(w, d.R[2])) return rc;
         for (int q = 0; q < Nt; ++q) {
-            if (int rc = step(m, w, tol_force, true)) return rc;
-            shift(m, drift / Nt);
+            if (int rc = step(m, w, d.rv[2 + q], tol_force, true)) return rc;
+            shift(m, d.pi[2], drift / Nt);
         }
-        if (int rc = step(m, w, tol, false)) return rc;
-        shift(m, -drift);
+        if (int rc = step(m, w, d.rv[2 + Nt], tol, false)) return rc;
+        shift(m, d.pi[2], -drift);
         return 0;
     };
+    // producers: one per member, alive over warm-up and timed sweeps, at most two sweeps ahead of their member
+    std::vector<std::thread> producers;
+    for (int w = 0; w < K; ++w)
+        producers.emplace_back([&, w] {
+            Member &m = mem[w];
+            for (;;) {
+                {
+                    std::unique_lock<std::mutex> lk(m.mu);
+                    m.cv.wait(lk, [&] { return m.stop || m.produced - m.consumed < 2; });
+                    if (m.stop) return;
+                }
+                draw(m, m.d[m.produced & 1]);
+                {
+                    std::lock_guard<std::mutex> lk(m.mu);
+                    ++m.produced;
+                }
+                m.cv.notify_all();
+            }
+        });
     auto run = [&](int count) {
         std::vector<std::thread> th;
         for (int w = 0; w < K; ++w)
             th.emplace_back([&, w] {
-                for (int q = 0; q < count && mem[w].rc == 0; ++q) mem[w].rc = sweep(mem[w], w);
+                Member &m = mem[w];
+                for (int q = 0; q < count && m.rc == 0; ++q) {
+                    {
+                        std::unique_lock<std::mutex> lk(m.mu);
+                        m.cv.wait(lk, [&] { return m.produced > m.consumed; });
+                    }
+                    m.rc = sweep(m, w, m.d[m.consumed & 1]);
+                    {
+                        std::lock_guard<std::mutex> lk(m.mu);
+                        ++m.consumed;
+                    }
+                    m.cv.notify_all();
+                }
             });
         for (auto &x : th) x.join();
     };
+    struct StopProducers {  // on every way out, errors included
+        std::vector<Member> &mem; std::vector<std::thread> &th;
+        ~StopProducers()
+        {
+            for (auto &m : mem) { { std::lock_guard<std::mutex> lk(m.mu); m.stop = true; } m.cv.notify_all(); }
+            for (auto &x : th) x.join();
+        }
+    } stop_producers{mem, producers};
     if (warmup_sweeps > 0) run(warmup_sweeps);
     for (auto &m : mem) { m.solves = 0; m.iters = 0; }
     const auto t0 = std::chrono::steady_clock::now();

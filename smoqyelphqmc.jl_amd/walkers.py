@@ -591,20 +591,23 @@ class TeamMember:
         self.iters_sum += it.value
         return np.transpose(out, tuple(range(out.ndim - 1, -1, -1))), it.value
 
-    def hmc_update(self, dt=None, send_x=True):
+    def hmc_update(self, dt=None, send_x=True, drawn=None):
         """hmc_update! (src/EFAPFFHMCUpdater.jl:102-276) for this walker with the trajectory on the device: the member draws what the
         reference draws from its rng (Φ deviates :133, momenta :142, one Lanczos start vector per solve), the library runs the leapfrog for
-        all members at once.  Returns (ΔH, x_new); the caller decides and reports with ``hmc_finish(accept)``."""
+        all members at once.  Returns (ΔH, x_new); the caller decides and reports with ``hmc_finish(accept)``.  ``drawn``: (R, P, rvs)
+        already drawn from this member's generator (``prefetch_randoms``)."""
         dt = np.pi / (2 * self.Nt) if dt is None else float(dt)          # tutorials/holstein_honeycomb.jl:542
-        flat = self.R.reshape(-1, order="F").view(np.float64)
-        self.rng.standard_normal(out=flat)
-        flat *= np.sqrt(0.5)
-        P = self.rng.standard_normal((self.Lt, max(self.Nph, 1)))
-        rvs = self.rng.standard_normal((self.Nt + 1, self.N))
+        if drawn is not None:
+            R, P, rvs = drawn
+        else:
+            R = self.R
+            self._draw_cn(R)
+            P = self.rng.standard_normal((self.Lt, max(self.Nph, 1)))
+            rvs = self.rng.standard_normal((self.Nt + 1, self.N))
         H0, H1 = np.zeros(3), np.zeros(3)
         x_new = np.empty_like(self.x)
         it = C.c_int(0)
-        self._hmc_call(L.ptr(self.x) if send_x else None, L.ptr(self.R), L.ptr(P), L.ptr(rvs), int(self.Nt), C.c_double(dt), C.c_double(self.tol_force), C.c_double(self.tol), int(self.maxiter),
+        self._hmc_call(L.ptr(self.x) if send_x else None, L.ptr(R), L.ptr(P), L.ptr(rvs), int(self.Nt), C.c_double(dt), C.c_double(self.tol_force), C.c_double(self.tol), int(self.maxiter),
                        L.ptr(H0), L.ptr(H1), L.ptr(x_new), C.byref(it))
         self.solves += self.Nt + 1
         self.iters_sum += it.value
@@ -619,26 +622,62 @@ class TeamMember:
     def sweep_device_hmc(self):
         """the sweep of ``WalkerBatch.sweep`` with device_efa = True for ONE walker: two local-move-like updates, then hmc_update! with the
         trajectory on the device, always rejected (bench.py's convention: the field distribution stays the one SURVEY.md §8(d) defines)"""
-        for _ in range(2):
-            self.sample_pseudofermion_fields()
-            pi = self.rng.standard_normal((self.Lt, self.free))
+        d = self._take_draws() if getattr(self, "_draw_pool", None) is not None else None
+        for i in range(2):
+            self.sample_pseudofermion_fields(None if d is None else d["R"][i])
+            pi = self.rng.standard_normal((self.Lt, self.free)) if d is None else d["pi"][i]
             self.x[:, : self.free] += self.drift * pi
-            self.pff_step(self.tol, moved=True, want_force=False)
+            self.pff_step(self.tol, moved=True, want_force=False, rv=None if d is None else d["rv"][i])
             self.x[:, : self.free] -= self.drift * pi
-        dH, _ = self.hmc_update()
+        dH, _ = self.hmc_update(drawn=None if d is None else (d["R"][2], d["P"], d["rvs"]))
         self.hmc_finish(False)
         return dH
 
-    def sample_pseudofermion_fields(self):
-        flat = self.R.reshape(-1, order="F").view(np.float64)
+    # ---- random numbers one sweep ahead (what WalkerBatch(prefetch_randoms=True) does for a lock-step batch) ------------------------
+    def prefetch_randoms(self, pool):
+        """From now on ``sweep_device_hmc`` takes its random numbers from arrays that ``pool`` (a ThreadPoolExecutor: one per team, or one
+        thread of a rank's own) fills one sweep ahead — the member's generator is asked for the same arrays in the same order, while the
+        member waits in the team's rendezvous instead of between two calls."""
+        self._draw_pool = pool
+        self._draw_sets = [{"R": [np.empty((self.Lt, self.N), dtype=np.complex128, order="F") for _ in range(3)], "pi": [np.empty((self.Lt, self.free)) for _ in range(2)],
+                            "rv": [np.empty(self.N) for _ in range(2)], "P": np.empty((self.Lt, max(self.Nph, 1))), "rvs": np.empty((self.Nt + 1, self.N))} for _ in range(2)]
+        self._draw_n = 0
+        self._draw_next = None
+
+    def _fill_draws(self, d):
+        for i in range(2):
+            self._draw_cn(d["R"][i])
+            self.rng.standard_normal(out=d["pi"][i])
+            self.rng.standard_normal(out=d["rv"][i])
+        self._draw_cn(d["R"][2])
+        self.rng.standard_normal(out=d["P"])
+        self.rng.standard_normal(out=d["rvs"])
+        return d
+
+    def _take_draws(self):
+        if self._draw_next is None:
+            self._draw_next = self._draw_pool.submit(self._fill_draws, self._draw_sets[self._draw_n & 1])
+        d = self._draw_next.result()
+        self._draw_n += 1
+        self._draw_next = self._draw_pool.submit(self._fill_draws, self._draw_sets[self._draw_n & 1])
+        return d
+
+    def _draw_cn(self, R):
+        flat = R.reshape(-1, order="F").view(np.float64)
         self.rng.standard_normal(out=flat)                    # randn!(rng, Φ), src/PFFCalculator.jl:67
         flat *= np.sqrt(0.5)
+
+    def sample_pseudofermion_fields(self, R=None):
+        if R is None:
+            R = self.R
+            self._draw_cn(R)
         rr = C.c_double(0.0)
-        self._sample_call(L.ptr(self.R), C.byref(rr))
+        self._sample_call(L.ptr(R), C.byref(rr))
         return rr.value
 
-    def pff_step(self, tol, moved, want_force):
-        rv = self.rng.standard_normal(self.N)                 # randn!(rng, v), KPMPreconditioner.jl:634
+    def pff_step(self, tol, moved, want_force, rv=None):
+        if rv is None:
+            rv = self.rng.standard_normal(self.N)             # randn!(rng, v), KPMPreconditioner.jl:634
         sf, eps, it = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
         self._step_call(L.ptr(self.x) if moved else None, L.ptr(rv), C.c_double(tol), int(self.maxiter), 1, C.byref(sf), C.byref(it), C.byref(eps),
                         L.ptr(self.dSdx) if want_force else None)

@@ -404,3 +404,31 @@ def test_team_greens_estimator_equals_the_batched_measurement(tmp_path):
         r = np.load(tmp_path / f"g{w}.npz")
         assert np.array_equal(r["G"], G_ref[w]) and int(r["it"]) == it_ref[w]
     # G(r = 0, τ = 0) + G(r = 0, τ = β) = 1 for equal orbitals is checked by tests/test_gpu_greens.py on the batched path this one equals
+
+
+def test_members_that_draw_their_random_numbers_one_sweep_ahead_run_the_same_sweeps():
+    """TeamMember.prefetch_randoms(pool): the member's generator is asked for the arrays of the next sweep_device_hmc by a pool thread
+    while the member waits in the rendezvous — the same arrays in the same order, hence the same ΔH and iteration counts as members that
+    draw on demand.  The native driver draws the same way (one producer thread per member); its counts are fixed by the sweep's shape."""
+    name, K, Nt = "holstein_honeycomb_L4_Ltau40", 3, 4
+    ta = WalkerTeam(name, K, device_efa=True, Nt=Nt)
+    tb = WalkerTeam(name, K, device_efa=True, Nt=Nt)
+    draw_pool = ThreadPoolExecutor(2)
+    for m in tb.members:
+        m.prefetch_randoms(draw_pool)
+    with ThreadPoolExecutor(2 * K) as pool:
+        for _ in range(3):
+            fa = [pool.submit(m.sweep_device_hmc) for m in ta.members]
+            fb = [pool.submit(m.sweep_device_hmc) for m in tb.members]
+            da, db = [f.result() for f in fa], [f.result() for f in fb]
+            assert da == db
+    assert [m.iters_sum for m in ta.members] == [m.iters_sum for m in tb.members]
+    draw_pool.shutdown(wait=True)
+    b = tb.batch
+    x0 = np.ascontiguousarray(np.stack([np.asarray(b.xs_force[w]) for w in range(K)]))
+    secs, so, itn = C.c_double(0.0), C.c_long(0), C.c_long(0)
+    tb.call("smoqy_team_bench_sweeps", L.ptr(x0), int(b.Nph), C.c_double(b.drift), Nt, C.c_double(b.tol), C.c_double(b.tol_force), int(b.maxiter), 1, 1, 2, 5,
+            C.byref(secs), C.byref(so), C.byref(itn))
+    assert so.value == K * 2 * (3 + Nt) and itn.value > so.value and secs.value > 0
+    ta.close()
+    tb.close()
