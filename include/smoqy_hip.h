@@ -450,6 +450,10 @@ int smoqy_member_ge_measure_GD0(smoqy_member *member, int a, int b, void *out);
 int smoqy_team_bench_sweeps(smoqy_team *team, const double *x0, int nfree, double drift, int Nt, double tol, double tol_force, int maxiter, int device_hmc, int warmup_sweeps,
                             int nsweeps, unsigned long seed, double *seconds, long *solves, long *iters);
 
+/* The normal deviates the native member threads draw (xoshiro256++ and a 128-layer ziggurat), exposed so that their distribution can be
+ * tested on the CPU: n numbers of standard deviation `scale` from the stream of `seed`.  Host code only; needs no GPU and no handle. */
+int smoqy_bench_randn(double *out, long n, unsigned long seed, double scale);
+
 /* HIP events on the handle's stream */
 int smoqy_timer_start(smoqy_ctx *ctx);
 int smoqy_timer_stop(smoqy_ctx *ctx, double *ms);

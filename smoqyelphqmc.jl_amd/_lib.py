@@ -96,6 +96,7 @@ SIGNATURES = {
     "smoqy_member_ge_update": [_p, _p, _p, _d, _i, _pi, _pd],
     "smoqy_member_ge_measure_GD0": [_p, _i, _i, _p],
     "smoqy_team_bench_sweeps": [_p, _p, _i, _d, _i, _d, _d, _i, _i, _i, _i, C.c_ulong, _pd, C.POINTER(C.c_long), C.POINTER(C.c_long)],
+    "smoqy_bench_randn": [_p, C.c_long, C.c_ulong, _d],
     "smoqy_matvec": [_p, _i, _p, _p, _i, _i],
     "smoqy_checkerboard_v": [_p, _i, _i, _i, _i, _i],
     "smoqy_checkerboard": [_p, _p, _i, _i, _i, _i, _i, _i],

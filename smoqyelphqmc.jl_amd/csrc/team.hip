@@ -867,7 +867,7 @@ extern "C" {
 // What a caller without an interpreter lock gets from a team: K std::threads, each running the per-walker sweep of the reference's
 // tutorial (tutorials/holstein_honeycomb.jl:611-684: two local-move-like updates, then an HMC trajectory of Nt force evaluations and the
 // closing action) against ITS OWN walker through smoqy_team_sample_phi / smoqy_team_pff_step, with its own random stream (xoshiro256++
-// and Box-Muller: the randn! calls of src/PFFCalculator.jl:67 and src/KPMPreconditioner.jl:634 are part of a member's host work).  The
+// and a ziggurat: the randn! calls of src/PFFCalculator.jl:67 and src/KPMPreconditioner.jl:634 are part of a member's host work).  The
 // phonon-field moves are the synthetic drift of bench.py's sweep (x += drift·π, restored afterwards), as in walkers.TeamMember.sweep.
 namespace {
 struct Xo {
@@ -876,13 +876,39 @@ struct Xo {
     static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
     uint64_t next() { const uint64_t r = rotl(s[0] + s[3], 23) + s[0], t = s[1] << 17; s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45); return r; }
     double uni() { return ((next() >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+    // standard normal deviates by the ziggurat method (128 layers; Marsaglia & Tsang 2000 with Doornik's separate draws for the layer
+    // index and the abscissa): a few ns per number, the class of generator behind randn! in the reference's driver
+    struct Zig {
+        double x[129], ratio[128];
+        Zig()
+        {
+            const double R = 3.442619855899, V = 9.91256303526217e-3;
+            double f = std::exp(-0.5 * R * R);
+            x[0] = V / f; x[1] = R; x[128] = 0.0;
+            for (int i = 2; i < 128; ++i) { x[i] = std::sqrt(-2.0 * std::log(V / x[i - 1] + f)); f = std::exp(-0.5 * x[i] * x[i]); }
+            for (int i = 0; i < 128; ++i) ratio[i] = x[i + 1] / x[i];
+        }
+    };
+    double one()
+    {
+        static const Zig z;
+        for (;;) {
+            const double u = 2.0 * uni() - 1.0;
+            const int i = (int)(next() >> 57);  // 7 bits of their own
+            if (std::fabs(u) < z.ratio[i]) return u * z.x[i];
+            if (i == 0) {  // the tail beyond R
+                double a, b;
+                do { a = std::log(uni()) / z.x[1]; b = std::log(uni()); } while (-2.0 * b < a * a);
+                return u < 0 ? a - z.x[1] : z.x[1] - a;
+            }
+            const double v = u * z.x[i];
+            const double f0 = std::exp(-0.5 * (z.x[i] * z.x[i] - v * v)), f1 = std::exp(-0.5 * (z.x[i + 1] * z.x[i + 1] - v * v));
+            if (f1 + uni() * (f0 - f1) < 1.0) return v;
+        }
+    }
     void normal(double *out, size_t n, double scale)
     {
-        for (size_t i = 0; i < n; i += 2) {
-            const double r = std::sqrt(-2.0 * std::log(uni())) * scale, a = 6.283185307179586 * uni();
-            out[i] = r * std::cos(a);
-            if (i + 1 < n) out[i + 1] = r * std::sin(a);
-        }
+        for (size_t i = 0; i < n; ++i) out[i] = scale * one();
     }
 };
 // what one sweep of a member asks its generator for, in the order it asks: drawn by the member's producer thread one sweep ahead, so that
@@ -905,6 +931,14 @@ struct Member {
     bool stop = false;
 };
 }  // namespace
+
+int smoqy_bench_randn(double *out, long n, unsigned long seed, double scale)
+{
+    if (!out || n < 0) return 1;
+    Xo rng((uint64_t)seed);
+    rng.normal(out, (size_t)n, scale);
+    return 0;
+}
 
 int smoqy_team_bench_sweeps(smoqy_team *t, const double *x0, int nfree, double drift, int Nt, double tol, double tol_force, int maxiter, int device_hmc, int warmup_sweeps, int nsweeps,
                             unsigned long seed, double *seconds, long *solves, long *iters)
