@@ -34,7 +34,7 @@ for k, g in sorted(gaps.items(), key=lambda kv: -len(kv[1]))[:14]:
     g.sort()
     print(f"{k[0] + ' -> ' + k[1]:48s} {len(g):7d} {g[len(g) // 2] / 1e3:14.2f} {sum(g) / len(g) / 1e3:8.2f} {g[int(.9 * len(g))] / 1e3:8.2f}")
 print("\nwhere the idle time of the window is (pairs by summed gap):")
-for k, g in sorted(gaps.items(), key=lambda kv: -sum(kv[1]))[:8]:
+for k, g in sorted(gaps.items(), key=lambda kv: -sum(kv[1]))[:16]:
     print(f"{k[0] + ' -> ' + k[1]:48s} {len(g):7d} {sum(g) / 1e6:11.2f} ms")
 loop = ["fdm_stream" if durs.get("fdm_stream") else "fdm_own", "tfft_kernel<2>", "cheb_own", "tfft_kernel<3>"]
 tot_k = sum(sorted(durs[k])[len(durs[k]) // 2] for k in loop if durs[k]) / 1e3
@@ -43,6 +43,8 @@ print(f"one iteration (medians): kernels {tot_k:.1f} us + boundaries {tot_g:.1f}
 span = ev[-1][1] - ev[0][0]
 busy = sum(e - s for s, e, _ in ev)
 print(f"window {span / 1e6:.2f} ms, kernels busy {busy / 1e6:.2f} ms ({100 * busy / span:.1f} %)")
+it_busy = sum(sum(durs[k]) for k in loop if durs[k])
+print(f"of which the four kernels of the CG iteration {it_busy / 1e6:.2f} ms ({100 * it_busy / span:.1f} % of the window); other kernels {(busy - it_busy) / 1e6:.2f} ms")
 # the tail of the iteration-closing boundary: how many of its gaps are not back to back, and what they add up to
 g = sorted(gaps[(loop[3], loop[0])])
 big = [x for x in g if x > 2000]
