@@ -368,7 +368,7 @@ def team_scan(args, counts, dev, walker0):
         if draw_pool is not None:
             draw_pool.shutdown(wait=True)
         team.close()
-        ob = WalkerBatch(args.workload, nwalkers=K, walker0=walker0 + 3000, device=dev, device_efa=dev_hmc)
+        ob = WalkerBatch(args.workload, nwalkers=K, walker0=walker0 + 3000, device=dev, device_efa=dev_hmc, prefetch_randoms=not getattr(args, "no_prefetch", False))
         ob.sweep()
         ob.h.call("smoqy_sync")
         t1 = time.perf_counter()
