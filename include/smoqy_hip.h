@@ -300,7 +300,7 @@ int smoqy_efa_checkpoint(smoqy_ctx *ctx, int restore);
 int smoqy_efa_restore_walkers(smoqy_ctx *ctx, const int *restore);
 /* the trajectory of hmc_update! between the momentum refresh and the final action (src/EFAPFFHMCUpdater.jl:148-206) in ONE call:
  * evolve(Δt/2), update!; Nt times { calculate_derivative_fermionic_action! at tol_force; p -= Δt ∂S_f/∂x; evolve(Δt, last step Δt/2);
- * update! }.  Φ in vector phi, Ψ left in psi.  randvecs: N x nwalkers x Nt Lanczos start vectors (the rng stays on the host); Sf, iters,
+ * update! }.  Φ in vector phi, Ψ left in psi.  randvecs: N x nwalkers x Nt Lanczos start vectors (2N each for a complex handle; the rng stays on the host; sent in one transfer); Sf, iters,
  * eps: nwalkers x Nt (any may be NULL).  Only the fermionic force is applied: anharmonic / dispersive phonon terms (:190-193) are the
  * caller's to add through smoqy_efa_evolve step by step.  A non-zero return (e.g. a non-finite residual) leaves x and p wherever the
  * trajectory stopped: the caller rejects the update with smoqy_efa_checkpoint(ctx, 1), as the reference's catch block does (:176-187). */

@@ -129,6 +129,8 @@ struct smoqy_ctx {
     int nslot = 0, maxorder = 64;
     std::vector<WalkerPrecond> pre;
     double *d_dbar = nullptr, *d_cbar = nullptr, *d_sbar = nullptr, *d_bounds = nullptr, *d_rand = nullptr, *d_lan = nullptr;
+    double *d_rand_traj = nullptr;  // [Nt][nw][N (2N: complex T)] start vectors of a device trajectory (smoqy_hmc_trajectory_v)
+    size_t rand_traj_cap = 0;
     int *d_order = nullptr, *d_active = nullptr;
     double2 *d_coefs = nullptr;
     KpmGeom kg{};
@@ -351,7 +353,7 @@ static int pin_reserve(smoqy_ctx *c, size_t bytes, char **slot)
             if (c->h_pin) (void)hipHostFree(c->h_pin);
             c->h_pin = nullptr;
             c->pin_cap = 0;
-            const size_t cap = std::max(need, (size_t)1 << 20);
+            const size_t cap = std::max(2 * need, (size_t)1 << 20);  // room for the small transfers that follow a large one
             HIPCHK(c, hipHostMalloc((void **)&c->h_pin, cap, hipHostMallocDefault));
             c->pin_cap = cap;
         }
@@ -419,7 +421,7 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->fft_info) rocfft_execution_info_destroy(c->fft_info);
     void *ptrs[] = {c->d_bonds, c->d_col_off, c->d_expV, c->d_ch, c->d_sh, c->d_lam, c->d_stage, c->d_stage_real, c->d_stage_int, c->scr[0], c->scr[1], c->scr[2], c->cg_r, c->cg_p,
                     c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->d_st_idle, c->fft_work, c->d_tw, c->d_th, c->d_wtab, c->d_tpos, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
-                    c->d_rand, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_big, c->d_shi, c->d_sbari};
+                    c->d_rand, c->d_rand_traj, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_big, c->d_shi, c->d_sbari};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (double2 *v : c->vecs)
@@ -1547,16 +1549,19 @@ static int pstat_wait(smoqy_ctx *c)
 // (update_B̄! :604-621), Lanczos from the caller's start vectors (calculate_bounds! :625-658) ending with the tridiagonal extremes, the
 // widening, the activation test and the "bounds moved by more than rbuf/2" decision (:569-593), then the expansion coefficients of the
 // walkers whose bounds were accepted (:734-795).  A 16-byte status record per walker follows the kernels to the host (pstat_wait).
-static int precond_update_range(smoqy_ctx *c, int w0, int nw, const double *randvecs)
+// d_randvecs: the start vectors are on the device already (a trajectory sends those of all its steps in one transfer) — no copy command
+// between the τ-means and the Lanczos kernel, and no arena turnover (a stream drain) every few steps of a large batch.
+static int precond_update_range(smoqy_ctx *c, int w0, int nw, const double *randvecs, const double *d_randvecs = nullptr)
 {
     const Geometry &g = c->g;
     const int n = c->nlanczos;
     if (int rc = pstat_wait(c)) return rc;  // one outstanding record at a time (h_pstat is about to be overwritten)
     launch_tau_means(c->stream, c->kg, c->d_expV, c->d_ch, c->d_sh, c->d_dbar, c->d_cbar, c->d_sbar, g.Lt, g.N, g.Nh, w0, nw, c->d_shi, c->d_sbari);
-    if (int rc = pin_h2d(c, c->d_rand, randvecs, (size_t)nw * g.N * (g.is_cplx ? 2 : 1) * sizeof(double))) return rc;  // complex T: N complex deviates per walker (:634); the caller's array may be pageable
+    if (!d_randvecs)
+        if (int rc = pin_h2d(c, c->d_rand, randvecs, (size_t)nw * g.N * (g.is_cplx ? 2 : 1) * sizeof(double))) return rc;  // complex T: N complex deviates per walker (:634); the caller's array may be pageable
     KpmArgs k = kpm_args(c, nullptr, nullptr);
     const PreUpd u = pre_upd(c);
-    launch_lanczos(c->stream, k, c->kg, w0, nw, c->d_rand, n, c->d_lan + (size_t)w0 * 1024, c->d_lan + (size_t)(g.nw + w0) * 1024, !g.is_sym, u);
+    launch_lanczos(c->stream, k, c->kg, w0, nw, d_randvecs ? d_randvecs : c->d_rand, n, c->d_lan + (size_t)w0 * 1024, c->d_lan + (size_t)(g.nw + w0) * 1024, !g.is_sym, u);
     launch_kpm_expansions(c->stream, u, w0, nw);
     HIPCHK(c, hipMemcpyAsync(c->h_pstat + 4 * (size_t)w0, c->d_pstat + 4 * (size_t)w0, (size_t)nw * 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_pstat, c->stream));
@@ -2422,10 +2427,11 @@ int smoqy_force_store_v(smoqy_ctx *c, int psi, double *out)
 // calculate_derivative_fermionic_action! (src/PFFCalculator.jl:119-157) on the fields as they stand: [update_preconditioner!], Ψ = Λ⁻ᵀΦ,
 // Ψ = (MᵀM)⁻¹Ψ, Ψ = Λ⁻¹Ψ, S_f = Φ·Ψ (left in d_dot_out), and with want_force the force in force.d_out.  No phonon-field upload, no
 // force download: the callers decide what crosses the boundary.
-static int pff_core(smoqy_ctx *c, int phi, int psi, const double *randvec_all, double tol, int maxiter, int use_precond, bool want_force, int *iters, double *eps)
+static int pff_core(smoqy_ctx *c, int phi, int psi, const double *randvec_all, double tol, int maxiter, int use_precond, bool want_force, int *iters, double *eps,
+                    const double *d_randvec_all = nullptr)
 {
     const Geometry &g = c->g;
-    if (randvec_all && use_precond) if (int rc = precond_update_range(c, 0, g.nw, randvec_all)) return rc;  // FermionDetMatrix.jl:259
+    if ((randvec_all || d_randvec_all) && use_precond) if (int rc = precond_update_range(c, 0, g.nw, randvec_all, d_randvec_all)) return rc;  // FermionDetMatrix.jl:259
     // Ψ = Λ⁻ᵀΦ (PFFCalculator.jl:97), ldiv!(Ψ, fdm, Ψ) (:99), Ψ = Λ⁻¹Ψ (:107) and the partials of S_f = Φ·Ψ (:109) in the kernels of the solve:
     // cg_init reads Φ through Λ⁻ᵀ, cg_finish writes Λ⁻¹x into the scratch vector that then becomes Ψ (CgArgs::lam)
     if (int rc = cg_dev(c, c->vecs[psi], nullptr, true, tol, maxiter, use_precond, iters, eps, c->vecs[phi], c->scr[0])) return rc;
@@ -2667,12 +2673,25 @@ int smoqy_hmc_trajectory_v(smoqy_ctx *c, int phi, int psi, int Nt, double dt, do
         c->traj_cap = (size_t)Nt * g.nsys;
     }
     double2 *hdot = c->h_traj_dot;
+    // the Lanczos start vectors of all Nt steps cross the boundary once, in front of the trajectory
+    const size_t rvn = (size_t)g.nw * g.N * (g.is_cplx ? 2 : 1);
+    if (use_precond) {
+        if ((size_t)Nt * rvn > c->rand_traj_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));  // a queued kernel may still read the old buffer
+            if (c->d_rand_traj) (void)hipFree(c->d_rand_traj);
+            c->d_rand_traj = nullptr;
+            c->rand_traj_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_rand_traj, (size_t)Nt * rvn * sizeof(double)));
+            c->rand_traj_cap = (size_t)Nt * rvn;
+        }
+        if (int rc = pin_h2d(c, c->d_rand_traj, randvecs, (size_t)Nt * rvn * sizeof(double))) return rc;
+    }
     // evolve_eom!(x, p, Δt/2); update!(fdm)                                                            EFAPFFHMCUpdater.jl:148-152
     if (int rc = efa_launch(c, 0, 0.5 * dt, 0.0, false)) return rc;
     if (int rc = refresh_from_device_x(c)) return rc;
     for (int t = 0; t < Nt; ++t) {                                                                   // :162
-        const double *rv = use_precond ? randvecs + (size_t)t * g.nw * g.N : nullptr;
-        if (int rc = pff_core(c, phi, psi, rv, tol_force, maxiter, use_precond, true, it.data(), ep.data())) return rc;  // :172 (force stays in force.d_out)
+        const double *d_rv = use_precond ? c->d_rand_traj + (size_t)t * rvn : nullptr;
+        if (int rc = pff_core(c, phi, psi, nullptr, tol_force, maxiter, use_precond, true, it.data(), ep.data(), d_rv)) return rc;  // :172 (force stays in force.d_out)
         HIPCHK(c, hipMemcpyAsync(hdot + (size_t)t * g.nsys, c->d_dot_out, (size_t)g.nsys * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
         // p -= Δt ∂S/∂x (:196) fused into evolve_eom!(x, p, Δt′) (:201-202); update!(fdm) (:204-205)
         if (int rc = efa_launch(c, 0, (t == Nt - 1) ? 0.5 * dt : dt, dt, true)) return rc;
