@@ -93,6 +93,7 @@ struct smoqy_ctx {
     CgState *d_st = nullptr, *h_st = nullptr, *d_st_idle = nullptr;
     void *h_poll_dot = nullptr;  // pinned staging for per-system scalars (smoqy_pff_step_v)
     double2 *h_traj_dot = nullptr;  // pinned [Nt][nsys]: S_f of every step of a device trajectory, read once at its end
+    double2 *d_traj_dot = nullptr;  // the same on the device: where the steps' dot_final kernels write
     size_t traj_cap = 0;
     int check_every = 4;
     // iterations the previous solve at (about) the same tolerance needed: consecutive solves of an HMC
@@ -421,7 +422,7 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->fft_info) rocfft_execution_info_destroy(c->fft_info);
     void *ptrs[] = {c->d_bonds, c->d_col_off, c->d_expV, c->d_ch, c->d_sh, c->d_lam, c->d_stage, c->d_stage_real, c->d_stage_int, c->scr[0], c->scr[1], c->scr[2], c->cg_r, c->cg_p,
                     c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->d_st_idle, c->fft_work, c->d_tw, c->d_th, c->d_wtab, c->d_tpos, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
-                    c->d_rand, c->d_rand_traj, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_big, c->d_shi, c->d_sbari};
+                    c->d_rand, c->d_rand_traj, c->d_traj_dot, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_big, c->d_shi, c->d_sbari};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (double2 *v : c->vecs)
@@ -2428,7 +2429,7 @@ int smoqy_force_store_v(smoqy_ctx *c, int psi, double *out)
 // Ψ = (MᵀM)⁻¹Ψ, Ψ = Λ⁻¹Ψ, S_f = Φ·Ψ (left in d_dot_out), and with want_force the force in force.d_out.  No phonon-field upload, no
 // force download: the callers decide what crosses the boundary.
 static int pff_core(smoqy_ctx *c, int phi, int psi, const double *randvec_all, double tol, int maxiter, int use_precond, bool want_force, int *iters, double *eps,
-                    const double *d_randvec_all = nullptr)
+                    const double *d_randvec_all = nullptr, double2 *d_dot = nullptr)
 {
     const Geometry &g = c->g;
     if ((randvec_all || d_randvec_all) && use_precond) if (int rc = precond_update_range(c, 0, g.nw, randvec_all, d_randvec_all)) return rc;  // FermionDetMatrix.jl:259
@@ -2436,7 +2437,7 @@ static int pff_core(smoqy_ctx *c, int phi, int psi, const double *randvec_all, d
     // cg_init reads Φ through Λ⁻ᵀ, cg_finish writes Λ⁻¹x into the scratch vector that then becomes Ψ (CgArgs::lam)
     if (int rc = cg_dev(c, c->vecs[psi], nullptr, true, tol, maxiter, use_precond, iters, eps, c->vecs[phi], c->scr[0])) return rc;
     std::swap(c->scr[0], c->vecs[psi]);
-    launch_dot_final(c->stream, c->part_c, c->d_dot_out, g.nsys, c->nchunk);
+    launch_dot_final(c->stream, c->part_c, d_dot ? d_dot : c->d_dot_out, g.nsys, c->nchunk);  // d_dot: a trajectory keeps the S_f of every step on the device until its end
     if (want_force) if (int rc = force_device(c, psi)) return rc;                                                               // :146-155
     return 0;
 }
@@ -2663,13 +2664,18 @@ int smoqy_hmc_trajectory_v(smoqy_ctx *c, int phi, int psi, int Nt, double dt, do
     if (use_precond && !randvecs) FAIL(c, 1, "randvecs is NULL");
     std::vector<int> it((size_t)g.nw);
     std::vector<double> ep((size_t)g.nw);
-    // S_f of every step lands in its own page-locked slot and is read once, behind the last step: no host synchronisation per step besides
-    // the solve's own (round 2 synchronised here 24 times per trajectory)
+    // S_f of every step stays in its own device slot and comes to the host in one transfer behind the last step: no host synchronisation
+    // per step besides the solve's own (round 2 synchronised here 24 times per trajectory) and no copy command between the force kernels
+    // and the leapfrog step either
     if ((size_t)Nt * g.nsys > c->traj_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->h_traj_dot) (void)hipHostFree(c->h_traj_dot);
+        if (c->d_traj_dot) (void)hipFree(c->d_traj_dot);
         c->h_traj_dot = nullptr;
+        c->d_traj_dot = nullptr;
         c->traj_cap = 0;
         HIPCHK(c, hipHostMalloc((void **)&c->h_traj_dot, (size_t)Nt * g.nsys * sizeof(double2), hipHostMallocDefault));
+        HIPCHK(c, hipMalloc((void **)&c->d_traj_dot, (size_t)Nt * g.nsys * sizeof(double2)));
         c->traj_cap = (size_t)Nt * g.nsys;
     }
     double2 *hdot = c->h_traj_dot;
@@ -2691,8 +2697,7 @@ int smoqy_hmc_trajectory_v(smoqy_ctx *c, int phi, int psi, int Nt, double dt, do
     if (int rc = refresh_from_device_x(c)) return rc;
     for (int t = 0; t < Nt; ++t) {                                                                   // :162
         const double *d_rv = use_precond ? c->d_rand_traj + (size_t)t * rvn : nullptr;
-        if (int rc = pff_core(c, phi, psi, nullptr, tol_force, maxiter, use_precond, true, it.data(), ep.data(), d_rv)) return rc;  // :172 (force stays in force.d_out)
-        HIPCHK(c, hipMemcpyAsync(hdot + (size_t)t * g.nsys, c->d_dot_out, (size_t)g.nsys * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+        if (int rc = pff_core(c, phi, psi, nullptr, tol_force, maxiter, use_precond, true, it.data(), ep.data(), d_rv, c->d_traj_dot + (size_t)t * g.nsys)) return rc;  // :172 (force stays in force.d_out)
         // p -= Δt ∂S/∂x (:196) fused into evolve_eom!(x, p, Δt′) (:201-202); update!(fdm) (:204-205)
         if (int rc = efa_launch(c, 0, (t == Nt - 1) ? 0.5 * dt : dt, dt, true)) return rc;
         if (int rc = refresh_from_device_x(c)) return rc;
@@ -2701,6 +2706,7 @@ int smoqy_hmc_trajectory_v(smoqy_ctx *c, int phi, int psi, int Nt, double dt, do
             if (eps) eps[(size_t)t * g.nw + w] = ep[w];
         }
     }
+    HIPCHK(c, hipMemcpyAsync(hdot, c->d_traj_dot, (size_t)Nt * g.nsys * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (Sf)
         for (int t = 0; t < Nt; ++t)
