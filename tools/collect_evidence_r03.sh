@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout -k 10 600 python -m pytest tests -m gpu -q > gpurun_out/r03_gpu_suite.log 2>&1; tail -3 gpurun_out/r03_gpu_suite.log
-timeout -k 10 500 python bench.py > gpurun_out/r03_bench_output.json 2> gpurun_out/r03_bench_output.err; echo bench rc=$?
+t0=$SECONDS; timeout -k 10 500 python bench.py > gpurun_out/r03_bench_output.json 2> gpurun_out/r03_bench_output.err; echo bench rc=$? wall $((SECONDS-t0)) s
 bash tools/profile_bench.sh r03 && echo prof ok
 bash tools/profile_roofline.sh r03 && echo roof ok
 bash tools/solo_profile.sh r03_hc16 16 && bash tools/solo_profile.sh r03_hc16_w1 1 && bash tools/solo_profile.sh r03_ossh 16 ossh_square_L12_Ltau100 && bash tools/solo_profile.sh r03_bssh 16 bssh_chain_L256_Ltau200 && bash tools/solo_profile.sh r03_hc8 16 holstein_honeycomb_L8_Ltau80
