@@ -260,3 +260,57 @@ def test_force_and_update_from_phonons_complex_T(kind, is_sym):
     if kind == "bssh":
         assert np.all(dS[0][:, -1] == 0)  # the infinite-mass partner mode receives no force
     h.close()
+
+
+@pytest.mark.parametrize("kind", ["bssh", "ossh"])
+def test_device_trajectory_complex_T(kind):
+    """smoqy_hmc_trajectory_v on a complex handle (Nt steps in one call; the Lanczos start vectors are N COMPLEX deviates per walker and
+    step, i.e. 2N doubles, sent in one transfer) against the same steps driven one by one through smoqy_pff_step_v + smoqy_efa_evolve on a
+    second handle: the same solves on the same fields, hence equal iteration counts, actions, positions and momenta."""
+    m, nt, perm, colors, fc, V0, t0 = _flux_ssh(kind)
+    Lt, N = m.fpi.Ltau, m.fpi.N
+    Nph = fc.x.shape[0]
+    Nt, dt, nw = 3, 0.13, 1
+    fm = np.asarray(fc.finite_mass, dtype=bool)
+    row = m.fpi.dtau * (1.0 + 4.0 / m.fpi.dtau**2 * np.sin(np.pi * np.arange(Lt) / Lt) ** 2)
+    q = np.asfortranarray(np.where(fm[:, None], row[None, :], np.inf))
+    g = np.random.default_rng(11)
+    Rphi = np.asfortranarray((g.standard_normal((Lt, N, 1)) + 1j * g.standard_normal((Lt, N, 1))) * np.sqrt(0.5))
+    R = np.ascontiguousarray(g.standard_normal((nw, Lt, Nph)))
+    rv = np.ascontiguousarray(g.standard_normal((Nt, nw, 2 * N)))
+    hs = []
+    for _ in range(2):
+        h = L.Handle(Lt, N, nt, colors, True, nw, 1, is_complex=True)
+        cs, keep = L.couplings_struct(fc)
+        h.call("smoqy_force_set_couplings", C.byref(cs))
+        h.call("smoqy_set_bare_model", L.ptr(V0), L.ptr(np.ascontiguousarray(t0)), L.ptr(perm))
+        h.call("smoqy_update_from_phonons_all", L.ptr(np.ascontiguousarray(np.asfortranarray(fc.x).T[None])))
+        h.call("smoqy_efa_config", L.ptr(q), L.ptr(q.copy(order="F")))
+        phi, psi = h.vec_alloc(), h.vec_alloc()
+        h.vec_upload(phi, Rphi)
+        h.call("smoqy_matvec_v", L.OP_MT, phi, phi)
+        h.call("smoqy_lambda_apply_v", L.LAMBDA_MULT, phi, phi)
+        K = np.zeros(nw)
+        h.call("smoqy_efa_initialize_momentum", L.ptr(R), L.ptr(K))
+        hs.append((h, phi, psi, keep))
+    (ha, pa, sa, _), (hb, pb, sb, _) = hs
+    sf = np.zeros((Nt, nw)); it = np.zeros((Nt, nw), dtype=np.int32); ep = np.zeros((Nt, nw))
+    ha.call("smoqy_hmc_trajectory_v", pa, sa, Nt, C.c_double(dt), C.c_double(1e-11), 10000, 1, L.ptr(rv), L.ptr(sf), L.ptr(it), L.ptr(ep))
+    sf2 = np.zeros((Nt, nw)); it2 = np.zeros((Nt, nw), dtype=np.int32)
+    hb.call("smoqy_efa_evolve", C.c_double(dt / 2), C.c_double(0.0), 1)
+    for t in range(Nt):
+        s1, i1, e1 = np.zeros(nw), np.zeros(nw, dtype=np.int32), np.zeros(nw)
+        dS = np.zeros((nw, Lt, Nph))
+        hb.call("smoqy_pff_step_v", pb, sb, None, L.ptr(np.ascontiguousarray(rv[t])), C.c_double(1e-11), 10000, 1, L.ptr(s1), L.ptr(i1), L.ptr(e1), L.ptr(dS))
+        sf2[t], it2[t] = s1, i1
+        hb.call("smoqy_efa_evolve", C.c_double(dt / 2 if t == Nt - 1 else dt), C.c_double(dt), 1)
+    assert np.array_equal(it, it2) and it.min() > 0 and ep.max() < 1e-11
+    np.testing.assert_allclose(sf, sf2, rtol=1e-10)
+    xa, pa_ = np.zeros((nw, Lt, Nph)), np.zeros((nw, Lt, Nph))
+    xb, pb_ = np.zeros((nw, Lt, Nph)), np.zeros((nw, Lt, Nph))
+    ha.call("smoqy_efa_get_state", L.ptr(xa), L.ptr(pa_))
+    hb.call("smoqy_efa_get_state", L.ptr(xb), L.ptr(pb_))
+    np.testing.assert_allclose(xa, xb, atol=1e-11 * np.abs(xb).max())
+    np.testing.assert_allclose(pa_, pb_, atol=1e-11 * np.abs(pb_).max())
+    assert np.abs(xa - np.asfortranarray(fc.x).T[None]).max() > 1e-4  # the fields did move
+    ha.close(); hb.close()
