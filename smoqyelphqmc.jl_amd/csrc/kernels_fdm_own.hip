@@ -538,10 +538,13 @@ bool fdm_own_supported(const FdmArgs &a, const FdmFast &ff, bool sym)
 // streaming MᵀM on the lane program: τ-independent hoppings (the caller passes cs_const), Sym, 256-lane lattices, R >= 2
 bool fdm_own_stream_supported(const FdmArgs &a, const FdmFast &ff, bool sym, bool cs_const)
 {
-    // opt-in (SMOQY_FDM_OWNSTREAM=1): 13.6 / 37.1 / 76.3 us against fdm_stream_kernel's 15.0 / 42.0 / 81.2 at 16 / 64 / 128 systems alone on the
-    // device, a 2 % shorter sweep for one stream of 16 walkers — and nothing in the bench, where four streams share the device and its 152 VGPRs
-    // (three waves per SIMD) cost what the shorter stage chain gains
-    static const int on = [] { const char *e = getenv("SMOQY_FDM_OWNSTREAM"); return (e && e[0] == '1') ? 1 : 0; }();
+    // for handles that carry 32 systems or more (SMOQY_FDM_OWNSTREAM=1: always, 0: never).  Alone on the device it is the shorter kernel at every size —
+    // 13.6 / 22.1 / 37.1 / 76.3 us against fdm_stream_kernel's 15.0 / 24.3 / 42.0 / 81.2 at 16 / 32 / 64 / 128 systems — but its 152 VGPRs
+    // (three waves per SIMD) cost what the shorter stage chain gains once other solves' kernels share the device: with eight batches of 16
+    // in flight (the bench) nothing is gained and its launches are longer, while one stream of 32 / 64 walkers gains 1-3 % per sweep, a
+    // 64-member team 3.7 %, and four teams of 32 or eight batches of 32 are unchanged.  Hence the rule by handle size.
+    static const int mode = [] { const char *e = getenv("SMOQY_FDM_OWNSTREAM"); return !e ? -1 : (e[0] == '1' ? 1 : 0); }();
+    const bool on = mode == 1 || (mode < 0 && a.nsys >= 32);  // the handle's systems, whatever part of them this launch covers (smoqy_cg_split)
     return on && sym && cs_const && ff.enabled && ff.own && ff.threads <= 256 && a.ncol >= 2 && a.ncol <= kFdmColours && a.run_len >= 2 && a.run_len % a.Tc == 0 &&
            a.Lt >= 4 && a.shi == nullptr;
 }

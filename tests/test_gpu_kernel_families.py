@@ -41,11 +41,12 @@ def test_bench_shape_with_the_round_2_twins_of_the_round_3_kernels(wl0):
     assert " passed" in r.stdout
 
 
-def test_streaming_mtm_on_the_lane_program():
-    """SMOQY_FDM_OWNSTREAM=1 selects fdm_own_stream_kernel (the streaming MᵀM with the owner-computes stage chain; opt-in)
-    wherever fdm_stream_kernel would run on a 256-lane lattice with τ-independent hoppings: the streaming tests and the headline bench shape
-    against the oracle, same tolerances."""
-    env = dict(os.environ, SMOQY_FDM_OWNSTREAM="1")
+@pytest.mark.parametrize("mode", ["1", "0"])
+def test_streaming_mtm_on_the_lane_program(mode):
+    """fdm_own_stream_kernel (the streaming MᵀM with the owner-computes stage chain, DESIGN §9) is chosen for handles of 32 systems or more;
+    SMOQY_FDM_OWNSTREAM=1 selects it wherever fdm_stream_kernel would run on a 256-lane lattice with τ-independent hoppings, =0 never: the
+    streaming tests and the bench shapes against the oracle with each kernel at every size, same tolerances."""
+    env = dict(os.environ, SMOQY_FDM_OWNSTREAM=mode)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_stream_mtm.py"), os.path.join(ROOT, "tests", "test_gpu_bench_shape.py"),
                         "-m", "gpu", "-x", "-q", "-k", "not switched_off"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
