@@ -638,7 +638,7 @@ def roofline_record(args, batch, per, S, dev, insitu, extra, L, np):
     prim_s, prim_src = (timed_s, "timed region, device clock") if timed_s else (iso_s, "isolated leg (no timed region in this run)")
     roofline = {
         "bound": "hbm",
-        "kernel": "fdm_stream_kernel<NCOL, CSV, FULL> (fused MᵀM apply, streaming form from 16 systems per launch; fdm_own_kernel at <= 8 systems, fdm_fast_kernel where the streaming form does not apply)",
+        "kernel": "fdm_stream_kernel<NCOL, CSV, FULL> (fused MᵀM apply, streaming form from 16 systems per launch — fdm_own_stream_kernel, the same pipeline on the owner-computes lane program, on handles of 32 systems or more, i.e. in the batch scan's 32 / 64 / 128 points, not in the timed region's batches of 16; fdm_own_kernel at <= 8 systems, fdm_fast_kernel where the streaming form does not apply)",
         "achieved": alg / prim_s / 1e9,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
