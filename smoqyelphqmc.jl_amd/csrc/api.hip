@@ -624,7 +624,7 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
             // form of the own tau-FFT when nobody chose one (smoqy_tfft_form, SMOQY_TFFT_SLIM): in place from 32 systems per launch — at that
             // size the launches are HBM bound and six workgroups per CU beat four (64 walkers on one stream: 253.7 -> 242.9 ms per sweep,
             // 128: 491 -> 464), below it the two-image form's fewer passes win (16 walkers: DESIGN.md §4.3)
-            static const bool form_free = getenv("SMOQY_TFFT_SLIM") == nullptr;
+            static const bool form_free = tuning_env(kTuneTfftSlim) < 0;
             if (form_free && c->tf.slim_ok && g.nsys >= 32) c->tf.slim = 1;
         }
     }
@@ -751,7 +751,7 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
                 c->kg.wl0 = ok ? (rot_dn ? 2 : (rot_up ? 3 : 1)) : 0;
             }
             // the MᵀM kernel for small launches shares the lane layout when it owns the same colour: the DPP form of the colour-0 exchange too
-            static const bool wl_env_off = [] { const char *e = getenv("SMOQY_CHEB_WL0"); return e && (e[0] == '0' || e[0] == '1'); }();
+            static const bool wl_env_off = tuning_env(kTuneChebWl0) == 0 || tuning_env(kTuneChebWl0) == 1;
             c->ff.wl0 = (q_fdm == q_cheb && c->kg.wl0 >= 2 && !wl_env_off) ? c->kg.wl0 : 0;
             if (q_fdm == q_cheb) { c->d_own_f = c->d_own; c->ff.own_n = c->kg.own_n; }
             else if (int rc = build_own(q_fdm, &c->d_own_f, &c->ff.own_n)) return rc;
@@ -1152,7 +1152,7 @@ int smoqy_vec_dot(smoqy_ctx *c, int a, int b, void *out)
 // SMOQY_FDM_STREAM=R forces R (0 switches the kernel off) for A/B measurements.
 static int stream_run_length(const smoqy_ctx *c, int count, bool cs_const)
 {
-    static const int env = [] { const char *e = getenv("SMOQY_FDM_STREAM"); return e ? atoi(e) : -1; }();
+    static const int env = tuning_env(kTuneFdmStream);
     const Geometry &g = c->g;
     if (!g.is_sym || g.is_cplx || !c->ff.enabled || c->d_big) return 0;
     // τ-dependent hoppings on three or more colours (optical SSH): measured even with the chunked kernel (11.3 against 11.9 µs at 16 systems,
@@ -1202,7 +1202,7 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
     a.run_len = (op == SMOQY_OP_MTM && in != out) ? stream_run_length(c, count, cs_const) : 0;
     {   // exp(-ΔτV) is read once per launch: where the vectors of several solves compete for the Infinity Cache (the in-place τ-FFT form is
         // the sign of it, see cg_iteration_fused) it is loaded past the caches (+1.1 % in the eight-stream bench, four alternating pairs)
-        static const int nt_env = [] { const char *e = getenv("SMOQY_NT_FIELDS"); return e ? atoi(e) : -1; }();  // A/B switch
+        static const int nt_env = tuning_env(kTuneNtFields);  // A/B switch
         a.nt_fields = nt_env < 0 ? (c->tf_ok && c->tf.slim) : (nt_env != 0);
     }
     if (a.run_len > 0 && fdm_own_stream_supported(a, c->ff, c->g.is_sym != 0, cs_const)) launch_fdm_own_stream(st, a, c->ff);
@@ -1876,7 +1876,7 @@ static int cg_iteration_fused(smoqy_ctx *c, const CgArgs &a, hipStream_t st, int
     // launch is HBM resident — the vectors of the solves in flight compete for the Infinity Cache, and x goes past it with nontemporal
     // loads and stores so that p, A p, r̂ and ẑ (each written by one kernel and read by the next) keep their hits: +2.4 % in the
     // eight-stream bench (four alternating pairs); a single small batch keeps x cached (one walker: 40.9 against 47.3 ms per sweep)
-    static const int xs_env = [] { const char *e = getenv("SMOQY_X_STREAM"); return e ? atoi(e) : -1; }();  // A/B switch
+    static const int xs_env = tuning_env(kTuneXStream);  // A/B switch
     t.x_stream = xs_env < 0 ? t.slim : (xs_env != 0);
     // Workgroups go to the eight XCDs round-robin.  When a launch covers a multiple of eight systems the τ-FFT and Chebyshev kernels take the
     // blockIdx -> system map the MᵀM kernels already use (XCD x works on the contiguous share [x·n/8, (x+1)·n/8) of the systems), so that in
@@ -1885,7 +1885,7 @@ static int cg_iteration_fused(smoqy_ctx *c, const CgArgs &a, hipStream_t st, int
     // rule), the eight-stream bench unchanged.  It is NOT inter-kernel L2 reuse: FETCH_SIZE per kernel is the same with either map
     // (8 walkers: 16.5 / 16.3 MB for the forward τ-FFT) — the L2s do not keep lines across kernel boundaries; what shrinks is the address
     // range an XCD walks per kernel (translation and fabric locality).
-    static const int xm_env = [] { const char *e = getenv("SMOQY_XCD_MAP"); return e ? atoi(e) : -1; }();  // A/B switch
+    static const int xm_env = tuning_env(kTuneXcdMap);  // A/B switch
     const size_t xcd_share = (size_t)(count / 8) * 4 * c->g.Lt * c->g.N * sizeof(double2);
     t.xcd_map = xm_env < 0 ? (count % 8 == 0 && xcd_share <= (size_t)8 << 20) : (xm_env != 0);
     t.part_rz = a.part_rz; t.nrz = a.nrz; t.rz_stride = a.rz_stride;

@@ -514,12 +514,7 @@ void launch_own_km(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff)
 
 int fdm_own_enabled()
 {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("SMOQY_FDM_OWN");  // A/B switch for measurements; default on
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v;
+    return tuning_env(kTuneFdmOwn) == 0 ? 0 : 1;  // A/B switch for measurements; default on
 }
 
 }  // namespace
@@ -530,7 +525,7 @@ int fdm_own_enabled()
 // 54.8 vs 60.3 µs at 64).  Hence the batch limit.
 bool fdm_own_supported(const FdmArgs &a, const FdmFast &ff, bool sym)
 {
-    static const int own_max = [] { const char *e = getenv("SMOQY_FDM_OWN_MAX"); return e ? atoi(e) : 8; }();  // experiment knob: systems per launch up to which this kernel is chosen
+    static const int own_max = tuning_env(kTuneFdmOwnMax) >= 0 ? tuning_env(kTuneFdmOwnMax) : 8;  // experiment knob: systems per launch up to which this kernel is chosen
     return sym && ff.enabled && ff.own && fdm_own_enabled() && a.sys_count <= own_max && a.ncol >= 1 && a.ncol <= kFdmColours && a.Tc + 1 <= 3 &&
            sizeof(double2) * 2 * (size_t)(a.Tc + 1 <= 2 ? 2 : 3) * 2 * (size_t)ff.threads <= 64 * 1024;
 }
@@ -543,7 +538,7 @@ bool fdm_own_stream_supported(const FdmArgs &a, const FdmFast &ff, bool sym, boo
     // (three waves per SIMD) cost what the shorter stage chain gains once other solves' kernels share the device: with eight batches of 16
     // in flight (the bench) nothing is gained and its launches are longer, while one stream of 32 / 64 walkers gains 1-3 % per sweep, a
     // 64-member team 3.7 %, and four teams of 32 or eight batches of 32 are unchanged.  Hence the rule by handle size.
-    static const int mode = [] { const char *e = getenv("SMOQY_FDM_OWNSTREAM"); return !e ? -1 : (e[0] == '1' ? 1 : 0); }();
+    static const int mode = tuning_env(kTuneFdmOwnStream) < 0 ? -1 : (tuning_env(kTuneFdmOwnStream) == 1 ? 1 : 0);
     const bool on = mode == 1 || (mode < 0 && a.nsys >= 32);  // the handle's systems, whatever part of them this launch covers (smoqy_cg_split)
     return on && sym && cs_const && ff.enabled && ff.own && ff.threads <= 256 && a.ncol >= 2 && a.ncol <= kFdmColours && a.run_len >= 2 && a.run_len % a.Tc == 0 &&
            a.Lt >= 4 && a.shi == nullptr;

@@ -1050,22 +1050,12 @@ __global__ void __launch_bounds__(1024) cheb_own_asym_kernel(KpmArgs k, KpmGeom 
 // A/B switch for measurements (default on)
 static int cheb_split_enabled()
 {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("SMOQY_CHEB_SPLIT");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v;
+    return tuning_env(kTuneChebSplit) == 0 ? 0 : 1;
 }
 
 static int cheb_own_enabled()
 {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("SMOQY_CHEB_OWN");  // A/B switch for measurements; default on
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v;
+    return tuning_env(kTuneChebOwn) == 0 ? 0 : 1;  // A/B switch for measurements; default on
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1216,7 +1206,7 @@ void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
             const bool split = cheb_split_active(k, kg);
             // heavy / light workgroups (see cheb_own_kernel): k.group > 0 says that k.heavy is the host's count of leading frequencies with
             // more than one term (possibly 0); otherwise every frequency gets its own workgroup(s).  SMOQY_CHEB_GROUP=1 for A/B runs.
-            static const int env_group = [] { const char *e = getenv("SMOQY_CHEB_GROUP"); return e ? atoi(e) : 0; }();
+            static const int env_group = tuning_env(kTuneChebGroup) > 0 ? tuning_env(kTuneChebGroup) : 0;
             KpmArgs kk = k;
             kk.group = std::min(8, env_group > 0 ? env_group : k.group);  // light workgroups hold at most 8 frequencies in registers
             if (kk.group <= 1) { kk.group = 1; kk.heavy = k.Lt; }
@@ -1224,9 +1214,9 @@ void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
             const int nlight = (k.Lt - kk.heavy + kk.group - 1) / kk.group;
             const size_t olds = (split ? sizeof(double) : sizeof(double2)) * 4 * (size_t)kg.threads + sizeof(double2) * (size_t)k.maxorder;
             const dim3 ogrid((unsigned)(((split ? 2 : 1) * kk.heavy + nlight) * ncnt));
-            static const int env_wl = [] { const char *e = getenv("SMOQY_CHEB_WL0"); return (e && e[0] == '0') ? 0 : 1; }();  // A/B switch, default on
+            static const int env_wl = tuning_env(kTuneChebWl0) == 0 ? 0 : 1;  // A/B switch, default on
             // wave-local colour-0 exchange: 0 off, 1 ds_bpermute, 2 / 3 DPP row rotations (KpmGeom::wl0; SMOQY_CHEB_WL0=0 / 1 caps it)
-            static const int env_wl_cap = [] { const char *e = getenv("SMOQY_CHEB_WL0"); return e ? atoi(e) : 3; }();
+            static const int env_wl_cap = tuning_env(kTuneChebWl0) >= 0 ? tuning_env(kTuneChebWl0) : 3;
             int wl0 = (k.ncol >= 3 && env_wl) ? kg.wl0 : 0;
             if (wl0 > 1 && (env_wl_cap == 1 || !split)) wl0 = 1;  // the DPP forms are instantiated for the component-split kernel only
 #define OWN_LAUNCH(C_)                                                                                          \

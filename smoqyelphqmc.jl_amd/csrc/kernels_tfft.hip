@@ -729,15 +729,15 @@ bool tfft_plan(int Lt, int N, TfftArgs &a)
     a.fpack = a.sfpack = 0;
     for (int f = 0; f < a.nfac; ++f) a.fpack |= (unsigned long long)a.fac[f] << (4 * f);
     for (int f = 0; f < a.snfac; ++f) a.sfpack |= (unsigned long long)a.sfac[f] << (4 * f);
-    static const int slim_env = [] { const char *e = getenv("SMOQY_TFFT_SLIM"); return e ? atoi(e) : 0; }();
+    static const int slim_env = tuning_env(kTuneTfftSlim) > 0 ? tuning_env(kTuneTfftSlim) : 0;
     a.x_stream = 0;  // decided per launch (api.hip: cg_iteration_fused)
     a.xcd_map = 0;   // decided per launch (api.hip: cg_iteration_fused)
     a.slim_ok = (m == 1) ? 1 : 0;           // lengths 2^a 3^b 5^c only
     a.slim = (slim_env && a.slim_ok) ? 1 : 0;  // default form: SMOQY_TFFT_SLIM, else smoqy_tfft_form
     a.SB = 16;
     size_t lds_cap = 64 * 1024;  // two or more workgroups per CU
-    if (const char *e = getenv("SMOQY_TFFT_SB")) {  // tuning knob: sites per tile (4, 8 or 16), also lifts the LDS cap
-        const int v = atoi(e);
+    {   // tuning knob SMOQY_TFFT_SB: sites per tile (4, 8 or 16), also lifts the LDS cap
+        const int v = tuning_env(kTuneTfftSb);
         if (v == 4 || v == 8 || v == 16) { a.SB = v; lds_cap = 150 * 1024; }
     }
     // the tile width follows the ping-pong footprint in both forms (the EFA kernel always runs the ping-pong passes)
@@ -745,7 +745,7 @@ bool tfft_plan(int Lt, int N, TfftArgs &a)
     if ((2 * (size_t)Lt * a.SB + Lt) * sizeof(double2) > 150 * 1024) return false;
     a.ntile = (N + a.SB - 1) / a.SB;
     // register-blocked two-image form (tfft_kernel<…, EDGE>): Lτ = 64 or 128 with exactly four slices per lane; SMOQY_TFFT_EDGE=0 switches it off
-    static const int edge_env = [] { const char *e = getenv("SMOQY_TFFT_EDGE"); return (e && e[0] == '0') ? 0 : 1; }();
+    static const int edge_env = tuning_env(kTuneTfftEdge) == 0 ? 0 : 1;
     a.edge = (edge_env && (Lt == 64 || Lt == 128) && Lt * a.SB == 4 * kTfftThreads) ? Lt / 16 : 0;
     return true;
 }

@@ -12,6 +12,7 @@
 #include <rocfft/rocfft.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -347,5 +348,32 @@ struct EfaArgs {
 void launch_efa(hipStream_t st, const EfaArgs &a);
 hipError_t configure_tfft_kernels(const char **what);
 void launch_tfft(hipStream_t st, int mode, const TfftArgs &a);
+
+
+// ---- measurement switches ------------------------------------------------------------------------------------------
+// Every environment variable the library looks at, in one place: A/B switches for the twins of the fast paths and a few tuning values,
+// none needed for normal use.  Read once per process; tuning_env("NAME") is the variable's integer value, or -1 when it is not set.
+enum TuningKnob {
+    kTuneChebWl0, kTuneChebSplit, kTuneChebOwn, kTuneChebGroup, kTuneFdmStream, kTuneFdmOwn, kTuneFdmOwnMax, kTuneFdmOwnStream, kTuneNtFields,
+    kTuneXStream, kTuneXcdMap, kTuneTfftSlim, kTuneTfftSb, kTuneTfftEdge, kTuneCount
+};
+inline int tuning_env(TuningKnob k)
+{
+    struct Table {
+        int v[kTuneCount];
+        Table()
+        {
+            static const char *const names[kTuneCount] = {"SMOQY_CHEB_WL0", "SMOQY_CHEB_SPLIT", "SMOQY_CHEB_OWN", "SMOQY_CHEB_GROUP", "SMOQY_FDM_STREAM", "SMOQY_FDM_OWN",
+                                                          "SMOQY_FDM_OWN_MAX", "SMOQY_FDM_OWNSTREAM", "SMOQY_NT_FIELDS", "SMOQY_X_STREAM", "SMOQY_XCD_MAP", "SMOQY_TFFT_SLIM",
+                                                          "SMOQY_TFFT_SB", "SMOQY_TFFT_EDGE"};
+            for (int q = 0; q < kTuneCount; ++q) {
+                const char *e = getenv(names[q]);
+                v[q] = e ? atoi(e) : -1;
+            }
+        }
+    };
+    static const Table t;
+    return t.v[k];
+}
 
 }  // namespace smoqy
