@@ -438,7 +438,7 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->ev_pstat) (void)hipEventDestroy(c->ev_pstat);
     if (c->force.h_out) (void)hipHostFree(c->force.h_out);
     if (c->force.h_part) (void)hipHostFree(c->force.h_part);
-    for (void *q : {c->force.blob, (void *)c->force.d_x, (void *)c->force.d_contrib, (void *)c->force.d_out, (void *)c->force.d_bare, (void *)c->force.d_p, (void *)c->force.d_x0, (void *)c->force.d_q,
+    for (void *q : {c->force.blob, (void *)c->force.d_x, (void *)c->force.d_out, (void *)c->force.d_bare, (void *)c->force.d_p, (void *)c->force.d_x0, (void *)c->force.d_q,
                     (void *)c->force.d_m, (void *)c->force.d_part, (void *)c->force.d_fm})
         if (q) (void)hipFree(q);
     for (auto &e : c->mvt.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -2167,7 +2167,7 @@ int smoqy_force_set_couplings(smoqy_ctx *c, const smoqy_couplings *cp)
     if (!cp || cp->Nph < 0 || cp->Nholstein < 0 || cp->Nssh < 0) FAIL(c, 1, "invalid couplings");
     auto &F = c->force;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (void *q : {F.blob, (void *)F.d_x, (void *)F.d_contrib, (void *)F.d_out, (void *)F.d_bare, (void *)F.d_p, (void *)F.d_x0, (void *)F.d_q, (void *)F.d_m, (void *)F.d_part, (void *)F.d_fm})
+    for (void *q : {F.blob, (void *)F.d_x, (void *)F.d_out, (void *)F.d_bare, (void *)F.d_p, (void *)F.d_x0, (void *)F.d_q, (void *)F.d_m, (void *)F.d_part, (void *)F.d_fm})
         if (q) (void)hipFree(q);
     if (F.h_out) (void)hipHostFree(F.h_out);
     if (F.h_part) (void)hipHostFree(F.h_part);
@@ -2251,9 +2251,11 @@ int smoqy_force_set_couplings(smoqy_ctx *c, const smoqy_couplings *cp)
     const size_t nx = (size_t)g.nw * g.Lt * std::max(Nph, 1);
     HIPCHK(c, hipMalloc(&F.d_x, nx * sizeof(double)));
     HIPCHK(c, hipMemset(F.d_x, 0, nx * sizeof(double)));
-    HIPCHK(c, hipMalloc(&F.d_out, nx * sizeof(double)));
+    // the force and the per-coupling contributions it is reduced from share one allocation: one memset per force evaluation clears both
+    const size_t nx_pad = (nx + 1) & ~(size_t)1;  // keeps d_contrib 16-byte aligned
+    HIPCHK(c, hipMalloc(&F.d_out, (nx_pad + (size_t)g.nw * g.Lt * std::max(Q, 1)) * sizeof(double)));
+    F.d_contrib = F.d_out + nx_pad;
     HIPCHK(c, hipHostMalloc(&F.h_out, nx * sizeof(double)));
-    HIPCHK(c, hipMalloc(&F.d_contrib, (size_t)g.nw * g.Lt * std::max(Q, 1) * sizeof(double)));
     HIPCHK(c, hipMalloc(&F.d_bare, ((size_t)g.N + 2 * (size_t)g.Nh + 1) * sizeof(double)));  // [V⁰ | Re t⁰ | Im t⁰ (complex T)] in checkerboard order
     F.Nph = Nph; F.Nhol = Nhol; F.Nssh = Nssh; F.Q = Q; F.dtau = cp->dtau; F.set = true;
     F.finite_mass.assign((size_t)std::max(Nph, 1), 1);
@@ -2303,8 +2305,7 @@ static int force_begin(smoqy_ctx *c)
 {
     if (!c->force.set) FAIL(c, 1, "call smoqy_force_set_couplings first");
     const size_t nx = (size_t)c->g.nw * c->g.Lt * std::max(c->force.Nph, 1);
-    HIPCHK(c, hipMemsetAsync(c->force.d_out, 0, nx * sizeof(double), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->force.d_contrib, 0, (size_t)c->g.nw * c->g.Lt * std::max(c->force.Q, 1) * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->force.d_out, 0, (((nx + 1) & ~(size_t)1) + (size_t)c->g.nw * c->g.Lt * std::max(c->force.Q, 1)) * sizeof(double), c->stream));  // d_out and d_contrib (one allocation)
     return 0;
 }
 
