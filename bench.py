@@ -129,7 +129,7 @@ def cpu_baseline(workload, tol, Nt):
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(w), "--workload", workload, "--cpu-tol", repr(tol), "--cpu-nt", str(Nt)],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True) for w in range(cores)]
-    rates, failures = [], []
+    rates, failures, its_rates, its_avgs = [], [], [], []
     for w, pr in enumerate(procs):
         try:
             out, err = pr.communicate(timeout=600)
@@ -141,7 +141,10 @@ def cpu_baseline(workload, tol, Nt):
         try:
             if pr.returncode != 0:
                 raise ValueError(f"exit code {pr.returncode}")
-            rates.append(float(json.loads(out.strip().splitlines()[-1])["value"]))
+            rec = json.loads(out.strip().splitlines()[-1])
+            rates.append(float(rec["value"]))
+            its_rates.append(float(rec["cg_iterations_per_s"]))
+            its_avgs.append(float(rec["avg_cg_iters"]))
         except (ValueError, IndexError, KeyError) as e:
             failures.append({"worker": w, "returncode": pr.returncode, "error": str(e), "stderr_tail": (err or "")[-300:]})
     agg = dict(single)
@@ -158,72 +161,48 @@ def cpu_baseline(workload, tol, Nt):
             "sample": f"{len(rates)} walkers, one per core and all at once, each: " + single["sample"].split(": ", 1)[1],
             "per_core_min": min(rates),
             "per_core_max": max(rates),
+            "cg_iterations_per_s": sum(its_rates),
+            "avg_cg_iters": sum(its_avgs) / len(its_avgs),
         })
     return agg
 
 
 def cpu_sample(workload, tol, Nt, walker=0):
-    """Time the CPU oracle (single thread) on a bounded sample of the workload: CPU_SWEEPS whole sweeps' worth of solves of one walker —
-    per sweep 3 preconditioned action solves (tol, fresh pseudofermion fields each) and Nt force solves (sqrt(tol)), every solve with its
-    update_preconditioner! — on the walker's initial phonon fields (the field moves between the solves are not part of the CPU sample).
-    Nothing is extrapolated."""
+    """Time the CPU oracle (single thread) on CPU_SWEEPS whole sweeps of one walker — THE SAME SWEEP the GPU leg times
+    (oracle/sweep.py restates WalkerBatch._sweep with the device trajectory): two global moves with an action solve each, then
+    hmc_update! with the EFA leapfrog — Nt force solves at sqrt(tol) on the EVOLVING fields, each followed by the force terms, the kick,
+    evolve_eom! and update!, then the final action solve at tol — with update_preconditioner! before every solve, the walker's own
+    PCG64 stream in the order the GPU walker draws it, and the move rejected at the end.  Field refreshes, force terms and the leapfrog
+    are inside the timed span, as they are on the GPU.  Nothing is extrapolated."""
     import numpy as np
 
-    import smoqyelphqmc_amd as sq
-    from oracle import oracle as orc
+    from oracle.sweep import timed_sweeps
 
-    lat = sq.lattice
-    m = lat.CONFIGS[workload](walker=walker)
-    nt, perm, colors = lat.checkerboard_decomposition(m.fpi.neighbor_table)
-    expV, ch, sh = orc.update_fields(m.fpi.V, m.fpi.t, perm, m.fpi.dtau, True)
-    o = orc.OracleFDM(nt, expV, ch, sh, True)
-    P = orc.OracleKPM(o)
-    g = np.random.default_rng(1 + walker)
-    Lt, N = expV.shape
-    hol = m.elph.holstein
-    if hol is not None:
-        Lam = orc.update_lambda(Lt, N, m.elph.x, m.elph.dtau, hol.coupling_to_phonon, hol.coupling_to_site, hol.alpha, hol.alpha3, hol.ph_sym_form)
-    else:
-        Lam = orc.update_lambda(Lt, N, m.elph.x, m.elph.dtau, [], [], [], [], [])
-
-    def rhs():
-        # the right-hand side the sweep solves for: b = Λ⁻ᵀ Φ with Φ = Λᵀ Mᵀ R (src/PFFCalculator.jl:56-99)
-        R = np.asfortranarray((g.standard_normal((Lt, N)) + 1j * g.standard_normal((Lt, N))) * np.sqrt(0.5))
-        return orc.lambda_apply(Lam, orc.lambda_apply(Lam, o.mul_Mt(R), "mulT"), "ldivT")
-
-    sqrt_tol = float(np.sqrt(tol))
-    it_a = it_f = 0
-    t_action = t_force = 0.0
-    t_start = time.perf_counter()
-    for _ in range(CPU_SWEEPS):
-        for _ in range(3):
-            b = rhs()
-            t0 = time.perf_counter()
-            P.update(g.standard_normal(N))
-            it_a += o.cg_solve(b, precond=P, tol=tol, maxiter=10000)[1]
-            t_action += time.perf_counter() - t0
-        for _ in range(Nt):
-            t0 = time.perf_counter()
-            P.update(g.standard_normal(N))
-            it_f += o.cg_solve(b, precond=P, tol=sqrt_tol, maxiter=10000)[1]
-            t_force += time.perf_counter() - t0
-    t_total = time.perf_counter() - t_start
+    t_total, its, w = timed_sweeps(workload, walker, CPU_SWEEPS, tol=tol, Nt=Nt)
+    per = len(its) // CPU_SWEEPS
+    it_a = sum(its[k] for k in range(len(its)) if k % per in (0, 1, per - 1))
+    it_f = sum(its) - it_a
     # matvec alone, for the GB/s comparison
+    g = np.random.default_rng(1 + walker)
+    b = np.asfortranarray(g.standard_normal((w.Lt, w.N)) + 1j * g.standard_normal((w.Lt, w.N)))
     t0 = time.perf_counter()
     reps = 5
     for _ in range(reps):
-        o.mul_MtM(b)
+        w.fdm.mul_MtM(b)
     t_mv = (time.perf_counter() - t0) / reps
-    V = Lt * N
-    alg = 2 * (2 * 16 * V + 8 * V + 16 * Lt * nt.shape[1])
+    V = w.Lt * w.N
+    alg = 2 * (2 * 16 * V + 8 * V + 16 * w.Lt * w.nt.shape[1])
     return {
         "value": CPU_SWEEPS / t_total,
         "unit": "sweeps/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"walker {walker} of {workload}: {CPU_SWEEPS} sweeps' worth of solves, {t_total:.1f} s — per sweep 3 action solves (tol {tol:g}, {it_a / (3 * CPU_SWEEPS):.1f} iters, "
-        f"{t_action / (3 * CPU_SWEEPS):.2f} s each) + {Nt} force solves (tol {sqrt_tol:g}, {it_f / (Nt * CPU_SWEEPS):.1f} iters, {t_force / (Nt * CPU_SWEEPS):.2f} s each) with the KPM "
-        f"preconditioner updated before every solve, single thread, fixed phonon fields, nothing extrapolated",
+        "avg_cg_iters": sum(its) / len(its),
+        "cg_iterations_per_s": sum(its) / t_total,
+        "solves_per_sweep": per,
+        "sample": f"walker {walker} of {workload}: {CPU_SWEEPS} whole sweeps, {t_total:.1f} s — the sweep the GPU leg times (oracle/sweep.py): per sweep 2 global moves + hmc_update! with the EFA "
+        f"leapfrog, i.e. 3 action solves (tol {tol:g}, {it_a / (3 * CPU_SWEEPS):.1f} iters) + {Nt} force solves on the evolving fields (tol {float(np.sqrt(tol)):g}, {it_f / (Nt * CPU_SWEEPS):.1f} iters), "
+        f"force terms, leapfrog and field refreshes included, KPM preconditioner updated before every solve, single thread, nothing extrapolated",
         "matvec_MtM_ms": t_mv * 1e3,
         "matvec_MtM_GBs": alg / t_mv / 1e9,
         "host_cores_available": available_cores(),
@@ -793,7 +772,25 @@ def main():
 
     if args.roofline_only:
         args.warmup, args.steps = 0, 0
-    run(args.warmup)
+    if args.timed_only or os.environ.get("SMOQY_BENCH_MAPS"):
+        # profiled runs keep the process's module map (every library loaded, every handle and stream created) so that an abort under
+        # rocprofv3 can be attributed: the two aborts on record (profiles/r03_profiler_sigsegv_stack.txt) had only "(unknown)" frames
+        try:
+            path = os.environ.get("SMOQY_BENCH_MAPS") or os.path.join(ROOT, "gpurun_out", f"bench_maps_rank{rank}.txt")
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                f.write(f"# /proc/self/maps of bench.py pid {os.getpid()} after the handles were created, before the first launch of the sweeps\n")
+                f.write(open("/proc/self/maps").read())
+        except OSError:
+            pass
+    # the FIRST sweep of every batch runs here, on the thread that created the handles, one batch after the other: the first launch of
+    # every kernel family (lazy code-object loading, per-stream runtime state, the profiler's queue interception when one is attached)
+    # never happens from two threads at once.  It is the first of the `--warmup` sweeps, untimed like the rest of them.
+    warm_seq = 1 if (args.warmup > 0 and pool is not None) else 0
+    for b in (batches if warm_seq else ()):
+        b.sweep()
+        b.h.call("smoqy_sync")
+    run(args.warmup - warm_seq)
     for b in batches:
         b.stats.solves = b.stats.iters_sum = 0
         # roofline: the dominant kernel's launches inside the timed region are sampled with HIP events on the stream
@@ -901,6 +898,10 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3 if args.steps else None,
+            # work-normalised rate: CG iterations (one walker's system advanced by one iteration) per second over all walkers and ranks;
+            # cpu_baseline carries the same two fields for the same sweep on the host cores
+            "avg_cg_iters": avg_iters,
+            "cg_iterations_per_s": value * batch.solves_per_sweep * avg_iters,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

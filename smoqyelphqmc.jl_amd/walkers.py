@@ -104,6 +104,7 @@ class WalkerBatch:
             V0, t0 = m0.bare_model()
             self.h.call("smoqy_set_bare_model", L.ptr(V0), L.ptr(t0), L.ptr(self.perm))
         self.stats = SweepStats()
+        self.iter_log = None   # set to a list to have every solve append its per-walker iteration counts (tests)
         self.refresh_fields(first=True)
         # EFA leapfrog on the device (parity unpinned — SmoQyDQMC's accelerator is not part of the reference tree):
         # x, p and the force stay on the GPU for the whole trajectory.  Off by default: the host-side drift stays the tested default.
@@ -260,6 +261,8 @@ class WalkerBatch:
         sf = self.h.vec_dot(self.phi, self.u)                                 # S = Φ·Ψ     (:109)
         self.stats.solves += self.nw
         self.stats.iters_sum += int(iters.sum())
+        if self.iter_log is not None:
+            self.iter_log.append(iters.copy())
         return sf.real, iters, eps
 
     def fermionic_force(self):
@@ -292,6 +295,8 @@ class WalkerBatch:
                 gate.release()
         self.stats.solves += self.nw
         self.stats.iters_sum += int(iters.sum())
+        if self.iter_log is not None:
+            self.iter_log.append(iters.copy())
         return (sf, iters, eps, self.dSdx) if want_force else (sf, iters, eps)
 
     # ---- measurements (GreensEstimator) -----------------------------------------------
@@ -387,6 +392,8 @@ class WalkerBatch:
                 gate.release()
         self.stats.solves += self.nw * self.Nt
         self.stats.iters_sum += int(iters.sum())
+        if self.iter_log is not None:
+            self.iter_log.extend(iters[t].copy() for t in range(self.Nt))
         last = self.pff_step(self.tol, moved=False, want_force=False)      # final action, :217
         K1, Sb1 = self.efa_energies()                                      # :238-244
         self.dH = (last[0] + Sb1 + K1) - (sf0 + Sb0 + K0)                   # :247-250
