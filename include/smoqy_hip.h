@@ -79,6 +79,13 @@ int smoqy_host_unregister(smoqy_ctx *ctx, void *ptr);
 /* size(fdm) (src/FermionDetMatrix.jl:243): dims = {Ltau, N, Nh, ncolors, nwalkers, nrhs} */
 int smoqy_dims(const smoqy_ctx *ctx, int dims[6]);
 
+/* traits = {is_sym, is_complex_T, register-resident KPM kernels in use, wave-local colour-0 exchange (0 off, 1 ds_bpermute, 2 / 3 DPP),
+ * one-wavefront-per-chain Chebyshev program (0 none, 1 ring, 2 plaquette), its lanes, register-resident operator kernels in use,
+ * every colour a perfect matching}: what the handle's geometry selected at smoqy_create (tests and bench records read it) */
+int smoqy_traits(const smoqy_ctx *ctx, int traits[8]);
+/* JSON object naming the kernel families the handle's last full-batch fused MtM / Chebyshev launches ran and its tau-FFT form */
+int smoqy_describe(const smoqy_ctx *ctx, char *buf, size_t n);
+
 /* tau-chunk of the slice kernels (time slices per workgroup); Tc <= 0 restores the heuristic */
 int smoqy_set_tau_chunk(smoqy_ctx *ctx, int Tc);
 int smoqy_get_tau_chunk(const smoqy_ctx *ctx, int *Tc);

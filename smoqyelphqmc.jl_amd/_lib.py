@@ -55,6 +55,8 @@ SIGNATURES = {
     "smoqy_host_register": [_p, _p, C.c_size_t],
     "smoqy_host_unregister": [_p, _p],
     "smoqy_dims": [_p, _pi],
+    "smoqy_traits": [_p, _pi],
+    "smoqy_describe": [_p, C.c_char_p, C.c_size_t],
     "smoqy_set_tau_chunk": [_p, _i],
     "smoqy_get_tau_chunk": [_p, _pi],
     "smoqy_update_fields": [_p, _i, _p, _p, _p],
@@ -321,6 +323,21 @@ class Handle:
         out = np.zeros(self.nsys, dtype=np.complex128)
         self.call("smoqy_vec_dot", a, b, ptr(out))
         return out
+
+    def traits(self):
+        """smoqy_traits as a dict (what the handle's geometry selected)."""
+        t = (C.c_int * 8)()
+        self.call("smoqy_traits", t)
+        keys = ("is_sym", "is_complex_T", "kpm_fast", "wl0", "wave_kind", "wave_lanes", "fdm_fast", "full")
+        return dict(zip(keys, list(t)))
+
+    def describe(self):
+        """Kernel families of the handle's last full-batch MᵀM / Chebyshev launches and its τ-FFT form (smoqy_describe)."""
+        import json
+
+        buf = C.create_string_buffer(512)
+        self.call("smoqy_describe", buf, 512)
+        return json.loads(buf.value.decode())
 
     def algorithmic_bytes(self, op):
         v = C.c_double(0)

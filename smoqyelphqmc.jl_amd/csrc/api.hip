@@ -2,6 +2,7 @@
 // layout conversion, rocFFT plans, the KPM preconditioner's host-side bookkeeping and the
 // on-device conjugate-gradient driver.  gfx950 / ROCm only; there is no CPU path.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -108,6 +109,8 @@ struct smoqy_ctx {
     int graph_next = 0;
     unsigned graph_epoch = 1;
     std::string graph_note;  // why the last capture failed (also appended to smoqy_last_error)
+    const char *mtm_name = "";   // kernel family of the last full-batch fused MᵀM launch / Chebyshev launch (smoqy_describe)
+    const char *cheb_name = "";
     // off by default: measured on MI355X the replay (≈10-16 µs per graph launch) does not beat six eager
     // launches per iteration (76.5 vs 80 ms per single-walker sweep); reset to 0 after a failed capture
     int use_graph = 0;
@@ -143,7 +146,7 @@ struct smoqy_ctx {
     std::vector<char> cs_const;  // [nw] 1 once the HOST has shown a walker's hoppings to be τ-independent (selects the one-pair-per-colour MᵀM kernel); 0 = unknown
     int2 *d_pbonds = nullptr, *d_psites = nullptr;
     int *d_pos = nullptr;
-    int *d_poff = nullptr, *d_psrc = nullptr, *d_own = nullptr, *d_own_f = nullptr;
+    int *d_poff = nullptr, *d_psrc = nullptr, *d_own = nullptr, *d_own_f = nullptr, *d_wave = nullptr;
     double2 *d_pcs = nullptr;
     double *h_lan = nullptr;  // pinned [nw][2][1024]
     // device-resident bookkeeping of update_preconditioner! (PreUpd, kernels_kpm.hip): the host reads a 16-byte status record per
@@ -422,7 +425,7 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->fft_info) rocfft_execution_info_destroy(c->fft_info);
     void *ptrs[] = {c->d_bonds, c->d_col_off, c->d_expV, c->d_ch, c->d_sh, c->d_lam, c->d_stage, c->d_stage_real, c->d_stage_int, c->scr[0], c->scr[1], c->scr[2], c->cg_r, c->cg_p,
                     c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->d_st_idle, c->fft_work, c->d_tw, c->d_th, c->d_wtab, c->d_tpos, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
-                    c->d_rand, c->d_rand_traj, c->d_traj_dot, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_big, c->d_shi, c->d_sbari};
+                    c->d_rand, c->d_rand_traj, c->d_traj_dot, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_wave, c->d_big, c->d_shi, c->d_sbari};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (double2 *v : c->vecs)
@@ -464,6 +467,93 @@ static int coef_table_stride(const smoqy_ctx *c)
 {
     const double a1 = c->g.is_sym ? 2.0 * c->a1 : c->a1;  // :263
     return (int)std::floor(2.0 * (a1 * c->g.Lt / M_PI + c->a2)) + 2;
+}
+
+// Lane program of cheb_wave_kernel (kernels_kpm_wave.hip): does the decomposition close into groups of four sites that a lane can own
+// with the twice-applied colours inside its registers?  kind 1 — two colours, both perfect matchings, alternating along ONE cycle of
+// N = 4·lanes sites (a ring): lane l owns r[4l … 4l+3].  kind 2 — four perfect matchings whose colours 1 and 2 close into 4-cycles
+// s0 -c1- s1 -c2- s2 -c1- s3 -c2- s0 (plaquettes) labelled so that colour 0 pairs position p with position p^1 and colour 3 pairs p
+// with 3-p of another plaquette, for EVERY site — the labelling is propagated from one plaquette and then verified in full; any
+// violation means "no wave program" (kind 0) and the handle keeps cheb_own_kernel.  Table rows are documented at the kernel.
+static void wave_program(int N, int ncol, const std::vector<int2> &pb, const std::vector<int> &psrc, const std::vector<int> &poff, const std::vector<std::vector<int>> &mate,
+                         const std::vector<std::vector<int>> &bidx, std::vector<int> &tab, int &kind, int &lanes)
+{
+    kind = 0; lanes = 0;
+    if ((ncol != 2 && ncol != 4) || N % 4 != 0 || N / 4 > 64 || N > 256) return;
+    for (int col = 0; col < ncol; ++col)
+        if (poff[col + 1] - poff[col] != N / 2) return;          // a padded list longer than N/2 holds self bonds
+    for (size_t k = 0; k < psrc.size(); ++k)
+        if (psrc[k] < 0 || pb[k].x == pb[k].y) return;
+    const int n = N / 4;
+    if (ncol == 2) {
+        std::vector<int> ring((size_t)N), seen((size_t)N, 0);
+        int s = pb[(size_t)poff[0]].x;
+        for (int q = 0; q < N; ++q) {
+            if (seen[s]) return;                                  // the cycle closed early: several rings
+            seen[s] = 1; ring[q] = s;
+            s = mate[q & 1][s];
+        }
+        if (s != ring[0]) return;
+        tab.assign((size_t)11 * 64, 0);
+        for (int l = 0; l < n; ++l) {
+            const int *r = &ring[(size_t)4 * l];
+            for (int p = 0; p < 4; ++p) tab[(size_t)p * 64 + l] = r[p];
+            tab[4 * 64 + l] = bidx[0][r[0]]; tab[5 * 64 + l] = bidx[0][r[2]];
+            tab[6 * 64 + l] = bidx[1][r[1]]; tab[7 * 64 + l] = bidx[1][r[3]]; tab[8 * 64 + l] = bidx[1][r[0]];
+            tab[9 * 64 + l] = (l + 1) % n; tab[10 * 64 + l] = (l + n - 1) % n;
+            if (mate[0][r[0]] != r[1] || mate[0][r[2]] != r[3] || mate[1][r[1]] != r[2] || mate[1][r[3]] != ring[(size_t)(4 * (l + 1)) % N] ||
+                mate[1][r[0]] != ring[(size_t)(4 * l + N - 1) % N]) return;
+        }
+        kind = 1; lanes = n;
+        return;
+    }
+    // plaquettes: label[site] = (plaquette, position), propagated breadth first through the colour-0 and colour-3 bonds
+    std::vector<int> plq((size_t)N, -1), posn((size_t)N, -1), queue;
+    std::vector<std::array<int, 4>> sites;
+    auto place = [&](int t, int q) -> bool {  // a new plaquette with site t at position q; edge q -> q+1 is colour 1 for even q, colour 2 for odd q
+        std::array<int, 4> s4{};
+        int cur = t;
+        for (int k = 0; k < 4; ++k) {
+            const int p = (q + k) & 3;
+            if (plq[cur] >= 0) return false;
+            s4[(size_t)p] = cur;
+            cur = mate[(p & 1) ? 2 : 1][cur];
+        }
+        if (cur != t) return false;                               // colours 1 and 2 do not close into a 4-cycle here
+        const int id = (int)sites.size();
+        for (int p = 0; p < 4; ++p) { plq[s4[(size_t)p]] = id; posn[s4[(size_t)p]] = p; }
+        sites.push_back(s4);
+        queue.push_back(id);
+        return true;
+    };
+    if (!place(0, 0)) return;
+    for (size_t h = 0; h < queue.size(); ++h) {
+        const std::array<int, 4> s4 = sites[(size_t)queue[h]];
+        for (int p = 0; p < 4; ++p) {
+            const int t0 = mate[0][s4[(size_t)p]], t3 = mate[3][s4[(size_t)p]];
+            if (plq[t0] < 0 && !place(t0, p ^ 1)) return;
+            if (plq[t3] < 0 && !place(t3, 3 - p)) return;
+        }
+    }
+    if ((int)sites.size() != n) return;                           // disconnected, or sites left over
+    tab.assign((size_t)28 * 64, 0);
+    for (int l = 0; l < n; ++l) {
+        const std::array<int, 4> &s4 = sites[(size_t)l];
+        for (int p = 0; p < 4; ++p) {
+            const int s = s4[(size_t)p], t0 = mate[0][s], t3 = mate[3][s];
+            if (plq[s] != l || posn[s] != p || posn[t0] != (p ^ 1) || posn[t3] != 3 - p || plq[t0] == l || plq[t3] == l) return;
+            if (mate[(p & 1) ? 2 : 1][s] != s4[(size_t)((p + 1) & 3)]) return;
+            tab[(size_t)p * 64 + l] = s;
+            tab[(size_t)(8 + p) * 64 + l] = bidx[0][s];
+            tab[(size_t)(12 + p) * 64 + l] = bidx[3][s];
+            tab[(size_t)(16 + p) * 64 + l] = plq[t0];
+            tab[(size_t)(20 + p) * 64 + l] = plq[t3];
+            tab[(size_t)(24 + p) * 64 + l] = t0;
+        }
+        tab[4 * 64 + l] = bidx[1][s4[0]]; tab[5 * 64 + l] = bidx[1][s4[2]];
+        tab[6 * 64 + l] = bidx[2][s4[1]]; tab[7 * 64 + l] = bidx[2][s4[3]];
+    }
+    kind = 2; lanes = n;
 }
 
 static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
@@ -753,6 +843,16 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
             // the MᵀM kernel for small launches shares the lane layout when it owns the same colour: the DPP form of the colour-0 exchange too
             static const bool wl_env_off = tuning_env(kTuneChebWl0) == 0 || tuning_env(kTuneChebWl0) == 1;
             c->ff.wl0 = (q_fdm == q_cheb && c->kg.wl0 >= 2 && !wl_env_off) ? c->kg.wl0 : 0;
+            {   // one-wavefront-per-chain lane program of the Sym Chebyshev kernel (kernels_kpm_wave.hip), where the lattice has one
+                std::vector<int> tab;
+                int kind = 0, lanes = 0;
+                wave_program(g.N, g.ncol, pb, psrc, poff, mate, bidx, tab, kind, lanes);
+                if (kind) {
+                    HIPCHK(c, hipMalloc(&c->d_wave, tab.size() * sizeof(int)));
+                    HIPCHK(c, hipMemcpy(c->d_wave, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+                    c->kg.wave = c->d_wave; c->kg.wave_kind = kind; c->kg.wave_lanes = lanes;
+                }
+            }
             if (q_fdm == q_cheb) { c->d_own_f = c->d_own; c->ff.own_n = c->kg.own_n; }
             else if (int rc = build_own(q_fdm, &c->d_own_f, &c->ff.own_n)) return rc;
             c->ff.own = c->d_own_f;
@@ -890,6 +990,23 @@ int smoqy_dims(const smoqy_ctx *c, int d[6])
 {
     CHECK_CTX(c);
     d[0] = c->g.Lt; d[1] = c->g.N; d[2] = c->g.Nh; d[3] = c->g.ncol; d[4] = c->g.nw; d[5] = c->g.nrhs;
+    return 0;
+}
+
+int smoqy_traits(const smoqy_ctx *c, int t[8])
+{
+    CHECK_CTX(c);
+    if (!t) return 1;
+    t[0] = c->g.is_sym; t[1] = c->g.is_cplx; t[2] = c->kg.fast; t[3] = c->kg.wl0; t[4] = c->kg.wave_kind; t[5] = c->kg.wave_lanes; t[6] = c->ff.enabled; t[7] = c->ff.full;
+    return 0;
+}
+
+int smoqy_describe(const smoqy_ctx *c, char *buf, size_t n)
+{
+    CHECK_CTX(c);
+    if (!buf || n == 0) return 1;
+    snprintf(buf, n, "{\"mtm\": \"%s\", \"cheb\": \"%s\", \"tfft\": \"%s\"}", c->mtm_name, c->cheb_name,
+             !c->tf_ok ? "rocFFT + cg_update kernels" : (c->tf.slim ? "tfft_kernel (in-place form)" : "tfft_kernel (two-image form)"));
     return 0;
 }
 
@@ -1205,11 +1322,13 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
         static const int nt_env = tuning_env(kTuneNtFields);  // A/B switch
         a.nt_fields = nt_env < 0 ? (c->tf_ok && c->tf.slim) : (nt_env != 0);
     }
-    if (a.run_len > 0 && fdm_own_stream_supported(a, c->ff, c->g.is_sym != 0, cs_const)) launch_fdm_own_stream(st, a, c->ff);
-    else if (a.run_len > 0 && fdm_stream_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_stream(st, a, c->ff, cs_const);
-    else if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_own(st, op, a, c->ff);
-    else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) launch_fdm_fast(st, op, a, c->ff, c->g.is_sym != 0, cs_const);
-    else launch_fdm(st, op, c->g.is_sym != 0, a, c->d_big ? 0 : fdm_lds_bytes(op, c->g.N, c->Tc));
+    const char *name;
+    if (a.run_len > 0 && fdm_own_stream_supported(a, c->ff, c->g.is_sym != 0, cs_const)) { launch_fdm_own_stream(st, a, c->ff); name = "fdm_own_stream_kernel"; }
+    else if (a.run_len > 0 && fdm_stream_supported(a, c->ff, c->g.is_sym != 0)) { launch_fdm_stream(st, a, c->ff, cs_const); name = cs_const ? "fdm_stream_kernel<CSV=false>" : "fdm_stream_kernel<CSV=true>"; }
+    else if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) { launch_fdm_own(st, op, a, c->ff); name = "fdm_own_kernel"; }
+    else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) { launch_fdm_fast(st, op, a, c->ff, c->g.is_sym != 0, cs_const); name = c->g.is_sym ? "fdm_fast_kernel" : "fdm_fast_asym_kernel"; }
+    else { launch_fdm(st, op, c->g.is_sym != 0, a, c->d_big ? 0 : fdm_lds_bytes(op, c->g.N, c->Tc)); name = "fdm_kernel"; }
+    if (op == SMOQY_OP_MTM && count == c->g.nsys) c->mtm_name = name;
     if (sample) HIPCHK(c, hipEventRecord(T.ev[T.used++].second, c->stream));
     return check_launch(c, "matvec");
 }
@@ -1707,6 +1826,7 @@ static int precond_core(smoqy_ctx *c, const double2 *src, double2 *v, const CgSt
     k.part_rz = part_rz;
     k.half = half ? 1 : 0;
     launch_cheb(c->stream, k, c->kg);                                                   // :381-400 (no transposes needed in this layout)
+    c->cheb_name = cheb_kernel_name(k, c->kg);
     if (half) launch_conj_mirror(c->stream, v, c->g.Lt, c->g.N, c->g.nsys);             // :334 / :468
     if (own) {
         TfftArgs t = c->tf;
@@ -1900,6 +2020,7 @@ static int cg_iteration_fused(smoqy_ctx *c, const CgArgs &a, hipStream_t st, int
     k.vout = c->cg_z;  // ẑ reuses the buffer of A p, which the forward kernel has consumed (one vector less in the cache-resident working set)
     k.part_rz = c->part_rz;
     launch_cheb(st, k, c->kg);                  // :237 in frequency space, partial r·z by Parseval
+    c->cheb_name = cheb_kernel_name(k, c->kg);
     if (tev) (void)hipEventRecord(tev[3], st);
     t.src = a.v;
     launch_tfft(st, 3, t);                      // inverse FFT + x += α p + :229-245
@@ -1979,6 +2100,7 @@ restart:
         k.vout = c->cg_z;
         k.part_rz = c->part_rz;
         launch_cheb(c->stream, k, c->kg);
+        c->cheb_name = cheb_kernel_name(k, c->kg);
         t.src = c->cg_z; t.dst = c->cg_z;
         launch_tfft(c->stream, 1, t);
     } else if (any_pre) if (int rc = precond_core(c, c->cg_r, c->cg_z, nullptr, c->part_rz)) return rc;  // z0 = P⁻¹ r0 (:200)

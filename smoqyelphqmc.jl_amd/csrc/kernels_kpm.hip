@@ -23,44 +23,11 @@
 // the fallback for decompositions with more than kMaxColours colours or more padded bonds per
 // colour than 1024.
 #include "smoqy_internal.h"
+#include "kpm_lane.h"
 
 #include <cstdlib>
 
 namespace smoqy {
-
-// Sum over the 64 lanes of a wavefront on the DPP data path (row shifts inside the rows of 16, then the two row broadcasts): six dependent
-// steps of two v_mov_b32_dpp + one v_add_f64 each, against six ds_bpermute round trips through the LDS crossbar for the __shfl_down tree
-// it replaces (round 3: the reductions sit at the end of the longest Chebyshev chain and inside every Lanczos step).  The total is
-// returned in EVERY lane (read out of lane 63); the order of the additions is fixed, so results are reproducible run to run.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_add(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
-    return v + __hiloint2double(hi, lo);  // lanes outside ROW_MASK (or with no source lane) add an exact zero
-}
-__device__ __forceinline__ double wsum_k(double v)
-{
-    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
-    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
-    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
-    v = dpp_add<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds its row's sum
-    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
-    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wavefront's sum
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
-}
-
-__device__ __forceinline__ double block_sum_real(double v, double *red /* >= 17 doubles */)
-{
-    v = wsum_k(v);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = (blockDim.x + 63) >> 6;
-    __syncthreads();  // the readers of an earlier call are done with red[]
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    double t = 0;
-    for (int w = 0; w < nwave; ++w) t += red[w];  // every lane adds the wave sums in the same order: one value, no third barrier
-    return t;
-}
 
 __device__ __forceinline__ double2 cmulk(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ double2 axpy2(double a, double2 x, double2 y) { return make_double2(a * x.x + y.x, a * x.y + y.y); }
@@ -459,9 +426,9 @@ __device__ __forceinline__ double2 shfl(double2 x, int lane) { return make_doubl
 template <int CTRL>
 __device__ __forceinline__ double row_rot(double x)
 {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    // a rotation gives every lane a source lane: mov_dpp, no "old" register to clear first
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 template <int CTRL>
@@ -490,6 +457,10 @@ struct OwnProg {
     int px[NCOL], py[NCOL];
     double2 cx[NCOL], cy[NCOL];
     double dx, dy, dmx, dmy;
+    // the fused centre stage C₀ D̄ C₀ as two coefficients per own site (round 4: 4 instead of 16 fp64 operations per lane and stage).
+    // Colour 0 foreign (NCOL >= 3):  a' = (c² d + s² d_mate) a + c s (d + d_mate) mate   with the site's colour-0 bond (c, s);
+    // colour 0 owned (NCOL = 2):     ax' = ex0 ax + ex1 ay,  ay' = ex1 ax + ey0 ay       (the 2x2 matrix C D̄ C of the own bond).
+    double ex0, ex1, ey0, ey1;
 };
 // table indices of a lane program: the first of its two rounds of loads (addresses known from the thread index alone)
 template <int NCOL>
@@ -535,6 +506,16 @@ __device__ __forceinline__ void own_load_prog(OwnProg<NCOL> &P, const OwnIdx<NCO
             P.cy[c] = pcs[I.cyi[c]];
         }
     }
+    if constexpr (NCOL >= 3) {
+        P.ex0 = P.cx[0].x * P.cx[0].x * P.dx + P.cx[0].y * P.cx[0].y * P.dmx;
+        P.ex1 = P.cx[0].x * P.cx[0].y * (P.dx + P.dmx);
+        P.ey0 = P.cy[0].x * P.cy[0].x * P.dy + P.cy[0].y * P.cy[0].y * P.dmy;
+        P.ey1 = P.cy[0].x * P.cy[0].y * (P.dy + P.dmy);
+    } else {
+        P.ex0 = P.cx[0].x * P.cx[0].x * P.dx + P.cx[0].y * P.cx[0].y * P.dy;
+        P.ey0 = P.cx[0].y * P.cx[0].y * P.dx + P.cx[0].x * P.cx[0].x * P.dy;
+        P.ex1 = P.ey1 = P.cx[0].x * P.cx[0].y * (P.dx + P.dy);
+    }
 }
 
 // Exchange and stage of the owner-computes lane program (used inside functions that define P, ax, ay, Wb0, Wb1, buf and the constants
@@ -566,22 +547,14 @@ __device__ __forceinline__ void own_load_prog(OwnProg<NCOL> &P, const OwnIdx<NCO
 #define OWN_CENTRE()                                                                                          \
     {                                                                                                         \
         if (Q == 0) {                                                                                         \
-            T x_ = lin(P.cx[0].x, ax, P.cx[0].y, ay), y_ = lin(P.cx[0].x, ay, P.cx[0].y, ax);                 \
-            x_ = scl(P.dx, x_);                                                                               \
-            y_ = scl(P.dy, y_);                                                                               \
-            ax = lin(P.cx[0].x, x_, P.cx[0].y, y_);                                                           \
-            ay = lin(P.cx[0].x, y_, P.cx[0].y, x_);                                                           \
+            const T x_ = lin(P.ex0, ax, P.ex1, ay);                                                           \
+            ay = lin(P.ey1, ax, P.ey0, ay);                                                                   \
+            ax = x_;                                                                                          \
         } else {                                                                                              \
             T mx_, my_;                                                                                       \
             OWN_EXCHANGE(0, mx_, my_)                                                                         \
-            T x_ = lin(P.cx[0].x, ax, P.cx[0].y, mx_), xm_ = lin(P.cx[0].x, mx_, P.cx[0].y, ax);              \
-            T y_ = lin(P.cy[0].x, ay, P.cy[0].y, my_), ym_ = lin(P.cy[0].x, my_, P.cy[0].y, ay);              \
-            x_ = scl(P.dx, x_);                                                                               \
-            xm_ = scl(P.dmx, xm_);                                                                            \
-            y_ = scl(P.dy, y_);                                                                               \
-            ym_ = scl(P.dmy, ym_);                                                                            \
-            ax = lin(P.cx[0].x, x_, P.cx[0].y, xm_);                                                          \
-            ay = lin(P.cy[0].x, y_, P.cy[0].y, ym_);                                                          \
+            ax = lin(P.ex0, ax, P.ex1, mx_);                                                                  \
+            ay = lin(P.ey0, ay, P.ey1, my_);                                                                  \
         }                                                                                                     \
     }
 
@@ -597,14 +570,8 @@ __device__ __forceinline__ void own_bbar_apply(const OwnProg<NCOL> &P, T &ax, T 
     if constexpr (WL0 && Q != 0) {  // the colour-0 mates sit in this wavefront (KpmGeom::wl0): shuffles instead of an LDS exchange
         T mx_, my_;
         wl_mates<WL0>(ax, ay, (P.px[0] - (int)blockDim.x) & 63, P.py[0] & 63, mx_, my_);
-        T x_ = lin(P.cx[0].x, ax, P.cx[0].y, mx_), xm_ = lin(P.cx[0].x, mx_, P.cx[0].y, ax);
-        T y_ = lin(P.cy[0].x, ay, P.cy[0].y, my_), ym_ = lin(P.cy[0].x, my_, P.cy[0].y, ay);
-        x_ = scl(P.dx, x_);
-        xm_ = scl(P.dmx, xm_);
-        y_ = scl(P.dy, y_);
-        ym_ = scl(P.dmy, ym_);
-        ax = lin(P.cx[0].x, x_, P.cx[0].y, xm_);
-        ay = lin(P.cy[0].x, y_, P.cy[0].y, ym_);
+        ax = lin(P.ex0, ax, P.ex1, mx_);
+        ay = lin(P.ey0, ay, P.ey1, my_);
     } else
     OWN_CENTRE()
 #pragma unroll
@@ -634,60 +601,58 @@ __device__ __forceinline__ void own_chain(const OwnProg<NCOL> &P, T &ax, T &ay, 
     }
     const double qcx = P.cx[CL].x * P.cx[CL].x + P.cx[CL].y * P.cx[CL].y, qsx = 2.0 * P.cx[CL].x * P.cx[CL].y;  // C_L²
     const double qcy = P.cy[CL].x * P.cy[CL].x + P.cy[CL].y * P.cy[CL].y, qsy = 2.0 * P.cy[CL].x * P.cy[CL].y;
-    T a1x = ax, a1y = ay, a2x = zero(T{}), a2y = zero(T{}), accx = zero(T{}), accy = zero(T{});
-    for (int kk = 1; kk < n; ++kk) {
-        const double2 ck = CF[kk];
+    const double imag2 = 2.0 * imag_;
+    // (xi, xj) = B̃ (ax, ay) on the lane's own sites; ax, ay are used up
+    auto apply = [&](T ax, T ay, T &xi, T &xj) {
 #pragma unroll
         for (int c = NCOL - 2; c >= 1; --c) OWN_STAGE(c)
-        if (Q == 0) {  // C₁ D̄ C₁ in registers
-            T x = lin(P.cx[0].x, ax, P.cx[0].y, ay), y = lin(P.cx[0].x, ay, P.cx[0].y, ax);
-            x = scl(P.dx, x);
-            y = scl(P.dy, y);
-            ax = lin(P.cx[0].x, x, P.cx[0].y, y);
-            ay = lin(P.cx[0].x, y, P.cx[0].y, x);
-        } else {       // one exchange; the mate's value after C₁ and D̄ is recomputed here (same bond, its own d̄)
+        if (Q == 0) {  // C₀ D̄ C₀ in registers: the 2x2 matrix of the own bond
+            const T x = lin(P.ex0, ax, P.ex1, ay);
+            ay = lin(P.ey1, ax, P.ey0, ay);
+            ax = x;
+        } else {       // one exchange; the mate's part of C₀ D̄ C₀ is folded into the two coefficients of the site (OwnProg::ex0 …)
             T mx, my;
             if constexpr (WL0) {
                 wl_mates<WL0>(ax, ay, wl_x, wl_y, mx, my);
             } else {
                 OWN_EXCHANGE(0, mx, my)
             }
-            T x = lin(P.cx[0].x, ax, P.cx[0].y, mx), xm = lin(P.cx[0].x, mx, P.cx[0].y, ax);
-            T y = lin(P.cy[0].x, ay, P.cy[0].y, my), ym = lin(P.cy[0].x, my, P.cy[0].y, ay);
-            x = scl(P.dx, x);
-            xm = scl(P.dmx, xm);
-            y = scl(P.dy, y);
-            ym = scl(P.dmy, ym);
-            ax = lin(P.cx[0].x, x, P.cx[0].y, xm);
-            ay = lin(P.cy[0].x, y, P.cy[0].y, ym);
+            ax = lin(P.ex0, ax, P.ex1, mx);
+            ay = lin(P.ey0, ay, P.ey1, my);
         }
 #pragma unroll
         for (int c = 1; c <= NCOL - 2; ++c) OWN_STAGE(c)
-        T xi, xj;
-        {
-            T mx, my;
-            OWN_EXCHANGE(CL, mx, my)
-            xi = lin(qcx, ax, qsx, mx);
-            xj = lin(qcy, ay, qsy, my);
-        }
-        // three-term recurrence on the lane's own sites (kpm_lmul!)
-        T a3x, a3y;
-        if (kk == 1) {
-            a3x = scl(imag_, sub(xi, scl(avg, a1x)));
-            a3y = scl(imag_, sub(xj, scl(avg, a1y)));
-            const double2 c0 = CF[0];
-            accx = add(cmul(c0, a1x), cmul(ck, a3x));
-            accy = add(cmul(c0, a1y), cmul(ck, a3y));
-        } else {
-            a3x = sub(scl(imag_, scl(2.0, sub(xi, scl(avg, a2x)))), a1x);
-            a3y = sub(scl(imag_, scl(2.0, sub(xj, scl(avg, a2y)))), a1y);
-            accx = add(accx, cmul(ck, a3x));
-            accy = add(accy, cmul(ck, a3y));
-            a1x = a2x; a1y = a2y;
-        }
-        a2x = a3x; a2y = a3y;
-        ax = a3x; ay = a3y;
+        T mx, my;
+        OWN_EXCHANGE(CL, mx, my)
+        xi = lin(qcx, ax, qsx, mx);
+        xj = lin(qcy, ay, qsy, my);
+    };
+    // three-term recurrence on the lane's own sites (kpm_lmul!): T_k = 2 B' T_{k-1} − T_{k-2} is written over T_{k-2}, so the two newest
+    // vectors ping-pong between (ax, ay) and (bx, by) and no register is moved (round 4)
+    T bx, by, accx, accy, xi, xj;
+    {   // k = 1
+        apply(ax, ay, xi, xj);
+        const double2 c0 = CF[0], c1 = CF[1];
+        bx = scl(imag_, sub(xi, scl(avg, ax)));
+        by = scl(imag_, sub(xj, scl(avg, ay)));
+        accx = add(cmul(c0, ax), cmul(c1, bx));
+        accy = add(cmul(c0, ay), cmul(c1, by));
     }
+#define OWN_STEP(cx_, cy_, ox_, oy_, ck_)                              \
+    {                                                                  \
+        apply(cx_, cy_, xi, xj);                                       \
+        ox_ = sub(scl(imag2, sub(xi, scl(avg, cx_))), ox_);            \
+        oy_ = sub(scl(imag2, sub(xj, scl(avg, cy_))), oy_);            \
+        accx = add(accx, cmul(ck_, ox_));                              \
+        accy = add(accy, cmul(ck_, oy_));                              \
+    }
+    int kk = 2;
+    for (; kk + 1 < n; kk += 2) {
+        OWN_STEP(bx, by, ax, ay, CF[kk])
+        OWN_STEP(ax, ay, bx, by, CF[kk + 1])
+    }
+    if (kk < n) OWN_STEP(bx, by, ax, ay, CF[kk])
+#undef OWN_STEP
     // back to the original basis: C_L⁻¹ on the accumulated sum
     {
         ax = accx; ay = accy;
@@ -729,75 +694,7 @@ __global__ void __launch_bounds__(1024) cheb_own_kernel(KpmArgs k, KpmGeom kg)
     const int Lo2 = (Lt + 1) / 2;
     double2 *przb = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride : nullptr;
     if (slotid >= heavy_slots) {
-        // ---- light workgroup: ranks [r0, r1), single-term expansions, at most GMAX of them ----
-        // Three rounds instead of a loop of dependent ones: the orders and leading coefficients of all its frequencies, then all their
-        // elements (a lane serves the sites j and j + Tn: N <= 2 Tn), then the stores and ONE reduction pass for all the Parseval sums.
-        constexpr int GMAX = 8;
-        const int r0 = heavy + (slotid - heavy_slots) * k.group, r1 = min(Lt, r0 + min(k.group, GMAX));
-        const bool sys_done = k.cg[sys].done != 0;  // (k.cg is never null)
-        const bool act = k.active[w] != 0;
-        int omg[GMAX];
-        double fg[GMAX];
-        bool useg[GMAX];
-#pragma unroll
-        for (int g = 0; g < GMAX; ++g) {
-            const int r = min(r0 + g, Lt - 1);
-            const int om = (r & 1) ? Lt - 1 - (r >> 1) : (r >> 1);
-            const int slot = om >= Lo2 ? Lt - om - 1 : om;  // :387
-            const int n = k.order[(size_t)w * k.nslot + slot];
-            const double c0 = k.coefs[((size_t)w * k.nslot + slot) * k.maxorder].x;
-            omg[g] = om;
-            useg[g] = r0 + g < r1 && !(k.half && om >= Lo2);
-            // n > 1 here would mean the host's count of multi-term frequencies and the device's order table disagree (both come from the
-            // same host vector): poison the output so that the solve fails loudly ("non-finite residual") instead of using a wrong P⁻¹
-            fg[g] = !act ? k.scale : (n <= 1 ? k.scale * c0 : __builtin_nan(""));
-        }
-        if (sys_done) return;
-        const int ia = min(j, N - 1), ib = min(j + Tn, N - 1);
-        const bool oka = j < N, okb = j + Tn < N;
-        double2 xa[GMAX], xb[GMAX];
-#pragma unroll
-        for (int g = 0; g < GMAX; ++g) {
-            const double2 *v = k.v + ((size_t)omg[g] * k.nsys + sys) * N;
-            xa[g] = v[ia];
-            xb[g] = v[ib];
-        }
-        const int wave = j >> 6, lane = j & 63, nwave = (Tn + 63) >> 6;
-        double *part = reinterpret_cast<double *>(lds);  // [2 GMAX][nwave] wave sums
-#pragma unroll
-        for (int g = 0; g < GMAX; ++g) {
-            const double f = fg[g];
-            double accr = 0.0, acci = 0.0;
-            if (useg[g]) {
-                double2 *vo = (k.vout ? k.vout : k.v) + ((size_t)omg[g] * k.nsys + sys) * N;
-                // the Parseval sums keep the form of the launch: per component with SPLIT (two slots per frequency), one sum otherwise;
-                // per lane the terms are added in the order of the one-workgroup-per-frequency form (site j, then j + Tn)
-                if (oka) {
-                    vo[ia] = make_double2(f * xa[g].x, f * xa[g].y);
-                    if constexpr (SPLIT) { accr += f * (xa[g].x * xa[g].x); acci += f * (xa[g].y * xa[g].y); }
-                    else accr += f * (xa[g].x * xa[g].x + xa[g].y * xa[g].y);
-                }
-                if (okb) {
-                    vo[ib] = make_double2(f * xb[g].x, f * xb[g].y);
-                    if constexpr (SPLIT) { accr += f * (xb[g].x * xb[g].x); acci += f * (xb[g].y * xb[g].y); }
-                    else accr += f * (xb[g].x * xb[g].x + xb[g].y * xb[g].y);
-                }
-            }
-            accr = wsum_k(accr);
-            acci = wsum_k(acci);
-            if (lane == 0) { part[(2 * g) * nwave + wave] = accr; part[(2 * g + 1) * nwave + wave] = acci; }
-        }
-        __syncthreads();
-        if (przb && j < 2 * GMAX) {
-            const int g = j >> 1, c = j & 1;
-            double t = 0.0;
-            for (int q = 0; q < nwave; ++q) t += part[j * nwave + q];  // wave order, as block_sum_real
-            if (r0 + g < r1 && !(k.half && (((r0 + g) & 1) ? Lt - 1 - ((r0 + g) >> 1) : ((r0 + g) >> 1)) >= Lo2)) {
-                const int r = r0 + g, om = (r & 1) ? Lt - 1 - (r >> 1) : (r >> 1);
-                if (SPLIT) przb[2 * om + c] = make_double2(t, 0.0);
-                else if (c == 0) przb[om] = make_double2(t, 0.0);
-            }
-        }
+        cheb_light_workgroup<SPLIT>(k, sys, w, slotid - heavy_slots, heavy, przb, lds);
         return;
     }
     // ---- heavy workgroup: one frequency (one component of it with SPLIT), heaviest first, the two components neighbours in the dispatch order ----
@@ -1195,6 +1092,15 @@ bool cheb_split_active(const KpmArgs &k, const KpmGeom &kg)
     return kg.fast && k.is_sym && k.ncol >= 2 && k.ncol <= 6 && kg.own && cheb_own_enabled() && cheb_split_enabled() && !k.half && k.sbari == nullptr;
 }
 
+const char *cheb_kernel_name(const KpmArgs &k, const KpmGeom &kg)
+{
+    if (!kg.fast) return "cheb_generic_kernel";
+    if (cheb_wave_supported(k, kg)) return kg.wave_kind == 2 ? "cheb_wave_kernel<plaquette>" : (kg.wave_lanes == 64 ? "cheb_wave_kernel<ring, DPP>" : "cheb_wave_kernel<ring>");
+    if (k.is_sym && k.ncol >= 2 && k.ncol <= 6 && kg.own && cheb_own_enabled()) return cheb_split_active(k, kg) ? (kg.wl0 && k.ncol >= 3 ? "cheb_own_kernel<split, WL0>" : "cheb_own_kernel<split>") : "cheb_own_kernel";
+    if (!k.is_sym && k.ncol >= 2 && k.ncol <= 6 && kg.own && cheb_own_enabled() && k.sbari == nullptr) return "cheb_own_asym_kernel";
+    return "cheb_fast_kernel";
+}
+
 void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
 {
     if (kg.fast) {
@@ -1202,7 +1108,9 @@ void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
         const int ncnt = k.sys_count > 0 ? k.sys_count : k.nsys;
         const dim3 grid((unsigned)(k.Lt * ncnt)), block((unsigned)kg.threads);
 #define CHEB_LAUNCH(S_, C_) hipLaunchKernelGGL((cheb_fast_kernel<S_, C_>), grid, block, lds, st, k, kg)
-        if (k.is_sym && k.ncol >= 2 && k.ncol <= 6 && kg.own && cheb_own_enabled()) {
+        if (cheb_wave_supported(k, kg)) {
+            launch_cheb_wave(st, k, kg);  // ring / plaquette lattices: one wavefront per chain, no LDS exchange, no barrier (kernels_kpm_wave.hip)
+        } else if (k.is_sym && k.ncol >= 2 && k.ncol <= 6 && kg.own && cheb_own_enabled()) {
             const bool split = cheb_split_active(k, kg);
             // heavy / light workgroups (see cheb_own_kernel): k.group > 0 says that k.heavy is the host's count of leading frequencies with
             // more than one term (possibly 0); otherwise every frequency gets its own workgroup(s).  SMOQY_CHEB_GROUP=1 for A/B runs.

@@ -149,6 +149,10 @@ struct KpmGeom {
     int own_q, own_n;
     int wl0;             // the colour-0 mates of every lane's two sites are held by lanes of the same wavefront, first site's mate in a second
                          // slot and vice versa: the centre exchange of cheb_own_kernel runs on wave shuffles (own_chain<…, WL0>)
+    // one-wavefront-per-chain lane program (kernels_kpm_wave.hip): 0 none, 1 ring (2 colours), 2 plaquette (4 colours); wave is
+    // [rows][64] ints (rows = 11 / 28), wave_lanes <= 64 lanes own four sites each
+    const int *wave;
+    int wave_kind, wave_lanes;
 };
 
 // geometry + packed hopping table of the register-resident FermionDetMatrix kernels
@@ -217,6 +221,10 @@ void launch_lanczos(hipStream_t st, const KpmArgs &k, const KpmGeom &kg, int w0,
 // update_kpm_expansion_coefs! (:734-795) on the device for walkers [w0, w0 + nw) whose `rebuild` flag is set
 void launch_kpm_expansions(hipStream_t st, const PreUpd &u, int w0, int nw);
 void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg);
+// one wavefront per chain (rings and plaquette lattices up to 256 sites, Sym, component split): kernels_kpm_wave.hip
+bool cheb_wave_supported(const KpmArgs &k, const KpmGeom &kg);
+const char *cheb_kernel_name(const KpmArgs &k, const KpmGeom &kg);  // the kernel launch_cheb picks for these arguments
+void launch_cheb_wave(hipStream_t st, const KpmArgs &k, const KpmGeom &kg);
 bool cheb_split_active(const KpmArgs &k, const KpmGeom &kg);  // true: the Chebyshev kernel writes 2·Lτ r·z partials per system instead of Lτ
 // v[Lτ-1-ω] = conj(v[ω]) for ω < cld(Lτ, 2) (KPMPreconditioner.jl:334 / :468; the middle frequency of an odd Lτ conjugates itself)
 void launch_conj_mirror(hipStream_t st, double2 *v, int Lt, int N, int nsys);
@@ -355,7 +363,7 @@ void launch_tfft(hipStream_t st, int mode, const TfftArgs &a);
 // none needed for normal use.  Read once per process; tuning_env("NAME") is the variable's integer value, or -1 when it is not set.
 enum TuningKnob {
     kTuneChebWl0, kTuneChebSplit, kTuneChebOwn, kTuneChebGroup, kTuneFdmStream, kTuneFdmOwn, kTuneFdmOwnMax, kTuneFdmOwnStream, kTuneNtFields,
-    kTuneXStream, kTuneXcdMap, kTuneTfftSlim, kTuneTfftSb, kTuneTfftEdge, kTuneCount
+    kTuneXStream, kTuneXcdMap, kTuneTfftSlim, kTuneTfftSb, kTuneTfftEdge, kTuneChebWave, kTuneCount
 };
 inline int tuning_env(TuningKnob k)
 {
@@ -365,7 +373,7 @@ inline int tuning_env(TuningKnob k)
         {
             static const char *const names[kTuneCount] = {"SMOQY_CHEB_WL0", "SMOQY_CHEB_SPLIT", "SMOQY_CHEB_OWN", "SMOQY_CHEB_GROUP", "SMOQY_FDM_STREAM", "SMOQY_FDM_OWN",
                                                           "SMOQY_FDM_OWN_MAX", "SMOQY_FDM_OWNSTREAM", "SMOQY_NT_FIELDS", "SMOQY_X_STREAM", "SMOQY_XCD_MAP", "SMOQY_TFFT_SLIM",
-                                                          "SMOQY_TFFT_SB", "SMOQY_TFFT_EDGE"};
+                                                          "SMOQY_TFFT_SB", "SMOQY_TFFT_EDGE", "SMOQY_CHEB_WAVE"};
             for (int q = 0; q < kTuneCount; ++q) {
                 const char *e = getenv(names[q]);
                 v[q] = e ? atoi(e) : -1;

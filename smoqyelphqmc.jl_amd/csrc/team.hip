@@ -90,6 +90,7 @@ struct smoqy_team {
     std::mutex m;
     std::condition_variable cv;
     int arrived = 0, op = OP_NONE;
+    bool running = false;  // the last arrival is inside run_round: the round's outputs go through every member's slot, nobody may leave
     unsigned long gen = 0;
     double timeout_s = 600.0;
     std::vector<Slot> slot;
@@ -383,21 +384,31 @@ static int rendezvous_locked(smoqy_team *t, int w, int op, const Slot &args)
     t->slot[w] = args;
     const unsigned long my_gen = t->gen;
     if (++t->arrived == t->K) {
+        t->running = true;
         lk.unlock();
         const int rc = run_round(t);  // every other member is blocked below: the slots and the staging buffers are this thread's
         lk.lock();
         for (auto &s : t->slot) s.rc = rc;
         t->arrived = 0;
         t->op = OP_NONE;
+        t->running = false;
         ++t->gen;
         lk.unlock();
         t->cv.notify_all();
         return rc;
     }
-    if (!t->cv.wait_for(lk, std::chrono::duration<double>(t->timeout_s), [&] { return t->gen != my_gen; })) {
-        --t->arrived;  // give up this round (the caller rejects its update, as the reference's catch block does)
-        t->err = "team rendezvous timed out: not every member made the call";
-        return 9;
+    // the deadline covers the wait for the OTHER MEMBERS only.  Once all K have arrived the round writes through every member's slot
+    // (stack / caller temporaries) and staging part, so a member whose deadline passes while the round runs keeps waiting for the
+    // round's result and is never taken out of `arrived` (leaving then was a use-after-return)
+    const auto pred = [&] { return t->gen != my_gen; };
+    if (!t->cv.wait_for(lk, std::chrono::duration<double>(t->timeout_s), pred)) {
+        if (t->running) {
+            t->cv.wait(lk, pred);
+        } else {
+            --t->arrived;  // give up this round (the caller rejects its update, as the reference's catch block does)
+            t->err = "team rendezvous timed out: not every member made the call";
+            return 9;
+        }
     }
     return t->slot[w].rc;
 }
