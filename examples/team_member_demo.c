@@ -4,7 +4,7 @@
  * (sample_pseudofermion_fields! + calculate_fermionic_action!, src/PFFCalculator.jl:56-116) and one hmc_update! whose trajectory runs on the
  * device for all members at once (src/EFAPFFHMCUpdater.jl:102-276) — and prints one JSON line.
  *
- *   gcc -std=c99 -Iinclude examples/team_member_demo.c -Lsmoqyelphqmc.jl_amd/csrc -lsmoqy_hip -lm -o team_member_demo
+ *   gcc -std=c99 -Iinclude examples/team_member_demo.c -Lsmoqyelphqmc.jl_amd/csrc -lsmoqy_member -lm -o team_member_demo   (libsmoqy_member.so: no HIP / rocFFT on this rank)
  *   ./team_member_demo /team-name <walker index> <sweeps> <Nt> <tol>
  */
 #include <math.h>

@@ -22,7 +22,7 @@ def build_member(out_dir):
     exe = os.path.join(out_dir, "team_member_demo")
     lib_dir = os.path.dirname(L.LIB_PATH)
     subprocess.run([shutil.which("gcc") or "gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "team_member_demo.c"),
-                    "-L" + lib_dir, "-lsmoqy_hip", "-lm", "-Wl,-rpath," + lib_dir, "-o", exe], check=True)
+                    "-L" + lib_dir, "-lsmoqy_member", "-lm", "-Wl,-rpath," + lib_dir, "-o", exe], check=True)
     return exe
 
 

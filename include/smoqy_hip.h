@@ -309,7 +309,9 @@ int smoqy_efa_restore_walkers(smoqy_ctx *ctx, const int *restore);
  * evolve(Δt/2), update!; Nt times { calculate_derivative_fermionic_action! at tol_force; p -= Δt ∂S_f/∂x; evolve(Δt, last step Δt/2);
  * update! }.  Φ in vector phi, Ψ left in psi.  randvecs: N x nwalkers x Nt Lanczos start vectors (2N each for a complex handle; the rng stays on the host; sent in one transfer); Sf, iters,
  * eps: nwalkers x Nt (any may be NULL).  Only the fermionic force is applied: anharmonic / dispersive phonon terms (:190-193) are the
- * caller's to add through smoqy_efa_evolve step by step.  A non-zero return (e.g. a non-finite residual) leaves x and p wherever the
+ * caller's to add through smoqy_efa_evolve step by step.  ASSUMES recenter! = identity — the default of hmc_update! (:112) and what every
+ * shipped script passes: the reference calls recenter!(x) after each evolve_eom! (:151, :203), which this call does not; a driver with
+ * another recenter! keeps the step-by-step form (smoqy_efa_evolve, then its recenter! on the host copy, smoqy_efa_set_state).  A non-zero return (e.g. a non-finite residual) leaves x and p wherever the
  * trajectory stopped: the caller rejects the update with smoqy_efa_checkpoint(ctx, 1), as the reference's catch block does (:176-187). */
 int smoqy_hmc_trajectory_v(smoqy_ctx *ctx, int phi, int psi, int Nt, double dt, double tol_force, int maxiter, int use_precond, const double *randvecs, double *Sf, int *iters, double *eps);
 

@@ -14,6 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libsmoqy_hip.so")
+MEMBER_LIB_PATH = os.path.join(CSRC, "libsmoqy_member.so")  # the member side of a published walker team alone: no HIP / rocFFT dependency
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "smoqy_hip.h")
 
 OP_M, OP_MT, OP_MTM, OP_MMT = 0, 1, 2, 3
@@ -28,8 +29,9 @@ class SmoqyError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [HEADER]
-    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp", ".map"))] + [HEADER, os.path.join(CSRC, "Makefile")]
+    stale = force or not (os.path.exists(LIB_PATH) and os.path.exists(MEMBER_LIB_PATH)) or any(
+        os.path.getmtime(s) > min(os.path.getmtime(LIB_PATH), os.path.getmtime(MEMBER_LIB_PATH)) for s in srcs)
     if stale:
         r = subprocess.run(["make", "-C", CSRC, "-j4"] + (["-B"] if force else []), capture_output=True, text=True)
         if r.returncode != 0:
@@ -189,6 +191,29 @@ def load():
     lib.smoqy_member_last_error.argtypes = [_p]
     lib.smoqy_member_last_error.restype = C.c_char_p
     _lib = lib
+    return lib
+
+
+_member_lib = None
+
+
+def load_member():
+    """dlopen libsmoqy_member.so — the smoqy_member_* entry points only, for a rank that joins a team another process serves and never
+    touches a GPU itself (no libamdhip64 / rocFFT is mapped into such a rank).  Same prototypes as in the full library."""
+    global _member_lib
+    if _member_lib is not None:
+        return _member_lib
+    if not os.path.exists(MEMBER_LIB_PATH):
+        raise SmoqyError(f"{MEMBER_LIB_PATH} is missing: run __graft_entry__.build()")
+    lib = C.CDLL(MEMBER_LIB_PATH)
+    for name, args in SIGNATURES.items():
+        if name.startswith("smoqy_member_"):
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+    lib.smoqy_member_last_error.argtypes = [_p]
+    lib.smoqy_member_last_error.restype = C.c_char_p
+    _member_lib = lib
     return lib
 
 

@@ -931,7 +931,13 @@ int smoqy_clone(smoqy_ctx **out, const smoqy_ctx *src, int nrhs)
     if (!out || !src || nrhs < 1) { g_create_error = "smoqy_clone: null handle or nrhs < 1"; return 1; }
     const Geometry &g = src->g;
     if (int rc = smoqy_create(out, g.Lt, g.N, g.Nh, g.ncol, src->in_nt.data(), src->in_cr.data(), g.is_sym, g.is_cplx, g.nw, nrhs, src->device)) return rc;
-    return smoqy_precond_config(*out, src->rbuf, src->nlanczos, src->a1, src->a2);
+    const int rc = smoqy_precond_config(*out, src->rbuf, src->nlanczos, src->a1, src->a2);
+    if (rc) {  // do not hand back (or leak) a half-configured handle
+        g_create_error = std::string("smoqy_clone: ") + (*out)->err;
+        smoqy_destroy(*out);
+        *out = nullptr;
+    }
+    return rc;
 }
 
 int smoqy_set_stream(smoqy_ctx *c, void *s)
@@ -1573,7 +1579,11 @@ int smoqy_precond_config(smoqy_ctx *c, double rbuf, int n_lanczos, double a1, do
     HIPCHK(c, hipMemset(c->d_order, 0, (size_t)c->g.nw * c->nslot * sizeof(int)));
     HIPCHK(c, hipMemset(c->d_pstat, 0, (size_t)c->g.nw * 4 * sizeof(int)));
     for (auto &p : c->pre) { p.active = 0; p.emin = p.emax = 0.0; std::fill(p.order.begin(), p.order.end(), 0); for (auto &v : p.coefs) v.clear(); }
+    // the page-locked mirror of the status records too: a later update of ONE walker consumes the records of ALL walkers, and stale
+    // "active" / heavy counts of the untouched ones would come back
+    std::memset(c->h_pstat, 0, (size_t)c->g.nw * 4 * sizeof(int));
     c->pstat_pending = false;
+    c->pstat_ever = false;
     c->mirrors_stale = false;
     c->cheb_heavy = 0;
     return 0;

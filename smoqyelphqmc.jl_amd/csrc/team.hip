@@ -29,57 +29,10 @@
 #include <vector>
 
 #include "../../include/smoqy_hip.h"
+#include "team_shm.h"
 
-namespace {
-enum { OP_NONE = 0, OP_SAMPLE = 1, OP_PFF = 2, OP_HMC = 3, OP_FINISH = 4, OP_GE_UPDATE = 5, OP_GE_GD0 = 6 };
-constexpr int kMaxNt = 64;  // leapfrog steps a team's staging is sized for (smoqy_team_hmc_update)
-struct Slot {
-    const void *R = nullptr;
-    const double *x = nullptr, *rv = nullptr;
-    double tol = 0;
-    int maxiter = 0, use_precond = 0;
-    double *Sf = nullptr, *eps = nullptr, *dSdx = nullptr, *RdotR = nullptr;
-    int *iters = nullptr;
-    // OP_HMC: momentum deviates, N x (Nt + 1) Lanczos start vectors, trajectory parameters, {S_f, S_b, K} before / after, proposed fields
-    const double *P = nullptr, *rvs = nullptr;
-    int Nt = 0;
-    double dt = 0, tol_force = 0;
-    double *H0 = nullptr, *H1 = nullptr, *x_new = nullptr;
-    int accept = 0;  // OP_FINISH
-    // GreensEstimator: Nrv random vectors (Ltau x N x Nrv, OP_GE_UPDATE); orbitals and the member's G(Δ,0) array (OP_GE_GD0)
-    const void *Rrv = nullptr;
-    void *G = nullptr;
-    int orb_a = 0, orb_b = 0;
-    int rc = 0;
-};
-// where a member's arrays are staged for the batched call: the team's own page-locked buffers, or the shared-memory segment
-struct Stage {
-    char *R = nullptr;
-    double *x = nullptr, *rv = nullptr, *dS = nullptr, *P = nullptr, *rvs = nullptr;
-    char *GR = nullptr, *G = nullptr;  // GreensEstimator: the members' random vectors (Nrv per member) and their G(Δ,0) arrays
-    int Nrv = 0;
-    size_t gbytes = 0;                 // bytes of one member's G(Δ,0)
-};
-// a member copies its OWN inputs in before the rendezvous and its own outputs out after it (K copies in parallel, outside any lock)
-void stage_in(const Stage &g, int K, int Lt, int N, int Nph, int w, const Slot &a)
-{
-    const size_t nR = (size_t)Lt * N * 16, nx = (size_t)(Nph > 0 ? Nph : 1) * Lt;
-    if (a.R) std::memcpy(g.R + (size_t)w * nR, a.R, nR);
-    if (a.x) std::memcpy(g.x + (size_t)w * nx, a.x, nx * sizeof(double));
-    if (a.rv) std::memcpy(g.rv + (size_t)w * N, a.rv, (size_t)N * sizeof(double));
-    if (a.P) std::memcpy(g.P + (size_t)w * nx, a.P, nx * sizeof(double));
-    if (a.Rrv && g.GR) std::memcpy(g.GR + (size_t)w * nR * g.Nrv, a.Rrv, nR * g.Nrv);
-    if (a.rvs && a.Nt >= 1 && a.Nt <= kMaxNt)  // the batched trajectory wants N x K x Nt: step-major, member w's vector of step t at (t K + w) N
-        for (int t = 0; t <= a.Nt; ++t) std::memcpy(g.rvs + ((size_t)t * K + w) * N, a.rvs + (size_t)t * N, (size_t)N * sizeof(double));
-}
-void stage_out(const Stage &g, int Lt, int Nph, int w, const Slot &a)
-{
-    const size_t nx = (size_t)(Nph > 0 ? Nph : 1) * Lt;
-    if (a.dSdx) std::memcpy(a.dSdx, g.dS + (size_t)w * nx, nx * sizeof(double));
-    if (a.x_new) std::memcpy(a.x_new, g.dS + (size_t)w * nx, nx * sizeof(double));  // OP_HMC returns the proposed fields through the force staging
-    if (a.G && g.G) std::memcpy(a.G, g.G + (size_t)w * g.gbytes, g.gbytes);
-}
-}  // namespace
+using namespace smoqy_team_detail;
+
 
 struct Served;
 
@@ -157,6 +110,11 @@ int smoqy_team_create(smoqy_team **out, smoqy_ctx *ctx, int Nph)
     int d[6];
     if (int rc = smoqy_dims(ctx, d)) return rc;
     if (d[5] != 1) { g_team_error = "smoqy_team_create: the handle must have nrhs = 1 (one system per walker)"; return 1; }
+    int tr[8];
+    if (int rc = smoqy_traits(ctx, tr)) return rc;
+    // the staging buffers and the shared-memory layout hold N doubles per Lanczos start vector; a handle with T = ComplexF64 reads 2N
+    // (randn! on a Vector{ComplexF64}, src/KPMPreconditioner.jl:229, 634).  No shipped script has complex hoppings: refused, not mis-staged.
+    if (tr[1]) { g_team_error = "smoqy_team_create: handles with complex hoppings (is_complex_T) are not supported by walker teams; drive them through the batched entry points"; return 1; }
     smoqy_team *t = new smoqy_team();
     t->c = ctx; t->Lt = d[0]; t->N = d[1]; t->K = d[4]; t->Nph = Nph;
     t->slot.resize((size_t)t->K);
@@ -504,45 +462,6 @@ int smoqy_team_ge_measure_GD0(smoqy_team *t, int w, int a, int b, void *out)
 // arrays into its part of the segment's staging area (page-locked in the serving process, so the batched upload reads it directly),
 // deposits its scalars and sleeps on a process-shared condition variable; a server thread in the process that owns the handle runs the
 // round once all K members have arrived — the same run_round as the in-process team, its slots pointing into the segment.
-namespace {
-constexpr uint64_t kShmMagic = 0x534d4f5159544d33ull;  // "SMOQYTM3"
-struct ShmMember {
-    int has_x, has_rv, want_force, maxiter, use_precond, iters, rc, attached;
-    int has_R, has_P, has_rvs, want_xnew, Nt, accept;
-    int has_Rrv, want_G, orb_a, orb_b;
-    double tol, Sf, eps, RdotR;
-    double dt, tol_force, H0[3], H1[3];
-};
-struct ShmHeader {
-    uint64_t magic;
-    int K, Lt, N, Nph;
-    int op, arrived, shutdown, rc;
-    unsigned long gen;
-    double timeout_s;
-    size_t off_members, off_R, off_x, off_rv, off_dS, off_P, off_rvs, off_GR, off_G, total;
-    int ge_Nrv, ge_pad;
-    size_t ge_gbytes;
-    pthread_mutex_t m;
-    pthread_cond_t cv_arrive, cv_done;
-    char err[256];
-};
-size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-int shm_lock(ShmHeader *h)
-{
-    const int e = pthread_mutex_lock(&h->m);
-    if (e == EOWNERDEAD) { pthread_mutex_consistent(&h->m); return 0; }  // a member died inside the lock: the state it guards is plain counters
-    return e;
-}
-timespec deadline_after(double seconds)
-{
-    timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    const double t = ts.tv_sec + ts.tv_nsec * 1e-9 + seconds;
-    ts.tv_sec = (time_t)t;
-    ts.tv_nsec = (long)((t - (double)ts.tv_sec) * 1e9);
-    return ts;
-}
-}  // namespace
 
 struct Served {
     std::string name;
@@ -554,13 +473,6 @@ struct Served {
     bool registered = false;
 };
 
-struct smoqy_member {
-    ShmHeader *h = nullptr;
-    int w = -1;
-    std::string err;
-};
-
-static std::string g_member_error;
 
 static void serve_loop(smoqy_team *t)
 {
@@ -590,9 +502,11 @@ static void serve_loop(smoqy_team *t)
             s.Sf = &q.Sf; s.iters = &q.iters; s.eps = &q.eps; s.RdotR = &q.RdotR; s.H0 = q.H0; s.H1 = q.H1;
             t->slot[w] = s;
         }
+        h->running = 1;  // from here to the broadcast below a member's deadline does not apply (member_round)
         pthread_mutex_unlock(&h->m);
         const int rc = run_round(t);  // every member is asleep on cv_done
         shm_lock(h);
+        h->running = 0;
         for (int w = 0; w < t->K; ++w) mem[w].rc = rc;
         h->rc = rc;
         snprintf(h->err, sizeof(h->err), "%s", rc ? t->err.c_str() : "");
@@ -634,6 +548,7 @@ int smoqy_team_serve(smoqy_team *t, const char *name, const double *x0)
     std::memset(h, 0, lay.off_R);
     h->K = t->K; h->Lt = t->Lt; h->N = t->N; h->Nph = t->Nph;
     h->timeout_s = t->timeout_s;
+    h->server_pid = (int)getpid();
     h->off_members = lay.off_members; h->off_R = lay.off_R; h->off_x = lay.off_x; h->off_rv = lay.off_rv; h->off_dS = lay.off_dS; h->off_P = lay.off_P; h->off_rvs = lay.off_rvs; h->off_GR = lay.off_GR; h->off_G = lay.off_G; h->total = lay.total;
     h->ge_Nrv = t->ge_Nrv; h->ge_gbytes = t->ge_gbytes;
     pthread_mutexattr_t ma;
@@ -686,188 +601,6 @@ int smoqy_team_unserve(smoqy_team *t)
     delete sv;
     t->served = nullptr;
     return 0;
-}
-
-const char *smoqy_member_last_error(const smoqy_member *m) { return m ? m->err.c_str() : g_member_error.c_str(); }
-
-int smoqy_member_attach(smoqy_member **out, const char *name, int w, double wait_seconds)
-{
-    if (!out || !name) { g_member_error = "smoqy_member_attach: null argument"; return 1; }
-    *out = nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    auto waited = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-    ShmHeader *h = nullptr;
-    for (;;) {  // the ranks of a job start together: the serving rank may not have published yet
-        const int fd = shm_open(name, O_RDWR, 0600);
-        if (fd >= 0) {
-            struct stat st;
-            if (fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(ShmHeader)) {
-                void *p = mmap(nullptr, (size_t)st.st_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-                if (p != MAP_FAILED) {
-                    ShmHeader *q = (ShmHeader *)p;
-                    if (__atomic_load_n(&q->magic, __ATOMIC_ACQUIRE) == kShmMagic && q->total == (size_t)st.st_size) { h = q; close(fd); break; }
-                    munmap(p, (size_t)st.st_size);
-                }
-            }
-            close(fd);
-        }
-        if (waited() >= wait_seconds) { g_member_error = std::string("smoqy_member_attach: no team published as ") + name; return 9; }
-        usleep(2000);
-    }
-    if (w < 0 || w >= h->K) { g_member_error = "smoqy_member_attach: member index outside the team"; munmap(h, h->total); return 1; }
-    ShmMember *mem = (ShmMember *)((char *)h + h->off_members);
-    shm_lock(h);
-    // `attached` holds the pid of the rank that owns the index; a rank that died without detaching (kill(pid, 0) says ESRCH) is replaced
-    const int owner = mem[w].attached;
-    const bool taken = owner != 0 && !(kill((pid_t)owner, 0) != 0 && errno == ESRCH);
-    if (!taken) mem[w].attached = (int)getpid();
-    pthread_mutex_unlock(&h->m);
-    if (taken) { g_member_error = "smoqy_member_attach: this member index is already attached"; munmap(h, h->total); return 1; }
-    smoqy_member *m = new smoqy_member();
-    m->h = h; m->w = w;
-    *out = m;
-    return 0;
-}
-
-int smoqy_member_detach(smoqy_member *m)
-{
-    if (!m) return 0;
-    if (m->h) {
-        ShmMember *mem = (ShmMember *)((char *)m->h + m->h->off_members);
-        shm_lock(m->h);
-        mem[m->w].attached = 0;
-        pthread_mutex_unlock(&m->h->m);
-        munmap(m->h, m->h->total);
-    }
-    delete m;
-    return 0;
-}
-
-int smoqy_member_dims(const smoqy_member *m, int *dims)
-{
-    if (!m || !dims) return 1;
-    dims[0] = m->h->Lt; dims[1] = m->h->N; dims[2] = m->h->K; dims[3] = m->h->Nph;
-    return 0;
-}
-
-int smoqy_member_fields(const smoqy_member *m, double *x)
-{
-    if (!m || !x) return 1;
-    const size_t nx = (size_t)std::max(m->h->Nph, 1) * m->h->Lt;
-    std::memcpy(x, (const char *)m->h + m->h->off_x + (size_t)m->w * nx * sizeof(double), nx * sizeof(double));
-    return 0;
-}
-
-}  // extern "C"
-
-static int member_round(smoqy_member *m, int op, const Slot &a)
-{
-    if (!m || !m->h) return 1;
-    ShmHeader *h = m->h;
-    const int w = m->w;
-    char *base = (char *)h;
-    Stage g;
-    g.R = base + h->off_R; g.x = (double *)(base + h->off_x); g.rv = (double *)(base + h->off_rv); g.dS = (double *)(base + h->off_dS);
-    g.P = (double *)(base + h->off_P); g.rvs = (double *)(base + h->off_rvs);
-    if (h->ge_Nrv > 0) { g.GR = base + h->off_GR; g.G = base + h->off_G; g.Nrv = h->ge_Nrv; g.gbytes = h->ge_gbytes; }
-    stage_in(g, h->K, h->Lt, h->N, h->Nph, w, a);
-    ShmMember &q = ((ShmMember *)(base + h->off_members))[w];
-    shm_lock(h);
-    if (h->shutdown) { m->err = h->err; pthread_mutex_unlock(&h->m); return 10; }
-    if (h->arrived > 0 && h->op != op) { m->err = "team members made different calls in the same round"; pthread_mutex_unlock(&h->m); return 8; }
-    h->op = op;
-    q.has_R = a.R != nullptr; q.has_x = a.x != nullptr; q.has_rv = a.rv != nullptr; q.has_P = a.P != nullptr; q.has_rvs = a.rvs != nullptr;
-    q.want_force = a.dSdx != nullptr; q.want_xnew = a.x_new != nullptr;
-    q.has_Rrv = a.Rrv != nullptr; q.want_G = a.G != nullptr; q.orb_a = a.orb_a; q.orb_b = a.orb_b;
-    q.tol = a.tol; q.maxiter = a.maxiter; q.use_precond = a.use_precond;
-    q.Nt = a.Nt; q.dt = a.dt; q.tol_force = a.tol_force; q.accept = a.accept;
-    const unsigned long my_gen = h->gen;
-    if (++h->arrived == h->K) pthread_cond_signal(&h->cv_arrive);
-    const timespec dl = deadline_after(h->timeout_s);
-    while (h->gen == my_gen) {
-        const int e = pthread_cond_timedwait(&h->cv_done, &h->m, &dl);
-        if (e == EOWNERDEAD) pthread_mutex_consistent(&h->m);
-        if (e == ETIMEDOUT && h->gen == my_gen) {
-            --h->arrived;
-            m->err = "team rendezvous timed out: not every member made the call";
-            pthread_mutex_unlock(&h->m);
-            return 9;
-        }
-    }
-    const int rc = q.rc;
-    if (rc) m->err = h->err;
-    const ShmMember r = q;  // this member's results, copied under the lock
-    pthread_mutex_unlock(&h->m);
-    if (rc == 0) {
-        if (a.Sf) *a.Sf = r.Sf;
-        if (a.iters) *a.iters = r.iters;
-        if (a.eps) *a.eps = r.eps;
-        if (a.RdotR) *a.RdotR = r.RdotR;
-        if (a.H0) std::memcpy(a.H0, r.H0, sizeof(r.H0));
-        if (a.H1) std::memcpy(a.H1, r.H1, sizeof(r.H1));
-        stage_out(g, h->Lt, h->Nph, w, a);
-    }
-    return rc;
-}
-
-extern "C" {
-
-int smoqy_member_sample_phi(smoqy_member *m, const void *R, double *RdotR)
-{
-    if (!R) return 1;
-    Slot s;
-    s.R = R; s.RdotR = RdotR;
-    return member_round(m, OP_SAMPLE, s);
-}
-
-int smoqy_member_pff_step(smoqy_member *m, const double *x, const double *randvec, double tol, int maxiter, int use_precond, double *Sf, int *iters, double *eps, double *dSdx)
-{
-    Slot s;
-    s.x = x; s.rv = randvec; s.tol = tol; s.maxiter = maxiter; s.use_precond = use_precond ? 1 : 0;
-    s.Sf = Sf; s.iters = iters; s.eps = eps; s.dSdx = dSdx;
-    return member_round(m, OP_PFF, s);
-}
-
-int smoqy_member_hmc_update(smoqy_member *m, const double *x, const void *R, const double *P, const double *randvecs, int Nt, double dt, double tol_force, double tol, int maxiter,
-                            double *H0, double *H1, double *x_new, int *iters)
-{
-    if (!R || !P || !randvecs) return 1;
-    if (Nt < 1 || Nt > kMaxNt) { if (m) m->err = "smoqy_member_hmc_update: Nt outside 1 … 64"; return 1; }
-    Slot s;
-    s.x = x; s.R = R; s.P = P; s.rvs = randvecs; s.Nt = Nt; s.dt = dt; s.tol_force = tol_force; s.tol = tol; s.maxiter = maxiter;
-    s.H0 = H0; s.H1 = H1; s.x_new = x_new; s.iters = iters;
-    return member_round(m, OP_HMC, s);
-}
-
-int smoqy_member_hmc_finish(smoqy_member *m, int accept)
-{
-    Slot s;
-    s.accept = accept ? 1 : 0;
-    return member_round(m, OP_FINISH, s);
-}
-
-int smoqy_member_ge_dims(const smoqy_member *m, int *Nrv, size_t *g_bytes)
-{
-    if (!m || !m->h) return 1;
-    if (Nrv) *Nrv = m->h->ge_Nrv;
-    if (g_bytes) *g_bytes = m->h->ge_gbytes;
-    return 0;
-}
-
-int smoqy_member_ge_update(smoqy_member *m, const void *R, const double *randvec, double tol, int maxiter, int *iters, double *eps)
-{
-    if (!R || !randvec) return 1;
-    Slot s;
-    s.Rrv = R; s.rv = randvec; s.tol = tol; s.maxiter = maxiter; s.iters = iters; s.eps = eps;
-    return member_round(m, OP_GE_UPDATE, s);
-}
-
-int smoqy_member_ge_measure_GD0(smoqy_member *m, int a, int b, void *out)
-{
-    if (!out) return 1;
-    Slot s;
-    s.orb_a = a; s.orb_b = b; s.G = out;
-    return member_round(m, OP_GE_GD0, s);
 }
 
 }  // extern "C"

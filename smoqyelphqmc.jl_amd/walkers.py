@@ -718,7 +718,7 @@ class RemoteMember(TeamMember):
     the run parameters the serving rank announces (``info``: the dict ``serve`` returned, sent over whatever channel the job has)."""
 
     def __init__(self, info: dict, w: int, seed: int = 0, wait_seconds: float = 60.0):
-        self.lib = L.load()
+        self.lib = L.load_member()  # libsmoqy_member.so: the rendezvous only — no HIP runtime, no rocFFT in this rank
         self._m = C.c_void_p()
         rc = self.lib.smoqy_member_attach(C.byref(self._m), info["name"].encode(), int(w), C.c_double(wait_seconds))
         if rc:

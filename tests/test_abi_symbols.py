@@ -28,6 +28,40 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert set(names) == set(L.SIGNATURES) | {"smoqy_last_error", "smoqy_team_last_error", "smoqy_member_last_error"}  # the three that return a string
 
 
+def test_only_the_c_abi_leaves_the_libraries():
+    """the internal C++ symbols (smoqy::launch_*, …) must not be exported next to the C entry points — a clash risk
+    inside a host process that loads other HIP libraries.  Both libraries are linked with an export map (csrc/smoqy.map)."""
+    import subprocess
+
+    L.build()
+    for path in (L.LIB_PATH, L.MEMBER_LIB_PATH):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+        assert names and all(n.startswith("smoqy_") for n in names), [n for n in names if not n.startswith("smoqy_")][:5]
+    declared = set(declared_symbols())
+    exported = {ln.split()[-1] for ln in subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout.splitlines() if ln.strip()}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+
+
+def test_member_library_has_no_gpu_dependency():
+    """libsmoqy_member.so (member side of a published walker team) is what a GPU-less rank loads: every smoqy_member_* entry point, and
+    no dependency on the HIP runtime or rocFFT."""
+    import subprocess
+
+    L.build()
+    lib = C.CDLL(L.MEMBER_LIB_PATH)
+    members = [n for n in declared_symbols() if n.startswith("smoqy_member_")]
+    assert len(members) >= 12
+    for n in members:
+        assert hasattr(lib, n), n
+    needed = subprocess.run(["readelf", "-d", L.MEMBER_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "amdhip" not in needed and "rocfft" not in needed and "hsa" not in needed, needed
+    ml = L.load_member()
+    m = C.c_void_p()
+    assert ml.smoqy_member_attach(C.byref(m), b"/smoqy-no-such-team", 0, C.c_double(0.05)) == 9
+    assert b"no team published" in ml.smoqy_member_last_error(None)
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
 
@@ -73,8 +107,8 @@ def test_header_and_c_example_compile_as_plain_c(tmp_path):
     assert out.exists()
     # the member rank of a served walker team (no GPU, no handle): examples/team_member_demo.c
     out2 = tmp_path / "team_member_demo"
-    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "team_member_demo.c"), "-L" + lib_dir, "-lsmoqy_hip", "-lm",
-                    "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(out2)], check=True)
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "team_member_demo.c"), "-L" + lib_dir, "-lsmoqy_member", "-lm",
+                    "-Wl,-rpath," + lib_dir, "-o", str(out2)], check=True)   # the member library alone: no ROCm on this rank's link line
     assert out2.exists()
 
 

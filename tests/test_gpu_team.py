@@ -432,3 +432,60 @@ def test_members_that_draw_their_random_numbers_one_sweep_ahead_run_the_same_swe
     assert so.value == K * 2 * (3 + Nt) and itn.value > so.value and secs.value > 0
     ta.close()
     tb.close()
+
+
+@pytest.mark.parametrize("published", [False, True])
+def test_a_deadline_that_passes_inside_a_running_round_is_not_a_time_out(published):
+    """the rendezvous deadline covers the wait for the OTHER MEMBERS only.  Here every member has arrived long before the
+    deadline, but the round itself (a whole hmc_update! of 16 leapfrog steps on the headline lattice) runs far longer than the 0.05 s the
+    team allows: the early members used to give up mid-round with code 9 while the round was still writing through their slots.  Now they
+    get the round's result; in-process threads and members attached through shared memory alike."""
+    import os
+
+    from smoqyelphqmc_amd.walkers import RemoteMember
+
+    K = 3
+    team = WalkerTeam("holstein_honeycomb_L16_Ltau128", K, device_efa=True, Nt=16)
+    team.call("smoqy_team_set_timeout", C.c_double(0.05))
+    if published:
+        info = team.serve(f"/smoqy-test-deadline-{os.getpid()}")
+        members = [RemoteMember(info, w, seed=5) for w in range(K)]
+        for w, m in enumerate(members):
+            m.rng = np.random.Generator(np.random.PCG64(1000 + w))
+    else:
+        members = team.members
+    with ThreadPoolExecutor(K) as pool:
+        res = list(pool.map(lambda m: m.hmc_update(), members))          # raises SmoqyError on any non-zero code
+        list(pool.map(lambda q: members[q].hmc_finish(False, res[q][1]), range(K)))
+    for dH, x_new in res:
+        assert np.isfinite(dH) and np.all(np.isfinite(x_new))
+    # a member that really is alone still times out (the deadline is not gone)
+    lib = team.lib
+    if not published:
+        R = np.asfortranarray(np.random.default_rng(1).standard_normal((team.batch.Lt, team.batch.N)) + 0j)
+        rr = C.c_double(0.0)
+        assert lib.smoqy_team_sample_phi(team._t, 0, L.ptr(R), C.byref(rr)) == 9
+    else:
+        with pytest.raises(L.SmoqyError) as e:
+            members[0].sample_pseudofermion_fields()
+        assert "(9)" in str(e.value)
+        for m in members:
+            m.close()
+        team.unserve()
+    team.close()
+
+
+def test_complex_handles_are_refused_by_teams():
+    """team staging holds N doubles per Lanczos start vector, a handle with T = ComplexF64 reads 2N — such handles are
+    refused at smoqy_team_create with a message instead of being mis-staged."""
+    import smoqyelphqmc_amd as sq
+
+    m = sq.lattice.bssh_chain(8, 6)
+    nt, perm, colors = sq.lattice.checkerboard_decomposition(m.fpi.neighbor_table)
+    h = L.Handle(6, 8, nt, colors, True, 2, 1, -1, is_complex=True)
+    lib = L.load()
+    t = C.c_void_p()
+    rc = lib.smoqy_team_create(C.byref(t), h._h, 8)
+    assert rc != 0 and not t
+    assert b"complex" in lib.smoqy_team_last_error(None)
+    h.close()
