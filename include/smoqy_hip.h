@@ -127,6 +127,12 @@ int smoqy_matvec_force_generic(smoqy_ctx *ctx, int on);
  * size.  Same stage order per site (outputs equal to rounding, FMA contraction aside); the p·Ap partial is formed as |M p|² instead of
  * p·(MᵀM p) (equal up to rounding, real and non-negative by construction). */
 int smoqy_matvec_stream(smoqy_ctx *ctx, int run_len);
+/* the same choice for the one-wavefront-per-run form (fdm_wave_kernel: the whole time slice in the registers of one wavefront, no LDS
+ * image, no barrier) that handles take when their decomposition has a lane program — rings of up to 256 sites (2 colours), plaquette
+ * lattices of up to 256 sites (4 colours), honeycomb lattices of up to 512 sites with hoppings that are τ-independent and equal on the
+ * bonds of a colour (3 colours): run_len = -1 automatic (the default), 0 never, R >= 1 wavefronts walk runs of R slices (rounded down to
+ * a multiple of the τ-chunk).  smoqy_describe names the kernel the last full-batch launch ran. */
+int smoqy_matvec_wave(smoqy_ctx *ctx, int run_len);
 /* host form: `count` vectors starting at system sys0 (fields of walker sys/nrhs); out == in allowed */
 int smoqy_matvec(smoqy_ctx *ctx, int op, void *out, const void *in, int sys0, int count);
 

@@ -74,6 +74,7 @@ SIGNATURES = {
     "smoqy_matvec_v": [_p, _i, _i, _i],
     "smoqy_matvec_force_generic": [_p, _i],
     "smoqy_matvec_stream": [_p, _i],
+    "smoqy_matvec_wave": [_p, _i],
     "smoqy_team_create": [C.POINTER(_p), _p, _i],
     "smoqy_team_destroy": [_p],
     "smoqy_team_size": [_p, _pi],
@@ -181,6 +182,8 @@ def load():
         raise SmoqyError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); there is no CPU fallback")
     lib = C.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
+        if os.environ.get("SMOQY_AB_OLD_LIBRARY") and not hasattr(lib, name):
+            continue  # tools/ab_libs.sh only: an older build of the library copied over the in-tree one lacks the newest entry points
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = args
         fn.restype = C.c_int

@@ -109,6 +109,8 @@ struct smoqy_ctx {
     int graph_next = 0;
     unsigned graph_epoch = 1;
     std::string graph_note;  // why the last capture failed (also appended to smoqy_last_error)
+    int wave_R = -1;             // run length of fdm_wave_kernel: -1 automatic (smoqy_matvec_wave)
+    bool wave_off = false;
     const char *mtm_name = "";   // kernel family of the last full-batch fused MᵀM launch / Chebyshev launch (smoqy_describe)
     const char *cheb_name = "";
     // off by default: measured on MI355X the replay (≈10-16 µs per graph launch) does not beat six eager
@@ -146,7 +148,8 @@ struct smoqy_ctx {
     std::vector<char> cs_const;  // [nw] 1 once the HOST has shown a walker's hoppings to be τ-independent (selects the one-pair-per-colour MᵀM kernel); 0 = unknown
     int2 *d_pbonds = nullptr, *d_psites = nullptr;
     int *d_pos = nullptr;
-    int *d_poff = nullptr, *d_psrc = nullptr, *d_own = nullptr, *d_own_f = nullptr, *d_wave = nullptr;
+    int *d_poff = nullptr, *d_psrc = nullptr, *d_own = nullptr, *d_own_f = nullptr, *d_wave = nullptr, *d_fwave = nullptr;
+    FdmWave fw{};
     double2 *d_pcs = nullptr;
     double *h_lan = nullptr;  // pinned [nw][2][1024]
     // device-resident bookkeeping of update_preconditioner! (PreUpd, kernels_kpm.hip): the host reads a 16-byte status record per
@@ -165,6 +168,7 @@ struct smoqy_ctx {
         double *d_x = nullptr, *d_contrib = nullptr, *d_out = nullptr, *h_out = nullptr;
         double *d_bare = nullptr;  // [V⁰ (N) | t⁰ in checkerboard order (Nh)]
         bool bare_set = false, t_done = false;
+        int t0_level = 1;  // 2: the bare hoppings are equal on every bond of a colour (set_cs_const level of walkers without SSH couplings)
         ForceArgs tmpl{};
         // EFA leapfrog: momenta, saved positions, per-(ω, mode) action eigenvalues and masses
         std::vector<int> finite_mass;
@@ -248,13 +252,25 @@ static void drop_graphs(smoqy_ctx *c)
 }
 
 // host-side proof that walker w's hoppings do (not) depend on τ; a change drops the captured CG graphs, which hold the kernel variant
-static void set_cs_const(smoqy_ctx *c, int w, bool v)
+// level: 0 unknown / τ-dependent, 1 τ-independent, 2 τ-independent AND the same (cosh, sinh) on every bond of a colour
+static void set_cs_const(smoqy_ctx *c, int w, int level)
 {
     if (c->cs_const.empty()) return;
-    if ((c->cs_const[(size_t)w] != 0) != v) {
-        c->cs_const[(size_t)w] = v ? 1 : 0;
+    if (c->cs_const[(size_t)w] != (char)level) {
+        c->cs_const[(size_t)w] = (char)level;
         drop_graphs(c);
     }
+}
+// 2 when v[h] is the same for all sorted bonds h of each colour, else 1 (v: one value per sorted bond, a τ-independent hopping table)
+static int cs_level_of(const smoqy_ctx *c, const double *v, size_t stride)
+{
+    const Geometry &g = c->g;
+    for (int col = 0; col < g.ncol; ++col) {
+        const int h0 = (int)c->in_cr[2 * (size_t)col] - 1, h1 = (int)c->in_cr[2 * (size_t)col + 1];  // 1-based inclusive range
+        for (int h = h0 + 1; h < h1; ++h)
+            if (v[(size_t)h * stride] != v[(size_t)h0 * stride]) return 1;
+    }
+    return 2;
 }
 
 static int check_vec(smoqy_ctx *c, int id)
@@ -425,7 +441,7 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->fft_info) rocfft_execution_info_destroy(c->fft_info);
     void *ptrs[] = {c->d_bonds, c->d_col_off, c->d_expV, c->d_ch, c->d_sh, c->d_lam, c->d_stage, c->d_stage_real, c->d_stage_int, c->scr[0], c->scr[1], c->scr[2], c->cg_r, c->cg_p,
                     c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->d_st_idle, c->fft_work, c->d_tw, c->d_th, c->d_wtab, c->d_tpos, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
-                    c->d_rand, c->d_rand_traj, c->d_traj_dot, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_wave, c->d_big, c->d_shi, c->d_sbari};
+                    c->d_rand, c->d_rand_traj, c->d_traj_dot, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_wave, c->d_fwave, c->d_big, c->d_shi, c->d_sbari};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (double2 *v : c->vecs)
@@ -853,6 +869,22 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
                     c->kg.wave = c->d_wave; c->kg.wave_kind = kind; c->kg.wave_lanes = lanes;
                 }
             }
+            {   // lane program of the one-wavefront-per-run MᵀM kernel (kernels_fdm_wave.hip): every colour a perfect matching, real hoppings
+                bool perfect = !g.is_cplx && g.ncol <= kFdmColours;
+                for (int col = 0; col < g.ncol && perfect; ++col) perfect = poff[col + 1] - poff[col] == g.N / 2 && g.N % 2 == 0;
+                for (size_t k = 0; k < psrc.size() && perfect; ++k) perfect = psrc[k] >= 0 && pb[k].x != pb[k].y;
+                if (perfect) {
+                    std::vector<int> tab;
+                    int kind = 0, lanes = 0;
+                    bool rot = false;
+                    fdm_wave_program(g.N, g.ncol, mate, bidx, tab, kind, lanes, rot);
+                    if (kind) {
+                        HIPCHK(c, hipMalloc(&c->d_fwave, tab.size() * sizeof(int)));
+                        HIPCHK(c, hipMemcpy(c->d_fwave, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+                        c->fw.tab = c->d_fwave; c->fw.kind = kind; c->fw.lanes = lanes; c->fw.rot = rot ? 1 : 0;
+                    }
+                }
+            }
             if (q_fdm == q_cheb) { c->d_own_f = c->d_own; c->ff.own_n = c->kg.own_n; }
             else if (int rc = build_own(q_fdm, &c->d_own_f, &c->ff.own_n)) return rc;
             c->ff.own = c->d_own_f;
@@ -1091,7 +1123,7 @@ int smoqy_update_fields(smoqy_ctx *c, int w, const double *expV, const double *c
         bool same = true;
         for (int h = 0; h < g.Nh && same; ++h)
             for (int l = 1; l < g.Lt && same; ++l) same = ch[(size_t)h * g.Lt + l] == ch[(size_t)h * g.Lt] && sh[(size_t)h * g.Lt + l] == sh[(size_t)h * g.Lt];
-        set_cs_const(c, w, same);
+        set_cs_const(c, w, !same ? 0 : std::min(cs_level_of(c, ch, (size_t)g.Lt), cs_level_of(c, sh, (size_t)g.Lt)));
     }
     launch_pack_csf(c->stream, c->d_ch + (size_t)w * g.Lt * g.Nh, c->d_sh + (size_t)w * g.Lt * g.Nh, c->d_psrc, c->d_csf + (size_t)w * g.Lt * c->kg.ptotal, c->d_cs_varies + w, g.Lt, g.Lt, g.Nh, c->kg.ptotal);
     return check_launch(c, "update_fields");
@@ -1134,7 +1166,13 @@ static int update_pi_range(smoqy_ctx *c, int w0, int nw, const double *V, const 
             bool same = true;
             for (int l = 1; l < g.Lt && same; ++l)
                 for (int h = 0; h < g.Nh && same; ++h) same = tw_[(size_t)l * g.Nh + h] == tw_[h];
-            set_cs_const(c, w0 + w, same);
+            int level = same ? 1 : 0;
+            if (same) {  // ... and equal hoppings on every bond of a colour (sorted bond n is model hopping perm[n]) give one pair per colour
+                std::vector<double> ts((size_t)g.Nh);
+                for (int n = 0; n < g.Nh; ++n) ts[(size_t)n] = tw_[perm[n] - 1];
+                level = cs_level_of(c, ts.data(), 1);
+            }
+            set_cs_const(c, w0 + w, level);
         }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1302,6 +1340,33 @@ static int stream_run_length(const smoqy_ctx *c, int count, bool cs_const)
     return R >= 2 ? R : 0;
 }
 
+// Run length (output slices per WAVEFRONT) of fdm_wave_kernel for a launch over `count` systems.  A run of R slices costs 2R + 1 propagates
+// and R + 2 slice loads, so long runs waste less; short runs give more wavefronts.  About two wavefronts per SIMD (2048 per launch) are
+// wanted; the τ-chunk is the unit (the p·Ap partials keep the chunk layout).  SMOQY_FDM_WAVE_R forces a value.
+static int wave_run_length(const smoqy_ctx *c, int count)
+{
+    static const int env = tuning_env(kTuneFdmWaveR);
+    const Geometry &g = c->g;
+    if (c->d_big || g.is_cplx || !g.is_sym) return 0;
+    int R = env > 0 ? env : c->wave_R;
+    if (R <= 0) {
+        // automatic, from the measurements of tools/wave_scan.py on MI355X (µs per launch, wave kernel against the workgroup kernels):
+        //   plaquette (optical-SSH square L = 12): 9.1 against 12.1 at 16 systems, 29.8 against 49.3 at 128 — always;
+        //   honeycomb blocks (L = 16): 15.1 / 15.1 at 16 systems, 33.3 / 38.0 at 64 (R = 8), 75.0 / 80.0 at 128 (R = 16) — from 64 systems;
+        //     L = 8 (a quarter of the lanes busy): 9.1 against 5.8 — never below 64 lanes... so only full wavefronts;
+        //   ring (bond-SSH chain L = 256): 11.3 / 11.3 at 16, 81.2 / 82.1 at 128 — no gain: the workgroup kernels stay.
+        // (at 16 systems every form moves ~4 TB/s out of the Infinity Cache with two slices of halo per run; longer runs have too few
+        // wavefronts to hide one wavefront's chain of 2R + 1 dependent propagates)
+        if (c->fw.kind == 1) return 0;
+        if (c->fw.kind == 3 && (count < 64 || c->fw.lanes < 64)) return 0;
+        R = c->Tc;
+        while (2 * R <= 32 && (long)((g.Lt + 2 * R - 1) / (2 * R)) * count >= 1024) R *= 2;
+    }
+    R = std::min(R, g.Lt);
+    R -= R % c->Tc;
+    return std::max(R, 0);
+}
+
 static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, double2 *partial, const CgState *cg, int sys0, int count, bool twiddled = false, hipStream_t st = nullptr)
 {
     if (!st) st = c->stream;
@@ -1329,7 +1394,19 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
         a.nt_fields = nt_env < 0 ? (c->tf_ok && c->tf.slim) : (nt_env != 0);
     }
     const char *name;
-    if (a.run_len > 0 && fdm_own_stream_supported(a, c->ff, c->g.is_sym != 0, cs_const)) { launch_fdm_own_stream(st, a, c->ff); name = "fdm_own_stream_kernel"; }
+    // one wavefront per run of slices, the slice in registers (kernels_fdm_wave.hip): lattices with a lane program, fused MᵀM out of place
+    int csm = 2;  // what the host has shown for EVERY walker of the launch: 2 τ-dependent (or unknown), 1 τ-independent, 0 and uniform per colour
+    if (cs_const) {
+        csm = 0;
+        for (int w = sys0 / c->g.nrhs; w <= (sys0 + count - 1) / c->g.nrhs; ++w) csm = std::max(csm, c->cs_const[(size_t)w] >= 2 ? 0 : 1);
+    }
+    const int wave_R = (op == SMOQY_OP_MTM && in != out && c->fw.kind && !c->wave_off) ? wave_run_length(c, count) : 0;
+    FdmArgs aw = a;
+    aw.run_len = wave_R;
+    if (wave_R > 0 && fdm_wave_supported(aw, c->ff, c->fw, c->g.is_sym != 0, csm)) {
+        launch_fdm_wave(st, aw, c->ff, c->fw, csm);
+        name = c->fw.kind == 1 ? "fdm_wave_kernel<ring>" : (c->fw.kind == 2 ? "fdm_wave_kernel<plaquette>" : "fdm_wave_kernel<honeycomb block>");
+    } else if (a.run_len > 0 && fdm_own_stream_supported(a, c->ff, c->g.is_sym != 0, cs_const)) { launch_fdm_own_stream(st, a, c->ff); name = "fdm_own_stream_kernel"; }
     else if (a.run_len > 0 && fdm_stream_supported(a, c->ff, c->g.is_sym != 0)) { launch_fdm_stream(st, a, c->ff, cs_const); name = cs_const ? "fdm_stream_kernel<CSV=false>" : "fdm_stream_kernel<CSV=true>"; }
     else if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) { launch_fdm_own(st, op, a, c->ff); name = "fdm_own_kernel"; }
     else if (fdm_fast_supported(a, c->ff, c->g.is_sym != 0)) { launch_fdm_fast(st, op, a, c->ff, c->g.is_sym != 0, cs_const); name = c->g.is_sym ? "fdm_fast_kernel" : "fdm_fast_asym_kernel"; }
@@ -1341,6 +1418,17 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
 
 // run length of the streaming MᵀM kernel: -1 = automatic (the default), 0 = chunked kernels only, R >= 2 = workgroups walk runs of R
 // slices (rounded down to a multiple of the τ-chunk)
+// run length of the one-wavefront-per-run MᵀM kernel: -1 = automatic (the default), 0 = never use it for this handle, R >= 1 = runs of R slices
+int smoqy_matvec_wave(smoqy_ctx *c, int run_len)
+{
+    CHECK_CTX(c);
+    if (run_len < -1) FAIL(c, 1, "run_len must be -1 (automatic), 0 (off) or >= 1");
+    c->wave_R = run_len;
+    c->wave_off = run_len == 0;
+    drop_graphs(c);
+    return 0;
+}
+
 int smoqy_matvec_stream(smoqy_ctx *c, int run_len)
 {
     CHECK_CTX(c);
@@ -2514,6 +2602,7 @@ int smoqy_set_bare_model(smoqy_ctx *c, const double *V0, const double *t0, const
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(c->force.d_bare, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->force.t0_level = (g.is_cplx || g.Nh == 0) ? 1 : cs_level_of(c, b.data() + g.N, 1);  // bare hoppings equal on every bond of a colour?
     c->force.bare_set = true;
     c->force.t_done = false;
     return 0;
@@ -2536,7 +2625,7 @@ int smoqy_update_from_phonons_all(smoqy_ctx *c, const double *x_all)
                          c->d_shi);
     if (do_t) {
         launch_pack_csf(c->stream, c->d_ch, c->d_sh, c->d_psrc, c->d_csf, c->d_cs_varies, g.nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal);
-        for (int w = 0; w < g.nw; ++w) set_cs_const(c, w, F.Nssh == 0);  // no SSH coupling: t is the bare per-bond hopping on every slice
+        for (int w = 0; w < g.nw; ++w) set_cs_const(c, w, F.Nssh == 0 ? F.t0_level : 0);  // no SSH coupling: t is the bare per-bond hopping on every slice
     }
     F.t_done = true;
     HIPCHK(c, hipStreamSynchronize(c->stream));  // x_all is the caller's again
@@ -2714,7 +2803,7 @@ static int refresh_from_device_x(smoqy_ctx *c)
                          c->d_shi);
     if (do_t) {
         launch_pack_csf(c->stream, c->d_ch, c->d_sh, c->d_psrc, c->d_csf, c->d_cs_varies, g.nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal);
-        for (int w = 0; w < g.nw; ++w) set_cs_const(c, w, F.Nssh == 0);  // no SSH coupling: t is the bare per-bond hopping on every slice
+        for (int w = 0; w < g.nw; ++w) set_cs_const(c, w, F.Nssh == 0 ? F.t0_level : 0);  // no SSH coupling: t is the bare per-bond hopping on every slice
     }
     F.t_done = true;
     return check_launch(c, "refresh_from_device_x");
@@ -2869,7 +2958,7 @@ int smoqy_copy_fields(smoqy_ctx *dst, int dst_walker, smoqy_ctx *src, int src_wa
     }
     if (nP) HIPCHK(dst, hipMemcpyAsync(dst->d_csf + dst_walker * nP, src->d_csf + src_walker * nP, nP * sizeof(double2), hipMemcpyDeviceToDevice, dst->stream));
     HIPCHK(dst, hipMemcpyAsync(dst->d_cs_varies + dst_walker, src->d_cs_varies + src_walker, sizeof(int), hipMemcpyDeviceToDevice, dst->stream));
-    set_cs_const(dst, dst_walker, !src->cs_const.empty() && src->cs_const[(size_t)src_walker] != 0);
+    set_cs_const(dst, dst_walker, src->cs_const.empty() ? 0 : (int)src->cs_const[(size_t)src_walker]);
     HIPCHK(dst, hipStreamSynchronize(dst->stream));
     return 0;
 }

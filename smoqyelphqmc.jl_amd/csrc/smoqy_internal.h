@@ -172,6 +172,14 @@ struct FdmFast {
     int wl0;             // fdm_own_kernel: the colour-0 mates are the lane's neighbours in its row of 16 lanes (2 / 3 as KpmGeom::wl0, else 0)
 };
 
+// lane program of fdm_wave_kernel (kernels_fdm_wave.hip): one wavefront holds a whole time slice in registers
+struct FdmWave {
+    const int *tab;   // [rows][64]: site ids per position, padded-bond index per bond slot, partner lane per remote relation (+ colour-0 partner sites)
+    int kind;         // 0 none, 1 ring (2 colours), 2 plaquette (4 colours), 3 honeycomb 2x2 cell blocks (3 colours)
+    int lanes;        // groups = active lanes (<= 64)
+    int rot;          // ring of exactly 64 lanes in lane order: partner fetches are DPP wave rotations
+};
+
 // ---- launchers (defined in the .hip files) -----------------------------------------------
 void launch_fdm(hipStream_t st, int op, bool sym, const FdmArgs &a, size_t lds_bytes);
 size_t fdm_lds_bytes(int op, int N, int Tc);
@@ -194,6 +202,10 @@ void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff
 bool fdm_stream_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
 void launch_fdm_stream(hipStream_t st, const FdmArgs &a, const FdmFast &ff, bool cs_const);
 hipError_t configure_fdm_stream_kernels(const char **what);
+// fused MᵀM, one wavefront per run of slices (csm: 0 hoppings uniform per colour and τ-independent, 1 τ-independent, 2 τ-dependent)
+bool fdm_wave_supported(const FdmArgs &a, const FdmFast &ff, const FdmWave &fw, bool sym, int csm);
+void launch_fdm_wave(hipStream_t st, const FdmArgs &a, const FdmFast &ff, const FdmWave &fw, int csm);
+void fdm_wave_program(int N, int ncol, const std::vector<std::vector<int>> &mate, const std::vector<std::vector<int>> &bidx, std::vector<int> &tab, int &kind, int &lanes, bool &rot);
 bool fdm_own_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
 void launch_fdm_own(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff);
 void launch_pack_csf(hipStream_t st, const double *ch, const double *sh, const int *psrc, double2 *csf, int *cs_varies, int Lt, int Lt1, int Nh, int ptotal);
@@ -363,7 +375,7 @@ void launch_tfft(hipStream_t st, int mode, const TfftArgs &a);
 // none needed for normal use.  Read once per process; tuning_env("NAME") is the variable's integer value, or -1 when it is not set.
 enum TuningKnob {
     kTuneChebWl0, kTuneChebSplit, kTuneChebOwn, kTuneChebGroup, kTuneFdmStream, kTuneFdmOwn, kTuneFdmOwnMax, kTuneFdmOwnStream, kTuneNtFields,
-    kTuneXStream, kTuneXcdMap, kTuneTfftSlim, kTuneTfftSb, kTuneTfftEdge, kTuneChebWave, kTuneCount
+    kTuneXStream, kTuneXcdMap, kTuneTfftSlim, kTuneTfftSb, kTuneTfftEdge, kTuneChebWave, kTuneFdmWave, kTuneFdmWaveR, kTuneCount
 };
 inline int tuning_env(TuningKnob k)
 {
@@ -373,7 +385,7 @@ inline int tuning_env(TuningKnob k)
         {
             static const char *const names[kTuneCount] = {"SMOQY_CHEB_WL0", "SMOQY_CHEB_SPLIT", "SMOQY_CHEB_OWN", "SMOQY_CHEB_GROUP", "SMOQY_FDM_STREAM", "SMOQY_FDM_OWN",
                                                           "SMOQY_FDM_OWN_MAX", "SMOQY_FDM_OWNSTREAM", "SMOQY_NT_FIELDS", "SMOQY_X_STREAM", "SMOQY_XCD_MAP", "SMOQY_TFFT_SLIM",
-                                                          "SMOQY_TFFT_SB", "SMOQY_TFFT_EDGE", "SMOQY_CHEB_WAVE"};
+                                                          "SMOQY_TFFT_SB", "SMOQY_TFFT_EDGE", "SMOQY_CHEB_WAVE", "SMOQY_FDM_WAVE", "SMOQY_FDM_WAVE_R"};
             for (int q = 0; q < kTuneCount; ++q) {
                 const char *e = getenv(names[q]);
                 v[q] = e ? atoi(e) : -1;

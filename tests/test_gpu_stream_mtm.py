@@ -27,6 +27,7 @@ def _handle(m, nw, walkers=None):
     for w in range(nw):
         mw = m if walkers is None else walkers[w]
         h.call("smoqy_update_from_path_integral", w, L.ptr(mw.fpi.V), L.ptr(mw.fpi.t), L.ptr(perm), C.c_double(mw.fpi.dtau))
+    h.call("smoqy_matvec_wave", 0)  # this file is about the WORKGROUP kernels: the one-wavefront-per-run kernel (tests/test_gpu_wave_mtm.py) stays out
     return h, nt, perm
 
 
@@ -95,6 +96,7 @@ def test_stream_equals_chunked_and_oracle(case, R):
 def test_stream_at_the_benchmarked_lattice(nw, R):
     batch = WalkerBatch("holstein_honeycomb_L16_Ltau128", nwalkers=nw)
     h = batch.h
+    h.call("smoqy_matvec_wave", 0)
     g = np.random.default_rng(6)
     v = np.asfortranarray(g.standard_normal((batch.Lt, batch.N, nw)) + 1j * g.standard_normal((batch.Lt, batch.N, nw)))
     a, b, c = h.vec_alloc(), h.vec_alloc(), h.vec_alloc()
