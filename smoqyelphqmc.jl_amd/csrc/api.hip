@@ -2,6 +2,8 @@
 // layout conversion, rocFFT plans, the KPM preconditioner's host-side bookkeeping and the
 // on-device conjugate-gradient driver.  gfx950 / ROCm only; there is no CPU path.
 #include <algorithm>
+#include <time.h>
+#include <chrono>
 #include <array>
 #include <cmath>
 #include <cstdio>
@@ -2206,6 +2208,7 @@ restart:
     if (int rc = check_launch(c, "cg setup")) return rc;
 
     int launched = 0;
+    bool finish_queued = false;  // cg_finish already sits behind the last burst (out-of-place form only)
     // smoqy_cg_split: fused path only (rocFFT plans and captured graphs cover the whole batch), and not while the fused-MᵀM launches are
     // being sampled for bench.py's roofline (the samples are of full-batch launches).  Automatic: two parts from 8 systems up (measured,
     // DESIGN.md §4.3).
@@ -2294,6 +2297,13 @@ restart:
                 if (int rc = cg_iteration(c, a, any_pre)) return rc;
         }
         launched += burst;
+        // Ψ = Λ⁻¹Θᴴx̃ and the Φ·Ψ partials go out BEHIND EVERY BURST where they are written out of place (the PFFCalculator solve: x̃ stays
+        // intact, the kernel may run any number of times): when the poll says "converged" the finish has already run, and the stream
+        // does not idle between the host's wake-up and its next launch (round 4; 25 µs per solve in profiles/r03_gap_probe_1walker.txt)
+        finish_queued = a.lam != nullptr;
+        if (finish_queued) launch_cg_finish(c->stream, a);
+        // (publishing the states into device-visible host memory and sleeping-then-spinning on a sequence number instead of this copy +
+        // synchronisation was built and measured in round 4: one walker 25.9-28.0 -> 28.2-29.3 ms per sweep — not kept)
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (int rc = check_launch(c, "cg loop")) return rc;
@@ -2322,7 +2332,7 @@ restart:
         c->hint_tol[hslot] = tol;
         c->hint_iters[hslot] = mx;
     }
-    launch_cg_finish(c->stream, a);  // x = Θᴴ x̃ (asynchronous: whoever reads x next is ordered behind it on the stream)
+    if (!finish_queued) launch_cg_finish(c->stream, a);  // x = Θᴴ x̃ (asynchronous: whoever reads x next is ordered behind it on the stream)
     if (launched == 0) {
         // no poll has brought the state back yet (maxiter = 0): the convergence test of cg_start is all there is
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
