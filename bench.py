@@ -49,8 +49,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="holstein_honeycomb_L16_Ltau128")
-    ap.add_argument("--walkers-per-gpu", type=int, default=128)
-    ap.add_argument("--streams", type=int, default=8, help="concurrent lock-step batches per GPU (one HIP stream + host thread each)")
+    ap.add_argument("--walkers-per-gpu", type=int, default=0, help="0 = the workload's measured best shape (DEFAULT_SHAPES; 128 for the headline lattice)")
+    ap.add_argument("--streams", type=int, default=0, help="concurrent lock-step batches per GPU (one HIP stream + host thread each); 0 = the workload's measured best shape")
     ap.add_argument("--solve-concurrency", type=int, default=4, help="at most this many batches inside the CG at once (0 = no limit)")
     ap.add_argument("--gate", choices=["library", "python"], default="library", help="where --solve-concurrency is enforced: inside the library around each CG loop, or in Python around whole calls")
     ap.add_argument("--cg-split", type=int, default=1, choices=[0, 1, 2, 3, 4],
@@ -88,6 +88,19 @@ def parse():
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="rehearsal of the N>1 control flow on a one-GPU box: every rank uses cuda:0 and the barrier / MAX reduction run over gloo")
     return ap.parse_args()
+
+
+# walkers per GPU x streams per workload, from the scans committed as profiles/r0*_config_scan.txt (headline lattice, round 3) and
+# profiles/r04_shape_scan.txt (the other lattices, round 4: their launches fill half a chip or less at 16 systems, so they want 64 per stream)
+DEFAULT_SHAPES = {
+    "holstein_honeycomb_L16_Ltau128": (128, 8),
+    "holstein_honeycomb_L8_Ltau80": (256, 4),     # 3355 sweeps/s against 2034 at 128 x 8
+    "holstein_honeycomb_L4_Ltau40": (256, 4),
+    "ossh_square_L12_Ltau100": (256, 4),          # 178.0 against 119.9
+    "ossh_square_L12_Ltau100_alpha0p2": (256, 4),
+    "bssh_chain_L256_Ltau200": (128, 8),          # 121.3; 256 x 8: 121.0, 256 x 4: 115.2 — flat
+    "bssh_chain_L256_Ltau200_alpha0p2": (128, 8),
+}
 
 
 def available_cores():
@@ -468,6 +481,7 @@ def iteration_kernels(args, dev, walker0, L, np):
     ob.h.call("smoqy_cg_iteration_timing_read", us, L.C.byref(n))
     Sb = 16.0 * ob.Lt * ob.N * nw
     Fb = (8.0 * ob.Lt * ob.N + 16.0 * ob.Lt * ob.Nh) * nw
+    names = ob.h.describe()
     ob.h.close()
     _, per_kernel, src = committed_iteration_traffic(args.workload)
     per_kernel = per_kernel or {}
@@ -476,9 +490,9 @@ def iteration_kernels(args, dev, walker0, L, np):
         hits = [v for k, v in per_kernel.items() if k.startswith(prefix)]
         return hits[0] if hits else None
 
-    rows = [("fused MtM (fdm_stream_kernel)", us[0], 2 * Sb + Fb, traffic("fdm_")),
+    rows = [(f"fused MtM ({names['mtm']})", us[0], 2 * Sb + Fb, traffic("fdm_")),
             ("forward tau-FFT + r update (tfft_kernel<2>)", us[1], 3 * Sb, traffic("tfft_kernel<2")),
-            ("Chebyshev apply (cheb_own_kernel)", us[2], 2 * Sb, traffic("cheb_")),
+            (f"Chebyshev apply ({names['cheb']})", us[2], 2 * Sb, traffic("cheb_")),
             ("inverse tau-FFT + x, p updates (tfft_kernel<3>)", us[3], 5 * Sb, traffic("tfft_kernel<3"))]
     prof, prof_src = committed_solo_durations(args.workload)
     out = []
@@ -499,13 +513,18 @@ def iteration_kernels(args, dev, walker0, L, np):
             "kernels": out}
 
 
+SOLO_TAGS = {"holstein_honeycomb_L16_Ltau128": "hc16", "holstein_honeycomb_L8_Ltau80": "hc8", "ossh_square_L12_Ltau100": "ossh", "bssh_chain_L256_Ltau200": "bssh",
+             "holstein_honeycomb_L4_Ltau40": "hc4"}  # tags of profiles/r*_solo_kernel_stats_<tag>.txt and r*_pmc_iteration_<tag>.json
+
+
 def committed_solo_durations(workload):
     """rocprofv3 per-dispatch averages (us) of the iteration's kernels in the newest committed one-stream, 16-walker profile
-    (profiles/r*_solo_kernel_stats_hc16.txt).  Headline lattice only."""
+    (profiles/r*_solo_kernel_stats_<tag>.txt) of this workload."""
     import glob
-    if workload != "holstein_honeycomb_L16_Ltau128":
+    tag = SOLO_TAGS.get(workload)
+    if tag is None:
         return {}, None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_solo_kernel_stats_hc16.txt")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_solo_kernel_stats_{tag}.txt")), reverse=True):
         out = {}
         try:
             for line in open(path):
@@ -525,13 +544,16 @@ def committed_solo_durations(workload):
 
 def committed_iteration_traffic(workload):
     """HBM-side bytes of ONE CG iteration at 16 systems per launch (all four kernels), from the newest committed rocprofv3 PMC pass
-    (profiles/r*_pmc_iteration.json; FETCH_SIZE x 2 + WRITE_SIZE per kernel, medians over a sweep).  Headline lattice only."""
+    (profiles/r*_pmc_iteration[_<tag>].json; FETCH_SIZE x 2 + WRITE_SIZE per kernel, medians over a sweep) of this workload."""
     import glob
-    if workload != "holstein_honeycomb_L16_Ltau128":
-        return None, None, None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_iteration.json")), reverse=True):
+    tag = SOLO_TAGS.get(workload)
+    names = [f"r*_pmc_iteration_{tag}.json"] + (["r*_pmc_iteration.json"] if tag == "hc16" else [])  # (rounds 1-3 profiled the headline lattice only, untagged)
+    paths = sorted((q for n in names for q in glob.glob(os.path.join(ROOT, "profiles", n))), key=os.path.basename, reverse=True) if tag else []
+    for path in paths:
         try:
             pmc = json.load(open(path))
+            if pmc.get("_workload", "holstein_honeycomb_L16_Ltau128") != workload:
+                continue
             per_kernel = {k.replace("void ", "").replace("smoqy::", "").replace("(anonymous namespace)::", "").split("(")[0]: v["traffic_MB"] * 2**20
                           for k, v in pmc.items() if isinstance(v, dict) and "traffic_MB" in v}
         except (OSError, ValueError, KeyError):
@@ -592,7 +614,7 @@ def roofline_record(args, batch, per, S, dev, insitu, extra, L, np):
             return {"bound": "hbm", "note": "no MtM launches were sampled in this run"}
         t_s = insitu["device_us"] * 1e-6
         traffic, traffic_src = committed_traffic(args.workload, per)
-        return {"bound": "hbm", "kernel": "fdm_stream_kernel<NCOL, CSV, FULL> (fused MtM, streaming form)", "achieved": alg / t_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t_s / 1e9 / HBM_PEAK_GBS,
+        return {"bound": "hbm", "kernel": h.describe()["mtm"] + " (fused MtM; the kernel family the handle's last full-batch launch ran, smoqy_describe)", "achieved": alg / t_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t_s / 1e9 / HBM_PEAK_GBS,
                 "frac_single_pass": 0.5 * alg / t_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_live": False, "frac_traffic": (traffic / t_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "avg_launch_us": insitu["device_us"], "duration_source": "timed region, device clock", "launches_sampled": insitu["device_n"], "event_pair_avg_us": insitu["event_us"],
                 "algorithmic_bytes_per_launch": alg, "systems_per_launch": per, "concurrent_streams": S}
@@ -617,7 +639,8 @@ def roofline_record(args, batch, per, S, dev, insitu, extra, L, np):
     prim_s, prim_src = (timed_s, "timed region, device clock") if timed_s else (iso_s, "isolated leg (no timed region in this run)")
     roofline = {
         "bound": "hbm",
-        "kernel": "fdm_stream_kernel<NCOL, CSV, FULL> (fused MᵀM apply, streaming form from 16 systems per launch — fdm_own_stream_kernel, the same pipeline on the owner-computes lane program, on handles of 32 systems or more, i.e. in the batch scan's 32 / 64 / 128 points, not in the timed region's batches of 16; fdm_own_kernel at <= 8 systems, fdm_fast_kernel where the streaming form does not apply)",
+        "kernel": h.describe()["mtm"] + " (fused MᵀM apply: the kernel family the timed batches' last full-batch launch ran, from smoqy_describe; batch_scan points carry their own)",
+        "iteration_kernels_of_the_timed_batches": h.describe(),
         "achieved": alg / prim_s / 1e9,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -669,7 +692,7 @@ def roofline_record(args, batch, per, S, dev, insitu, extra, L, np):
             tcv = L.C.c_int(0)
             hb.call("smoqy_get_tau_chunk", L.C.byref(tcv))
             tr, _ = committed_traffic(args.workload, nb)
-            rec = {"batch": nb, "tau_chunk": tcv.value, "us": t_s * 1e6, "GBs": algb / t_s / 1e9, "frac": algb / t_s / 1e9 / HBM_PEAK_GBS,
+            rec = {"batch": nb, "kernel": hb.describe()["mtm"], "tau_chunk": tcv.value, "us": t_s * 1e6, "GBs": algb / t_s / 1e9, "frac": algb / t_s / 1e9 / HBM_PEAK_GBS,
                    "frac_single_pass": 0.5 * algb / t_s / 1e9 / HBM_PEAK_GBS, "physical": algb / t_s / 1e9 <= HBM_PEAK_GBS,
                    "working_set_MiB": (2 * 16.0 * batch.Lt * batch.N * nb + nb * (8.0 * batch.Lt * batch.N + 16.0 * batch.Lt * batch.Nh)) / 2**20,
                    "traffic_GBs": (tr / t_s / 1e9) if tr else None, "frac_traffic": (tr / t_s / 1e9 / HBM_PEAK_GBS) if tr else None}
@@ -729,6 +752,11 @@ def main():
 
     from smoqyelphqmc_amd.sharding import aggregate_throughput, reduce_max_time, walker_range
 
+    shape = DEFAULT_SHAPES.get(args.workload, (128, 8))
+    if not args.walkers_per_gpu:
+        args.walkers_per_gpu = shape[0] if not args.streams else 16 * args.streams
+    if not args.streams:
+        args.streams = shape[1] if args.walkers_per_gpu % shape[1] == 0 else 1
     wpg, S = args.walkers_per_gpu, max(1, args.streams)
     if wpg % S:
         raise SystemExit("--walkers-per-gpu must be a multiple of --streams")
@@ -882,11 +910,11 @@ def main():
         # real bytes: one CG iteration of a 16-system batch moves `it_traffic` bytes beyond L2 (committed PMC pass); iterations per second
         # come from this run
         it_traffic, it_per_kernel, it_src = committed_iteration_traffic(args.workload)
-        if it_traffic and per == 16 and args.steps:
-            its_per_s = value * batch.solves_per_sweep * avg_iters / 16.0  # 16-system iterations per second over all streams and ranks
-            gbs = its_per_s * it_traffic / 1e9
+        if it_traffic and args.steps:
+            its_per_s = value * batch.solves_per_sweep * avg_iters / 16.0  # 16-system iterations per second over all streams and ranks (the PMC pass was
+            gbs = its_per_s * it_traffic / 1e9                            # taken at 16 systems per launch; bytes scale with the systems of a launch)
             copy_gbs = (roofline.get("copy_ceiling") or {}).get("GBs")
-            extra["cg_iteration_traffic"] = {"bytes_per_16_system_iteration": it_traffic, "per_kernel_bytes": it_per_kernel, "source": it_src, "measured_live": False,
+            extra["cg_iteration_traffic"] = {"systems_per_launch_in_this_run": per, "bytes_per_16_system_iteration": it_traffic, "per_kernel_bytes": it_per_kernel, "source": it_src, "measured_live": False,
                                              "iterations_per_s_16_systems": its_per_s, "achieved": gbs, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * world),
                                              "frac_of_copy_ceiling": (gbs / (copy_gbs * world)) if copy_gbs else None,
                                              "note": "whole step, everything outside the CG loops counted as zero bytes: measured traffic of the four iteration kernels x the iterations all walkers ran per second"}

@@ -8,8 +8,9 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf $out
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -o run -- python3 tools/one_stream.py ${PMC_WALKERS:-16} ${PMC_WORKLOAD:-} > gpurun_out/pmci_$ctr.log 2>&1 || exit 1
 done
-python3 - <<'PY'
-import csv, glob, json, collections
+python3 - "${PMC_WORKLOAD:-holstein_honeycomb_L16_Ltau128}" "${PMC_WALKERS:-16}" "${PMC_TAG:-}" <<'PY'
+import csv, glob, json, collections, sys
+wl, nwk, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 res = collections.defaultdict(dict)
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"gpurun_out/pmci_{ctr}/**/*counter_collection.csv", recursive=True)[0]
@@ -25,10 +26,11 @@ out = {}
 for k, d in res.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         out[k] = dict(d, traffic_MB=(2 * d["FETCH_SIZE"]["median_KB"] + d["WRITE_SIZE"]["median_KB"]) / 1024)
-out["_note"] = "median per launch over one sweep of 16 walkers (holstein_honeycomb_L16_Ltau128); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950); early-exit launches after convergence pull the mean down, hence the median"
-json.dump(out, open("gpurun_out/pmc_iteration.json", "w"), indent=1)
+out["_workload"] = wl
+out["_note"] = f"median per launch over one sweep of {nwk} walkers ({wl}); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950); early-exit launches after convergence pull the mean down, hence the median"
+json.dump(out, open(f"gpurun_out/pmc_iteration{('_' + tag) if tag else ''}.json", "w"), indent=1)
 for k, d in out.items():
-    if k != "_note":
+    if not k.startswith("_"):
         print(f"{k[:70]:70s} fetch {d['FETCH_SIZE']['median_KB']/1024:7.1f} MB (x2)  write {d['WRITE_SIZE']['median_KB']/1024:7.1f} MB  traffic {d['traffic_MB']:7.1f} MB")
 PY
 rm -rf gpurun_out/pmci_FETCH_SIZE gpurun_out/pmci_WRITE_SIZE
