@@ -153,7 +153,11 @@ def test_pcg_at_the_benchmarked_shape(shape, tol, in_place):
         # identical algorithm on identical data: the iterates agree far below the solve tolerance (short solves); long solves agree
         # to the accuracy either has, κ·tol
         assert relerr(x[:, :, w], xo) < (1e-9 if not long_solve else 1e-7) * max(1.0, tol / 1e-10), (w, relerr(x[:, :, w], xo))
-        # true residual of the returned x equals the reported eps (the recurrence residual) to a few percent
+        # true residual of the returned x equals the reported eps (the recurrence residual) to a few percent.  Short solves: res < tol, no slack.
+        # Long solves (α = 1 SSH, 290-560 iterations): cg_solve! stops on the RECURRENCE residual r_k = r_{k-1} − α A p (ConjugateGradient.jl:229),
+        # which drifts from b − A x_k by O(k·ε·κ) — the reference's own iterate has the same property (the oracle's true residual overshoots
+        # tol by the same few per cent) — hence 1.05·tol and 20 % between res and eps there.  Beyond κ·tol the agreement of the two long
+        # iterates is not a parity statement: PARITY UNPINNED for these cases (no reference output exists to say which rounding is "right").
         res = np.linalg.norm(o.mul_MtM(x[:, :, w]) - bv[:, :, w]) / np.linalg.norm(bv[:, :, w])
         assert res < tol * (1.0 if not long_solve else 1.05) and abs(res - eps[w]) < (0.05 if not long_solve else 0.2) * eps[w] + 1e-13, (w, res, eps[w])
     shape.h.call("smoqy_tfft_form", 0)

@@ -4,13 +4,14 @@ streams overlap?  usage: trace_overlap.py <dir> [fraction_of_trace_to_skip_at_st
 import csv, glob, sys, collections
 d = sys.argv[1]
 skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+stop = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0   # fraction of the trace where the window ends (process teardown is idle time of no interest)
 f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0")) for r in rows]
 ev.sort()
 t0, t1 = ev[0][0], max(e[1] for e in ev)
 cut = t0 + skip * (t1 - t0)
-ev = [e for e in ev if e[0] >= cut]
+ev = [e for e in ev if e[0] >= cut and e[1] <= t0 + stop * (t1 - t0)]
 t0, t1 = ev[0][0], max(e[1] for e in ev)
 span = t1 - t0
 tot = sum(e[1] - e[0] for e in ev)
