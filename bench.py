@@ -774,6 +774,9 @@ def main():
                            host_threads=rng_threads, measure_nrv=args.measure_nrv, device_efa=args.hmc == "device", cg_split=args.cg_split, prefetch_randoms=not args.no_prefetch,
                            tfft_in_place=(S > 1 and _only_factors(lat_Lt, (2, 3))) if args.tfft_form == "auto" else args.tfft_form == "in-place") for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
     batch = batches[0]
+    if os.environ.get("SMOQY_BENCH_ASYNC"):  # A/B aid: the asynchronous trajectory (smoqy_hmc_async) on / off in the timed batches
+        for b in batches:
+            b.h.call("smoqy_hmc_async", int(os.environ["SMOQY_BENCH_ASYNC"]), None, None)
     if os.environ.get("SMOQY_BENCH_GRAPH"):  # A/B aid: hipGraph replay of the CG iterations in the timed batches (needs --no-mtm-sampling)
         for b in batches:
             b.h.call("smoqy_cg_use_graph", int(os.environ["SMOQY_BENCH_GRAPH"]))

@@ -320,6 +320,13 @@ int smoqy_efa_restore_walkers(smoqy_ctx *ctx, const int *restore);
  * another recenter! keeps the step-by-step form (smoqy_efa_evolve, then its recenter! on the host copy, smoqy_efa_set_state).  A non-zero return (e.g. a non-finite residual) leaves x and p wherever the
  * trajectory stopped: the caller rejects the update with smoqy_efa_checkpoint(ctx, 1), as the reference's catch block does (:176-187). */
 int smoqy_hmc_trajectory_v(smoqy_ctx *ctx, int phi, int psi, int Nt, double dt, double tol_force, int maxiter, int use_precond, const double *randvecs, double *Sf, int *iters, double *eps);
+/* How smoqy_hmc_trajectory_v waits.  on = 0: for every force solve (a poll of the CG states per step).  on = 1 (the default): not at all
+ * until the trajectory's end — each solve is launched with the iterations its step needed in the previous trajectory of the same length
+ * and tolerance plus a margin, the per-step states stay on the device, and at the end EVERY solve is checked (converged, finite residual);
+ * if one is not, x, p and the fields are put back and the trajectory is repeated with polls.  Same kernels, same iterations: the results
+ * of the two forms are identical.  on < 0 leaves the setting alone; *runs / *misses (may be NULL) count the asynchronous trajectories and
+ * the ones that had to be repeated. */
+int smoqy_hmc_async(smoqy_ctx *ctx, int on, long *runs, long *misses);
 
 /* ---- device-side update! from the phonon fields ------------------- */
 

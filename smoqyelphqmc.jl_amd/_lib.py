@@ -152,6 +152,7 @@ SIGNATURES = {
     "smoqy_efa_checkpoint": [_p, _i],
     "smoqy_efa_restore_walkers": [_p, _p],
     "smoqy_hmc_trajectory_v": [_p, _i, _i, _i, _d, _d, _i, _i, _p, _p, _p, _p],
+    "smoqy_hmc_async": [_p, _i, C.POINTER(C.c_long), C.POINTER(C.c_long)],
     "smoqy_copy_fields": [_p, _i, _p, _i],
     "smoqy_ge_config": [_p, _i, _i, _p],
     "smoqy_ge_measure_GD0": [_p, _i, _i, _i, _i, _p],

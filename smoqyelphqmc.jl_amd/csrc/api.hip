@@ -111,6 +111,17 @@ struct smoqy_ctx {
     int graph_next = 0;
     unsigned graph_epoch = 1;
     std::string graph_note;  // why the last capture failed (also appended to smoqy_last_error)
+    // Asynchronous trajectory (round 4, smoqy_hmc_async): the force solves of smoqy_hmc_trajectory_v are launched on the iteration counts the
+    // PREVIOUS trajectory needed step by step (+ a margin), their states are kept per step on the device, and the host does not wait for any
+    // of them until the trajectory's end, where every solve is checked (converged, finite); a miss restores x, p and runs the polling form.
+    int traj_async = 1;
+    std::vector<int> traj_hint;   // iterations step t of the last verified trajectory took (max over systems)
+    double traj_hint_tol = 0.0;
+    int traj_margin = 2;
+    CgState *d_traj_st = nullptr, *h_traj_st = nullptr;
+    double *d_traj_save = nullptr;   // x and p at the start of the trajectory (the fall-back's starting point)
+    size_t traj_st_cap = 0, traj_save_cap = 0;
+    long traj_async_runs = 0, traj_async_misses = 0;
     int wave_R = -1;             // run length of fdm_wave_kernel: -1 automatic (smoqy_matvec_wave)
     bool wave_off = false;
     const char *mtm_name = "";   // kernel family of the last full-batch fused MᵀM launch / Chebyshev launch (smoqy_describe)
@@ -449,6 +460,9 @@ int smoqy_destroy(smoqy_ctx *c)
     for (double2 *v : c->vecs)
         if (v) (void)hipFree(v);
     if (c->h_st) (void)hipHostFree(c->h_st);
+    if (c->h_traj_st) (void)hipHostFree(c->h_traj_st);
+    if (c->d_traj_st) (void)hipFree(c->d_traj_st);
+    if (c->d_traj_save) (void)hipFree(c->d_traj_save);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_poll_dot) (void)hipHostFree(c->h_poll_dot);
     if (c->h_traj_dot) (void)hipHostFree(c->h_traj_dot);
@@ -2143,8 +2157,11 @@ constexpr int kGraphIters = 4;  // iterations per captured graph (smoqy_cg_use_g
 
 // pff_phi / pff_out: the solve of calculate_fermionic_action! with its Λ applies folded in (CgArgs::lam): b = Λ⁻ᵀ·pff_phi is formed by
 // cg_init (b itself is not read), Ψ = Λ⁻¹x lands in pff_out with the partials of Φ·Ψ in part_c; x then holds the twiddled iterate only.
+// async_step >= 0 (smoqy_hmc_trajectory_v only; needs the PFFCalculator form and x === b): launch c->traj_hint[async_step] + margin iterations,
+// the finish kernel and a device-side copy of the states into slot async_step of c->d_traj_st, and return WITHOUT waiting; iters / eps are
+// not touched, the caller verifies the states at the end of the trajectory.
 static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, double tol, int maxiter, int use_precond, int *iters, double *eps, const double2 *pff_phi = nullptr,
-                  double2 *pff_out = nullptr)
+                  double2 *pff_out = nullptr, int async_step = -1)
 {
     const Geometry &g = c->g;
     if (maxiter < 0) FAIL(c, 1, "maxiter < 0");
@@ -2220,11 +2237,13 @@ restart:
     int hint = 0, hslot = -1;
     for (int q = 0; q < 4; ++q)
         if (c->hint_tol[q] > 0 && std::fabs(std::log(c->hint_tol[q] / tol)) < 0.7) { hint = c->hint_iters[q]; hslot = q; }
+    const bool async = async_step >= 0 && pff_phi != nullptr && x_is_b;
     while (launched < maxiter) {
         int burst = std::min(c->check_every, maxiter - launched);
+        if (async) burst = std::min(maxiter, c->traj_hint[(size_t)async_step] + c->traj_margin);
         // first burst: one iteration MORE than the previous solve at this tolerance needed.  Consecutive solves of a trajectory differ by
         // at most an iteration or so; overshooting costs a few early-exit launches (≈ 1 µs each), a second poll costs ≈ 25 µs of idle stream
-        if (launched == 0 && hint + 1 > burst) burst = std::min(hint + 1, maxiter);
+        if (!async && launched == 0 && hint + 1 > burst) burst = std::min(hint + 1, maxiter);
         hipGraphExec_t gexec = nullptr;
         if (c->use_graph) {
             // kGraphIters CG iterations captured once per (x, preconditioning, kernel configuration) and replayed:
@@ -2302,6 +2321,10 @@ restart:
         // does not idle between the host's wake-up and its next launch (round 4; 25 µs per solve in profiles/r03_gap_probe_1walker.txt)
         finish_queued = a.lam != nullptr;
         if (finish_queued) launch_cg_finish(c->stream, a);
+        if (async) {  // the states of this solve stay on the device; nobody waits here
+            HIPCHK(c, hipMemcpyAsync(c->d_traj_st + (size_t)async_step * g.nsys, c->d_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyDeviceToDevice, c->stream));
+            return check_launch(c, "cg loop (asynchronous)");
+        }
         // (publishing the states into device-visible host memory and sleeping-then-spinning on a sequence number instead of this copy +
         // synchronisation was built and measured in round 4: one walker 25.9-28.0 -> 28.2-29.3 ms per sweep — not kept)
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
@@ -2661,13 +2684,13 @@ int smoqy_force_store_v(smoqy_ctx *c, int psi, double *out)
 // Ψ = (MᵀM)⁻¹Ψ, Ψ = Λ⁻¹Ψ, S_f = Φ·Ψ (left in d_dot_out), and with want_force the force in force.d_out.  No phonon-field upload, no
 // force download: the callers decide what crosses the boundary.
 static int pff_core(smoqy_ctx *c, int phi, int psi, const double *randvec_all, double tol, int maxiter, int use_precond, bool want_force, int *iters, double *eps,
-                    const double *d_randvec_all = nullptr, double2 *d_dot = nullptr)
+                    const double *d_randvec_all = nullptr, double2 *d_dot = nullptr, int async_step = -1)
 {
     const Geometry &g = c->g;
     if ((randvec_all || d_randvec_all) && use_precond) if (int rc = precond_update_range(c, 0, g.nw, randvec_all, d_randvec_all)) return rc;  // FermionDetMatrix.jl:259
     // Ψ = Λ⁻ᵀΦ (PFFCalculator.jl:97), ldiv!(Ψ, fdm, Ψ) (:99), Ψ = Λ⁻¹Ψ (:107) and the partials of S_f = Φ·Ψ (:109) in the kernels of the solve:
     // cg_init reads Φ through Λ⁻ᵀ, cg_finish writes Λ⁻¹x into the scratch vector that then becomes Ψ (CgArgs::lam)
-    if (int rc = cg_dev(c, c->vecs[psi], nullptr, true, tol, maxiter, use_precond, iters, eps, c->vecs[phi], c->scr[0])) return rc;
+    if (int rc = cg_dev(c, c->vecs[psi], nullptr, true, tol, maxiter, use_precond, iters, eps, c->vecs[phi], c->scr[0], async_step)) return rc;
     std::swap(c->scr[0], c->vecs[psi]);
     launch_dot_final(c->stream, c->part_c, d_dot ? d_dot : c->d_dot_out, g.nsys, c->nchunk);  // d_dot: a trajectory keeps the S_f of every step on the device until its end
     if (want_force) if (int rc = force_device(c, psi)) return rc;                                                               // :146-155
@@ -2883,6 +2906,18 @@ int smoqy_efa_restore_walkers(smoqy_ctx *c, const int *restore)
     return 0;
 }
 
+// 0: smoqy_hmc_trajectory_v waits for every force solve (the polling form); 1 (default): the asynchronous form where a previous trajectory
+// of the same length and tolerance has left iteration counts to launch on.  runs / misses (may be NULL): asynchronous trajectories so far
+// and how many of them had to be repeated with polls.
+int smoqy_hmc_async(smoqy_ctx *c, int on, long *runs, long *misses)
+{
+    CHECK_CTX(c);
+    if (on >= 0) c->traj_async = on ? 1 : 0;
+    if (runs) *runs = c->traj_async_runs;
+    if (misses) *misses = c->traj_async_misses;
+    return 0;
+}
+
 int smoqy_hmc_trajectory_v(smoqy_ctx *c, int phi, int psi, int Nt, double dt, double tol_force, int maxiter, int use_precond, const double *randvecs, double *Sf, int *iters, double *eps)
 {
     CHECK_CTX(c);
@@ -2924,9 +2959,83 @@ int smoqy_hmc_trajectory_v(smoqy_ctx *c, int phi, int psi, int Nt, double dt, do
         }
         if (int rc = pin_h2d(c, c->d_rand_traj, randvecs, (size_t)Nt * rvn * sizeof(double))) return rc;
     }
+    // ---- asynchronous form: no host wait between the steps (round 4) ----
+    // Along a trajectory the host used to wait for every force solve (a poll of the CG states: 25-35 µs of idle stream per solve, then ~20
+    // launches of force, leapfrog, field and preconditioner kernels issued behind an empty queue).  The iteration counts of step t change
+    // by at most a step or two from one trajectory to the next, so each solve is launched with the count its step needed LAST time plus
+    // a margin (iterations past convergence are early-exit launches), and the whole trajectory is queued without a single host wait.
+    // Nothing is taken on trust: the per-step states are read back at the end, and unless EVERY solve converged (done = 1, finite ϵ — a
+    // preconditioner whose status record changed under the launches shows up as a poisoned or unconverged solve) x, p and the fields are
+    // put back and the polling form below runs the trajectory again.  Results are those of the polling form bit for bit: the same
+    // kernels run the same iterations; iterations after `done` never touch a system's state.
+    const size_t nxp = (size_t)g.nw * g.Lt * c->force.Nph;
+    bool async = c->traj_async && use_precond && c->traj_hint.size() == (size_t)Nt && c->traj_hint_tol == tol_force;
+    for (int t = 0; t < Nt && async; ++t) async = c->traj_hint[(size_t)t] > 0;
+    if (async) {
+        if ((size_t)Nt * g.nsys > c->traj_st_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->h_traj_st) (void)hipHostFree(c->h_traj_st);
+            if (c->d_traj_st) (void)hipFree(c->d_traj_st);
+            c->h_traj_st = nullptr; c->d_traj_st = nullptr; c->traj_st_cap = 0;
+            HIPCHK(c, hipHostMalloc((void **)&c->h_traj_st, (size_t)Nt * g.nsys * sizeof(CgState), hipHostMallocDefault));
+            HIPCHK(c, hipMalloc((void **)&c->d_traj_st, (size_t)Nt * g.nsys * sizeof(CgState)));
+            c->traj_st_cap = (size_t)Nt * g.nsys;
+        }
+        if (2 * nxp > c->traj_save_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->d_traj_save) (void)hipFree(c->d_traj_save);
+            c->d_traj_save = nullptr; c->traj_save_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_traj_save, std::max<size_t>(2 * nxp, 1) * sizeof(double)));
+            c->traj_save_cap = 2 * nxp;
+        }
+        if (nxp) {
+            HIPCHK(c, hipMemcpyAsync(c->d_traj_save, c->force.d_x, nxp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->d_traj_save + nxp, c->force.d_p, nxp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        }
+        int rc = efa_launch(c, 0, 0.5 * dt, 0.0, false);
+        if (!rc) rc = refresh_from_device_x(c);
+        for (int t = 0; t < Nt && !rc; ++t) {
+            rc = pff_core(c, phi, psi, nullptr, tol_force, maxiter, use_precond, true, nullptr, nullptr, c->d_rand_traj + (size_t)t * rvn, c->d_traj_dot + (size_t)t * g.nsys, t);
+            if (!rc) rc = efa_launch(c, 0, (t == Nt - 1) ? 0.5 * dt : dt, dt, true);
+            if (!rc) rc = refresh_from_device_x(c);
+        }
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->h_traj_st, c->d_traj_st, (size_t)Nt * g.nsys * sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hdot, c->d_traj_dot, (size_t)Nt * g.nsys * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (int rc2 = check_launch(c, "hmc_trajectory (asynchronous)")) return rc2;
+        ++c->traj_async_runs;
+        bool ok = true;
+        for (size_t k = 0; k < (size_t)Nt * g.nsys && ok; ++k) ok = c->h_traj_st[k].done == 1 && std::isfinite(c->h_traj_st[k].eps);
+        if (ok) {
+            for (int t = 0; t < Nt; ++t) {
+                int mx = 0;
+                for (int w = 0; w < g.nw; ++w) {
+                    const CgState &st = c->h_traj_st[(size_t)t * g.nsys + w];
+                    mx = std::max(mx, st.iters);
+                    if (iters) iters[(size_t)t * g.nw + w] = st.iters;
+                    if (eps) eps[(size_t)t * g.nw + w] = st.eps;
+                    if (Sf) Sf[(size_t)t * g.nw + w] = hdot[(size_t)t * g.nsys + w].x;
+                }
+                c->traj_hint[(size_t)t] = mx;
+            }
+            return 0;
+        }
+        // a solve did not converge within what was launched (or its preconditioner changed under it): back to the start, with polls
+        ++c->traj_async_misses;
+        c->traj_margin = std::min(c->traj_margin + 2, 16);
+        if (nxp) {
+            HIPCHK(c, hipMemcpyAsync(c->force.d_x, c->d_traj_save, nxp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->force.d_p, c->d_traj_save + nxp, nxp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        }
+        if (int rc2 = refresh_from_device_x(c)) return rc2;
+        if (int rc2 = pstat_wait(c)) return rc2;
+    }
     // evolve_eom!(x, p, Δt/2); update!(fdm)                                                            EFAPFFHMCUpdater.jl:148-152
     if (int rc = efa_launch(c, 0, 0.5 * dt, 0.0, false)) return rc;
     if (int rc = refresh_from_device_x(c)) return rc;
+    c->traj_hint.assign((size_t)Nt, 0);
+    c->traj_hint_tol = tol_force;
     for (int t = 0; t < Nt; ++t) {                                                                   // :162
         const double *d_rv = use_precond ? c->d_rand_traj + (size_t)t * rvn : nullptr;
         if (int rc = pff_core(c, phi, psi, nullptr, tol_force, maxiter, use_precond, true, it.data(), ep.data(), d_rv, c->d_traj_dot + (size_t)t * g.nsys)) return rc;  // :172 (force stays in force.d_out)
@@ -2936,6 +3045,7 @@ int smoqy_hmc_trajectory_v(smoqy_ctx *c, int phi, int psi, int Nt, double dt, do
         for (int w = 0; w < g.nw; ++w) {
             if (iters) iters[(size_t)t * g.nw + w] = it[w];
             if (eps) eps[(size_t)t * g.nw + w] = ep[w];
+            c->traj_hint[(size_t)t] = std::max(c->traj_hint[(size_t)t], it[w]);   // what the next trajectory's asynchronous form launches
         }
     }
     HIPCHK(c, hipMemcpyAsync(hdot, c->d_traj_dot, (size_t)Nt * g.nsys * sizeof(double2), hipMemcpyDeviceToHost, c->stream));

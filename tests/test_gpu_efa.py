@@ -162,3 +162,77 @@ def test_sweeps_with_the_random_numbers_drawn_one_sweep_ahead_are_the_same_sweep
     b.h.close()                                            # waits for them before the page-locked arrays go
     assert all(f.done() for f in b._draws_next[1])
     a.h.close()
+
+
+def _drive(b, Rphi, R, rv, Nt, dt, tol):
+    """One trajectory on batch b from given deviates; returns (Sf, iters, eps, x, p)."""
+    nw = b.nw
+    b.h.vec_upload(b.phi, Rphi)
+    b.h.call("smoqy_matvec_v", L.OP_MT, b.phi, b.phi)
+    b.h.call("smoqy_lambda_apply_v", L.LAMBDA_MULT, b.phi, b.phi)
+    K = np.zeros(nw)
+    b.h.call("smoqy_efa_initialize_momentum", L.ptr(R), L.ptr(K))
+    sf = np.zeros((Nt, nw)); it = np.zeros((Nt, nw), dtype=np.int32); ep = np.zeros((Nt, nw))
+    b.h.call("smoqy_hmc_trajectory_v", b.phi, b.u, Nt, C.c_double(dt), C.c_double(tol), 10000, 1, L.ptr(rv), L.ptr(sf), L.ptr(it), L.ptr(ep))
+    x, p = host_state(b)
+    return sf, it, ep, x, p
+
+
+def _async_counts(b):
+    runs, misses = C.c_long(0), C.c_long(0)
+    b.h.call("smoqy_hmc_async", -1, C.byref(runs), C.byref(misses))
+    return runs.value, misses.value
+
+
+@pytest.mark.parametrize("name,nw", [("holstein_honeycomb_L4_Ltau40", 3), ("holstein_honeycomb_L16_Ltau128", 16), ("ossh_square_L12_Ltau100_alpha0p2", 2), ("bssh_chain_L256_Ltau200_alpha0p2", 2)])
+def test_asynchronous_trajectory_equals_the_polling_trajectory(name, nw):
+    """smoqy_hmc_async (round 4): from its second trajectory on a handle launches every force solve on the iteration count the step needed
+    last time (+ margin) and waits for nothing until the end, where every solve is verified.  Same kernels, same iterations: positions,
+    momenta, actions, iteration counts and residuals are IDENTICAL to the polling form's, trajectory after trajectory."""
+    Nt, dt, tol = 6, 0.09, 1e-6
+    a = WalkerBatch(name, nwalkers=nw, device_efa=True, Nt=Nt)
+    bb = WalkerBatch(name, nwalkers=nw, device_efa=True, Nt=Nt)
+    bb.h.call("smoqy_hmc_async", 0, None, None)
+    g = np.random.default_rng(17)
+    for trip in range(4):
+        Rphi = np.asfortranarray((g.standard_normal((a.Lt, a.N, nw)) + 1j * g.standard_normal((a.Lt, a.N, nw))) * np.sqrt(0.5))
+        R = np.ascontiguousarray(g.standard_normal((nw, a.Lt, a.Nph_force)))
+        rv = np.ascontiguousarray(g.standard_normal((Nt, nw, a.N)))
+        outs = [_drive(b, Rphi, R, rv, Nt, dt, tol) for b in (a, bb)]
+        for u, v in zip(*outs):
+            assert np.array_equal(u, v), trip
+        assert np.all(outs[0][2] < tol) and np.all(outs[0][1] > 0)
+        for b in (a, bb):   # the move is rejected: both start the next trajectory from the same fields
+            b.h.call("smoqy_efa_checkpoint", 1)
+    runs, misses = _async_counts(a)
+    assert runs == 3 and misses == 0          # the first trajectory of a handle has no counts to launch on: it polls
+    assert _async_counts(bb) == (0, 0)
+    a.h.close(); bb.h.close()
+
+
+def test_asynchronous_trajectory_falls_back_when_a_solve_needs_more_iterations():
+    """The counts come from a trajectory on nearly free fields (x scaled down: the solves take a handful of iterations); the next one runs
+    on the rough fields and needs three times as many — the check at the end of the asynchronous form finds unconverged solves, puts x, p
+    and the fields back and repeats the trajectory with polls.  The caller sees the polling form's result, and a miss in the counters."""
+    name, nw, Nt, dt, tol = "holstein_honeycomb_L4_Ltau40", 2, 5, 0.08, 1e-7
+    a = WalkerBatch(name, nwalkers=nw, device_efa=True, Nt=Nt)
+    bb = WalkerBatch(name, nwalkers=nw, device_efa=True, Nt=Nt)
+    bb.h.call("smoqy_hmc_async", 0, None, None)
+    g = np.random.default_rng(23)
+    x_rough, p0 = host_state(a)
+    iters = []
+    for scale in (0.02, 1.0):
+        Rphi = np.asfortranarray((g.standard_normal((a.Lt, a.N, nw)) + 1j * g.standard_normal((a.Lt, a.N, nw))) * np.sqrt(0.5))
+        R = np.ascontiguousarray(g.standard_normal((nw, a.Lt, a.Nph_force)))
+        rv = np.ascontiguousarray(g.standard_normal((Nt, nw, a.N)))
+        outs = []
+        for b in (a, bb):
+            b.h.call("smoqy_efa_set_state", L.ptr(np.ascontiguousarray(scale * x_rough)), L.ptr(p0))
+            outs.append(_drive(b, Rphi, R, rv, Nt, dt, tol))
+        for u, v in zip(*outs):
+            assert np.array_equal(u, v), scale
+        iters.append(outs[0][1].max())
+    assert iters[1] > iters[0] + 4, iters       # the premise: the second trajectory needs more than the margin covers
+    runs, misses = _async_counts(a)
+    assert (runs, misses) == (1, 1)
+    a.h.close(); bb.h.close()

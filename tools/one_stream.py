@@ -9,5 +9,6 @@ import os
 # isolated per-kernel durations are taken with the CG pipeline off (full-batch launches, one after the other); SMOQY_SPLIT=0 -> the library's automatic choice
 b = WalkerBatch(wl, nwalkers=nw, is_sym=form != "asym", cg_split=int(os.environ.get("SMOQY_SPLIT", "1")), device_efa=os.environ.get("SMOQY_EFA", "0") == "1", prefetch_randoms=os.environ.get("SMOQY_PREFETCH", "0") == "1")  # SMOQY_EFA=1: bench.py's sweep (device trajectory)
 if os.environ.get('SMOQY_GRAPH'): b.h.call('smoqy_cg_use_graph', int(os.environ['SMOQY_GRAPH']))
+if os.environ.get('SMOQY_ASYNC'): b.h.call('smoqy_hmc_async', int(os.environ['SMOQY_ASYNC']), None, None)
 b.sweep(); b.sweep()
 t0 = time.perf_counter(); b.sweep(); b.h.call("smoqy_sync"); print("sweep ms", 1e3 * (time.perf_counter() - t0))
