@@ -94,6 +94,8 @@ struct smoqy_ctx {
     double2 *part_pz = nullptr, *part_rz = nullptr, *part_c = nullptr, *d_dot_out = nullptr;
     double *part_rr = nullptr, *part_bb = nullptr;
     CgState *d_st = nullptr, *h_st = nullptr, *d_st_idle = nullptr;
+    CgState *h_st0 = nullptr;  // page-locked template of the initial CG states (see cg_dev)
+    bool st0_valid = false; double st0_tol = 0.0; int st0_maxiter = 0, st0_pre = 0;
     void *h_poll_dot = nullptr;  // pinned staging for per-system scalars (smoqy_pff_step_v)
     double2 *h_traj_dot = nullptr;  // pinned [Nt][nsys]: S_f of every step of a device trajectory, read once at its end
     double2 *d_traj_dot = nullptr;  // the same on the device: where the steps' dot_final kernels write
@@ -120,6 +122,8 @@ struct smoqy_ctx {
     int traj_margin = 2;
     CgState *d_traj_st = nullptr, *h_traj_st = nullptr;
     double *d_traj_save = nullptr;   // x and p at the start of the trajectory (the fall-back's starting point)
+    char *d_traj_pre = nullptr;      // ... and the preconditioner's device state: accepted bounds, activation, orders, coefficients, status records
+    size_t traj_pre_cap = 0;
     size_t traj_st_cap = 0, traj_save_cap = 0;
     long traj_async_runs = 0, traj_async_misses = 0;
     int wave_R = -1;             // run length of fdm_wave_kernel: -1 automatic (smoqy_matvec_wave)
@@ -186,6 +190,7 @@ struct smoqy_ctx {
         // EFA leapfrog: momenta, saved positions, per-(ω, mode) action eigenvalues and masses
         std::vector<int> finite_mass;
         bool efa_set = false;
+        bool x0_valid = false;  // smoqy_efa_checkpoint(ctx, 0) has stored a checkpoint since smoqy_efa_config (restoring without one is refused)
         double *d_p = nullptr, *d_x0 = nullptr, *d_q = nullptr, *d_m = nullptr, *d_part = nullptr, *h_part = nullptr;
         int *d_fm = nullptr;
         int efa_SB = 8, efa_ntile = 0;
@@ -460,9 +465,11 @@ int smoqy_destroy(smoqy_ctx *c)
     for (double2 *v : c->vecs)
         if (v) (void)hipFree(v);
     if (c->h_st) (void)hipHostFree(c->h_st);
+    if (c->h_st0) (void)hipHostFree(c->h_st0);
     if (c->h_traj_st) (void)hipHostFree(c->h_traj_st);
     if (c->d_traj_st) (void)hipFree(c->d_traj_st);
     if (c->d_traj_save) (void)hipFree(c->d_traj_save);
+    if (c->d_traj_pre) (void)hipFree(c->d_traj_pre);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_poll_dot) (void)hipHostFree(c->h_poll_dot);
     if (c->h_traj_dot) (void)hipHostFree(c->h_traj_dot);
@@ -688,6 +695,7 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     HIPCHK(c, hipMalloc(&c->d_st_idle, (size_t)g.nsys * sizeof(CgState)));
     HIPCHK(c, hipMemset(c->d_st_idle, 0, (size_t)g.nsys * sizeof(CgState)));
     HIPCHK(c, hipHostMalloc(&c->h_st, (size_t)g.nsys * sizeof(CgState)));
+    HIPCHK(c, hipHostMalloc(&c->h_st0, (size_t)g.nsys * sizeof(CgState)));
     HIPCHK(c, hipHostMalloc(&c->h_poll_dot, (size_t)g.nsys * sizeof(double2)));
     choose_chunking(c);
     if (fdm_lds_bytes(SMOQY_OP_MTM, g.N, 1) > 160 * 1024 - 256) {
@@ -2177,13 +2185,21 @@ static int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, doubl
     // kernels read orders and activation flags from device memory.  Warm-started solves and the very first solve of a handle wait as before.
     bool speculate = x_is_b && c->pstat_pending && c->pstat_ever;
 restart:
-    for (int s = 0; s < g.nsys; ++s) {
-        std::memset(&c->h_st[s], 0, sizeof(CgState));
-        c->h_st[s].precond_on = use_precond ? 1 : 0;  // informational (the Chebyshev kernel reads each walker's `active` flag from the device)
-        c->h_st[s].tol = tol;
-        c->h_st[s].maxiter = maxiter;
+    // The initial states go to the device from the page-locked template h_st0, which is rewritten only when (tol, maxiter, use_precond)
+    // change — and then behind a stream synchronisation.  (h_st itself is the target of the polls; an asynchronous trajectory queues the
+    // next solve's upload while this one's may not have run yet: rewriting the source in between zeroed tol / maxiter under a pending
+    // copy — seen as spurious "unconverged" solves when the host ran far ahead of a small lattice.)
+    if (!(c->st0_valid && c->st0_tol == tol && c->st0_maxiter == maxiter && c->st0_pre == (use_precond ? 1 : 0))) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int s = 0; s < g.nsys; ++s) {
+            std::memset(&c->h_st0[s], 0, sizeof(CgState));
+            c->h_st0[s].precond_on = use_precond ? 1 : 0;  // informational (the Chebyshev kernel reads each walker's `active` flag from the device)
+            c->h_st0[s].tol = tol;
+            c->h_st0[s].maxiter = maxiter;
+        }
+        c->st0_valid = true; c->st0_tol = tol; c->st0_maxiter = maxiter; c->st0_pre = use_precond ? 1 : 0;
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_st, c->h_st, (size_t)g.nsys * sizeof(CgState), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_st, c->h_st0, (size_t)g.nsys * sizeof(CgState), hipMemcpyHostToDevice, c->stream));
 
     CgArgs a{};
     a.Lt = g.Lt; a.N = g.N; a.nsys = g.nsys; a.nrhs = g.nrhs; a.Tc = c->Tc; a.nchunk = c->nchunk;
@@ -2782,6 +2798,8 @@ int smoqy_efa_config(smoqy_ctx *c, const double *q, const double *m)
     HIPCHK(c, hipMalloc(&F.d_p, nx * sizeof(double)));
     HIPCHK(c, hipMemset(F.d_p, 0, nx * sizeof(double)));
     HIPCHK(c, hipMalloc(&F.d_x0, nx * sizeof(double)));
+    HIPCHK(c, hipMemset(F.d_x0, 0, nx * sizeof(double)));
+    F.x0_valid = false;
     HIPCHK(c, hipMalloc(&F.d_q, nqm * sizeof(double)));
     HIPCHK(c, hipMalloc(&F.d_m, nqm * sizeof(double)));
     HIPCHK(c, hipMalloc(&F.d_fm, F.finite_mass.size() * sizeof(int)));
@@ -2878,7 +2896,9 @@ int smoqy_efa_checkpoint(smoqy_ctx *c, int restore)
     const size_t nx = (size_t)c->g.nw * c->g.Lt * c->force.Nph;
     if (!restore) {
         if (nx) HIPCHK(c, hipMemcpyAsync(c->force.d_x0, c->force.d_x, nx * sizeof(double), hipMemcpyDeviceToDevice, c->stream));  // copyto!(x0, x), :130
+        c->force.x0_valid = true;
     } else {
+        if (!c->force.x0_valid) FAIL(c, 1, "smoqy_efa_checkpoint(ctx, 1): there is no checkpoint to restore (call smoqy_efa_checkpoint(ctx, 0) first)");
         if (nx) HIPCHK(c, hipMemcpyAsync(c->force.d_x, c->force.d_x0, nx * sizeof(double), hipMemcpyDeviceToDevice, c->stream));  // copyto!(x, x0) + update!, :266-275
         if (int rc = refresh_from_device_x(c)) return rc;
     }
@@ -2893,6 +2913,7 @@ int smoqy_efa_restore_walkers(smoqy_ctx *c, const int *restore)
     CHECK_CTX(c);
     CHECK_EFA(c);
     if (!restore) FAIL(c, 1, "restore is NULL");
+    if (!c->force.x0_valid) FAIL(c, 1, "smoqy_efa_restore_walkers: there is no checkpoint to restore (call smoqy_efa_checkpoint(ctx, 0) first)");
     const size_t slab = (size_t)c->g.Lt * c->force.Nph;
     bool any = false;
     for (int w = 0; w < c->g.nw; ++w)
@@ -2992,6 +3013,28 @@ int smoqy_hmc_trajectory_v(smoqy_ctx *c, int phi, int psi, int Nt, double dt, do
             HIPCHK(c, hipMemcpyAsync(c->d_traj_save, c->force.d_x, nxp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->d_traj_save + nxp, c->force.d_p, nxp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         }
+        // update_preconditioner! carries state from solve to solve (the accepted bounds decide whether order / coefficients are rebuilt,
+        // src/KPMPreconditioner.jl:582): a repeated trajectory must start from the preconditioner this one started from, or it is a
+        // different (equally valid) sequence of preconditioners and its iterates differ at the level of the tolerance
+        if (int rc0 = pstat_wait(c)) return rc0;
+        const size_t pre_b[6] = {(size_t)g.nw * 2 * sizeof(double), (size_t)g.nw * sizeof(int), (size_t)g.nw * c->nslot * sizeof(int), (size_t)g.nw * c->nslot * c->maxorder * sizeof(double2),
+                                 (size_t)g.nw * 4 * sizeof(int), (size_t)g.nw * sizeof(int)};
+        void *const pre_p[6] = {c->d_bounds, c->d_active, c->d_order, c->d_coefs, c->d_pstat, c->d_rebuild};
+        size_t pre_off[7] = {0};
+        for (int q = 0; q < 6; ++q) pre_off[q + 1] = pre_off[q] + ((pre_b[q] + 255) / 256) * 256;
+        if (pre_off[6] > c->traj_pre_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->d_traj_pre) (void)hipFree(c->d_traj_pre);
+            c->d_traj_pre = nullptr; c->traj_pre_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_traj_pre, pre_off[6]));
+            c->traj_pre_cap = pre_off[6];
+        }
+        for (int q = 0; q < 6; ++q) HIPCHK(c, hipMemcpyAsync(c->d_traj_pre + pre_off[q], pre_p[q], pre_b[q], hipMemcpyDeviceToDevice, c->stream));
+        std::vector<int> pre_active((size_t)g.nw), pre_hstat(c->h_pstat, c->h_pstat + (size_t)g.nw * 4);
+        for (int w = 0; w < g.nw; ++w) pre_active[(size_t)w] = c->pre[w].active;
+        const int pre_heavy = c->cheb_heavy;
+        const bool pre_stale = c->mirrors_stale;
+        const int pre_maxorder = c->maxorder;
         int rc = efa_launch(c, 0, 0.5 * dt, 0.0, false);
         if (!rc) rc = refresh_from_device_x(c);
         for (int t = 0; t < Nt && !rc; ++t) {
@@ -3030,6 +3073,12 @@ int smoqy_hmc_trajectory_v(smoqy_ctx *c, int phi, int psi, int Nt, double dt, do
         }
         if (int rc2 = refresh_from_device_x(c)) return rc2;
         if (int rc2 = pstat_wait(c)) return rc2;
+        if (c->maxorder != pre_maxorder) FAIL(c, 7, "internal: the preconditioner's coefficient table was resized inside an asynchronous trajectory");
+        for (int q = 0; q < 6; ++q) HIPCHK(c, hipMemcpyAsync(pre_p[q], c->d_traj_pre + pre_off[q], pre_b[q], hipMemcpyDeviceToDevice, c->stream));
+        std::memcpy(c->h_pstat, pre_hstat.data(), pre_hstat.size() * sizeof(int));
+        for (int w = 0; w < g.nw; ++w) c->pre[w].active = pre_active[(size_t)w];
+        if (c->cheb_heavy != pre_heavy) { c->cheb_heavy = pre_heavy; drop_graphs(c); }
+        c->mirrors_stale = pre_stale || c->mirrors_stale;
     }
     // evolve_eom!(x, p, Δt/2); update!(fdm)                                                            EFAPFFHMCUpdater.jl:148-152
     if (int rc = efa_launch(c, 0, 0.5 * dt, 0.0, false)) return rc;

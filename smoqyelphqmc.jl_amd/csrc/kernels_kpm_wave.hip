@@ -251,16 +251,13 @@ __global__ void __launch_bounds__(128) cheb_wave_kernel(KpmArgs k, KpmGeom kg)
     double2 *prz = przb ? przb + 2 * om + comp : nullptr;
     const int n = act ? n_raw : 1;
     const double2 *coefs = k.coefs + ((size_t)w * k.nslot + slot) * k.maxorder;
-    if (n <= 1) {  // single-term expansion: scalar multiply (:398)
-        const double f = k.scale * (act ? coefs[0].x : 1.0);
-        double acc = 0.0;
-        for (int i = lane; i < N; i += 64) {
-            const double x = comp ? v[i].y : v[i].x;
-            if (comp) vo[i].y = f * x; else vo[i].x = f * x;
-            acc += f * (x * x);
-        }
-        acc = wsum_k(acc);
-        if (prz && lane == 0) *prz = make_double2(acc, 0.0);
+    if (n <= 1) {
+        // single-term expansion (:398) that the host's count of chain-carrying frequencies put in front of the light ones (the count is an
+        // upper bound; it may lag the device's table by an update).  Run it EXACTLY as a light workgroup would — same lanes, same order of
+        // the Parseval sum — so that r·z, and with it every iterate of the solve, does not depend on the host's count.
+        KpmArgs k1 = k;
+        k1.group = 1;
+        cheb_light_workgroup<true>(k1, sys, w, 0, rank, przb, lds);
         return;
     }
     const double avg = 0.5 * (emax + emin), imag_ = 1.0 / (0.5 * (emax - emin));

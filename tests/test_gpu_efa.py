@@ -194,13 +194,15 @@ def test_asynchronous_trajectory_equals_the_polling_trajectory(name, nw):
     bb = WalkerBatch(name, nwalkers=nw, device_efa=True, Nt=Nt)
     bb.h.call("smoqy_hmc_async", 0, None, None)
     g = np.random.default_rng(17)
+    for b in (a, bb):
+        b.h.call("smoqy_efa_checkpoint", 0)   # copyto!(x0, x): what every trajectory below is rejected back to
     for trip in range(4):
         Rphi = np.asfortranarray((g.standard_normal((a.Lt, a.N, nw)) + 1j * g.standard_normal((a.Lt, a.N, nw))) * np.sqrt(0.5))
         R = np.ascontiguousarray(g.standard_normal((nw, a.Lt, a.Nph_force)))
         rv = np.ascontiguousarray(g.standard_normal((Nt, nw, a.N)))
         outs = [_drive(b, Rphi, R, rv, Nt, dt, tol) for b in (a, bb)]
         for u, v in zip(*outs):
-            assert np.array_equal(u, v), trip
+            assert np.array_equal(u, v), (trip, _async_counts(a), outs[0][1].T.tolist(), outs[1][1].T.tolist())
         assert np.all(outs[0][2] < tol) and np.all(outs[0][1] > 0)
         for b in (a, bb):   # the move is rejected: both start the next trajectory from the same fields
             b.h.call("smoqy_efa_checkpoint", 1)

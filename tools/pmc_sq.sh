@@ -5,8 +5,8 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 out=$GRAFT_REPO_ROOT/gpurun_out/pmcsq_$tag
 rm -rf $out
-rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o run -- python3 tools/one_stream.py 16 > gpurun_out/pmcsq_$tag.log 2>&1 || exit 1
-python3 - "$out" <<'PY'
+rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o run -- python3 tools/one_stream.py ${PMC_WALKERS:-16} ${PMC_WORKLOAD:-} > gpurun_out/pmcsq_$tag.log 2>&1 || exit 1
+python3 - "$out" > gpurun_out/pmc_sq_$tag.txt <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -19,3 +19,4 @@ for k, d in acc.items():
         v.sort(); print(f"   {c:28s} median {v[len(v)//2]:14.0f}")
 PY
 rm -rf $out
+cat gpurun_out/pmc_sq_$tag.txt
