@@ -133,9 +133,6 @@ int smoqy_matvec_stream(smoqy_ctx *ctx, int run_len);
  * bonds of a colour (3 colours): run_len = -1 automatic (the default), 0 never, R >= 1 wavefronts walk runs of R slices (rounded down to
  * a multiple of the τ-chunk).  smoqy_describe names the kernel the last full-batch launch ran. */
 int smoqy_matvec_wave(smoqy_ctx *ctx, int run_len);
-/* form of that kernel: 1 — one wavefront per run holding complex values; 2 — a pair of wavefronts per run, one with the real and one
- * with the imaginary parts (B_l is real; the hop phase of the CG is rotated away on load and back on store); 0 — automatic (default) */
-int smoqy_matvec_wave_form(smoqy_ctx *ctx, int form);
 /* host form: `count` vectors starting at system sys0 (fields of walker sys/nrhs); out == in allowed */
 int smoqy_matvec(smoqy_ctx *ctx, int op, void *out, const void *in, int sys0, int count);
 

@@ -75,7 +75,6 @@ SIGNATURES = {
     "smoqy_matvec_force_generic": [_p, _i],
     "smoqy_matvec_stream": [_p, _i],
     "smoqy_matvec_wave": [_p, _i],
-    "smoqy_matvec_wave_form": [_p, _i],
     "smoqy_team_create": [C.POINTER(_p), _p, _i],
     "smoqy_team_destroy": [_p],
     "smoqy_team_size": [_p, _pi],

@@ -128,7 +128,6 @@ struct smoqy_ctx {
     long traj_async_runs = 0, traj_async_misses = 0;
     int wave_R = -1;             // run length of fdm_wave_kernel: -1 automatic (smoqy_matvec_wave)
     bool wave_off = false;
-    int wave_form = 0;           // 0 automatic, 1 one wavefront per run, 2 a pair of wavefronts per run (smoqy_matvec_wave_form)
     const char *mtm_name = "";   // kernel family of the last full-batch fused MᵀM launch / Chebyshev launch (smoqy_describe)
     const char *cheb_name = "";
     // off by default: measured on MI355X the replay (≈10-16 µs per graph launch) does not beat six eager
@@ -1401,7 +1400,6 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
         a.hop_re = std::cos(M_PI / c->g.Lt);
         a.hop_im = -std::sin(M_PI / c->g.Lt);
         a.antiperiodic = 0;
-        a.phase = c->d_th;
     }
     auto &T = c->mvt;
     const bool sample = T.every > 0 && op == SMOQY_OP_MTM && count == c->g.nsys && T.used < (int)T.ev.size() && (T.seen++ % T.every) == 0;
@@ -1430,13 +1428,8 @@ static int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, dou
     FdmArgs aw = a;
     aw.run_len = wave_R;
     if (wave_R > 0 && fdm_wave_supported(aw, c->ff, c->fw, c->g.is_sym != 0, csm)) {
-        static const int form_env = tuning_env(kTuneFdmWaveForm);
-        int form = form_env > 0 ? form_env : c->wave_form;
-        if (form == 0) form = 1;
-        if (form == 2 && !fdm_wave_pair_supported(aw)) form = 1;
-        launch_fdm_wave(st, aw, c->ff, c->fw, csm, form);
-        if (form == 2) name = c->fw.kind == 1 ? "fdm_wave2_kernel<ring>" : (c->fw.kind == 2 ? "fdm_wave2_kernel<plaquette>" : "fdm_wave2_kernel<honeycomb block>");
-        else name = c->fw.kind == 1 ? "fdm_wave_kernel<ring>" : (c->fw.kind == 2 ? "fdm_wave_kernel<plaquette>" : "fdm_wave_kernel<honeycomb block>");
+        launch_fdm_wave(st, aw, c->ff, c->fw, csm);
+        name = c->fw.kind == 1 ? "fdm_wave_kernel<ring>" : (c->fw.kind == 2 ? "fdm_wave_kernel<plaquette>" : "fdm_wave_kernel<honeycomb block>");
     } else if (a.run_len > 0 && fdm_own_stream_supported(a, c->ff, c->g.is_sym != 0, cs_const)) { launch_fdm_own_stream(st, a, c->ff); name = "fdm_own_stream_kernel"; }
     else if (a.run_len > 0 && fdm_stream_supported(a, c->ff, c->g.is_sym != 0)) { launch_fdm_stream(st, a, c->ff, cs_const); name = cs_const ? "fdm_stream_kernel<CSV=false>" : "fdm_stream_kernel<CSV=true>"; }
     else if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) { launch_fdm_own(st, op, a, c->ff); name = "fdm_own_kernel"; }
@@ -1456,16 +1449,6 @@ int smoqy_matvec_wave(smoqy_ctx *c, int run_len)
     if (run_len < -1) FAIL(c, 1, "run_len must be -1 (automatic), 0 (off) or >= 1");
     c->wave_R = run_len;
     c->wave_off = run_len == 0;
-    drop_graphs(c);
-    return 0;
-}
-
-// which form of the wavefront kernel: 0 automatic, 1 one wavefront per run (complex registers), 2 a pair of wavefronts per run, one per component
-int smoqy_matvec_wave_form(smoqy_ctx *c, int form)
-{
-    CHECK_CTX(c);
-    if (form < 0 || form > 2) FAIL(c, 1, "form must be 0 (automatic), 1 or 2");
-    c->wave_form = form;
     drop_graphs(c);
     return 0;
 }

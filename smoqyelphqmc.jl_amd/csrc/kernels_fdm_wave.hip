@@ -274,203 +274,6 @@ __global__ void __launch_bounds__(64) fdm_wave_kernel(FdmArgs a, FdmFast ff, Fdm
     stamp_end(a.stamp);
 }
 
-// ---- the same walk with a PAIR of wavefronts per run: one per component ------------------------------------------------------------
-// B_l is a real matrix: MᵀM acts on the real and the imaginary parts of a vector separately, except for the phase on the inter-slice
-// hop.  In the basis x[l] = φ_l·v[l], φ_l = exp(+iπ l/Lτ), that phase is the reference operator's real antiperiodic sign (Θ M Θᴴ is how
-// the CG got its uniform phase in the first place, kernels_vec.hip), so the pair of wavefronts of a workgroup walks the SAME run, wavefront
-// 0 with Re x and wavefront 1 with Im x: half the registers and half the dependent arithmetic per wavefront, twice the wavefronts in flight.
-// Both wavefronts load the full (re, im) slice (the second one hits in L1: the store exchange below keeps the pair in step) and rotate it by
-// φ_l on the way into registers; on the way out they trade components through LDS (one barrier per output slice, double buffered), each
-// rotates HALF of the positions back by conj(φ) and stores them as full double2.  a.phase == nullptr is the reference operator itself (φ = 1).
-template <class D, int CSM, bool ROT>
-__global__ void __launch_bounds__(128) fdm_wave2_kernel(FdmArgs a, FdmFast ff, FdmWave fw)
-{
-    constexpr int S = D::S, NCOL = D::NCOL, NB = D::NB, NR = D::NR, H = S / 2;
-    __shared__ double xch[2][ROT ? 1 : S * 64];
-    __shared__ double mix[2][2][S * 64];
-    __shared__ double red;
-    const int Lt = a.Lt, N = a.N, lane = threadIdx.x & 63, comp = threadIdx.x >> 6;
-    const int R = a.run_len, nrun = (Lt + R - 1) / R;
-    const int nblk = gridDim.x;
-    int bid = blockIdx.x;
-    if ((nblk & 7) == 0) bid = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
-    const int run = bid % nrun, sys = a.sys_first + bid / nrun;
-    stamp_begin(a.stamp);
-    const int sys_done = a.cg[sys].done;
-    const int w = sys / a.nrhs;
-    const int la = run * R, lb = min(Lt, la + R);
-    const size_t sstride = (size_t)a.nsys * N;
-    const double2 *in = a.in + (size_t)sys * N;
-    double2 *out = a.out + (size_t)sys * N;
-    const double *expV = a.expV + (size_t)w * Lt * N;
-    const double2 *csf = ff.csf + (size_t)w * Lt * ff.ptotal;
-    double *const myx = xch[comp];
-    const double wrap_sign = (a.phase || a.antiperiodic) ? -1.0 : 1.0;
-
-    const bool on = lane < fw.lanes;
-    const int lq = on ? lane : 0;
-    int site[S], msite[D::REMOTE0 ? S : 1], bnd[CSM ? NB : 1], rl[NR];
-    static_for<0, S>([&](auto P) { site[P] = fw.tab[P * 64 + lq]; });
-    if constexpr (CSM != 0) static_for<0, NB>([&](auto B) { bnd[B] = fw.tab[(S + B) * 64 + lq]; });
-    static_for<0, NR>([&](auto Rw) { rl[Rw] = on ? fw.tab[(S + NB + Rw) * 64 + lq] : lane; });
-    if constexpr (D::REMOTE0) static_for<0, S>([&](auto P) { msite[P] = fw.tab[(S + NB + NR + P) * 64 + lq]; });
-    (void)msite; (void)bnd;
-
-    double2 ucs[CSM == 0 ? NCOL : 1], kcs[CSM == 1 ? NB : 1];
-    if constexpr (CSM == 0) static_for<0, NCOL>([&](auto C) { ucs[C] = csf[ff.poff[C]]; });
-    if constexpr (CSM == 1) static_for<0, NB>([&](auto B) { kcs[B] = csf[bnd[B]]; });
-    (void)ucs; (void)kcs;
-
-    // φ of slice m as the pair (ca, cb) with x_comp = ca·re + cb·im:  Re(φ v) = φr re − φi im,  Im(φ v) = φi re + φr im
-    auto phase_of = [&](int m) -> double2 {
-        if (!a.phase) return comp == 0 ? make_double2(1.0, 0.0) : make_double2(0.0, 1.0);
-        const double2 th = a.phase[wrapl(m, Lt)];  // θ = conj(φ)
-        return comp == 0 ? make_double2(th.x, th.y) : make_double2(-th.y, th.x);
-    };
-    auto load_slice = [&](double2 (&x)[S], int m) {
-        const double2 *row = in + (size_t)wrapl(m, Lt) * sstride;
-        static_for<0, S>([&](auto P) { x[P] = row[site[P]]; });
-    };
-    auto rotate_in = [&](double (&x)[S], const double2 (&v)[S], double2 ph) { static_for<0, S>([&](auto P) { x[P] = ph.x * v[P].x + ph.y * v[P].y; }); };
-    struct Raw { double d[S], dm[D::REMOTE0 ? S : 1]; };
-    auto load_raw = [&](Raw &r, int m) {
-        const int l = wrapl(m, Lt);
-        const double *ev = expV + (size_t)l * N;
-        static_for<0, S>([&](auto P) {
-            r.d[P] = ev[site[P]];
-            if constexpr (D::REMOTE0) r.dm[P] = ev[msite[P]];
-        });
-    };
-    SliceFields<D, CSM> F;
-    auto load_cs = [&](int m) {
-        if constexpr (CSM == 2) {
-            const int l = wrapl(m, Lt);
-            static_for<0, NB>([&](auto B) { F.cs[B] = csf[(size_t)l * ff.ptotal + bnd[B]]; });
-        }
-    };
-    auto CS = [&](auto C, auto P) -> double2 {
-        if constexpr (CSM == 0) return ucs[C];
-        else if constexpr (CSM == 1) return kcs[D::bs(decltype(C)::value, decltype(P)::value)];
-        else return F.cs[D::bs(decltype(C)::value, decltype(P)::value)];
-    };
-    auto set_fields = [&](const Raw &r) {
-        static_for<0, S>([&](auto P) {
-            const double2 k = CS(std::integral_constant<int, 0>{}, P);
-            double dq;
-            if constexpr (D::REMOTE0) dq = r.dm[P]; else dq = r.d[D::pp(0, decltype(P)::value)];
-            F.e0[P] = k.x * k.x * r.d[P] + k.y * k.y * dq;
-            F.e1[P] = k.x * k.y * (r.d[P] + dq);
-        });
-    };
-    auto partners = [&](auto C, const double (&x)[S], double (&m)[S]) {
-        if constexpr (!ROT) {
-            static_for<0, S>([&](auto P) {
-                if constexpr (D::rr(decltype(C)::value, decltype(P)::value) >= 0) myx[decltype(P)::value * 64 + lane] = x[P];
-            });
-        }
-        static_for<0, S>([&](auto P) {
-            constexpr int q = D::pp(decltype(C)::value, decltype(P)::value), r = D::rr(decltype(C)::value, decltype(P)::value);
-            if constexpr (r < 0) m[P] = x[q];
-            else if constexpr (ROT) m[P] = wave_rot<(r == 0 ? 0x134 : 0x13C)>(x[q]);
-            else m[P] = myx[q * 64 + rl[r]];
-        });
-    };
-    auto stage = [&](auto C, double (&x)[S]) {
-        double m[S];
-        partners(C, x, m);
-        static_for<0, S>([&](auto P) {
-            const double2 k = CS(C, P);
-            x[P] = k.x * x[P] + k.y * m[P];
-        });
-    };
-    auto apply_B = [&](double (&x)[S]) {
-        static_for<1, NCOL>([&](auto I) { stage(std::integral_constant<int, NCOL - decltype(I)::value>{}, x); });
-        {
-            double m[S];
-            partners(std::integral_constant<int, 0>{}, x, m);
-            static_for<0, S>([&](auto P) { x[P] = F.e0[P] * x[P] + F.e1[P] * m[P]; });
-        }
-        static_for<1, NCOL>([&](auto I) { stage(I, x); });
-    };
-
-    double vprev[S], vcur[S], y[S], yprev[S];
-    double2 vnext[S];
-    Raw raw;
-    load_slice(vnext, la - 1);
-    rotate_in(vprev, vnext, phase_of(la - 1));
-    load_slice(vnext, la);
-    rotate_in(vcur, vnext, phase_of(la));
-    load_raw(raw, la);
-    load_cs(la);
-    asm volatile("" ::: "memory");
-    if (sys_done) return;           // workgroup-uniform; no barrier has been reached and nothing has been stored yet
-    double accr = 0.0;
-    int buf = 0;
-    for (int m = la; m <= lb; ++m) {
-        set_fields(raw);
-        double2 phn = make_double2(0.0, 0.0);
-        if (m < lb) {
-            load_slice(vnext, m + 1);
-            load_raw(raw, m + 1);
-            phn = phase_of(m + 1);
-        }
-        // y[m] = x[m] − σ_m B_m x[m−1]   (σ_m = −1 on the link that closes the τ circle)
-        apply_B(vprev);
-        const double sg = wrapl(m, Lt) == 0 ? wrap_sign : 1.0;
-        static_for<0, S>([&](auto P) { y[P] = vcur[P] - sg * vprev[P]; });
-        if (m < lb && on) static_for<0, S>([&](auto P) { accr += y[P] * y[P]; });
-        if (m > la) {
-            // w[m−1] = y[m−1] − σ_m B_m y[m]
-            double u[S];
-            static_for<0, S>([&](auto P) { u[P] = y[P]; });
-            apply_B(u);
-            if (m < lb) load_cs(m + 1);
-            static_for<0, S>([&](auto P) { mix[buf][comp][decltype(P)::value * 64 + lane] = yprev[P] - sg * u[P]; });
-            __syncthreads();
-            // out[m−1] = conj(φ_{m−1})·(w_re + i w_im), this wavefront's half of the positions
-            double2 th = make_double2(1.0, 0.0);
-            if (a.phase) th = a.phase[m - 1];
-            double2 *row = out + (size_t)(m - 1) * sstride;
-            auto store_half = [&](auto H0) {
-                static_for<0, H>([&](auto Q) {
-                    constexpr int P = decltype(H0)::value + decltype(Q)::value;
-                    const double wr = mix[buf][0][P * 64 + lane], wi = mix[buf][1][P * 64 + lane];
-                    if (on) row[site[P]] = make_double2(th.x * wr - th.y * wi, th.x * wi + th.y * wr);
-                });
-            };
-            if (comp == 0) store_half(std::integral_constant<int, 0>{});
-            else store_half(std::integral_constant<int, H>{});
-            buf ^= 1;
-        } else if (m < lb) {
-            load_cs(m + 1);
-        }
-        static_for<0, S>([&](auto P) { yprev[P] = y[P]; vprev[P] = vcur[P]; });
-        if (m < lb) rotate_in(vcur, vnext, phn);
-    }
-    if (a.partial) {
-        for (int off = 32; off > 0; off >>= 1) accr += __shfl_down(accr, off, 64);
-        if (comp == 1 && lane == 0) red = accr;
-        __syncthreads();
-        if (comp == 0 && lane == 0) {
-            accr += red;
-            const int c0 = la / a.Tc, c1 = (lb + a.Tc - 1) / a.Tc;
-            a.partial[(size_t)sys * a.nchunk + c0] = make_double2(accr, 0.0);
-            for (int c = c0 + 1; c < c1; ++c) a.partial[(size_t)sys * a.nchunk + c] = make_double2(0.0, 0.0);
-        }
-    }
-    stamp_end(a.stamp);
-}
-
-template <class D, bool ROT>
-void launch_kind2(hipStream_t st, const FdmArgs &a, const FdmFast &ff, const FdmWave &fw, int csm)
-{
-    const int nrun = (a.Lt + a.run_len - 1) / a.run_len;
-    const dim3 grid((unsigned)(nrun * a.sys_count)), block(128);
-    if (csm == 0) hipLaunchKernelGGL((fdm_wave2_kernel<D, 0, ROT>), grid, block, 0, st, a, ff, fw);
-    else if (csm == 1) hipLaunchKernelGGL((fdm_wave2_kernel<D, 1, ROT>), grid, block, 0, st, a, ff, fw);
-    else hipLaunchKernelGGL((fdm_wave2_kernel<D, 2, ROT>), grid, block, 0, st, a, ff, fw);
-}
-
 template <class D, bool ROT>
 void launch_kind(hipStream_t st, const FdmArgs &a, const FdmFast &ff, const FdmWave &fw, int csm)
 {
@@ -492,21 +295,16 @@ bool fdm_wave_supported(const FdmArgs &a, const FdmFast &ff, const FdmWave &fw, 
     return true;
 }
 
-// form: 1 — one wavefront per run with complex registers, 2 — a pair of wavefronts per run, one per component (needs the hop phase as
-// a.phase, or the reference operator)
-bool fdm_wave_pair_supported(const FdmArgs &a) { return a.phase != nullptr || (a.hop_re == 1.0 && a.hop_im == 0.0); }
-
-void launch_fdm_wave(hipStream_t st, const FdmArgs &a, const FdmFast &ff, const FdmWave &fw, int csm, int form)
+void launch_fdm_wave(hipStream_t st, const FdmArgs &a, const FdmFast &ff, const FdmWave &fw, int csm)
 {
     static const int env = tuning_env(kTuneFdmWave);
-    const bool pair = form == 2 && fdm_wave_pair_supported(a);
     switch (fw.kind) {
         case 1:
-            if (fw.rot && env != 2) pair ? launch_kind2<RingD, true>(st, a, ff, fw, csm) : launch_kind<RingD, true>(st, a, ff, fw, csm);
-            else pair ? launch_kind2<RingD, false>(st, a, ff, fw, csm) : launch_kind<RingD, false>(st, a, ff, fw, csm);
+            if (fw.rot && env != 2) launch_kind<RingD, true>(st, a, ff, fw, csm);
+            else launch_kind<RingD, false>(st, a, ff, fw, csm);
             break;
-        case 2: pair ? launch_kind2<PlaqD, false>(st, a, ff, fw, csm) : launch_kind<PlaqD, false>(st, a, ff, fw, csm); break;
-        default: pair ? launch_kind2<HoneyD, false>(st, a, ff, fw, 0) : launch_kind<HoneyD, false>(st, a, ff, fw, 0); break;
+        case 2: launch_kind<PlaqD, false>(st, a, ff, fw, csm); break;
+        default: launch_kind<HoneyD, false>(st, a, ff, fw, 0); break;
     }
 }
 

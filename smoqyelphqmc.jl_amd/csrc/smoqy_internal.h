@@ -74,7 +74,6 @@ struct FdmArgs {
     unsigned long long *stamp;
     int run_len;  // fdm_stream_kernel: output slices per workgroup (a multiple of Tc); 0 = not a streaming launch
     int nt_fields;  // fdm_stream_kernel: nontemporal loads of exp(-ΔτV)
-    const double2 *phase;  // θ_l = exp(-iπ l/Lτ) when the hop phase is the CG's exp(-iπ/Lτ) (Θ M Θᴴ), nullptr for the reference operator (fdm_wave2_kernel)
 };
 
 // stamps for FdmArgs::stamp
@@ -205,8 +204,7 @@ void launch_fdm_stream(hipStream_t st, const FdmArgs &a, const FdmFast &ff, bool
 hipError_t configure_fdm_stream_kernels(const char **what);
 // fused MᵀM, one wavefront per run of slices (csm: 0 hoppings uniform per colour and τ-independent, 1 τ-independent, 2 τ-dependent)
 bool fdm_wave_supported(const FdmArgs &a, const FdmFast &ff, const FdmWave &fw, bool sym, int csm);
-void launch_fdm_wave(hipStream_t st, const FdmArgs &a, const FdmFast &ff, const FdmWave &fw, int csm, int form);
-bool fdm_wave_pair_supported(const FdmArgs &a);
+void launch_fdm_wave(hipStream_t st, const FdmArgs &a, const FdmFast &ff, const FdmWave &fw, int csm);
 void fdm_wave_program(int N, int ncol, const std::vector<std::vector<int>> &mate, const std::vector<std::vector<int>> &bidx, std::vector<int> &tab, int &kind, int &lanes, bool &rot);
 bool fdm_own_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
 void launch_fdm_own(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff);
@@ -377,7 +375,7 @@ void launch_tfft(hipStream_t st, int mode, const TfftArgs &a);
 // none needed for normal use.  Read once per process; tuning_env("NAME") is the variable's integer value, or -1 when it is not set.
 enum TuningKnob {
     kTuneChebWl0, kTuneChebSplit, kTuneChebOwn, kTuneChebGroup, kTuneFdmStream, kTuneFdmOwn, kTuneFdmOwnMax, kTuneFdmOwnStream, kTuneNtFields,
-    kTuneXStream, kTuneXcdMap, kTuneTfftSlim, kTuneTfftSb, kTuneTfftEdge, kTuneChebWave, kTuneFdmWave, kTuneFdmWaveR, kTuneFdmWaveForm, kTuneCount
+    kTuneXStream, kTuneXcdMap, kTuneTfftSlim, kTuneTfftSb, kTuneTfftEdge, kTuneChebWave, kTuneFdmWave, kTuneFdmWaveR, kTuneCount
 };
 inline int tuning_env(TuningKnob k)
 {
@@ -387,7 +385,7 @@ inline int tuning_env(TuningKnob k)
         {
             static const char *const names[kTuneCount] = {"SMOQY_CHEB_WL0", "SMOQY_CHEB_SPLIT", "SMOQY_CHEB_OWN", "SMOQY_CHEB_GROUP", "SMOQY_FDM_STREAM", "SMOQY_FDM_OWN",
                                                           "SMOQY_FDM_OWN_MAX", "SMOQY_FDM_OWNSTREAM", "SMOQY_NT_FIELDS", "SMOQY_X_STREAM", "SMOQY_XCD_MAP", "SMOQY_TFFT_SLIM",
-                                                          "SMOQY_TFFT_SB", "SMOQY_TFFT_EDGE", "SMOQY_CHEB_WAVE", "SMOQY_FDM_WAVE", "SMOQY_FDM_WAVE_R", "SMOQY_FDM_WAVE_FORM"};
+                                                          "SMOQY_TFFT_SB", "SMOQY_TFFT_EDGE", "SMOQY_CHEB_WAVE", "SMOQY_FDM_WAVE", "SMOQY_FDM_WAVE_R"};
             for (int q = 0; q < kTuneCount; ++q) {
                 const char *e = getenv(names[q]);
                 v[q] = e ? atoi(e) : -1;

@@ -76,9 +76,8 @@ def test_wave_mtm_against_oracle_and_workgroup_kernels(kind, Ls, Lt, hop, expect
         ref = h.vec_download(b)
         assert "fdm_wave" not in h.describe()["mtm"]
         assert relerr(ref, want) < 1e-13
-        for R, form in [(R, f) for R in (-1, 1, 2, 3, 6, 64) for f in (1, 2)]:   # automatic; runs that do not divide Lτ; a run longer than Lτ (rounded down to a multiple of the τ-chunk)
+        for R in (-1, 1, 2, 3, 6, 64):   # automatic; runs that do not divide Lτ; a run longer than Lτ (rounded down to a multiple of the τ-chunk)
             h.call("smoqy_matvec_wave", R)
-            h.call("smoqy_matvec_wave_form", form)   # 1: one wavefront per run; 2: a pair, one per component
             h.call("smoqy_matvec_v", L.OP_MTM, c, a)
             got = h.vec_download(c)
             name = h.describe()["mtm"]
@@ -91,8 +90,6 @@ def test_wave_mtm_against_oracle_and_workgroup_kernels(kind, Ls, Lt, hop, expect
                 assert took == (expect == "plaquette"), name   # the automatic choice at three systems: plaquette lattices only (api.hip, wave_run_length)
             else:
                 assert took and expect in name, (name, R, Tc)
-            if took:
-                assert ("fdm_wave2" in name) == (form == 2), name
             assert relerr(got, want) < 1e-13, (kind, Ls, R, Tc, name)
             assert relerr(got, ref) < 1e-13
     # in place (out == in) keeps the workgroup kernels
@@ -105,21 +102,17 @@ def test_wave_mtm_against_oracle_and_workgroup_kernels(kind, Ls, Lt, hop, expect
     rv = np.ascontiguousarray(g.standard_normal((nw, N)))
     h.call("smoqy_precond_update_all", L.ptr(rv))
     its, sols = {}, {}
-    for r, form in ((0, 1), (2, 1), (2, 2)):
+    for r in (0, 2):
         h.call("smoqy_matvec_wave", r)
-        h.call("smoqy_matvec_wave_form", form)
         h.vec_upload(b, v)
         it, eps = np.zeros(nw, dtype=np.int32), np.zeros(nw)
         h.call("smoqy_cg_solve_v", b, b, C.c_double(1e-10), 10000, 1, L.ptr(it), L.ptr(eps))
-        its[r, form], sols[r, form] = it.copy(), h.vec_download(b)
+        its[r], sols[r] = it.copy(), h.vec_download(b)
         assert np.all(eps < 1e-10)
-        if r and expect:
-            assert ("fdm_wave2" in h.describe()["mtm"]) == (form == 2), h.describe()
-    for key in ((2, 1), (2, 2)):
-        assert np.all(np.abs(its[0, 1] - its[key]) <= 1), (its[0, 1], its[key])
-        assert relerr(sols[key], sols[0, 1]) < 1e-8
-        for w in range(nw):   # and it IS the solution: (MᵀM) x = b by the oracle
-            assert relerr(oracles[w].mul_MtM(sols[key][:, :, w]), v[:, :, w]) < 1e-8
+    assert np.all(np.abs(its[0] - its[2]) <= 1), (its[0], its[2])
+    assert relerr(sols[2], sols[0]) < 1e-8
+    for w in range(nw):   # and it IS the solution: (MᵀM) x = b by the oracle
+        assert relerr(oracles[w].mul_MtM(sols[2][:, :, w]), v[:, :, w]) < 1e-8
     h.close()
 
 
@@ -137,16 +130,9 @@ def test_wave_mtm_at_the_benchmarked_shapes(name, nw):
     h.call("smoqy_matvec_v", L.OP_MTM, b, a)
     assert "fdm_wave" not in h.describe()["mtm"]
     h.call("smoqy_matvec_wave", 2)   # forced: the automatic choice takes it for plaquette lattices and for 64 or more honeycomb systems only
-    h.call("smoqy_matvec_wave_form", 1)
     h.call("smoqy_matvec_v", L.OP_MTM, c, a)
-    assert "fdm_wave_kernel" in h.describe()["mtm"], h.describe()
+    assert "fdm_wave" in h.describe()["mtm"], h.describe()
     ref, got = h.vec_download(b), h.vec_download(c)
-    assert relerr(got, ref) < 1e-13
-    h.call("smoqy_matvec_wave_form", 2)
-    h.call("smoqy_vec_copy", c, a)
-    h.call("smoqy_matvec_v", L.OP_MTM, c, a)
-    assert "fdm_wave2_kernel" in h.describe()["mtm"], h.describe()
-    got = h.vec_download(c)
     assert relerr(got, ref) < 1e-13
     for w in sorted({0, nw // 2, nw - 1}):
         m = batch.models[w]

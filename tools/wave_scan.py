@@ -10,7 +10,6 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "holstein_honeycomb_L16_Ltau128"
 batches = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "1,16,128").split(",")]
 runs = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "0,-1,2,4,8,16,32").split(",")]
 Tc = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # τ-chunk of the handle (0 = the library's choice); runs are multiples of it
-forms = [int(v) for v in (sys.argv[5] if len(sys.argv) > 5 else "1").split(",")]  # 1 one wavefront per run, 2 a pair (one per component)
 for nw in batches:
     b = WalkerBatch(wl, nwalkers=nw)
     h = b.h
@@ -20,11 +19,10 @@ for nw in batches:
     va, vb = h.vec_alloc(), h.vec_alloc()
     h.vec_upload(va, np.asfortranarray(g.standard_normal((b.Lt, b.N, nw)) + 1j * g.standard_normal((b.Lt, b.N, nw))))
     row = []
-    for R, form in [(R, f) for R in runs for f in (forms if R > 0 else forms[:1])]:
+    for R in runs:
         h.call("smoqy_matvec_wave", R)
-        h.call("smoqy_matvec_wave_form", form)
         h.bench_matvec(L.OP_MTM, vb, va, 20)
         us = h.bench_matvec(L.OP_MTM, vb, va, 200) / 200 * 1e3
-        row.append(f"R={R}/{form}: {us:.2f} us [{h.describe()['mtm'][:18]}]")
+        row.append(f"R={R}: {us:.2f} us [{h.describe()['mtm'][:18]}]")
     print(f"{wl} nsys={nw}: " + " | ".join(row), flush=True)
     h.close()
