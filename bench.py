@@ -517,6 +517,17 @@ SOLO_TAGS = {"holstein_honeycomb_L16_Ltau128": "hc16", "holstein_honeycomb_L8_Lt
              "holstein_honeycomb_L4_Ltau40": "hc4"}  # tags of profiles/r*_solo_kernel_stats_<tag>.txt and r*_pmc_iteration_<tag>.json
 
 
+def _async_stats(batches, L):
+    """smoqy_hmc_async counters of rank 0's batches: trajectories launched without host waits, and how many of those had to be repeated
+    with polls (a repeat costs the trajectory twice; the library stops trying where solves are long or misses recur)."""
+    runs = misses = 0
+    for b in batches:
+        r, m = L.C.c_long(0), L.C.c_long(0)
+        b.h.call("smoqy_hmc_async", -1, L.C.byref(r), L.C.byref(m))
+        runs, misses = runs + r.value, misses + m.value
+    return {"trajectories_without_host_waits": runs, "of_which_repeated_with_polls": misses, "scope": "rank 0, warm-up included"}
+
+
 def committed_solo_durations(workload):
     """rocprofv3 per-dispatch averages (us) of the iteration's kernels in the newest committed one-stream, 16-walker profile
     (profiles/r*_solo_kernel_stats_<tag>.txt) of this workload."""
@@ -953,6 +964,7 @@ def main():
                 "tfft_form": ("in-place" if _in_place_tfft_exists(batch.Lt) else "two-image (in-place requested; Ltau has a factor 7)") if batch.tfft_in_place else "two-image",
                 "hmc": ("EFA leapfrog on the device, Nt = %d steps of dt = pi/(2 Nt), trajectory always rejected (x restored) so the field distribution stays the one SURVEY.md 8(d) defines" % batch.Nt)
                 if args.hmc == "device" else "synthetic host-side drift (round-1 form)",
+                "hmc_async": _async_stats(batches, L) if args.hmc == "device" else None,
                 "random_numbers": "one PCG64 generator per walker on the host" + ("" if args.no_prefetch else ", drawn one sweep ahead by the batch's host-thread pool while the device runs the current sweep (inside the timed region; same numbers as drawn on demand)"),
                 "parallelism": f"walker-parallel, {world} rank(s) x {wpg} walkers ({S} lock-step batches of {per}), no collective",
             },

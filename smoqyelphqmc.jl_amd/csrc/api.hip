@@ -120,6 +120,7 @@ struct smoqy_ctx {
     std::vector<int> traj_hint;   // iterations step t of the last verified trajectory took (max over systems)
     double traj_hint_tol = 0.0;
     int traj_margin = 2;
+    int traj_backoff = 0, traj_skip = 0;  // after a repeated trajectory the next traj_skip ones poll (doubling per consecutive miss, halving per success)
     CgState *d_traj_st = nullptr, *h_traj_st = nullptr;
     double *d_traj_save = nullptr;   // x and p at the start of the trajectory (the fall-back's starting point)
     char *d_traj_pre = nullptr;      // ... and the preconditioner's device state: accepted bounds, activation, orders, coefficients, status records
@@ -2990,8 +2991,15 @@ int smoqy_hmc_trajectory_v(smoqy_ctx *c, int phi, int psi, int Nt, double dt, do
     // put back and the polling form below runs the trajectory again.  Results are those of the polling form bit for bit: the same
     // kernels run the same iterations; iterations after `done` never touch a system's state.
     const size_t nxp = (size_t)g.nw * g.Lt * c->force.Nph;
+    // When it pays: a poll costs 25-40 us per solve, a miss costs the whole trajectory a second time.  Solves of a few dozen iterations
+    // (Holstein lattices: counts move by a step or two between trajectories) gain 1-4 % (L = 16) to 50 % (L = 4); solves of a hundred and
+    // more iterations (SSH models at alpha = 1: counts move by tens) gain nothing from the missing polls and miss often — measured before
+    // this rule: optical SSH 180 -> 105, bond SSH 125 -> 71 sweeps/s.  So: only below kAsyncMaxIters iterations per solve, and after a
+    // miss the next trajectories poll (1, 2, 4 ... 64 of them for consecutive misses).
+    constexpr int kAsyncMaxIters = 64;
     bool async = c->traj_async && use_precond && c->traj_hint.size() == (size_t)Nt && c->traj_hint_tol == tol_force;
-    for (int t = 0; t < Nt && async; ++t) async = c->traj_hint[(size_t)t] > 0;
+    for (int t = 0; t < Nt && async; ++t) async = c->traj_hint[(size_t)t] > 0 && c->traj_hint[(size_t)t] <= kAsyncMaxIters;
+    if (async && c->traj_skip > 0) { --c->traj_skip; async = false; }
     if (async) {
         if ((size_t)Nt * g.nsys > c->traj_st_cap) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -3062,11 +3070,14 @@ int smoqy_hmc_trajectory_v(smoqy_ctx *c, int phi, int psi, int Nt, double dt, do
                 }
                 c->traj_hint[(size_t)t] = mx;
             }
+            c->traj_backoff /= 2;
             return 0;
         }
         // a solve did not converge within what was launched (or its preconditioner changed under it): back to the start, with polls
         ++c->traj_async_misses;
         c->traj_margin = std::min(c->traj_margin + 2, 16);
+        c->traj_backoff = std::min(std::max(1, 2 * c->traj_backoff), 64);
+        c->traj_skip = c->traj_backoff;
         if (nxp) {
             HIPCHK(c, hipMemcpyAsync(c->force.d_x, c->d_traj_save, nxp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->force.d_p, c->d_traj_save + nxp, nxp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));

@@ -1,6 +1,7 @@
 """Walker teams (include/smoqy_hip.h "walker teams", csrc/team.hip): K host threads, each running the per-walker update sequence of
 the reference (one walker per MPI rank, tutorials/holstein_honeycomb_mpi.jl:60-72) against its own walker index, must get exactly what
-the batched entry points give when one caller drives all K walkers in lock step."""
+the batched entry points give when one caller drives all K walkers in lock step — and what the oracle's restatement of the reference's
+per-walker sequence gives for that walker (oracle/sweep.py; parity unpinned like everything that rests on the oracle)."""
 import ctypes as C
 import threading
 from concurrent.futures import ThreadPoolExecutor
@@ -10,6 +11,8 @@ import pytest
 
 from smoqyelphqmc_amd import _lib as L
 from smoqyelphqmc_amd.walkers import WalkerBatch, WalkerTeam
+from oracle import oracle as orc
+from oracle.sweep import OracleWalker
 
 pytestmark = pytest.mark.gpu
 
@@ -58,6 +61,21 @@ def test_team_members_equal_the_batched_calls(name, K):
         assert rr == rr_ref[w] and s == sf[w] and i == it[w] and e == ep[w]  # same kernels on the same batch: bit for bit
         assert np.array_equal(d, dS[w])
         assert i2 == i and abs(s2 - s) <= 1e-9 * abs(s)  # same fields, a fresh Lanczos with the same start vector: the same solve
+    # and against the oracle, walker by walker: Φ = Λᵀ M† R on the initial fields (src/PFFCalculator.jl:67-73), then S_f and ∂S_f/∂x on
+    # the fields of xs (:79-116, :146-155)
+    for w in range(K):
+        ow = OracleWalker(name, walker=w)
+        assert np.array_equal(ow.x, ref.xs_force[w].T)
+        ow.phi = orc.lambda_apply(ow.Lam, ow.fdm.mul_Mt(np.asfortranarray(Rs[:, :, w])), "mulT")
+        ow.x[...] = xs[w].T
+        ow.refresh_fields()
+        s_o, it_o, eps_o = ow.action(1e-10, rvs[w])
+        dS_o = ow.force()
+        rr, s, i, e, d, s2, i2 = out[w]
+        assert abs(rr - np.vdot(Rs[:, :, w], Rs[:, :, w]).real) < 1e-12 * rr
+        assert abs(i - it_o) <= 1 and e < 1e-10 and eps_o < 1e-10
+        assert abs(s - s_o) < 1e-8 * abs(s_o), (s, s_o)
+        assert np.abs(d.T - dS_o).max() < 1e-7 * np.abs(dS_o).max(), np.abs(d.T - dS_o).max()
     team.close()
     ref.h.close()
 

@@ -7,7 +7,7 @@ bash tools/pmc_traffic.sh 64 ossh_square_L12_Ltau100 ossh > /dev/null && echo pm
 mkdir -p profiles_new; cp gpurun_out/pmc_traffic_fdm_mtm_b*_*.json gpurun_out/pmc_iteration_*.json profiles_new/ 2>/dev/null
 # bench.py reads the committed PMC files from profiles/: give this run the ones just taken
 for f in gpurun_out/pmc_traffic_fdm_mtm_b*_*.json; do cp $f profiles/r04_$(basename $f); done
-for f in gpurun_out/pmc_iteration_*.json; do cp $f profiles/r04_$(basename $f); done
+for f in gpurun_out/pmc_iteration_*.json; do [ -e "$f" ] && cp $f profiles/r04_$(basename $f); done
 for wl in ${WORKLOADS:-holstein_honeycomb_L8_Ltau80 ossh_square_L12_Ltau100 bssh_chain_L256_Ltau200 holstein_honeycomb_L4_Ltau40}; do
   t0=$SECONDS
   timeout -k 10 500 python bench.py --workload $wl --steps ${STEPS:-6} --warmup 2 --no-proc-scan > gpurun_out/r04_bench_$wl.json 2> gpurun_out/r04_bench_$wl.err; echo $wl rc=$? wall $((SECONDS-t0)) s
