@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(kThreads) fdm_kernel(FdmArgs a)
     extern __shared__ double2 lds[];
     __shared__ double red[16];
     const int chunk = blockIdx.x % a.nchunk, sys = a.sys_first + blockIdx.x / a.nchunk;
-    if (a.cg[sys].done) return;  // a.cg is never null (api.hip: an all-zero state outside CG loops)
+    if (a.cg[sys].done) return;  // a.cg is never null (api_handle.hip, fdm_args / kpm_args: an all-zero state outside CG loops)
     const int w = sys / a.nrhs;
     const int Lt = a.Lt, N = a.N;
     const int l0 = chunk * a.Tc;

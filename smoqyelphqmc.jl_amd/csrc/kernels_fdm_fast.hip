@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
     if ((nblk & 7) == 0) bid = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
     const int chunk = bid % a.nchunk, sys = a.sys_first + bid / a.nchunk;
     stamp_begin(a.stamp);
-    if (a.cg[sys].done) return;  // a.cg is never null (api.hip: an all-zero state outside CG loops)
+    if (a.cg[sys].done) return;  // a.cg is never null (api_handle.hip, fdm_args / kpm_args: an all-zero state outside CG loops)
     const int w = sys / a.nrhs;
     const int Lt = a.Lt, N = a.N;
     const int l0 = chunk * a.Tc;
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(1024) fdm_fast_asym_kernel(FdmArgs a, FdmFast 
     if ((nblk & 7) == 0) bid = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
     const int chunk = bid % a.nchunk, sys = a.sys_first + bid / a.nchunk;
     stamp_begin(a.stamp);
-    if (a.cg[sys].done) return;  // a.cg is never null (api.hip: an all-zero state outside CG loops)
+    if (a.cg[sys].done) return;  // a.cg is never null (api_handle.hip, fdm_args / kpm_args: an all-zero state outside CG loops)
     const int w = sys / a.nrhs;
     const int Lt = a.Lt, N = a.N;
     const int l0 = chunk * a.Tc;

@@ -23,7 +23,7 @@
 // with the next slice and its fields requested one iteration ahead, straight from global memory into registers; `out` is stored from
 // registers; p·Ap is Σ|y[m]|² over the run's own slices, as in fdm_stream_kernel.  No s_barrier in the kernel; LDS only as the wavefront's
 // private exchange image for values that live in another lane (rings of 64 lanes: DPP wave rotations, no LDS at all).
-// The host finds the groups from the neighbour table alone (api.hip, group_program) and verifies every relation the kernel relies on;
+// The host finds the groups from the neighbour table alone (fdm_wave_program below, called from api_handle.hip) and verifies every relation the kernel relies on;
 // lattices that do not fit keep fdm_stream_kernel / fdm_fast_kernel.  Per-site arithmetic equals theirs up to the folded centre
 // stage (two roundings instead of five) — compared with the oracle at 1e-13 like every operator kernel.
 #include "smoqy_internal.h"
@@ -55,7 +55,7 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-// ---- lane programs (compile-time part; the host side in api.hip holds the same tables: GroupDesc) --------------------------------
+// ---- lane programs (compile-time part; the host side below holds the same tables: GroupDesc) --------------------------------
 // pp(c, p): position of the partner of own position p under colour c (in this lane, or in the lane of row rr(c, p) of the table when
 // rr >= 0); bs(c, p): the lane's bond slot holding that bond's (cosh, sinh).
 struct RingD {

@@ -1,7 +1,7 @@
 // GreensEstimator contractions on the device: the stochastic estimate of G(Δ,0) from the
 // solved vectors GR = M⁻¹R and the conjugated random vectors, averaged over translations with FFT cross-correlations.
 // Reference: measure_GΔ0! src/Measurements/GreensEstimator.jl:179-233, _aperiodic_copyto! :656-671,
-// _translational_average! :677-708.  The (D+1)-dimensional transforms themselves are rocFFT plans (api.hip); these
+// _translational_average! :677-708.  The (D+1)-dimensional transforms themselves are rocFFT plans (api_greens.hip); these
 // kernels are the data movement around them.
 #include "smoqy_internal.h"
 

@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
     const int sys = k.sys_first + blockIdx.x % ncnt_, rank = blockIdx.x / ncnt_;
     const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);  // heaviest orders first
     const int w = sys / k.nrhs;
-    if (k.cg[sys].done) return;  // k.cg is never null (api.hip: an all-zero state outside CG loops)
+    if (k.cg[sys].done) return;  // k.cg is never null (api_handle.hip, fdm_args / kpm_args: an all-zero state outside CG loops)
     const double2 *v = k.v + ((size_t)om * k.nsys + sys) * N;
     double2 *vo = (k.vout ? k.vout : k.v) + ((size_t)om * k.nsys + sys) * N;
     double2 *prz = k.part_rz ? k.part_rz + (size_t)sys * k.rz_stride + om : nullptr;
@@ -1039,7 +1039,7 @@ __global__ void __launch_bounds__(kThreads) cheb_generic_kernel(KpmArgs k)
     const int sys = k.sys_first + blockIdx.x % ncnt_, rank = blockIdx.x / ncnt_;
     const int om = (rank & 1) ? Lt - 1 - (rank >> 1) : (rank >> 1);
     const int w = sys / k.nrhs;
-    if (k.cg[sys].done) return;  // k.cg is never null (api.hip: an all-zero state outside CG loops)
+    if (k.cg[sys].done) return;  // k.cg is never null (api_handle.hip, fdm_args / kpm_args: an all-zero state outside CG loops)
     if (k.half && om >= (Lt + 1) / 2) return;
     const double *dbar = k.dbar + (size_t)w * N, *cbar = k.cbar + (size_t)w * k.Nh, *sbar = k.sbar + (size_t)w * k.Nh;
     const double *sbari = k.sbari ? k.sbari + (size_t)w * k.Nh : nullptr;
@@ -1201,7 +1201,7 @@ void launch_conj_mirror(hipStream_t st, double2 *v, int Lt, int N, int nsys)
 // device-side bookkeeping of update_preconditioner! (KPMPreconditioner.jl:565-597, 696-731): runs at the end of the Lanczos kernel,
 // in the same workgroup (one per walker)
 // ---------------------------------------------------------------------------------------------
-// number of eigenvalues of the symmetric tridiagonal (a, b) below x (Sturm sequence; the host restatement it replaces: api.hip `sturm`)
+// number of eigenvalues of the symmetric tridiagonal (a, b) below x (Sturm sequence; the host restatement it replaces: round 2's host `sturm`)
 __device__ __forceinline__ int sturm_count_dev(const double *a, const double *b, int n, double x)
 {
     int cnt = 0;

@@ -14,7 +14,7 @@
 //   plaquette (4 colours, N = 4·n sites, n <= 64; the optical-SSH square lattice L = 12 is n = 36): colours 1 and 2 — the ones the
 //         basis change α̃ = C₃α leaves twice in a step — close into 4-cycles s0 -c1- s1 -c2- s2 -c1- s3 -c2- s0 (the plaquettes of the
 //         square lattice); a lane owns one.  Colours 1, 2 are register arithmetic; colour 0 pairs site p with site p^1 of another
-//         lane, colour 3 pairs p with 3-p of another lane (the host labels the plaquettes so and VERIFIES it: api.hip, wave_program):
+//         lane, colour 3 pairs p with 3-p of another lane (the host labels the plaquettes so and VERIFIES it: api_handle.hip, wave_program):
 //         four ds_bpermute pairs each.
 //
 // A chain therefore runs without LDS images and without a single workgroup barrier.  The two components of a frequency vector (B̄, the

@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(256, (SLIM || EDGE) ? 6 : 1) tfft_kernel(TfftA
     double2 *A = lds, *B = A + (size_t)Lt * SB, *WT = (SLIM || EDGE) ? B : B + (size_t)Lt * SB;  // one image in the in-place and register-blocked forms
     int *POS = reinterpret_cast<int *>(WT + Lt);  // SLIM only
     // XCD-aware order (workgroups go to the eight XCDs round-robin): XCD x works on the same contiguous share of the systems as in the MᵀM
-    // and Chebyshev kernels — every kernel of the iteration then walks the same eighth of each vector on a given XCD (api.hip,
+    // and Chebyshev kernels — every kernel of the iteration then walks the same eighth of each vector on a given XCD (api_cg.hip,
     // cg_iteration_fused, for what that buys and what it does not)
     int bid_ = blockIdx.x;
     if (a.xcd_map && (gridDim.x & 7) == 0) bid_ = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -730,8 +730,8 @@ bool tfft_plan(int Lt, int N, TfftArgs &a)
     for (int f = 0; f < a.nfac; ++f) a.fpack |= (unsigned long long)a.fac[f] << (4 * f);
     for (int f = 0; f < a.snfac; ++f) a.sfpack |= (unsigned long long)a.sfac[f] << (4 * f);
     static const int slim_env = tuning_env(kTuneTfftSlim) > 0 ? tuning_env(kTuneTfftSlim) : 0;
-    a.x_stream = 0;  // decided per launch (api.hip: cg_iteration_fused)
-    a.xcd_map = 0;   // decided per launch (api.hip: cg_iteration_fused)
+    a.x_stream = 0;  // decided per launch (api_cg.hip: cg_iteration_fused)
+    a.xcd_map = 0;   // decided per launch (api_cg.hip: cg_iteration_fused)
     a.slim_ok = (m == 1) ? 1 : 0;           // lengths 2^a 3^b 5^c only
     a.slim = (slim_env && a.slim_ok) ? 1 : 0;  // default form: SMOQY_TFFT_SLIM, else smoqy_tfft_form
     a.SB = 16;

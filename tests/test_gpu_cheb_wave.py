@@ -1,7 +1,7 @@
 """cheb_wave_kernel (kernels_kpm_wave.hip, round 4): the Sym Chebyshev apply with one wavefront per chain — rings (2 colours) and
 plaquette lattices (4 colours) of up to 256 sites — against the oracle's ldiv!(u', P, u) (src/KPMPreconditioner.jl:355-414), through the
 preconditioned CG, and against the owner-computes kernel it replaces (SMOQY_CHEB_WAVE=0, child process).  The host's lane-program
-detection (api.hip, wave_program) is checked through smoqy_traits: lattices it must accept, lattices it must refuse."""
+detection (api_handle.hip, wave_program) is checked through smoqy_traits: lattices it must accept, lattices it must refuse."""
 import ctypes as C
 import os
 import subprocess

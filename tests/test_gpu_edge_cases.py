@@ -402,7 +402,7 @@ def test_cg_pipeline_parts_agree(nw, bitwise):
 @pytest.mark.parametrize("entry", ["path_integral", "fields"])
 def test_tau_independent_hoppings_select_and_leave_the_one_pair_kernel(entry):
     """The Sym LDS-resident MᵀM kernel keeps one (cosh, sinh) pair per colour once the HOST has seen that no walker of the launch has
-    τ-dependent hoppings (FermionDetMatrix.jl:224-231 computes them per slice; api.hip set_cs_const).  The choice must follow the
+    τ-dependent hoppings (FermionDetMatrix.jl:224-231 computes them per slice; api_handle.hip set_cs_const).  The choice must follow the
     fields: constant -> one walker made τ-dependent -> constant again, through both upload entry points, 12 systems per launch (the
     LDS-resident kernel) and with a graph-captured solve in between (a captured graph holds the kernel variant)."""
     Lt, Lc = 10, 3

@@ -87,7 +87,7 @@ def test_wave_mtm_against_oracle_and_workgroup_kernels(kind, Ls, Lt, hop, expect
             elif expect is None:
                 assert not took, name
             elif R == -1:
-                assert took == (expect == "plaquette"), name   # the automatic choice at three systems: plaquette lattices only (api.hip, wave_run_length)
+                assert took == (expect == "plaquette"), name   # the automatic choice at three systems: plaquette lattices only (api_operator.hip, wave_run_length)
             else:
                 assert took and expect in name, (name, R, Tc)
             assert relerr(got, want) < 1e-13, (kind, Ls, R, Tc, name)

@@ -43,6 +43,8 @@ print(f"one iteration (medians): kernels {tot_k:.1f} us + boundaries {tot_g:.1f}
 span = ev[-1][1] - ev[0][0]
 busy = sum(e - s for s, e, _ in ev)
 print(f"window {span / 1e6:.2f} ms, kernels busy {busy / 1e6:.2f} ms ({100 * busy / span:.1f} %)")
+print(f"{len(ev)} dispatches in the window: one every {span / len(ev) / 1e3:.1f} us against an average kernel of {busy / len(ev) / 1e3:.1f} us — under the tracer the host's launch path "
+      "is slower than without it, and where the first figure is the larger one the stream waits for the HOST, not for a poll")
 it_busy = sum(sum(durs[k]) for k in loop if durs[k])
 print(f"of which the four kernels of the CG iteration {it_busy / 1e6:.2f} ms ({100 * it_busy / span:.1f} % of the window); other kernels {(busy - it_busy) / 1e6:.2f} ms")
 # the tail of the iteration-closing boundary: how many of its gaps are not back to back, and what they add up to
