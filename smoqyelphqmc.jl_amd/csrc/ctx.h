@@ -90,7 +90,7 @@ struct smoqy_ctx {
     int traj_async = 1;
     std::vector<int> traj_hint;   // iterations step t of the last verified trajectory took (max over systems)
     double traj_hint_tol = 0.0;
-    int traj_margin = 2;
+    int traj_margin = 4;   // early-exit iterations launched past the hint: 4 x ~10 us per solve against a repeated trajectory per miss (3 of 93 at margin 2)
     int traj_backoff = 0, traj_skip = 0;  // after a repeated trajectory the next traj_skip ones poll (doubling per consecutive miss, halving per success)
     CgState *d_traj_st = nullptr, *h_traj_st = nullptr;
     double *d_traj_save = nullptr;   // x and p at the start of the trajectory (the fall-back's starting point)
