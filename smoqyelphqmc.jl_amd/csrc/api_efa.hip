@@ -117,7 +117,7 @@ static int refresh_from_device_x(smoqy_ctx *c)
     launch_phonon_fields(c->stream, a, F.d_bare, F.d_bare + g.N, c->d_expV, c->d_ch, c->d_sh, c->d_lam, g.is_sym ? F.dtau / 2 : F.dtau, do_t, g.is_cplx ? F.d_bare + g.N + g.Nh : nullptr,
                          c->d_shi);
     if (do_t) {
-        launch_pack_csf(c->stream, c->d_ch, c->d_sh, c->d_psrc, c->d_csf, c->d_cs_varies, g.nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal);
+        launch_pack_csf(c->stream, c->d_ch, c->d_sh, c->d_psrc, c->d_csf, c->d_cs_varies, g.nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal, c->d_csi ? c->d_shi : nullptr, c->d_csi);
         for (int w = 0; w < g.nw; ++w) set_cs_const(c, w, F.Nssh == 0 ? F.t0_level : 0);  // no SSH coupling: t is the bare per-bond hopping on every slice
     }
     F.t_done = true;

@@ -25,6 +25,7 @@ int smoqy_copy_fields(smoqy_ctx *dst, int dst_walker, smoqy_ctx *src, int src_wa
         if (a.is_cplx) HIPCHK(dst, hipMemcpyAsync(dst->d_shi + dst_walker * nT, src->d_shi + src_walker * nT, nT * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
     }
     if (nP) HIPCHK(dst, hipMemcpyAsync(dst->d_csf + dst_walker * nP, src->d_csf + src_walker * nP, nP * sizeof(double2), hipMemcpyDeviceToDevice, dst->stream));
+    if (nP && dst->d_csi && src->d_csi) HIPCHK(dst, hipMemcpyAsync(dst->d_csi + dst_walker * nP, src->d_csi + src_walker * nP, nP * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
     HIPCHK(dst, hipMemcpyAsync(dst->d_cs_varies + dst_walker, src->d_cs_varies + src_walker, sizeof(int), hipMemcpyDeviceToDevice, dst->stream));
     set_cs_const(dst, dst_walker, src->cs_const.empty() ? 0 : (int)src->cs_const[(size_t)src_walker]);
     HIPCHK(dst, hipStreamSynchronize(dst->stream));

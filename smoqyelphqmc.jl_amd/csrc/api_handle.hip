@@ -208,7 +208,7 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->fft_info) rocfft_execution_info_destroy(c->fft_info);
     void *ptrs[] = {c->d_bonds, c->d_col_off, c->d_expV, c->d_ch, c->d_sh, c->d_lam, c->d_stage, c->d_stage_real, c->d_stage_int, c->scr[0], c->scr[1], c->scr[2], c->cg_r, c->cg_p,
                     c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->d_st_idle, c->fft_work, c->d_tw, c->d_th, c->d_wtab, c->d_tpos, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
-                    c->d_rand, c->d_rand_traj, c->d_traj_dot, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_wave, c->d_fwave, c->d_big, c->d_shi, c->d_sbari};
+                    c->d_rand, c->d_rand_traj, c->d_traj_dot, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_wave, c->d_fwave, c->d_big, c->d_shi, c->d_sbari, c->d_csi};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (double2 *v : c->vecs)
@@ -662,13 +662,18 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
         }
         HIPCHK(c, hipMalloc(&c->d_csf, (size_t)g.nw * g.Lt * std::max<size_t>(pb.size(), 1) * sizeof(double2)));
         HIPCHK(c, hipMemset(c->d_csf, 0, (size_t)g.nw * g.Lt * std::max<size_t>(pb.size(), 1) * sizeof(double2)));
+        if (g.is_cplx && g.is_sym) {
+            HIPCHK(c, hipMalloc(&c->d_csi, (size_t)g.nw * g.Lt * std::max<size_t>(pb.size(), 1) * sizeof(double)));
+            HIPCHK(c, hipMemset(c->d_csi, 0, (size_t)g.nw * g.Lt * std::max<size_t>(pb.size(), 1) * sizeof(double)));
+        }
         HIPCHK(c, hipMalloc(&c->d_cs_varies, (size_t)g.nw * sizeof(int)));
         HIPCHK(c, hipMemset(c->d_cs_varies, 0, (size_t)g.nw * sizeof(int)));
         c->ff.cs_varies = c->d_cs_varies;
         c->cs_const.assign((size_t)g.nw, 0);
         c->ff.psites = c->d_psites; c->ff.pos = c->d_pos;
-        c->ff.pbonds = c->d_pbonds; c->ff.poff = c->d_poff; c->ff.csf = c->d_csf; c->ff.ptotal = c->kg.ptotal; c->ff.threads = c->kg.threads;
-        c->ff.enabled = (!g.is_cplx && g.ncol >= 1 && g.ncol <= kFdmColours && maxp <= 1024) ? 1 : 0;  // Sym: fdm_fast/own kernels; Asym: fdm_fast_asym_kernel
+        c->ff.pbonds = c->d_pbonds; c->ff.poff = c->d_poff; c->ff.csf = c->d_csf; c->ff.csi = c->d_csi; c->ff.ptotal = c->kg.ptotal; c->ff.threads = c->kg.threads;
+        // Sym: fdm_fast / own / stream / wave kernels; Asym: fdm_fast_asym_kernel; complex hoppings: Sym only, fdm_fast_kernel<…, CPLX> (the other families test ff.csi)
+        c->ff.enabled = ((!g.is_cplx || g.is_sym) && g.ncol >= 1 && g.ncol <= kFdmColours && maxp <= 1024) ? 1 : 0;
         {   // FdmFast::full: no padded self bond anywhere and every list exactly one bond per lane
             bool full = g.ncol >= 1 && g.N == 2 * c->kg.threads;
             for (int col = 0; col < g.ncol && full; ++col) full = poff[col + 1] - poff[col] == c->kg.threads;
@@ -884,6 +889,9 @@ int smoqy_update_fields(smoqy_ctx *c, int w, const double *expV, const double *c
         for (size_t k = 0; k < cnt; ++k) { re[k] = sh[2 * k]; im[k] = sh[2 * k + 1]; }
         if (int rc = upload_real_field(c, re.data(), c->d_sh + (size_t)w * cnt, g.Nh)) return rc;
         if (int rc = upload_real_field(c, im.data(), c->d_shi + (size_t)w * cnt, g.Nh)) return rc;
+        if (c->d_csi)
+            launch_pack_csf(c->stream, c->d_ch + (size_t)w * cnt, c->d_sh + (size_t)w * cnt, c->d_psrc, c->d_csf + (size_t)w * g.Lt * c->kg.ptotal, c->d_cs_varies + w, g.Lt, g.Lt, g.Nh, c->kg.ptotal,
+                            c->d_shi + (size_t)w * cnt, c->d_csi + (size_t)w * g.Lt * c->kg.ptotal);
         return check_launch(c, "update_fields");
     }
     if (int rc = upload_real_field(c, ch, c->d_ch + (size_t)w * g.Lt * g.Nh, g.Nh)) return rc;
@@ -923,6 +931,9 @@ static int update_pi_range(smoqy_ctx *c, int w0, int nw, const double *V, const 
     if (g.is_cplx) {
         launch_fields_from_path_integral_c(c->stream, V ? dV : nullptr, do_t ? (const double2 *)dT : nullptr, c->d_stage_int, c->d_expV + (size_t)w0 * nV, c->d_ch + (size_t)w0 * nT, c->d_sh + (size_t)w0 * nT,
                                            c->d_shi + (size_t)w0 * nT, nw * g.Lt, g.N, g.Nh, dtau, g.is_sym ? dtau / 2 : dtau);
+        if (do_t && c->d_csi)
+            launch_pack_csf(c->stream, c->d_ch + (size_t)w0 * nT, c->d_sh + (size_t)w0 * nT, c->d_psrc, c->d_csf + (size_t)w0 * g.Lt * c->kg.ptotal, c->d_cs_varies + w0, nw * g.Lt, g.Lt, g.Nh, c->kg.ptotal,
+                            c->d_shi + (size_t)w0 * nT, c->d_csi + (size_t)w0 * g.Lt * c->kg.ptotal);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return check_launch(c, "update_from_path_integral");
     }

@@ -184,7 +184,7 @@ int smoqy_matvec_force_generic(smoqy_ctx *c, int on)
 {
     CHECK_CTX(c);
     const Geometry &g = c->g;
-    c->ff.enabled = (!on && !g.is_cplx && g.ncol >= 1 && g.ncol <= kFdmColours && c->ff.threads <= 1024) ? 1 : 0;
+    c->ff.enabled = (!on && (!g.is_cplx || g.is_sym) && g.ncol >= 1 && g.ncol <= kFdmColours && c->ff.threads <= 1024) ? 1 : 0;
     drop_graphs(c);
     choose_chunking(c);
     return 0;

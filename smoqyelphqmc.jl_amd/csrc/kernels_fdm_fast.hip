@@ -39,14 +39,29 @@ __device__ __forceinline__ double2 hopcomb(double2 v, double2 u, bool wrap, bool
 
 // CSV = false: the host has shown the hoppings to be τ-independent (FdmFast::cs_const), one (cosh, sinh) pair per colour is kept
 // instead of one per slice — 12 fewer registers per colour and no copies
-template <bool CSV = true>
+template <bool CSV = true, bool CPLX = false>
 struct LaneT {
+    static constexpr bool kCplx = CPLX;
     int2 b[kFdmColours];
     bool on[kFdmColours];
-    double2 cs[kFdmColours][CSV ? KMAX : 1];  // (cosh, sinh) of the lane's bond in colour c on slice k
+    double2 cs[kFdmColours][CSV ? KMAX : 1];  // (cosh, Re sinh) of the lane's bond in colour c on slice k
+    double si[CPLX ? kFdmColours : 1][CPLX ? (CSV ? KMAX : 1) : 1];  // T = ComplexF64: Im sinh (round 4)
     double di[KMAX], dj[KMAX];                // exp(-ΔτV) at the two sites of the lane's first-colour bond
     __device__ __forceinline__ double2 csk(int c, int k) const { return cs[c][CSV ? k : 0]; }
+    __device__ __forceinline__ double sik(int c, int k) const { return CPLX ? si[CPLX ? c : 0][CPLX && CSV ? k : 0] : 0.0; }
 };
+// the bond factor [[c, s], [conj(s), c]] on the pair (a, d) = (u_i, u_j) of a bond (i, j) in the order of the neighbour table
+// (src/checkerboard_matrix_multiply.jl:60-68): a' = c a + s d, d' = c d + conj(s) a.  Real hoppings: si = 0 and the two extra terms fold away.
+template <bool CPLX>
+__device__ __forceinline__ void bond_apply(double c, double sr, double si, double2 a, double2 d, double2 &oa, double2 &od)
+{
+    oa = lin(c, a, sr, d);
+    od = lin(c, d, sr, a);
+    if (CPLX) {
+        oa.x -= si * d.y; oa.y += si * d.x;
+        od.x += si * a.y; od.y -= si * a.x;
+    }
+}
 using Lane = LaneT<true>;
 
 // one plain colour stage on nk LDS-resident slices; SH selects the slice->register offset
@@ -60,9 +75,10 @@ __device__ __forceinline__ void stage(double2 *U, int N, int nk, const LN &ln)
                 double2 *row = U + (size_t)k * N;
                 const double2 a = row[ln.b[C].x], d = row[ln.b[C].y];
                 const double2 cs_ = ln.csk(C, k + SH);
-                const double c = cs_.x, s = cs_.y;
-                row[ln.b[C].x] = lin(c, a, s, d);
-                row[ln.b[C].y] = lin(c, d, s, a);
+                double2 oa, od;
+                bond_apply<LN::kCplx>(cs_.x, cs_.y, ln.sik(C, k + SH), a, d, oa, od);
+                row[ln.b[C].x] = oa;
+                row[ln.b[C].y] = od;
             }
         }
     }
@@ -80,14 +96,18 @@ __device__ __forceinline__ void middle(double2 *U, int N, int nk, const LN &ln, 
                 double2 *row = U + (size_t)k * N;
                 const double2 a = row[ln.b[0].x], d = row[ln.b[0].y];
                 const double2 cs_ = ln.csk(0, k + SH);
-                const double c = cs_.x, s = cs_.y;
-                const double2 x = scl(ln.di[k + SH], lin(c, a, s, d)), y = scl(ln.dj[k + SH], lin(c, d, s, a));
+                const double c = cs_.x, s = cs_.y, si = ln.sik(0, k + SH);
+                double2 x, y, ox, oy;
+                bond_apply<LN::kCplx>(c, s, si, a, d, x, y);
+                x = scl(ln.di[k + SH], x);
+                y = scl(ln.dj[k + SH], y);
+                bond_apply<LN::kCplx>(c, s, si, x, y, ox, oy);
                 if (LAST) {
-                    ri[k] = lin(c, x, s, y);
-                    rj[k] = lin(c, y, s, x);
+                    ri[k] = ox;
+                    rj[k] = oy;
                 } else {
-                    row[ln.b[0].x] = lin(c, x, s, y);
-                    row[ln.b[0].y] = lin(c, y, s, x);
+                    row[ln.b[0].x] = ox;
+                    row[ln.b[0].y] = oy;
                 }
             }
         }
@@ -106,9 +126,7 @@ __device__ __forceinline__ void last_stage(const double2 *U, int N, int nk, cons
                 const double2 *row = U + (size_t)k * N;
                 const double2 a = row[ln.b[C].x], d = row[ln.b[C].y];
                 const double2 cs_ = ln.csk(C, k + SH);
-                const double c = cs_.x, s = cs_.y;
-                ri[k] = lin(c, a, s, d);
-                rj[k] = lin(c, d, s, a);
+                bond_apply<LN::kCplx>(cs_.x, cs_.y, ln.sik(C, k + SH), a, d, ri[k], rj[k]);
             }
         }
     }
@@ -132,7 +150,7 @@ __device__ __forceinline__ void propagate_sym(double2 *U, int N, int nk, const L
     last_stage<NCOL - 1, SH>(U, N, nk, ln, ri, rj);
 }
 
-template <int NCOL, int OP, bool CSV>
+template <int NCOL, int OP, bool CSV, bool CPLX = false>
 __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
 {
     extern __shared__ double2 U[];
@@ -160,7 +178,9 @@ __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
     const int ubase = (OP == SMOQY_OP_M || OP == SMOQY_OP_MTM) ? l0 - 1 : (OP == SMOQY_OP_MT ? l0 + 1 : l0);  // source slice of U[0]
 
     // ---- everything this workgroup needs from memory is requested here, up front ----
-    LaneT<CSV> ln;
+    static_assert(!CPLX || CSV, "complex hoppings are instantiated with one (cosh, sinh) set per slice only");
+    LaneT<CSV, CPLX> ln;
+    const double *csi = CPLX ? ff.csi + (size_t)w * Lt * ff.ptotal : nullptr;
     // hoppings that do not depend on τ (e.g. Holstein: t constant) are detected when the fields are
     // packed; the lane then fetches its (cosh, sinh) pair once instead of once per slice
     const bool cs_varies = CSV && ff.cs_varies[w] != 0;
@@ -179,6 +199,13 @@ __global__ void __launch_bounds__(1024) fdm_fast_kernel(FdmArgs a, FdmFast ff)
                 if (CSV && !cs_varies) {
 #pragma unroll
                     for (int k = 1; k < (CSV ? KMAX : 1); ++k) ln.cs[c][k] = ln.cs[c][0];
+                }
+                if constexpr (CPLX) {
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) {
+                        ln.si[c][k] = 0.0;
+                        if (k < K1) ln.si[c][k] = csi[(cs_varies ? (size_t)wrapl(fbase + k, Lt) : (size_t)0) * ff.ptotal + idx];
+                    }
                 }
             }
         }
@@ -913,16 +940,16 @@ void launch_ncol_asym(hipStream_t st, int op, const FdmArgs &a, const FdmFast &f
     }
 }
 
-template <int NCOL, bool CSV>
+template <int NCOL, bool CSV, bool CPLX = false>
 void launch_ncol(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff)
 {
     const dim3 grid((unsigned)(a.nchunk * a.sys_count)), block((unsigned)ff.threads);
     const size_t lds = sizeof(double2) * (size_t)a.N * (size_t)(a.Tc + 1);
     switch (op) {
-        case SMOQY_OP_M: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_M, CSV>), grid, block, lds, st, a, ff); break;
-        case SMOQY_OP_MT: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MT, CSV>), grid, block, lds, st, a, ff); break;
-        case SMOQY_OP_MTM: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MTM, CSV>), grid, block, lds, st, a, ff); break;
-        default: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MMT, CSV>), grid, block, lds, st, a, ff); break;
+        case SMOQY_OP_M: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_M, CSV, CPLX>), grid, block, lds, st, a, ff); break;
+        case SMOQY_OP_MT: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MT, CSV, CPLX>), grid, block, lds, st, a, ff); break;
+        case SMOQY_OP_MTM: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MTM, CSV, CPLX>), grid, block, lds, st, a, ff); break;
+        default: hipLaunchKernelGGL((fdm_fast_kernel<NCOL, SMOQY_OP_MMT, CSV, CPLX>), grid, block, lds, st, a, ff); break;
     }
 }
 
@@ -931,7 +958,8 @@ void launch_ncol(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff)
 bool fdm_fast_supported(const FdmArgs &a, const FdmFast &ff, bool sym)
 {
     // the Asym kernel keeps a second LDS image for the fused products
-    return ff.enabled && a.ncol >= 1 && a.ncol <= kFdmColours && a.Tc + 1 <= KMAX && sizeof(double2) * (size_t)a.N * (size_t)(a.Tc + 1) * (sym ? 1 : 2) <= 60 * 1024;
+    // complex hoppings (ff.csi): the Sym kernel only (round 4); Asym complex handles keep the generic kernel
+    return ff.enabled && (sym || !ff.csi) && a.ncol >= 1 && a.ncol <= kFdmColours && a.Tc + 1 <= KMAX && sizeof(double2) * (size_t)a.N * (size_t)(a.Tc + 1) * (sym ? 1 : 2) <= 60 * 1024;
 }
 
 void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff, bool sym, bool cs_const)
@@ -942,6 +970,15 @@ void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff
             case 2: launch_ncol_asym<2>(st, op, a, ff); break;
             case 3: launch_ncol_asym<3>(st, op, a, ff); break;
             default: launch_ncol_asym<4>(st, op, a, ff); break;
+        }
+        return;
+    }
+    if (ff.csi) {  // T = ComplexF64
+        switch (a.ncol) {
+            case 1: launch_ncol<1, true, true>(st, op, a, ff); break;
+            case 2: launch_ncol<2, true, true>(st, op, a, ff); break;
+            case 3: launch_ncol<3, true, true>(st, op, a, ff); break;
+            default: launch_ncol<4, true, true>(st, op, a, ff); break;
         }
         return;
     }
@@ -965,7 +1002,7 @@ void launch_fdm_fast(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff
 // streaming MᵀM: Sym, real hoppings, run length a multiple of the τ-chunk (the p·Ap partials keep the chunk layout), at least two slices
 bool fdm_stream_supported(const FdmArgs &a, const FdmFast &ff, bool sym)
 {
-    return sym && ff.enabled && a.ncol >= 1 && a.ncol <= kFdmColours && a.run_len >= 2 && a.run_len % a.Tc == 0 && a.Lt >= 4 && a.N <= 2 * ff.threads &&
+    return sym && ff.enabled && !ff.csi && a.ncol >= 1 && a.ncol <= kFdmColours && a.run_len >= 2 && a.run_len % a.Tc == 0 && a.Lt >= 4 && a.N <= 2 * ff.threads &&
            sizeof(double2) * 4 * (size_t)a.N <= 150 * 1024;
 }
 
@@ -1029,30 +1066,38 @@ hipError_t configure_fdm_stream_kernels(const char **what)
 // pack cosh/sinh into the padded interleaved table csf[l][idx] = (c, s) (self bonds: (1, 0)) and note
 // per walker whether the hoppings depend on τ at all (Lt = nwalkers * Lt1 slices in a row)
 __global__ void pack_csf_kernel(const double *__restrict__ ch, const double *__restrict__ sh, const int *__restrict__ psrc, double2 *__restrict__ csf, int *__restrict__ cs_varies, int Lt, int Lt1, int Nh,
-                                int ptotal)
+                                int ptotal, const double *__restrict__ shi, double *__restrict__ csi)
 {
     const size_t tot = (size_t)Lt * ptotal;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
         const int l = (int)(idx / ptotal), j = (int)(idx - (size_t)l * ptotal);
         const int h = psrc[j];
         double2 v = make_double2(1.0, 0.0);
+        double im = 0.0;
         if (h >= 0) {
             v = make_double2(ch[(size_t)l * Nh + h], sh[(size_t)l * Nh + h]);
             const int w = l / Lt1, lf = w * Lt1;  // first slice of this walker
-            if (v.x != ch[(size_t)lf * Nh + h] || v.y != sh[(size_t)lf * Nh + h]) cs_varies[w] = 1;  // benign race: every writer stores 1
+            bool differs = v.x != ch[(size_t)lf * Nh + h] || v.y != sh[(size_t)lf * Nh + h];
+            if (shi) {
+                im = shi[(size_t)l * Nh + h];
+                differs = differs || im != shi[(size_t)lf * Nh + h];
+            }
+            if (differs) cs_varies[w] = 1;  // benign race: every writer stores 1
         }
         csf[idx] = v;
+        if (csi) csi[idx] = im;
     }
 }
 
-void launch_pack_csf(hipStream_t st, const double *ch, const double *sh, const int *psrc, double2 *csf, int *cs_varies, int Lt, int Lt1, int Nh, int ptotal)
+// shi / csi: Im sinh per bond and its padded copy (T = ComplexF64), or nullptr
+void launch_pack_csf(hipStream_t st, const double *ch, const double *sh, const int *psrc, double2 *csf, int *cs_varies, int Lt, int Lt1, int Nh, int ptotal, const double *shi, double *csi)
 {
     const size_t tot = (size_t)Lt * ptotal;
     if (tot == 0) return;
     (void)hipMemsetAsync(cs_varies, 0, sizeof(int) * (size_t)(Lt / Lt1), st);
     int blocks = (int)((tot + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(pack_csf_kernel, dim3(blocks), dim3(256), 0, st, ch, sh, psrc, csf, cs_varies, Lt, Lt1, Nh, ptotal);
+    hipLaunchKernelGGL(pack_csf_kernel, dim3(blocks), dim3(256), 0, st, ch, sh, psrc, csf, cs_varies, Lt, Lt1, Nh, ptotal, shi, csi);
 }
 
 }  // namespace smoqy

@@ -526,7 +526,7 @@ int fdm_own_enabled()
 bool fdm_own_supported(const FdmArgs &a, const FdmFast &ff, bool sym)
 {
     static const int own_max = tuning_env(kTuneFdmOwnMax) >= 0 ? tuning_env(kTuneFdmOwnMax) : 8;  // experiment knob: systems per launch up to which this kernel is chosen
-    return sym && ff.enabled && ff.own && fdm_own_enabled() && a.sys_count <= own_max && a.ncol >= 1 && a.ncol <= kFdmColours && a.Tc + 1 <= 3 &&
+    return sym && ff.enabled && !ff.csi && ff.own && fdm_own_enabled() && a.sys_count <= own_max && a.ncol >= 1 && a.ncol <= kFdmColours && a.Tc + 1 <= 3 &&
            sizeof(double2) * 2 * (size_t)(a.Tc + 1 <= 2 ? 2 : 3) * 2 * (size_t)ff.threads <= 64 * 1024;
 }
 

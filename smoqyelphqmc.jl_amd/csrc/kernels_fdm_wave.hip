@@ -290,7 +290,7 @@ void launch_kind(hipStream_t st, const FdmArgs &a, const FdmFast &ff, const FdmW
 bool fdm_wave_supported(const FdmArgs &a, const FdmFast &ff, const FdmWave &fw, bool sym, int csm)
 {
     static const int env = tuning_env(kTuneFdmWave);
-    if (env == 0 || !sym || !ff.enabled || fw.kind == 0 || !fw.tab || a.run_len < 1 || a.run_len % a.Tc != 0 || a.Lt < 2) return false;
+    if (env == 0 || !sym || !ff.enabled || ff.csi || fw.kind == 0 || !fw.tab || a.run_len < 1 || a.run_len % a.Tc != 0 || a.Lt < 2) return false;
     if (fw.kind == 3 && csm != 0) return false;  // eight sites per lane leave no registers for a (cosh, sinh) pair per bond slot
     return true;
 }

@@ -162,6 +162,7 @@ struct FdmFast {
     const int *pos;      // [N] site -> LDS position
     const int *poff;     // [ncol + 1] (device)
     const double2 *csf;  // [nw][Lt][ptotal] (cosh, sinh) per padded bond, (1, 0) on self bonds
+    const double *csi;   // [nw][Lt][ptotal] Im sinh per padded bond for T = ComplexF64 (fdm_fast_kernel<…, CPLX>), nullptr for real hoppings
     const int *cs_varies; // [nw] 0 when a walker's hoppings are the same on every time slice
     int ptotal;
     int threads;
@@ -208,7 +209,7 @@ void launch_fdm_wave(hipStream_t st, const FdmArgs &a, const FdmFast &ff, const 
 void fdm_wave_program(int N, int ncol, const std::vector<std::vector<int>> &mate, const std::vector<std::vector<int>> &bidx, std::vector<int> &tab, int &kind, int &lanes, bool &rot);
 bool fdm_own_supported(const FdmArgs &a, const FdmFast &ff, bool sym);
 void launch_fdm_own(hipStream_t st, int op, const FdmArgs &a, const FdmFast &ff);
-void launch_pack_csf(hipStream_t st, const double *ch, const double *sh, const int *psrc, double2 *csf, int *cs_varies, int Lt, int Lt1, int Nh, int ptotal);
+void launch_pack_csf(hipStream_t st, const double *ch, const double *sh, const int *psrc, double2 *csf, int *cs_varies, int Lt, int Lt1, int Nh, int ptotal, const double *shi = nullptr, double *csi = nullptr);
 
 // device stream-copy ceiling (kernels_vec.hip): dst[i] = src[i], 16 bytes per lane, grid-stride
 void launch_stream_copy(hipStream_t st, double2 *dst, const double2 *src, size_t n);

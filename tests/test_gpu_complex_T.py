@@ -1,7 +1,9 @@
 """Matrix-element type T = ComplexF64 (complex hoppings) on the GPU against the CPU oracle, whose complex-T restatement is pinned by
 dense matrices in tests/test_oracle_complex_T.py.  Reference: the bond factor [[c, s], [conj(s), c]] with
 s = sign(conj t)·sinh(Δτ′|t|) (src/checkerboard_matrix_multiply.jl:60-68, src/FermionDetMatrix.jl:224-231); the operator type is
-FermionDetMatrix{T<:Number} (:19).  Complex handles run on the generic kernels (kernels_fdm.hip, cheb_generic_kernel, generic Lanczos)."""
+FermionDetMatrix{T<:Number} (:19).  Round 4: Sym complex handles run the register-resident operator kernel (fdm_fast_kernel<…, CPLX>) up to
+a τ-chunk of 2; Asym complex handles, larger chunks and the preconditioner run on the generic kernels (kernels_fdm.hip,
+cheb_generic_kernel, generic Lanczos) — both families are compared with the oracle here."""
 import ctypes as C
 
 import numpy as np
@@ -86,6 +88,8 @@ def test_matvec_complex_T(kind, is_sym, Tc):
         got = h.vec_download(b)
         for s in range(4):
             assert relerr(got[:, :, s], getattr(o[s // 2], name)(v[:, :, s])) < OP_TOL, (kind, is_sym, Tc, name, s)
+    h.call("smoqy_matvec_v", L.OP_MTM, b, a)
+    assert h.describe()["mtm"] == ("fdm_fast_kernel" if is_sym and Tc <= 2 else "fdm_kernel"), h.describe()
     # adjoint identity across separate launches
     h.call("smoqy_matvec_v", L.OP_M, b, a)
     Mv = h.vec_download(b)
