@@ -19,7 +19,8 @@
  *     the hopping-derived arrays cross the boundary as complex128 (interleaved re, im) exactly where the reference holds a
  *     Matrix{T}: cosh_dtt / sinh_dtt of smoqy_update_fields / smoqy_get_fields (Ltau x Nh), t of
  *     smoqy_update_from_path_integral[_all] (Nh x Ltau), and the Lanczos start vectors of smoqy_precond_update[_all] (N complex
- *     deviates per walker: randn! on a Vector{ComplexF64}).  V, expV and Λ stay real.  Complex handles run on the generic kernels.
+ *     deviates per walker: randn! on a Vector{ComplexF64}).  V, expV and Λ stay real.  Sym complex handles run register-resident operator and Chebyshev kernels with the
+ *     complex bond factor (round 4; 1.4x the real-T iteration at 16 walkers); Asym complex handles, τ-chunks above 2 and the Lanczos bounds run on the generic kernels.
  *     Round 3: the force terms and the device-side update! from the phonon fields take complex T as well — t0 of smoqy_set_bare_model is
  *     complex128 (Nh) and the SSH couplings carry their imaginary parts in smoqy_couplings.s_alpha*_im.
  *

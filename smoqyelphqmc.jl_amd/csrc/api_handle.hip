@@ -208,7 +208,7 @@ int smoqy_destroy(smoqy_ctx *c)
     if (c->fft_info) rocfft_execution_info_destroy(c->fft_info);
     void *ptrs[] = {c->d_bonds, c->d_col_off, c->d_expV, c->d_ch, c->d_sh, c->d_lam, c->d_stage, c->d_stage_real, c->d_stage_int, c->scr[0], c->scr[1], c->scr[2], c->cg_r, c->cg_p,
                     c->cg_z, c->cg_v, c->part_pz, c->part_rz, c->part_c, c->d_dot_out, c->part_rr, c->part_bb, c->d_st, c->d_st_idle, c->fft_work, c->d_tw, c->d_th, c->d_wtab, c->d_tpos, c->d_dbar, c->d_cbar, c->d_sbar, c->d_bounds,
-                    c->d_rand, c->d_rand_traj, c->d_traj_dot, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_wave, c->d_fwave, c->d_big, c->d_shi, c->d_sbari, c->d_csi};
+                    c->d_rand, c->d_rand_traj, c->d_traj_dot, c->d_lan, c->d_order, c->d_active, c->d_coefs, c->d_pbonds, c->d_poff, c->d_psrc, c->d_pcs, c->d_csf, c->d_cs_varies, c->d_psites, c->d_pos, c->d_own, c->d_own_f == c->d_own ? nullptr : c->d_own_f, c->d_wave, c->d_fwave, c->d_big, c->d_shi, c->d_sbari, c->d_csi, c->d_pcsi};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (double2 *v : c->vecs)
@@ -565,6 +565,12 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
         HIPCHK(c, hipMemcpy(c->d_poff, poff.data(), poff.size() * sizeof(int), hipMemcpyHostToDevice));
         c->kg.psites = c->d_psites; c->kg.pos = c->d_pos;
         c->kg.pbonds = c->d_pbonds; c->kg.poff = c->d_poff; c->kg.psrc = c->d_psrc; c->kg.pcs = c->d_pcs;
+        if (g.is_cplx && g.is_sym && g.ncol >= 1 && g.ncol <= kMaxColours && maxp <= 1024) {  // complex hoppings: the Sym Chebyshev kernel on the padded lists (round 4)
+            HIPCHK(c, hipMalloc(&c->d_pcsi, (size_t)g.nw * std::max<size_t>(pb.size(), 1) * sizeof(double)));
+            HIPCHK(c, hipMemset(c->d_pcsi, 0, (size_t)g.nw * std::max<size_t>(pb.size(), 1) * sizeof(double)));
+            c->kg.pcsi = c->d_pcsi;
+            c->kg.cplx_fast = 1;
+        }
         if (c->kg.fast) {
             // owner-computes tables: the owned colour is one that is applied twice (per Chebyshev step in
             // cheb_own_kernel, per B apply in fdm_own_kernel), so that its two stages need no exchange at all

@@ -198,6 +198,7 @@ int smoqy_precond_force_generic(smoqy_ctx *c, int on)
     (void)g;
     maxp = c->kg.threads;
     c->kg.fast = (!on && !g.is_cplx && g.ncol >= 1 && g.ncol <= kMaxColours && maxp <= 1024) ? 1 : 0;
+    c->kg.cplx_fast = (!on && c->d_pcsi) ? 1 : 0;
     drop_graphs(c);
     return 0;
 }

@@ -44,6 +44,7 @@ struct smoqy_ctx {
     // fields [nw][Lt][*]
     double *d_expV = nullptr, *d_ch = nullptr, *d_sh = nullptr, *d_lam = nullptr;
     double *d_shi = nullptr, *d_sbari = nullptr;  // T = ComplexF64 only: Im sinhΔτt [nw][Lt][Nh] and its tau-mean [nw][Nh]
+    double *d_pcsi = nullptr;  // T = ComplexF64, Sym: τ-mean of Im sinh per padded bond [nw][ptotal] beside d_pcs (cheb_fast_kernel<…, CPLX>)
     double *d_csi = nullptr;   // T = ComplexF64, Sym: Im sinh per padded bond [nw][Lt][ptotal] beside d_csf (fdm_fast_kernel<…, CPLX>)
     // user vectors
     std::vector<double2 *> vecs;

@@ -37,7 +37,7 @@ __device__ __forceinline__ double2 lin2(double a, double2 x, double b, double2 y
 // update_B̄! (:604-621) for every walker in one launch, plus the padded (c̄, s̄) table
 // ---------------------------------------------------------------------------------------------
 __global__ void tau_means_kernel(const double *__restrict__ expV, const double *__restrict__ ch, const double *__restrict__ sh, double *dbar, double *cbar, double *sbar, double2 *pcs,
-                                 const int *__restrict__ psrc, int ptotal, int Lt, int N, int Nh, const double *__restrict__ shi, double *sbari)
+                                 const int *__restrict__ psrc, int ptotal, int Lt, int N, int Nh, const double *__restrict__ shi, double *sbari, double *pcsi)
 {
     // 64 outputs x 4 tau-groups per workgroup: lanes run over sites/bonds (coalesced), each
     // thread sums every 4th slice with 8 loads in flight, then one LDS hop across the groups
@@ -80,6 +80,7 @@ __global__ void tau_means_kernel(const double *__restrict__ expV, const double *
             a = 1.0; b = 0.0;  // identity self bond
         }
         pcs[(size_t)w * ptotal + (j - N)] = make_double2(a, b);
+        if (pcsi) pcsi[(size_t)w * ptotal + (j - N)] = h >= 0 ? bi / Lt : 0.0;
     }
 }
 
@@ -88,7 +89,8 @@ void launch_tau_means(hipStream_t st, const KpmGeom &kg, const double *expV, con
 {
     dim3 grid((N + kg.ptotal + 63) / 64, nw);
     hipLaunchKernelGGL(tau_means_kernel, grid, dim3(64, 4), 0, st, expV + (size_t)w0 * Lt * N, ch + (size_t)w0 * Lt * Nh, sh + (size_t)w0 * Lt * Nh, dbar + (size_t)w0 * N, cbar + (size_t)w0 * Nh,
-                       sbar + (size_t)w0 * Nh, kg.pcs + (size_t)w0 * kg.ptotal, kg.psrc, kg.ptotal, Lt, N, Nh, shi ? shi + (size_t)w0 * Lt * Nh : nullptr, sbari ? sbari + (size_t)w0 * Nh : nullptr);
+                       sbar + (size_t)w0 * Nh, kg.pcs + (size_t)w0 * kg.ptotal, kg.psrc, kg.ptotal, Lt, N, Nh, shi ? shi + (size_t)w0 * Lt * Nh : nullptr, sbari ? sbari + (size_t)w0 * Nh : nullptr,
+                       (kg.pcsi && shi) ? kg.pcsi + (size_t)w0 * kg.ptotal : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -98,6 +100,7 @@ struct LaneBonds {
     int2 b[kMaxColours];  // LDS positions
     int2 s0, sL;          // site ids of the first / last colour's bond
     double2 cs[kMaxColours];
+    double si[kMaxColours];  // Im s̄ for T = ComplexF64 (KpmGeom::pcsi), else 0 and unused
     bool on[kMaxColours];
 };
 
@@ -111,12 +114,14 @@ __device__ __forceinline__ void load_lane_bonds(LaneBonds &lb, const KpmGeom &kg
         lb.on[c] = false;
         lb.b[c] = make_int2(0, 0);
         lb.cs[c] = make_double2(1.0, 0.0);
+        lb.si[c] = 0.0;
         if (c < ncol) {
             const int idx = kg.poff[c] + (int)threadIdx.x;
             if (idx < kg.poff[c + 1]) {
                 lb.on[c] = true;
                 lb.b[c] = kg.pbonds[idx];
                 lb.cs[c] = kg.pcs[(size_t)w * kg.ptotal + idx];
+                if (kg.pcsi) lb.si[c] = kg.pcsi[(size_t)w * kg.ptotal + idx];
             }
         }
     }
@@ -131,6 +136,31 @@ __device__ __forceinline__ void load_lane_bonds(LaneBonds &lb, const KpmGeom &kg
             W[lb.b[c_].y] = lin2(lb.cs[c_].x, d_, lb.cs[c_].y, a_);             \
         }                                                                       \
         __syncthreads();                                                        \
+    }
+
+// the bond factor [[c, s], [conj(s), c]] on (a, d) = (u_i, u_j), bond (i, j) in neighbour-table order (checkerboard_matrix_multiply.jl:60-68);
+// CPLX = false: s real, the plain pair of lin2
+template <bool CPLX>
+__device__ __forceinline__ void bond2(double c, double sr, double si, double2 a, double2 d, double2 &oa, double2 &od)
+{
+    oa = lin2(c, a, sr, d);
+    od = lin2(c, d, sr, a);
+    if (CPLX) {
+        oa.x -= si * d.y; oa.y += si * d.x;
+        od.x += si * a.y; od.y -= si * a.x;
+    }
+}
+// PLAIN_STAGE with the bond factor of a complex s̄ when CPLX (a template parameter in scope) says so
+#define PLAIN_STAGE_C(c_)                                                                         \
+    {                                                                                             \
+        if (lb.on[c_]) {                                                                          \
+            const double2 a_ = W[lb.b[c_].x], d_ = W[lb.b[c_].y];                                 \
+            double2 oa_, od_;                                                                     \
+            bond2<CPLX>(lb.cs[c_].x, lb.cs[c_].y, lb.si[c_], a_, d_, oa_, od_);                   \
+            W[lb.b[c_].x] = oa_;                                                                  \
+            W[lb.b[c_].y] = od_;                                                                  \
+        }                                                                                         \
+        __syncthreads();                                                                          \
     }
 
 // W <- B W where B = Sym B̄ (MODE 0), Asym B̄ = D̄Γ̄ (MODE 1) or Asym B̄ᵀB̄ = Γ̄ᵀD̄²Γ̄ (MODE 2); plain form
@@ -179,7 +209,7 @@ __device__ __forceinline__ void bbar_apply_regs(double2 *W, const LaneBonds &lb,
 // ---------------------------------------------------------------------------------------------
 // One polynomial: on entry the lane holds the input at its last-colour site pair in (vi, vj);
 // on exit (vi, vj) hold Σ_k coefs[k] T_k(B') v at the same sites.  W is the N-vector in LDS.
-template <bool SYM>
+template <bool SYM, bool CPLX = false>
 __device__ __forceinline__ void kpm_poly_regs(double2 *W, const LaneBonds &lb, int ncol, const double2 *__restrict__ coefs, int n, double avg, double imag_, double di, double dj, double dLi, double dLj,
                                               double2 &vi, double2 &vj)
 {
@@ -188,20 +218,19 @@ __device__ __forceinline__ void kpm_poly_regs(double2 *W, const LaneBonds &lb, i
     // last-colour data (runtime colour index -> select through an unrolled scan)
     int2 bL = make_int2(0, 0);
     double2 csL = make_double2(1.0, 0.0);
+    double siL = 0.0;
     bool onL = false;
 #pragma unroll
     for (int c = 0; c < kMaxColours; ++c)
-        if (c == cl) { bL = lb.b[c]; csL = lb.cs[c]; onL = lb.on[c]; }
+        if (c == cl) { bL = lb.b[c]; csL = lb.cs[c]; siL = lb.si[c]; onL = lb.on[c]; }
     // Sym with L >= 2 runs in the basis α̃ = C_L α
     const bool xf = SYM && L >= 2;
     double2 a1i = vi, a1j = vj;
-    if (xf) {
-        a1i = lin2(csL.x, vi, csL.y, vj);
-        a1j = lin2(csL.x, vj, csL.y, vi);
-    }
+    if (xf) bond2<CPLX>(csL.x, csL.y, siL, vi, vj, a1i, a1j);
     if (onL) { W[bL.x] = a1i; W[bL.y] = a1j; }
     __syncthreads();
-    const double q_c = csL.x * csL.x + csL.y * csL.y, q_s = 2.0 * csL.x * csL.y;  // C_L²
+    // C_L² = [[c² + |s|², 2cs], [2c conj(s), c² + |s|²]]
+    const double q_c = CPLX ? csL.x * csL.x + csL.y * csL.y + siL * siL : csL.x * csL.x + csL.y * csL.y, q_s = 2.0 * csL.x * csL.y, q_si = CPLX ? 2.0 * csL.x * siL : 0.0;
     double2 a2i = make_double2(0, 0), a2j = a2i, acci = a2i, accj = a2i;
     for (int k = 1; k < n; ++k) {
         const double2 ck = coefs[k];  // issued early; consumed after the stages
@@ -209,38 +238,38 @@ __device__ __forceinline__ void kpm_poly_regs(double2 *W, const LaneBonds &lb, i
         if (SYM) {
 #pragma unroll
             for (int c = kMaxColours - 2; c >= 1; --c)
-                if (c < L - 1) PLAIN_STAGE(c)
+                if (c < L - 1) PLAIN_STAGE_C(c)
             if (L >= 2) {
                 if (lb.on[0]) {
                     const double2 a = W[lb.b[0].x], d = W[lb.b[0].y];
-                    double2 x = lin2(lb.cs[0].x, a, lb.cs[0].y, d), y = lin2(lb.cs[0].x, d, lb.cs[0].y, a);
+                    double2 x, y, ox, oy;
+                    bond2<CPLX>(lb.cs[0].x, lb.cs[0].y, lb.si[0], a, d, x, y);
                     x = make_double2(di * x.x, di * x.y);
                     y = make_double2(dj * y.x, dj * y.y);
-                    W[lb.b[0].x] = lin2(lb.cs[0].x, x, lb.cs[0].y, y);
-                    W[lb.b[0].y] = lin2(lb.cs[0].x, y, lb.cs[0].y, x);
+                    bond2<CPLX>(lb.cs[0].x, lb.cs[0].y, lb.si[0], x, y, ox, oy);
+                    W[lb.b[0].x] = ox;
+                    W[lb.b[0].y] = oy;
                 }
                 __syncthreads();
 #pragma unroll
                 for (int c = 1; c < kMaxColours - 1; ++c)
-                    if (c < L - 1) PLAIN_STAGE(c)
+                    if (c < L - 1) PLAIN_STAGE_C(c)
                 const double2 a = W[bL.x], d = W[bL.y];
-                xi = lin2(q_c, a, q_s, d);
-                xj = lin2(q_c, d, q_s, a);
+                bond2<CPLX>(q_c, q_s, q_si, a, d, xi, xj);
             } else {  // single colour: B̄ = C₁ D̄ C₁, state owned by colour 0 itself
                 const double2 a = W[bL.x], d = W[bL.y];
-                double2 x = lin2(csL.x, a, csL.y, d), y = lin2(csL.x, d, csL.y, a);
+                double2 x, y;
+                bond2<CPLX>(csL.x, csL.y, siL, a, d, x, y);
                 x = make_double2(di * x.x, di * x.y);
                 y = make_double2(dj * y.x, dj * y.y);
-                xi = lin2(csL.x, x, csL.y, y);
-                xj = lin2(csL.x, y, csL.y, x);
+                bond2<CPLX>(csL.x, csL.y, siL, x, y, xi, xj);
             }
         } else {
 #pragma unroll
             for (int c = 0; c < kMaxColours - 1; ++c)
-                if (c < L - 1) PLAIN_STAGE(c)
+                if (c < L - 1) PLAIN_STAGE_C(c)
             const double2 a = W[bL.x], d = W[bL.y];
-            xi = lin2(csL.x, a, csL.y, d);
-            xj = lin2(csL.x, d, csL.y, a);
+            bond2<CPLX>(csL.x, csL.y, siL, a, d, xi, xj);
             xi = make_double2(dLi * xi.x, dLi * xi.y);
             xj = make_double2(dLj * xj.x, dLj * xj.y);
         }
@@ -269,9 +298,16 @@ __device__ __forceinline__ void kpm_poly_regs(double2 *W, const LaneBonds &lb, i
         }
     }
     if (xf) {  // back to the original basis: C_L⁻¹
-        const double idet = 1.0 / (csL.x * csL.x - csL.y * csL.y);
-        vi = make_double2((csL.x * acci.x - csL.y * accj.x) * idet, (csL.x * acci.y - csL.y * accj.y) * idet);
-        vj = make_double2((csL.x * accj.x - csL.y * acci.x) * idet, (csL.x * accj.y - csL.y * acci.y) * idet);
+        if (CPLX) {  // C_L⁻¹ = [[c, −s], [−conj(s), c]] / (c² − |s|²)
+            const double idet = 1.0 / (csL.x * csL.x - csL.y * csL.y - siL * siL);
+            bond2<true>(csL.x, -csL.y, -siL, acci, accj, vi, vj);
+            vi = make_double2(vi.x * idet, vi.y * idet);
+            vj = make_double2(vj.x * idet, vj.y * idet);
+        } else {
+            const double idet = 1.0 / (csL.x * csL.x - csL.y * csL.y);
+            vi = make_double2((csL.x * acci.x - csL.y * accj.x) * idet, (csL.x * acci.y - csL.y * accj.y) * idet);
+            vj = make_double2((csL.x * accj.x - csL.y * acci.x) * idet, (csL.x * accj.y - csL.y * acci.y) * idet);
+        }
     } else {
         vi = acci;
         vj = accj;
@@ -288,7 +324,7 @@ __device__ __forceinline__ double2 block_sum_cplx(double2 v, double *red)
 
 // NCOL > 0 fixes the number of colours at compile time (the per-stage colour tests fold away);
 // NCOL = 0 reads it at run time.
-template <bool SYM, int NCOL>
+template <bool SYM, int NCOL, bool CPLX = false>
 __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
 {
     const int ncol = NCOL > 0 ? NCOL : k.ncol;
@@ -358,11 +394,11 @@ __global__ void __launch_bounds__(1024) cheb_fast_kernel(KpmArgs k, KpmGeom kg)
     }
     __syncthreads();
     if (SYM) {
-        kpm_poly_regs<true>(W, lb, ncol, CF, n, avg, imag_, di, dj, dLi, dLj, vi, vj);  // :394
+        kpm_poly_regs<true, CPLX>(W, lb, ncol, CF, n, avg, imag_, di, dj, dLi, dLj, vi, vj);  // :394
     } else {
-        kpm_poly_regs<false>(W, lb, ncol, CF2, n2, avg, imag_, di, dj, dLi, dLj, vi, vj);
+        kpm_poly_regs<false, CPLX>(W, lb, ncol, CF2, n2, avg, imag_, di, dj, dLi, dLj, vi, vj);
         __syncthreads();
-        kpm_poly_regs<false>(W, lb, ncol, CF, n, avg, imag_, di, dj, dLi, dLj, vi, vj);
+        kpm_poly_regs<false, CPLX>(W, lb, ncol, CF, n, avg, imag_, di, dj, dLi, dLj, vi, vj);
     }
     double2 acc = make_double2(0.0, 0.0);
     if (onL) {
@@ -1092,8 +1128,13 @@ bool cheb_split_active(const KpmArgs &k, const KpmGeom &kg)
     return kg.fast && k.is_sym && k.ncol >= 2 && k.ncol <= 6 && kg.own && cheb_own_enabled() && cheb_split_enabled() && !k.half && k.sbari == nullptr;
 }
 
+// complex hoppings (round 4): Sym handles whose geometry fits the padded lists run cheb_fast_kernel<true, NCOL, CPLX>; everything else of
+// a complex handle (Lanczos, Asym, the real-vector method) stays on the generic kernels (kg.fast = 0)
+static bool cheb_cplx_fast(const KpmArgs &k, const KpmGeom &kg) { return !kg.fast && kg.cplx_fast && kg.pcsi && k.is_sym && k.sbari != nullptr; }
+
 const char *cheb_kernel_name(const KpmArgs &k, const KpmGeom &kg)
 {
+    if (cheb_cplx_fast(k, kg)) return "cheb_fast_kernel<complex T>";
     if (!kg.fast) return "cheb_generic_kernel";
     if (cheb_wave_supported(k, kg)) return kg.wave_kind == 2 ? "cheb_wave_kernel<plaquette>" : (kg.wave_lanes == 64 ? "cheb_wave_kernel<ring, DPP>" : "cheb_wave_kernel<ring>");
     if (k.is_sym && k.ncol >= 2 && k.ncol <= 6 && kg.own && cheb_own_enabled()) return cheb_split_active(k, kg) ? (kg.wl0 && k.ncol >= 3 ? "cheb_own_kernel<split, WL0>" : "cheb_own_kernel<split>") : "cheb_own_kernel";
@@ -1103,6 +1144,19 @@ const char *cheb_kernel_name(const KpmArgs &k, const KpmGeom &kg)
 
 void launch_cheb(hipStream_t st, const KpmArgs &k, const KpmGeom &kg)
 {
+    if (cheb_cplx_fast(k, kg)) {
+        const size_t lds = sizeof(double2) * ((size_t)k.N + 2 * (size_t)k.maxorder);
+        const int ncnt = k.sys_count > 0 ? k.sys_count : k.nsys;
+        const dim3 grid((unsigned)(k.Lt * ncnt)), block((unsigned)kg.threads);
+        switch (k.ncol) {
+            case 1: hipLaunchKernelGGL((cheb_fast_kernel<true, 1, true>), grid, block, lds, st, k, kg); break;
+            case 2: hipLaunchKernelGGL((cheb_fast_kernel<true, 2, true>), grid, block, lds, st, k, kg); break;
+            case 3: hipLaunchKernelGGL((cheb_fast_kernel<true, 3, true>), grid, block, lds, st, k, kg); break;
+            case 4: hipLaunchKernelGGL((cheb_fast_kernel<true, 4, true>), grid, block, lds, st, k, kg); break;
+            default: hipLaunchKernelGGL((cheb_fast_kernel<true, 0, true>), grid, block, lds, st, k, kg); break;
+        }
+        return;
+    }
     if (kg.fast) {
         const size_t lds = sizeof(double2) * ((size_t)k.N + 2 * (size_t)k.maxorder);
         const int ncnt = k.sys_count > 0 ? k.sys_count : k.nsys;

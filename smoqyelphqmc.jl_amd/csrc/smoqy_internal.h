@@ -138,6 +138,8 @@ struct KpmGeom {
     const int *poff;     // [ncol + 1] (device)
     const int *psrc;     // [ptotal] source bond index, -1 for a self bond
     double2 *pcs;        // [nw][ptotal] tau-averaged (cosh, sinh) per padded bond
+    double *pcsi;        // [nw][ptotal] tau-averaged Im sinh per padded bond (T = ComplexF64, Sym), else nullptr
+    int cplx_fast;       // complex hoppings, Sym, geometry within the padded lists: cheb_fast_kernel<true, NCOL, CPLX> although fast = 0
     int ptotal;
     int threads;         // workgroup size = padded bonds per colour rounded up to a wavefront
     int fast;            // 0: use the generic kernels

@@ -2,8 +2,8 @@
 dense matrices in tests/test_oracle_complex_T.py.  Reference: the bond factor [[c, s], [conj(s), c]] with
 s = sign(conj t)·sinh(Δτ′|t|) (src/checkerboard_matrix_multiply.jl:60-68, src/FermionDetMatrix.jl:224-231); the operator type is
 FermionDetMatrix{T<:Number} (:19).  Round 4: Sym complex handles run the register-resident operator kernel (fdm_fast_kernel<…, CPLX>) up to
-a τ-chunk of 2; Asym complex handles, larger chunks and the preconditioner run on the generic kernels (kernels_fdm.hip,
-cheb_generic_kernel, generic Lanczos) — both families are compared with the oracle here."""
+a τ-chunk of 2 and the register-resident Chebyshev kernel (cheb_fast_kernel<true, NCOL, CPLX>); Asym complex handles, larger chunks and
+the Lanczos bounds run on the generic kernels (kernels_fdm.hip, cheb_generic_kernel, generic Lanczos) — both families are compared with the oracle here."""
 import ctypes as C
 
 import numpy as np
@@ -162,6 +162,16 @@ def test_kpm_preconditioner_and_pcg_complex_T(kind, is_sym):
     h.call("smoqy_precond_apply", L.ptr(out), L.ptr(v), 0, 2)
     for s in range(2):
         assert relerr(out[:, :, s], P.apply(v[:, :, s])) < 1e-11
+    # Sym: the register-resident Chebyshev kernel with the complex bond factor (round 4); Asym: the generic kernel.  Both forms of the Sym
+    # handle must agree with the oracle (smoqy_precond_force_generic switches)
+    assert h.describe()["cheb"] == ("cheb_fast_kernel<complex T>" if is_sym else "cheb_generic_kernel"), h.describe()
+    if is_sym:
+        h.call("smoqy_precond_force_generic", 1)
+        out2 = np.zeros_like(v)
+        h.call("smoqy_precond_apply", L.ptr(out2), L.ptr(v), 0, 2)
+        assert h.describe()["cheb"] == "cheb_generic_kernel"
+        assert relerr(out2, out) < 1e-12
+        h.call("smoqy_precond_force_generic", 0)
     for rocfft in (0, 1):  # fused tau-FFT iteration and the rocFFT + BLAS-1 form
         h.call("smoqy_fft_use_rocfft", rocfft)
         x = np.zeros_like(v)
