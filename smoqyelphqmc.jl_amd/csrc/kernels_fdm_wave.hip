@@ -27,6 +27,7 @@
 // lattices that do not fit keep fdm_stream_kernel / fdm_fast_kernel.  Per-site arithmetic equals theirs up to the folded centre
 // stage (two roundings instead of five) — compared with the oracle at 1e-13 like every operator kernel.
 #include "smoqy_internal.h"
+#include "wave_desc.h"
 
 #include <algorithm>
 #include <array>
@@ -35,6 +36,7 @@
 #include <vector>
 
 namespace smoqy {
+using namespace wave_desc;
 namespace {
 
 __device__ __forceinline__ int wrapl(int l, int Lt) { return l >= Lt ? l - Lt : (l < 0 ? l + Lt : l); }
@@ -46,66 +48,10 @@ __device__ __forceinline__ double2 hopcomb(double2 v, double2 u, bool wrap, bool
     return make_double2(v.x - (pr * u.x - pi * u.y), v.y - (pr * u.y + pi * u.x));
 }
 
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-// ---- lane programs (compile-time part; the host side below holds the same tables: GroupDesc) --------------------------------
-// pp(c, p): position of the partner of own position p under colour c (in this lane, or in the lane of row rr(c, p) of the table when
-// rr >= 0); bs(c, p): the lane's bond slot holding that bond's (cosh, sinh).
-struct RingD {
-    static constexpr int S = 4, NCOL = 2, NB = 5, NR = 2, KIND = 1;
-    static constexpr bool REMOTE0 = false;
-    __host__ __device__ static constexpr int pp(int c, int p) { constexpr int t[2][4] = {{1, 0, 3, 2}, {3, 2, 1, 0}}; return t[c][p]; }
-    __host__ __device__ static constexpr int rr(int c, int p) { constexpr int t[2][4] = {{-1, -1, -1, -1}, {1, -1, -1, 0}}; return t[c][p]; }
-    __host__ __device__ static constexpr int bs(int c, int p) { constexpr int t[2][4] = {{0, 0, 1, 1}, {4, 2, 2, 3}}; return t[c][p]; }
-};
-struct PlaqD {
-    static constexpr int S = 4, NCOL = 4, NB = 12, NR = 8, KIND = 2;
-    static constexpr bool REMOTE0 = true;
-    __host__ __device__ static constexpr int pp(int c, int p) { constexpr int t[4][4] = {{1, 0, 3, 2}, {1, 0, 3, 2}, {3, 2, 1, 0}, {3, 2, 1, 0}}; return t[c][p]; }
-    __host__ __device__ static constexpr int rr(int c, int p) { constexpr int t[4][4] = {{0, 1, 2, 3}, {-1, -1, -1, -1}, {-1, -1, -1, -1}, {4, 5, 6, 7}}; return t[c][p]; }
-    __host__ __device__ static constexpr int bs(int c, int p) { constexpr int t[4][4] = {{4, 5, 6, 7}, {0, 0, 1, 1}, {3, 2, 2, 3}, {8, 9, 10, 11}}; return t[c][p]; }
-};
-// 2 x 2 unit cells: cell k = dx + 2 dy holds A at position 2k and B at 2k + 1; colour 0 = A–B of a cell, colour 1 = A(x) – B(x − 1),
-// colour 2 = A(y) – B(y − 1); rows of the lane table: 0 left, 1 right, 2 below, 3 above
-struct HoneyD {
-    static constexpr int S = 8, NCOL = 3, NB = 16, NR = 4, KIND = 3;
-    static constexpr bool REMOTE0 = false;
-    __host__ __device__ static constexpr int pp(int c, int p)
-    {
-        constexpr int t[3][8] = {{1, 0, 3, 2, 5, 4, 7, 6}, {3, 2, 1, 0, 7, 6, 5, 4}, {5, 4, 7, 6, 1, 0, 3, 2}};
-        return t[c][p];
-    }
-    __host__ __device__ static constexpr int rr(int c, int p)
-    {
-        constexpr int t[3][8] = {{-1, -1, -1, -1, -1, -1, -1, -1}, {0, -1, -1, 1, 0, -1, -1, 1}, {2, -1, 2, -1, -1, 3, -1, 3}};
-        return t[c][p];
-    }
-    __host__ __device__ static constexpr int bs(int c, int p)
-    {
-        constexpr int t[3][8] = {{0, 0, 1, 1, 2, 2, 3, 3}, {6, 4, 4, 8, 7, 5, 5, 9}, {12, 10, 13, 11, 10, 14, 11, 15}};
-        return t[c][p];
-    }
-};
-
 __device__ __forceinline__ double2 shfl2(double2 x, int lane)
 {
     return make_double2(__shfl(x.x, lane, 64), __shfl(x.y, lane, 64));
 }
-template <int CTRL>
-__device__ __forceinline__ double wave_rot(double x)
-{
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
 // the fields of one time slice as a lane needs them: (cosh, sinh) per bond slot (CSM = 2: τ-dependent, reloaded per slice), the two
 // folded centre coefficients per own site
 template <class D, int CSM>
