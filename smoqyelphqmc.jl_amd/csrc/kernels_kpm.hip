@@ -1493,12 +1493,27 @@ __global__ void __launch_bounds__(1024) lanczos_own_kernel(KpmArgs k, KpmGeom kg
     const bool two = P.on && P.sy != P.sx;
     const int wave = j >> 6, lane = j & 63, nwave = (Tn + 63) >> 6;
     int rb = 0;
+    if (j < 32) red2[j >> 4][j & 15] = 0.0;  // rows past the last wavefront stay zero: the sum below reads a fixed number of slots
+    __syncthreads();
     auto bsum = [&](double v) {  // workgroup sum, one barrier: safe because consecutive calls alternate rows and a barrier lies between two uses of a row
         v = wsum_k(v);
         if (lane == 0) red2[rb][wave] = v;
         __syncthreads();
+        // the wave sums are added in wave order, as before; reading a FIXED count (4 or 16 slots, zeros behind the last wavefront: x + 0 = x)
+        // lets the reads issue together — the loop over the run-time wave count compiled to one LDS round trip per wave sum, ~480 cycles of
+        // the ~2600 of a Lanczos step, twice per step (round 4, tools/phase_probe.hip for the primitives)
+        const double *r = red2[rb];
         double t = 0.0;
-        for (int q = 0; q < nwave; ++q) t += red2[rb][q];
+        if (nwave <= 4) {
+            const double r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+            t = (((t + r0) + r1) + r2) + r3;
+        } else {
+            double rr[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) rr[q] = r[q];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += rr[q];
+        }
         rb ^= 1;
         return t;
     };
@@ -1514,15 +1529,19 @@ __global__ void __launch_bounds__(1024) lanczos_own_kernel(KpmArgs k, KpmGeom kg
         const double wx = ax - al * vkx - bprev * vmx;
         const double wy = two ? ay - al * vky - bprev * vmy : 0.0;
         const double nb = sqrt(bsum(P.on ? wx * wx + wy * wy : 0.0));
-        if (j == 0) {
-            alpha[s] = al; sa[s] = al;
-            if (s < nsteps - 1) { beta[s] = nb; sb[s] = nb; }
+        if (j == 0) {  // LDS only inside the loop: a global store here is waited for (vmcnt) at the next barrier of every step
+            sa[s] = al;
+            if (s < nsteps - 1) sb[s] = nb;
         }
         vmx = vkx; vmy = vky;
         vkx = wx / nb; vky = wy / nb;
         bprev = nb;
     }
     __syncthreads();
+    for (int q = j; q < nsteps; q += Tn) {   // smoqy_precond_get reads them back
+        alpha[q] = sa[q];
+        if (q < nsteps - 1) beta[q] = sb[q];
+    }
     precond_bookkeeping(sa, sb, nsteps, w, u, sh);
 }
 
