@@ -1255,17 +1255,32 @@ void launch_conj_mirror(hipStream_t st, double2 *v, int Lt, int N, int nsys)
 // device-side bookkeeping of update_preconditioner! (KPMPreconditioner.jl:565-597, 696-731): runs at the end of the Lanczos kernel,
 // in the same workgroup (one per walker)
 // ---------------------------------------------------------------------------------------------
-// number of eigenvalues of the symmetric tridiagonal (a, b) below x (Sturm sequence; the host restatement it replaces: round 2's host `sturm`)
+// number of eigenvalues of the symmetric tridiagonal (a, b) below x: sign changes of the leading principal minors p_i(x) of T − x
+// (p_0 = 1, p_1 = a_0 − x, p_{i+1} = (a_i − x) p_i − b_{i-1}² p_{i-1}).  Round 4: the quotient form q_i = p_i / p_{i-1} this replaces put one fp64
+// DIVISION (77 cycles, tools/phase_probe.hip) on the dependent chain of every one of the n steps of every one of the 11 rounds of the
+// 64-section below — ~17 of the 44 us of a 20-step Lanczos launch; here the chain is one multiply-add per step.  A zero minor takes the sign
+// of its predecessor (the quotient form's "q = 0 is not negative"); the pair is rescaled by an exact power of two before it can leave the
+// double range (n_lanczos may be as large as 1024).
 __device__ __forceinline__ int sturm_count_dev(const double *a, const double *b, int n, double x)
 {
-    int cnt = 0;
-    double q = a[0] - x;
-    if (q < 0) ++cnt;
-    for (int i = 1; i < n; ++i) {
-        const double den = (fabs(q) < 1e-300) ? (q < 0 ? -1e-300 : 1e-300) : q;
-        q = a[i] - x - b[i - 1] * b[i - 1] / den;
-        if (q < 0) ++cnt;
+    double p0 = 1.0, p1 = a[0] - x;
+    bool s1 = p1 < 0.0;  // sign of p_1 against p_0 = 1
+    int cnt = s1 ? 1 : 0;
+    int i = 1;
+    auto step = [&](double ai, double bi) {
+        const double p2 = (ai - x) * p1 - (bi * bi) * p0;
+        const bool s2 = p2 != 0.0 ? (p2 < 0.0) : s1;
+        cnt += (s2 != s1) ? 1 : 0;
+        p0 = p1; p1 = p2; s1 = s2;
+    };
+    for (; i + 3 < n; i += 4) {
+        const double a0 = a[i], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3];   // the loads of a block issue together
+        const double b0 = b[i - 1], b1 = b[i], b2 = b[i + 1], b3 = b[i + 2];
+        step(a0, b0); step(a1, b1); step(a2, b2); step(a3, b3);
+        if (fabs(p1) > 0x1p+400 || fabs(p0) > 0x1p+400) { p0 *= 0x1p-400; p1 *= 0x1p-400; }
+        else if (fabs(p1) < 0x1p-400 && fabs(p0) < 0x1p-400) { p0 *= 0x1p+400; p1 *= 0x1p+400; }
     }
+    for (; i < n; ++i) step(a[i], b[i - 1]);
     return cnt;
 }
 

@@ -48,8 +48,41 @@ void run(const char *name, int threads)
     printf("%-44s %4d lanes: %7.1f ns per iteration, %7.1f shader-clock ticks -> %5.2f GHz\n", name, threads, h[0] * 10.0 / 1000.0, h[1] / 1000.0, (double)h[1] / (h[0] * 10.0));
     (void)hipFree(d); (void)hipFree(t);
 }
+// the shader clock a stream of small kernels runs at: `wgs` workgroups of 256 lanes spin on dependent FMAs for ~10 us, launched back to back
+// (or with a host synchronisation after each launch: the "trickle" of a polling driver); workgroup 0 stamps both clocks
+__global__ void spin(double *out, unsigned long long *t, int iters, int slot)
+{
+    double x = 1.0 + threadIdx.x * 1e-9;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) x = x * 1.0000001 + 1e-9;
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_amdgcn_s_memtime();
+    if (x == 0.5) out[0] = x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { t[2 * slot] = r1 - r0; t[2 * slot + 1] = c1 - c0; }
+}
+void clocks(const char *name, int wgs, bool sync_each)
+{
+    const int n = 2000;
+    double *d; unsigned long long *t;
+    (void)hipMalloc(&d, 8); (void)hipMalloc(&t, 2 * n * sizeof(unsigned long long));
+    unsigned long long *h = new unsigned long long[2 * n];
+    for (int i = 0; i < n; ++i) {
+        hipLaunchKernelGGL(spin, dim3(wgs), dim3(256), 0, 0, d, t, 4000, i);
+        if (sync_each) (void)hipDeviceSynchronize();
+    }
+    (void)hipMemcpy(h, t, 2 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    printf("%-58s", name);
+    const int at[5] = {0, 10, 100, 1000, 1999};
+    for (int q = 0; q < 5; ++q) printf("  #%d: %5.1f us %4.2f GHz", at[q], h[2 * at[q]] * 0.01, (double)h[2 * at[q] + 1] / (h[2 * at[q]] * 10.0));
+    printf("\n");
+    delete[] h; (void)hipFree(d); (void)hipFree(t);
+}
 int main()
 {
+    clocks("64 workgroups, back to back", 64, false);
+    clocks("64 workgroups, host synchronisation after each launch", 64, true);
+    clocks("1 workgroup, back to back", 1, false);
+    clocks("1 workgroup, host synchronisation after each launch", 1, true);
+    clocks("2048 workgroups, back to back", 2048, false);
     run<5>("dependent fp64 FMA", 64);
     run<6>("four independent FMAs + sum", 64);
     run<0>("DPP wavefront sum (wsum_k) + FMA", 64);
