@@ -325,8 +325,10 @@ int smoqy_hmc_trajectory_v(smoqy_ctx *ctx, int phi, int psi, int Nt, double dt, 
  * until the trajectory's end — each solve is launched with the iterations its step needed in the previous trajectory of the same length
  * and tolerance plus a margin, the per-step states stay on the device, and at the end EVERY solve is checked (converged, finite residual);
  * if one is not, x, p and the fields are put back and the trajectory is repeated with polls.  Same kernels, same iterations: the results
- * of the two forms are identical.  on < 0 leaves the setting alone; *runs / *misses (may be NULL) count the asynchronous trajectories and
- * the ones that had to be repeated. */
+ * of the two forms are identical.  The library takes the asynchronous form only where it pays: every step of the previous trajectory
+ * within 64 iterations (longer solves gain nothing from the missing polls and their counts move by tens), and after a repeated trajectory
+ * the next 1, 2, 4 … 64 ones poll.  on < 0 leaves the setting alone; *runs / *misses (may be NULL) count the asynchronous trajectories
+ * and the ones that had to be repeated. */
 int smoqy_hmc_async(smoqy_ctx *ctx, int on, long *runs, long *misses);
 
 /* ---- device-side update! from the phonon fields ------------------- */
