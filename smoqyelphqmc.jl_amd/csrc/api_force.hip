@@ -132,6 +132,8 @@ ForceArgs force_args(smoqy_ctx *c, double nu, const double2 *u, const double2 *v
     a.Nph = c->force.Nph; a.Nhol = c->force.Nhol; a.Nssh = c->force.Nssh; a.Q = c->force.Q;
     a.x = c->force.d_x; a.contrib = c->force.d_contrib;
     a.scratch = c->d_big; a.scratch_stride = c->big_stride;
+    a.cs_slice0 = (c->g.is_sym && !c->cs_const.empty()) ? 1 : 0;
+    for (int w = 0; w < g.nw && a.cs_slice0; ++w) a.cs_slice0 = c->cs_const[(size_t)w] != 0;
     return a;
 }
 

@@ -23,11 +23,13 @@ __device__ __forceinline__ int wrapf(int l, int Lt) { return l >= Lt ? l - Lt : 
 // 132-141), and the SSH derivative ΔτdK is complex: ν Re[conj(u'_j) dK v'_i + conj(u'_i) conj(dK) v'_j] (:225-227).  Real handles take the
 // branches they always took.
 __device__ __forceinline__ void colour_step(const ForceArgs &a, double2 *UP, double2 *VP, int nk, int l0, int w, int c, const double *ch, const double *sh, const double *shi, bool accumulate, int pass,
-                                            double dtau_k, double nu, bool apply_u, bool apply_v)
+                                            double dtau_k, double nu, bool apply_u, bool apply_v, const double2 *F = nullptr, const int2 *BL = nullptr, const int *OL = nullptr)
 {
     const int N = a.N, Lt = a.Lt;
-    for (int h = a.col_off[c] + (int)threadIdx.x; h < a.col_off[c + 1]; h += (int)blockDim.x) {
-        const int2 b = a.bonds[h];
+    const int2 *bonds_ = BL ? BL : a.bonds;
+    const int *coff_ = OL ? OL : a.col_off;
+    for (int h = coff_[c] + (int)threadIdx.x; h < coff_[c + 1]; h += (int)blockDim.x) {
+        const int2 b = bonds_[h];
         for (int k = 0; k < nk; ++k) {
             const int l = l0 + k;
             double2 *ur = UP + (size_t)k * N, *vr = VP + (size_t)k * N;
@@ -48,7 +50,7 @@ __device__ __forceinline__ void colour_step(const ForceArgs &a, double2 *UP, dou
                     a.contrib[((size_t)w * Lt + l) * a.Q + a.Nhol + 2 * cpl + pass] = val;
                 }
             }
-            const double cc = ch[(size_t)l * a.Nh + h], ss = sh[(size_t)l * a.Nh + h];
+            const double cc = F ? F[(size_t)k * a.Nh + h].x : ch[(size_t)l * a.Nh + h], ss = F ? F[(size_t)k * a.Nh + h].y : sh[(size_t)l * a.Nh + h];
             if (shi) {
                 const double ti = shi[(size_t)l * a.Nh + h];  // s = ss + i ti
                 if (apply_u) {
@@ -75,13 +77,16 @@ __device__ __forceinline__ void colour_step(const ForceArgs &a, double2 *UP, dou
 }
 
 // plain colour on one array (building B v)
-__device__ __forceinline__ void colour_plain(const ForceArgs &a, double2 *X, int nk, int l0, int c, const double *ch, const double *sh, const double *shi)
+__device__ __forceinline__ void colour_plain(const ForceArgs &a, double2 *X, int nk, int l0, int c, const double *ch, const double *sh, const double *shi, const double2 *F = nullptr, const int2 *BL = nullptr, const int *OL = nullptr)
 {
     const int N = a.N;
-    for (int h = a.col_off[c] + (int)threadIdx.x; h < a.col_off[c + 1]; h += (int)blockDim.x) {
-        const int2 b = a.bonds[h];
+    const int2 *bonds_ = BL ? BL : a.bonds;
+    const int *coff_ = OL ? OL : a.col_off;  // (LDS copies made by the kernel's prologue: no dependent global load at the head of a pass)
+    for (int h = coff_[c] + (int)threadIdx.x; h < coff_[c + 1]; h += (int)blockDim.x) {
+        const int2 b = bonds_[h];
         for (int k = 0; k < nk; ++k) {
-            const double cc = ch[(size_t)(l0 + k) * a.Nh + h], ss = sh[(size_t)(l0 + k) * a.Nh + h];
+            // F: the chunk's (cosh, sinh) staged in LDS by the kernel's prologue (all loads in flight at once) instead of a dependent global load per pass
+            const double cc = F ? F[(size_t)k * a.Nh + h].x : ch[(size_t)(l0 + k) * a.Nh + h], ss = F ? F[(size_t)k * a.Nh + h].y : sh[(size_t)(l0 + k) * a.Nh + h];
             double2 *r = X + (size_t)k * N;
             const double2 x = r[b.x], y = r[b.y];
             if (shi) {
@@ -92,6 +97,34 @@ __device__ __forceinline__ void colour_plain(const ForceArgs &a, double2 *X, int
             }
             r[b.x] = make_double2(cc * x.x + ss * y.x, cc * x.y + ss * y.y);
             r[b.y] = make_double2(cc * y.x + ss * x.x, cc * y.y + ss * x.y);
+        }
+    }
+    __syncthreads();
+}
+
+// the same colour on TWO arrays in one pass (one barrier, one read of the bond's factors): X and Y both take C_c
+__device__ __forceinline__ void colour_plain2(const ForceArgs &a, double2 *X, double2 *Y, int nk, int l0, int c, const double *ch, const double *sh, const double *shi, const double2 *F = nullptr, const int2 *BL = nullptr, const int *OL = nullptr)
+{
+    const int N = a.N;
+    const int2 *bonds_ = BL ? BL : a.bonds;
+    const int *coff_ = OL ? OL : a.col_off;  // (LDS copies made by the kernel's prologue: no dependent global load at the head of a pass)
+    for (int h = coff_[c] + (int)threadIdx.x; h < coff_[c + 1]; h += (int)blockDim.x) {
+        const int2 b = bonds_[h];
+        for (int k = 0; k < nk; ++k) {
+            // F: the chunk's (cosh, sinh) staged in LDS by the kernel's prologue (all loads in flight at once) instead of a dependent global load per pass
+            const double cc = F ? F[(size_t)k * a.Nh + h].x : ch[(size_t)(l0 + k) * a.Nh + h], ss = F ? F[(size_t)k * a.Nh + h].y : sh[(size_t)(l0 + k) * a.Nh + h];
+            const double ti = shi ? shi[(size_t)(l0 + k) * a.Nh + h] : 0.0;
+            for (int q = 0; q < 2; ++q) {
+                double2 *r = (q == 0 ? X : Y) + (size_t)k * N;
+                const double2 x = r[b.x], y = r[b.y];
+                if (shi) {
+                    r[b.x] = make_double2(cc * x.x + (ss * y.x - ti * y.y), cc * x.y + (ss * y.y + ti * y.x));
+                    r[b.y] = make_double2(cc * y.x + (ss * x.x + ti * x.y), cc * y.y + (ss * x.y - ti * x.x));
+                } else {
+                    r[b.x] = make_double2(cc * x.x + ss * y.x, cc * x.y + ss * y.y);
+                    r[b.y] = make_double2(cc * y.x + ss * x.x, cc * y.y + ss * x.y);
+                }
+            }
         }
     }
     __syncthreads();
@@ -117,26 +150,48 @@ __global__ void __launch_bounds__(kThreads) dmdx_kernel(ForceArgs a)
         VP[idx] = (l == 0) ? x : make_double2(-x.x, -x.y);
         UP[idx] = u[(size_t)l * sstride + i];
     }
+    // round 4: the chunk's bond factors go to LDS here, with the slices (every load of the prologue in flight together).  Each of the ten to
+    // thirteen colour passes below used to start with a dependent global load of its factors: ~4 us per pass, 42 us per launch at 16 walkers
+    double2 *F = a.fac_lds ? VP + (size_t)a.Tc * N : nullptr;
+    int2 *BL = F ? reinterpret_cast<int2 *>(F + (size_t)a.Tc * a.Nh) : nullptr;   // ... and the bond table and the colour offsets: the loop head of every pass
+    int *OL = BL ? reinterpret_cast<int *>(BL + a.Nh) : nullptr;                  // read them from global memory, two dependent loads per pass
+    if (F) {
+        for (int h = threadIdx.x; h < a.Nh; h += blockDim.x) BL[h] = a.bonds[h];
+        if ((int)threadIdx.x <= a.ncol) OL[threadIdx.x] = a.col_off[threadIdx.x];
+    }
+    if (F)
+        for (int idx = threadIdx.x; idx < nk * a.Nh; idx += blockDim.x) {
+            const int k = idx / a.Nh, h = idx - k * a.Nh;
+            const size_t row = a.cs_slice0 ? (size_t)0 : (size_t)(l0 + k);  // τ-independent hoppings (the host has shown it for every walker): every slice holds slice 0's values; 12 KB per walker, cache resident, instead of Lτ copies
+            F[idx] = make_double2(ch[row * a.Nh + h], sh[row * a.Nh + h]);
+        }
     __syncthreads();
     if (SYM) {
-        for (int c = a.ncol - 1; c >= 0; --c) colour_plain(a, VP, nk, l0, c, ch, sh, shi);              // :33
+        // Holstein couplings only: |u'> := Γᵀ|u'> (:66-69) runs the same colours in the same order as the first half of B on |v'> (:33) and
+        // neither reads the other: one pass per colour for both arrays (round 4: three barrier phases and their factor loads fewer of
+        // thirteen; the arithmetic per array is unchanged)
+        const bool merged = a.Nssh == 0;
+        for (int c = a.ncol - 1; c >= 0; --c) {
+            if (merged) colour_plain2(a, VP, UP, nk, l0, c, ch, sh, shi, F, BL, OL);
+            else colour_plain(a, VP, nk, l0, c, ch, sh, shi, F, BL, OL);                                           // :33
+        }
         for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {                              // :36
             const int k = idx / N, i = idx - k * N;
             const double d = expV[(size_t)(l0 + k) * N + i];
             VP[idx] = make_double2(d * VP[idx].x, d * VP[idx].y);
         }
         __syncthreads();
-        for (int c = 0; c < a.ncol; ++c) colour_plain(a, VP, nk, l0, c, ch, sh, shi);                   // :39
+        for (int c = 0; c < a.ncol; ++c) colour_plain(a, VP, nk, l0, c, ch, sh, shi, F, BL, OL);                   // :39
         if (a.Nssh > 0) {
-            for (int c = a.ncol - 1; c >= 0; --c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, shi, true, 0, a.dtau / 2, nu, true, true);  // :50-63
+            for (int c = a.ncol - 1; c >= 0; --c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, shi, true, 0, a.dtau / 2, nu, true, true, F, BL, OL);  // :50-63
         } else {
             // |u'> := Γᵀ|u'> (colours last..first), |v'> := checkerboard_ldiv!(transposed = true) = colours
             // first..last with inverted factors, exactly as the reference does it (:66-74)
-            for (int c = a.ncol - 1; c >= 0; --c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, shi, false, 0, 0.0, 0.0, true, false);
-            for (int c = 0; c < a.ncol; ++c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, shi, false, 0, 0.0, 0.0, false, true);
+            // (|u'> took its colours together with |v'> above)
+            for (int c = 0; c < a.ncol; ++c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, shi, false, 0, 0.0, 0.0, false, true, F, BL, OL);
         }
     } else {
-        for (int c = 0; c < a.ncol; ++c) colour_plain(a, VP, nk, l0, c, ch, sh, shi);                   // :146
+        for (int c = 0; c < a.ncol; ++c) colour_plain(a, VP, nk, l0, c, ch, sh, shi, F, BL, OL);                   // :146
         for (int idx = threadIdx.x; idx < nk * N; idx += blockDim.x) {                              // :149
             const int k = idx / N, i = idx - k * N;
             const double d = expV[(size_t)(l0 + k) * N + i];
@@ -164,9 +219,9 @@ __global__ void __launch_bounds__(kThreads) dmdx_kernel(ForceArgs a)
         }
         __syncthreads();
         if (SYM) {
-            for (int c = 0; c < a.ncol; ++c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, shi, true, 1, a.dtau / 2, nu, true, true);     // :95-109
+            for (int c = 0; c < a.ncol; ++c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, shi, true, 1, a.dtau / 2, nu, true, true, F, BL, OL);     // :95-109
         } else {
-            for (int c = a.ncol - 1; c >= 0; --c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, shi, true, 0, a.dtau, nu, true, true);    // :172-183
+            for (int c = a.ncol - 1; c >= 0; --c) colour_step(a, UP, VP, nk, l0, w, c, ch, sh, shi, true, 0, a.dtau, nu, true, true, F, BL, OL);    // :172-183
         }
     }
 }
@@ -275,10 +330,14 @@ hipError_t configure_force_kernels(const char **what)
 
 void launch_dmdx(hipStream_t st, const ForceArgs &a, bool sym)
 {
-    const size_t lds = a.scratch ? 0 : sizeof(double2) * 2 * (size_t)a.Tc * a.N;
+    size_t lds = a.scratch ? 0 : sizeof(double2) * 2 * (size_t)a.Tc * a.N;
+    ForceArgs b = a;
+    const size_t fac = sizeof(double2) * (size_t)a.Tc * a.Nh + sizeof(int2) * (size_t)a.Nh + sizeof(int) * 16;  // factors, bond table, colour offsets
+    b.fac_lds = (!a.scratch && !a.shi && a.Nh > 0 && a.ncol <= 15 && lds + fac <= 96 * 1024) ? 1 : 0;   // real hoppings, slices in LDS: the factors join them
+    if (b.fac_lds) lds += fac;
     const dim3 grid((unsigned)(a.nchunk * a.nsys));
-    if (sym) hipLaunchKernelGGL((dmdx_kernel<true>), grid, dim3(kThreads), lds, st, a);
-    else hipLaunchKernelGGL((dmdx_kernel<false>), grid, dim3(kThreads), lds, st, a);
+    if (sym) hipLaunchKernelGGL((dmdx_kernel<true>), grid, dim3(kThreads), lds, st, b);
+    else hipLaunchKernelGGL((dmdx_kernel<false>), grid, dim3(kThreads), lds, st, b);
 }
 
 void launch_dldx(hipStream_t st, const ForceArgs &a)

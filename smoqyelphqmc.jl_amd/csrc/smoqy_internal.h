@@ -299,6 +299,8 @@ struct ForceArgs {
     double *contrib;                    // [nw][Lt][Q]
     double2 *scratch;                   // see FdmArgs::scratch
     size_t scratch_stride;
+    int cs_slice0;  // dmdx_kernel: every walker's hoppings are τ-independent (host-proved, smoqy_ctx::cs_const): the factors are read from slice 0
+    int fac_lds;  // dmdx_kernel: the chunk's (cosh, sinh) are staged in LDS behind the two slice images (set by launch_dmdx)
 };
 hipError_t configure_force_kernels(const char **what);
 void launch_dmdx(hipStream_t st, const ForceArgs &a, bool sym);
