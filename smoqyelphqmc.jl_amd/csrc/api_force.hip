@@ -166,7 +166,7 @@ int smoqy_force_dMdx_v(smoqy_ctx *c, double nu, int u, int v, double *out)
     if (int rc = force_begin(c)) return rc;
     ForceArgs a = force_args(c, nu, c->vecs[u], c->vecs[v]);
     if (!c->d_big && sizeof(double2) * 2 * (size_t)a.N > 160 * 1024 - 256) FAIL(c, 5, "N = %d does not fit the force kernel's LDS tile", a.N);
-    launch_dmdx(c->stream, a, c->g.is_sym != 0);
+    launch_dmdx(c->stream, a, c->g.is_sym != 0, &c->ff);
     return force_finish(c, a, out, true);
 }
 
@@ -192,7 +192,7 @@ static int force_device(smoqy_ctx *c, int psi)
     if (int rc = matvec_dev(c, SMOQY_OP_M, APsi, LPsi, nullptr, nullptr, 0, g.nsys)) return rc;                      // AΨ = MΛΨ      :148
     ForceArgs a = force_args(c, -2.0, APsi, LPsi);
     if (!c->d_big && sizeof(double2) * 2 * (size_t)a.N > 160 * 1024 - 256) FAIL(c, 5, "N = %d does not fit the force kernel's LDS tile", a.N);
-    launch_dmdx(c->stream, a, g.is_sym != 0);                                                                        // -2 Re<AΨ|∂M/∂x|ΛΨ>   :150
+    launch_dmdx(c->stream, a, g.is_sym != 0, &c->ff);                                                                      // -2 Re<AΨ|∂M/∂x|ΛΨ>   :150
     if (int rc = matvec_dev(c, SMOQY_OP_MT, MtAPsi, APsi, nullptr, nullptr, 0, g.nsys)) return rc;                   // MᵀAΨ          :153
     ForceArgs b = force_args(c, -2.0, MtAPsi, Psi);
     launch_dldx(c->stream, b);                                                                                       // -2 Re<MᵀAΨ|∂Λ/∂x|Ψ>  :155

@@ -318,6 +318,98 @@ __global__ void phonon_fields_kernel(ForceArgs a, const double *__restrict__ V0,
     }
 }
 
+// Lane-owned form of dmdx_kernel for Holstein couplings (round 4; Sym, real hoppings, <= kFdmColours colours, no SSH coupling): the same
+// colour passes in the same order — |u'>, |v'> := Γᵀ (colours last..first), |v'> := D|v'>, |v'> := Γ|v'> (first..last),
+// |v'> := (Γᵀ)⁻¹|v'> (inverse factors, first..last), src/fermion_det_matrix_dervative.jl:27-39, 66-74, then the Holstein term :81-84 — on the
+// tables of fdm_fast_kernel: a lane owns one (padded) bond per colour and keeps its (cosh, sinh) in registers from the prologue on, the
+// slice images sit in LDS in position order, the colour-0 passes around D chain in registers (C₀, D, C₀ without an LDS round trip).  Eight
+// barrier phases with one LDS read-modify-write each, where the generic kernel's run-time bond loops cost 0.85 us per pass.
+template <int NCOL>
+__global__ void __launch_bounds__(1024) dmdx_fast_kernel(ForceArgs a, FdmFast ff)
+{
+    extern __shared__ double2 lds[];
+    const int l = blockIdx.x % a.Lt, sys = blockIdx.x / a.Lt;
+    const int w = sys / a.nrhs, Lt = a.Lt, N = a.N, j = threadIdx.x;
+    double2 *U = lds, *V = lds + N;
+    const size_t sstride = (size_t)a.nsys * N;
+    const double2 *u = a.u + (size_t)sys * N + (size_t)l * sstride, *v = a.v + (size_t)sys * N + (size_t)(l == 0 ? Lt - 1 : l - 1) * sstride;
+    const double *expV = a.expV + ((size_t)w * Lt + l) * N;
+    const double2 *csf = ff.csf + ((size_t)w * Lt + (ff.cs_varies[w] ? l : 0)) * ff.ptotal;
+    const double nu = -a.nu;
+    int2 b[kFdmColours];
+    bool on[kFdmColours];
+    double2 cs[kFdmColours];
+#pragma unroll
+    for (int c = 0; c < kFdmColours; ++c) {
+        on[c] = false; b[c] = make_int2(0, 0); cs[c] = make_double2(1.0, 0.0);
+        if (c < NCOL) {
+            const int idx = ff.poff[c] + j;
+            if (idx < ff.poff[c + 1]) { on[c] = true; b[c] = ff.pbonds[idx]; cs[c] = csf[idx]; }
+        }
+    }
+    const int2 s0 = on[0] ? ff.psites[ff.poff[0] + j] : make_int2(0, 0);
+    const double di = on[0] ? expV[s0.x] : 1.0, dj = on[0] ? expV[s0.y] : 1.0;
+    for (int i = j; i < N; i += blockDim.x) {
+        const double2 x = v[i];
+        V[ff.pos[i]] = (l == 0) ? x : make_double2(-x.x, -x.y);   // v'[l] = ∓ v[l-1]  (:27-30)
+        U[ff.pos[i]] = u[i];
+    }
+    __syncthreads();
+    auto fwd = [](double c, double s, double2 x, double2 y, double2 &ox, double2 &oy) {
+        ox = make_double2(c * x.x + s * y.x, c * x.y + s * y.y);
+        oy = make_double2(c * y.x + s * x.x, c * y.y + s * x.y);
+    };
+    auto inv = [](double c, double s, double2 x, double2 y, double2 &ox, double2 &oy) {   // checkerboard_ldiv!: (c, −s)
+        ox = make_double2(c * x.x - s * y.x, c * x.y - s * y.y);
+        oy = make_double2(c * y.x - s * x.x, c * y.y - s * x.y);
+    };
+    // Γᵀ on both arrays, colours NCOL-1 .. 1
+#pragma unroll
+    for (int c = kFdmColours - 1; c >= 1; --c)
+        if (c < NCOL) {
+            if (on[c]) {
+                double2 ox, oy;
+                fwd(cs[c].x, cs[c].y, U[b[c].x], U[b[c].y], ox, oy); U[b[c].x] = ox; U[b[c].y] = oy;
+                fwd(cs[c].x, cs[c].y, V[b[c].x], V[b[c].y], ox, oy); V[b[c].x] = ox; V[b[c].y] = oy;
+            }
+            __syncthreads();
+        }
+    // colour 0 (padded to cover every site): U takes C₀; V takes C₀, then D, then the C₀ that opens Γ
+    if (on[0]) {
+        double2 ox, oy;
+        fwd(cs[0].x, cs[0].y, U[b[0].x], U[b[0].y], ox, oy); U[b[0].x] = ox; U[b[0].y] = oy;
+        fwd(cs[0].x, cs[0].y, V[b[0].x], V[b[0].y], ox, oy);
+        ox = make_double2(di * ox.x, di * ox.y);
+        oy = make_double2(dj * oy.x, dj * oy.y);
+        double2 px, py;
+        fwd(cs[0].x, cs[0].y, ox, oy, px, py); V[b[0].x] = px; V[b[0].y] = py;
+    }
+    __syncthreads();
+    // the rest of Γ on V: colours 1 .. NCOL-1
+#pragma unroll
+    for (int c = 1; c < kFdmColours; ++c)
+        if (c < NCOL) {
+            if (on[c]) { double2 ox, oy; fwd(cs[c].x, cs[c].y, V[b[c].x], V[b[c].y], ox, oy); V[b[c].x] = ox; V[b[c].y] = oy; }
+            __syncthreads();
+        }
+    // (Γᵀ)⁻¹ on V: inverse factors, colours 0 .. NCOL-1
+#pragma unroll
+    for (int c = 0; c < kFdmColours; ++c)
+        if (c < NCOL) {
+            if (on[c]) { double2 ox, oy; inv(cs[c].x, cs[c].y, V[b[c].x], V[b[c].y], ox, oy); V[b[c].x] = ox; V[b[c].y] = oy; }
+            __syncthreads();
+        }
+    // Holstein term  -ν Re[<u'|Δτ ∂V/∂x|v'>]   (:81-84)
+    for (int c = j; c < a.Nhol; c += blockDim.x) {
+        const int p = a.h_c2p[c], i = a.h_c2s[c];
+        const double xx = a.x[((size_t)w * Lt + l) * a.Nph + p];
+        const double dV = a.dtau * (a.h_alpha[c] + 2 * a.h_alpha2[c] * xx + 3 * a.h_alpha3[c] * xx * xx + 4 * a.h_alpha4[c] * xx * xx * xx);  // :280
+        const int q = ff.pos[i];
+        const double2 uu = U[q], vv = V[q];
+        a.contrib[((size_t)w * Lt + l) * a.Q + c] = nu * dV * (uu.x * vv.x + uu.y * vv.y);           // :282
+    }
+}
+
 }  // namespace
 
 hipError_t configure_force_kernels(const char **what)
@@ -328,8 +420,21 @@ hipError_t configure_force_kernels(const char **what)
     return first;
 }
 
-void launch_dmdx(hipStream_t st, const ForceArgs &a, bool sym)
+void launch_dmdx(hipStream_t st, const ForceArgs &a, bool sym, const FdmFast *ff)
 {
+    static const int fast_env = tuning_env(kTuneDmdxFast);  // SMOQY_DMDX_FAST=0: A/B switch
+    if (fast_env != 0 && sym && ff && ff->enabled && !ff->csi && !a.shi && !a.scratch && a.Nssh == 0 && a.Tc == 1 && a.ncol >= 1 && a.ncol <= kFdmColours &&
+        sizeof(double2) * 2 * (size_t)a.N <= 64 * 1024) {
+        const dim3 grid((unsigned)(a.Lt * a.nsys)), block((unsigned)ff->threads);
+        const size_t lds = sizeof(double2) * 2 * (size_t)a.N;
+        switch (a.ncol) {
+            case 1: hipLaunchKernelGGL((dmdx_fast_kernel<1>), grid, block, lds, st, a, *ff); break;
+            case 2: hipLaunchKernelGGL((dmdx_fast_kernel<2>), grid, block, lds, st, a, *ff); break;
+            case 3: hipLaunchKernelGGL((dmdx_fast_kernel<3>), grid, block, lds, st, a, *ff); break;
+            default: hipLaunchKernelGGL((dmdx_fast_kernel<4>), grid, block, lds, st, a, *ff); break;
+        }
+        return;
+    }
     size_t lds = a.scratch ? 0 : sizeof(double2) * 2 * (size_t)a.Tc * a.N;
     ForceArgs b = a;
     const size_t fac = sizeof(double2) * (size_t)a.Tc * a.Nh + sizeof(int2) * (size_t)a.Nh + sizeof(int) * 16;  // factors, bond table, colour offsets

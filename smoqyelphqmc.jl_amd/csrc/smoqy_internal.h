@@ -303,7 +303,7 @@ struct ForceArgs {
     int fac_lds;  // dmdx_kernel: the chunk's (cosh, sinh) are staged in LDS behind the two slice images (set by launch_dmdx)
 };
 hipError_t configure_force_kernels(const char **what);
-void launch_dmdx(hipStream_t st, const ForceArgs &a, bool sym);
+void launch_dmdx(hipStream_t st, const ForceArgs &a, bool sym, const FdmFast *ff = nullptr);  // ff: the handle's padded-bond tables (dmdx_fast_kernel), or nullptr
 void launch_dldx(hipStream_t st, const ForceArgs &a);
 void launch_force_reduce(hipStream_t st, const ForceArgs &a, double *out);
 // V(x), t(x) -> expV, cosh, sinh (+ Λ) for every walker from the device copy of the phonon fields
@@ -380,7 +380,7 @@ void launch_tfft(hipStream_t st, int mode, const TfftArgs &a);
 // none needed for normal use.  Read once per process; tuning_env("NAME") is the variable's integer value, or -1 when it is not set.
 enum TuningKnob {
     kTuneChebWl0, kTuneChebSplit, kTuneChebOwn, kTuneChebGroup, kTuneFdmStream, kTuneFdmOwn, kTuneFdmOwnMax, kTuneFdmOwnStream, kTuneNtFields,
-    kTuneXStream, kTuneXcdMap, kTuneTfftSlim, kTuneTfftSb, kTuneTfftEdge, kTuneChebWave, kTuneFdmWave, kTuneFdmWaveR, kTuneCount
+    kTuneXStream, kTuneXcdMap, kTuneTfftSlim, kTuneTfftSb, kTuneTfftEdge, kTuneChebWave, kTuneFdmWave, kTuneFdmWaveR, kTuneDmdxFast, kTuneCount
 };
 inline int tuning_env(TuningKnob k)
 {
@@ -390,7 +390,7 @@ inline int tuning_env(TuningKnob k)
         {
             static const char *const names[kTuneCount] = {"SMOQY_CHEB_WL0", "SMOQY_CHEB_SPLIT", "SMOQY_CHEB_OWN", "SMOQY_CHEB_GROUP", "SMOQY_FDM_STREAM", "SMOQY_FDM_OWN",
                                                           "SMOQY_FDM_OWN_MAX", "SMOQY_FDM_OWNSTREAM", "SMOQY_NT_FIELDS", "SMOQY_X_STREAM", "SMOQY_XCD_MAP", "SMOQY_TFFT_SLIM",
-                                                          "SMOQY_TFFT_SB", "SMOQY_TFFT_EDGE", "SMOQY_CHEB_WAVE", "SMOQY_FDM_WAVE", "SMOQY_FDM_WAVE_R"};
+                                                          "SMOQY_TFFT_SB", "SMOQY_TFFT_EDGE", "SMOQY_CHEB_WAVE", "SMOQY_FDM_WAVE", "SMOQY_FDM_WAVE_R", "SMOQY_DMDX_FAST"};
             for (int q = 0; q < kTuneCount; ++q) {
                 const char *e = getenv(names[q]);
                 v[q] = e ? atoi(e) : -1;

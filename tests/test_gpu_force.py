@@ -40,6 +40,13 @@ def test_force_terms_against_oracle(kind, is_sym):
     sq.mul_nuRe_dMdx(got, 1.7, u, v, fdm)
     want = orc.mul_dMdx(o, e, fdm._colors, 1.7, u, v, out=np.asfortranarray(0.5 * np.ones((Nph, Lt))))
     assert np.abs(got - want).max() < 1e-12 * max(1.0, np.abs(want).max())
+    # Holstein, Sym: the lane-owned kernel (dmdx_fast_kernel, round 4) ran above; with the register-resident kernels switched off the generic
+    # dmdx_kernel walks the same colour passes in the same order — the two must agree far below the comparison with the oracle
+    fdm.handle.call("smoqy_matvec_force_generic", 1)
+    got_generic = np.asfortranarray(0.5 * np.ones((Nph, Lt)))
+    sq.mul_nuRe_dMdx(got_generic, 1.7, u, v, fdm)
+    fdm.handle.call("smoqy_matvec_force_generic", 0)
+    assert np.abs(got_generic - got).max() < 1e-13 * max(1.0, np.abs(want).max())
     if kind == "holstein":
         hol = m.elph.holstein
         Lam = orc.update_lambda(Lt, N, m.elph.x, m.elph.dtau, hol.coupling_to_phonon, hol.coupling_to_site, hol.alpha, hol.alpha3, hol.ph_sym_form)
