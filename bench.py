@@ -58,7 +58,8 @@ def parse():
                          "full-batch MtM launches), 0 = the library's automatic choice, 2 = on.  The one-stream legs always use the library default (automatic).")
     ap.add_argument("--tfft-form", choices=["auto", "two-image", "in-place"], default="auto",
                     help="τ-FFT of the timed batches (smoqy_tfft_form): in-place has more workgroups per CU (+2.7 %% sweeps/s with six streams), two-image is faster alone; "
-                         "auto = in-place when more than one stream shares the GPU and Ltau = 2^a 3^b.  The one-stream legs keep the library default (two-image).")
+                         "auto = in-place when more than one stream shares the GPU, Ltau = 2^a 3^b 5^c and the lattice has at least 14400 space-time sites (round 4: "
+                         "bond-SSH chain 122 -> 135, optical-SSH square 178 -> 197 sweeps/s; honeycomb L = 8 and 4 indifferent, profiles/r04_tfft_form_scan.txt).  The one-stream legs keep the library default (two-image).")
     ap.add_argument("--no-mtm-sampling", action="store_true", help="do not sample MtM launches inside the timed region (roofline falls back to the isolated leg)")
     ap.add_argument("--measure-nrv", type=int, default=0, help="add update_greens_estimator! + measure_GΔ0! with this many random vectors to every sweep (27 + Nrv solves)")
     ap.add_argument("--hmc", choices=["device", "host"], default="device",
@@ -776,14 +777,15 @@ def main():
     # auto: the in-place τ-FFT pays where the launches fill the chip and the transform has no radix-5 pass (headline lattice +2.7 %;
     # measured slower on the Lτ = 80 / 100 / 200 lattices of BASELINE.json, whose launches are half a chip or less)
     from smoqyelphqmc_amd import lattice as _lat
-    lat_Lt = _lat.CONFIGS[args.workload](walker=0).fpi.Ltau
+    _m0 = _lat.CONFIGS[args.workload](walker=0)
+    lat_Lt, lat_N = _m0.fpi.Ltau, _m0.fpi.N
     # host threads of this rank: S stream threads + a small RNG pool per batch, bounded by the cores the rank can count on (a full node
     # gives every rank available_cores() // world; one GPU box gives 16)
     cores_rank = max(1, available_cores() // world)
     rng_threads = max(1, min(max(2, 16 // S), cores_rank // S))
     batches = [WalkerBatch(args.workload, nwalkers=per, walker0=mine.start + s * per, device=dev, check_every=args.check_every or None, tau_chunk=args.tau_chunk or None,
                            host_threads=rng_threads, measure_nrv=args.measure_nrv, device_efa=args.hmc == "device", cg_split=args.cg_split, prefetch_randoms=not args.no_prefetch,
-                           tfft_in_place=(S > 1 and _only_factors(lat_Lt, (2, 3))) if args.tfft_form == "auto" else args.tfft_form == "in-place") for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
+                           tfft_in_place=(S > 1 and _in_place_tfft_exists(lat_Lt) and lat_Lt * lat_N >= 14400) if args.tfft_form == "auto" else args.tfft_form == "in-place") for s in range(S)]  # the box gives one GPU 16 cores: S stream threads + small RNG pools
     batch = batches[0]
     if os.environ.get("SMOQY_BENCH_ASYNC"):  # A/B aid: the asynchronous trajectory (smoqy_hmc_async) on / off in the timed batches
         for b in batches:
