@@ -487,19 +487,23 @@ def iteration_kernels(args, dev, walker0, L, np):
     _, per_kernel, src = committed_iteration_traffic(args.workload)
     per_kernel = per_kernel or {}
 
+    def hit(k, prefix):  # "tfft<2" stands for both τ-FFT kernels' CG modes: tfft_kernel<2, …> and tfft_rb_kernel<2, …>
+        return (k.startswith("tfft_kernel<" + prefix[5:]) or k.startswith("tfft_rb_kernel<" + prefix[5:])) if prefix.startswith("tfft<") else k.startswith(prefix)
+
     def traffic(prefix):
-        hits = [v for k, v in per_kernel.items() if k.startswith(prefix)]
+        hits = [v for k, v in per_kernel.items() if hit(k, prefix)]
         return hits[0] if hits else None
 
+    tf = names.get("tfft", "tfft_kernel")
     rows = [(f"fused MtM ({names['mtm']})", us[0], 2 * Sb + Fb, traffic("fdm_")),
-            ("forward tau-FFT + r update (tfft_kernel<2>)", us[1], 3 * Sb, traffic("tfft_kernel<2")),
+            (f"forward tau-FFT + r update ({tf}, mode 2)", us[1], 3 * Sb, traffic("tfft<2")),
             (f"Chebyshev apply ({names['cheb']})", us[2], 2 * Sb, traffic("cheb_")),
-            ("inverse tau-FFT + x, p updates (tfft_kernel<3>)", us[3], 5 * Sb, traffic("tfft_kernel<3"))]
+            (f"inverse tau-FFT + x, p updates ({tf}, mode 3)", us[3], 5 * Sb, traffic("tfft<3"))]
     prof, prof_src = committed_solo_durations(args.workload)
     out = []
-    for (name, t_us, least, tr), key in zip(rows, ("fdm_", "tfft_kernel<2", "cheb_", "tfft_kernel<3")):
+    for (name, t_us, least, tr), key in zip(rows, ("fdm_", "tfft<2", "cheb_", "tfft<3")):
         t_s = t_us * 1e-6
-        p_us = next((v for k, v in prof.items() if k.startswith(key)), None)
+        p_us = next((v for k, v in prof.items() if hit(k, key)), None)
         out.append({"kernel": name, "us": t_us, "least_bytes": least, "frac_least": (least / t_s / 1e9 / HBM_PEAK_GBS) if t_s else None,
                     "traffic_bytes": tr, "frac_traffic": (tr / t_s / 1e9 / HBM_PEAK_GBS) if (tr and t_s) else None,
                     "rocprof_us": p_us, "frac_least_rocprof": (least / (p_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if p_us else None})
@@ -963,6 +967,7 @@ def main():
                 "cg_tol": batch.tol,
                 "avg_cg_iters": sum(b.stats.iters_sum for b in batches) / max(sum(b.stats.solves for b in batches), 1),
                 "preconditioner": "KPM (Sym)",
+                "tfft_kernel": batch.h.describe().get("tfft"),  # what the timed batches' τ-FFT launches ran (the register-blocked forms stand in for either request)
                 "tfft_form": ("in-place" if _in_place_tfft_exists(batch.Lt) else "two-image (in-place requested; Ltau has a factor 7)") if batch.tfft_in_place else "two-image",
                 "hmc": ("EFA leapfrog on the device, Nt = %d steps of dt = pi/(2 Nt), trajectory always rejected (x restored) so the field distribution stays the one SURVEY.md 8(d) defines" % batch.Nt)
                 if args.hmc == "device" else "synthetic host-side drift (round-1 form)",

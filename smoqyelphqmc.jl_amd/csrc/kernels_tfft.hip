@@ -620,6 +620,236 @@ __global__ void __launch_bounds__(256, (SLIM || EDGE) ? 6 : 1) tfft_kernel(TfftA
 }
 
 
+// ---- register-blocked form for the lengths Lτ = R · M · R that are not 4 · M · 4 on 256 lanes: Lτ = 80 (4·5·4), 100 (5·4·5), 200 (5·8·5) —
+// the time extents of BASELINE configs 2, 3 and 5.  R · M · SB lanes (320 for all three with the plan's tile width), R slices per lane:
+//   X[k2 + R k1] = Σ_n1 W_Lτ^{n1 k2} [Σ_n2 x[n1 + (Lτ/R) n2] W_R^{n2 k2}] W_{Lτ/R}^{n1 k1},      n1 = R a + b,  k1 = k' + M u:
+//   y_k2[n1] (radix-R butterfly on the lane's R staged slices n1 + (Lτ/R)·n2, in registers)
+//     ->  Z_{k2,b}[k'] = Σ_a y_k2[R a + b] W_M^{a k'}   (the ONE LDS pass, in place)
+//     ->  X[l0 + (Lτ/R) u] = Σ_b W_R^{b u} W_Lτ^{R b k'} Z_{k2,b}[k']   (radix-R butterfly in registers: the lane's R epilogue slices),
+// k2 = l0 mod R, k' = l0 div R.  Same structure as tfft_kernel<…, EDGE> (R = 4, 256 lanes), which keeps Lτ = 64 and 128 bit for bit;
+// here the mixed-radix lengths go from three or four LDS passes to one (the chain's τ-FFTs were 55 % of its CG iteration).
+template <int NT>
+__device__ __forceinline__ void bsum4_n(double2 &u, double2 &v, double *red)
+{
+    u.x = wsum_t(u.x); u.y = wsum_t(u.y);
+    v.x = wsum_t(v.x); v.y = wsum_t(v.y);
+    constexpr int nwave = (NT + 63) >> 6;
+    static_assert(nwave <= 8, "red[] holds eight wave sums of four values");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[4 * wave] = u.x; red[4 * wave + 1] = u.y; red[4 * wave + 2] = v.x; red[4 * wave + 3] = v.y; }
+    __syncthreads();
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int w = 0; w < nwave; ++w)  // every lane adds the wave sums in the same fixed order: no second barrier, no broadcast slot
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] += red[4 * w + q];
+    u = make_double2(t[0], t[1]);
+    v = make_double2(t[2], t[3]);
+}
+
+template <int MODE, int R, int M, int SB>
+__global__ void __launch_bounds__(R * M * SB, 4) tfft_rb_kernel(TfftArgs a)
+{
+    constexpr int NT = R * M * SB, LT = R * M * R, LSTEP = M * R;
+    constexpr bool INV = (MODE == MODE_PLAIN_INV || MODE == MODE_INV_CG);
+    static_assert(NT % 64 == 0 && NT <= 512, "whole wavefronts");
+    extern __shared__ double2 lds[];
+    __shared__ double red[40];   // [0, 32): wave sums of bsum4_n; [32, 40): wave sums of the epilogue's |r|²
+    double2 *A = lds, *WT = A + (size_t)LT * SB;
+    const int N = a.N;
+    int bid_ = blockIdx.x;
+    if (a.xcd_map && (gridDim.x & 7) == 0) bid_ = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // as in tfft_kernel
+    const int tile = bid_ % a.ntile, sys = a.sys_first + bid_ / a.ntile;
+    int st_done = 0, st_stop = 0;
+    if (MODE == MODE_FWD_CG) st_done = a.st[sys].done;
+    double st_normb2 = 1.0, st_tol = 0.0;
+    double2 st_alpha = make_double2(0.0, 0.0), st_rho = make_double2(1.0, 0.0);
+    if (MODE == MODE_INV_CG) {
+        const CgState &s0 = a.st[sys];
+        st_stop = s0.stop;
+        st_normb2 = s0.normb2; st_tol = s0.tol;
+        st_alpha = make_double2(s0.alpha_re, s0.alpha_im);
+        st_rho = make_double2(s0.rho_re, s0.rho_im);
+    }
+    const int i0 = tile * SB, ns = min(SB, N - i0);
+    const size_t sstride = (size_t)a.nsys * N;
+    const size_t base = (size_t)sys * N + i0;
+    const int sb = threadIdx.x % SB, l0 = threadIdx.x / SB;  // l0 in [0, M·R): the lane's slices are l0 + LSTEP·u, u < R
+    const bool act = sb < ns;
+    const size_t col = base + (act ? sb : 0);
+
+    // one round of loads, nothing waited for in between: twiddle table entry, partial sums of the previous kernels, the lane's R slices,
+    // the first-stage twiddles
+    const double2 wt0_ = a.wtab[min((int)threadIdx.x, LT - 1)];
+    double2 q1 = make_double2(0.0, 0.0), q2 = make_double2(0.0, 0.0);
+    if (MODE == MODE_FWD_CG) {
+        const double2 *prz = a.part_rz + (size_t)sys * a.rz_stride, *ppz = a.part_pz + (size_t)sys * a.pz_stride;
+        const double2 v1 = prz[min((int)threadIdx.x, a.nrz - 1)], v2 = ppz[min((int)threadIdx.x, a.npz - 1)];
+        if ((int)threadIdx.x < a.nrz) q1 = v1;
+        if ((int)threadIdx.x < a.npz) q2 = v2;
+    } else if (MODE == MODE_INV_CG) {
+        const double *prr = a.part_rr + (size_t)sys * a.rr_stride;
+        const double2 *prz = a.part_rz + (size_t)sys * a.rz_stride;
+        const double v1 = prr[min((int)threadIdx.x, a.nrr - 1)];
+        const double2 v2 = prz[min((int)threadIdx.x, a.nrz - 1)];
+        if ((int)threadIdx.x < a.nrr) q1.x = v1;
+        if ((int)threadIdx.x < a.nrz) q2 = v2;
+    }
+    const double2 *src = (MODE == MODE_FWD_CG) ? a.z : a.src;  // forward CG mode transforms A p
+    double2 v[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) v[u] = src[(size_t)(l0 + u * LSTEP) * sstride + col];
+    double2 ew[R];
+#pragma unroll
+    for (int k2 = 1; k2 < R; ++k2) ew[k2] = a.wtab[k2 * l0];  // W_Lτ^{n1 k2}, n1 = l0 < Lτ/R
+    if ((int)threadIdx.x < LT) WT[threadIdx.x] = wt0_;
+    if (NT < LT) for (int q = threadIdx.x + NT; q < LT; q += NT) WT[q] = a.wtab[q];
+    // the early exits (workgroup-uniform), with the loads above in flight — see tfft_kernel for the done / stop protocol
+    if (MODE == MODE_FWD_CG && st_done) {
+        if (tile == 0 && threadIdx.x == 0) a.st[sys].stop = st_done;
+        return;
+    }
+    if (MODE == MODE_INV_CG && st_stop) return;
+    // first stage in registers
+    if (!act) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = make_double2(0.0, 0.0);
+    }
+    if (MODE != MODE_FWD_CG && MODE != MODE_INV_CG && a.pre_tw && act) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = cm(v[u], a.pre_tw[l0 + u * LSTEP]);
+    }
+    dft<R>(v, nullptr, 0, INV);
+    A[(size_t)(l0 * R) * SB + sb] = v[0];
+#pragma unroll
+    for (int k2 = 1; k2 < R; ++k2) {
+        double2 w = ew[k2];
+        if (INV) w.y = -w.y;
+        A[(size_t)(l0 * R + k2) * SB + sb] = cm(v[k2], w);
+    }
+    // the scalars of the recurrence: remaining partial sums, wave sums into red[] — the barrier that publishes them is the one the
+    // LDS image needs anyway
+    if (MODE == MODE_FWD_CG) {
+        const double2 *prz = a.part_rz + (size_t)sys * a.rz_stride, *ppz = a.part_pz + (size_t)sys * a.pz_stride;
+        for (int c = threadIdx.x + NT; c < a.nrz; c += NT) { q1.x += prz[c].x; q1.y += prz[c].y; }
+        for (int c = threadIdx.x + NT; c < a.npz; c += NT) { q2.x += ppz[c].x; q2.y += ppz[c].y; }
+        bsum4_n<NT>(q1, q2, red);  // q1 = r·z, q2 = p·Ap
+    } else if (MODE == MODE_INV_CG) {
+        const double *prr = a.part_rr + (size_t)sys * a.rr_stride;
+        const double2 *prz = a.part_rz + (size_t)sys * a.rz_stride;
+        for (int c = threadIdx.x + NT; c < a.nrr; c += NT) q1.x += prr[c];
+        for (int c = threadIdx.x + NT; c < a.nrz; c += NT) { q2.x += prz[c].x; q2.y += prz[c].y; }
+        bsum4_n<NT>(q1, q2, red);  // q1.x = |r|², q2 = r·z
+    } else {
+        __syncthreads();
+    }
+    // the LDS pass: work item (b, k2, sb) = w holds the M values y_k2[R a + b] at A[w + a·R²·SB] -> Z_{k2,b}[k'] at A[w + k'·R²·SB]
+    for (int w = threadIdx.x; w < R * R * SB; w += NT) {
+        double2 *x = A + w;
+        double2 m_[M];
+#pragma unroll
+        for (int a_ = 0; a_ < M; ++a_) m_[a_] = x[(size_t)a_ * R * R * SB];
+        dft<M>(m_, nullptr, 0, INV);
+#pragma unroll
+        for (int kp = 0; kp < M; ++kp) x[(size_t)kp * R * R * SB] = m_[kp];
+    }
+    __syncthreads();
+    // last stage in registers: the lane's outputs are the slices l0 + LSTEP·u
+    double2 eo[R];
+    {
+        const int k2 = l0 % R, kp = l0 / R;
+#pragma unroll
+        for (int b = 0; b < R; ++b) {
+            double2 z = A[(size_t)((kp * R + b) * R + k2) * SB + sb];
+            if (b > 0) {
+                double2 w = WT[R * b * kp];
+                if (INV) w.y = -w.y;
+                z = cm(z, w);
+            }
+            eo[b] = z;
+        }
+        dft<R>(eo, nullptr, 0, INV);
+    }
+
+    if (MODE == MODE_FWD_CG) {
+        // ConjugateGradient.jl:219-226 in frequency space: α = (r·z)/(p·Ap), r̂ -= α·FFT(Ap), |r|² = Σ|r̂|²/Lτ
+        const double2 rz = q1, pz = q2;
+        const double2 alpha = cdivt(rz, pz);
+        double acc = 0.0;
+        if (act) {
+            double2 rv[R];
+#pragma unroll
+            for (int u = 0; u < R; ++u) rv[u] = a.r[(size_t)(l0 + u * LSTEP) * sstride + base + sb];
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const double2 rn = csub(rv[u], cm(alpha, eo[u]));
+                a.r[(size_t)(l0 + u * LSTEP) * sstride + base + sb] = rn;
+                acc += rn.x * rn.x + rn.y * rn.y;
+            }
+        }
+        acc = wsum_t(acc);
+        if ((threadIdx.x & 63) == 0) red[32 + (threadIdx.x >> 6)] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) t += red[32 + w];
+            a.part_rr[(size_t)sys * a.rr_stride + tile] = t / LT;
+            if (tile == 0) {
+                CgState &s = a.st[sys];
+                s.rho_re = rz.x; s.rho_im = rz.y;
+                s.alpha_re = alpha.x; s.alpha_im = alpha.y;
+            }
+        }
+    } else if (MODE == MODE_INV_CG) {
+        // ConjugateGradient.jl:220 (x += α p, deferred to here), :229-245: stop test on the unpreconditioned residual, p = z + β p
+        const double rr = q1.x;
+        const double eps = sqrt(rr) / sqrt(st_normb2);
+        const bool conv = eps < st_tol;
+        const double2 alpha = st_alpha;
+        double2 beta = make_double2(0.0, 0.0);
+        if (!conv) beta = cdivt(q2, st_rho);
+        if (act) {
+            double2 pv[R], xv[R];
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const size_t off = (size_t)(l0 + u * LSTEP) * sstride + base + sb;
+                pv[u] = a.p[off];
+                if (a.x_stream) {
+                    const v2d_t t_ = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(a.x + off));
+                    xv[u] = make_double2(t_.x, t_.y);
+                } else xv[u] = a.x[off];
+            }
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const size_t off = (size_t)(l0 + u * LSTEP) * sstride + base + sb;
+                const double2 xn_ = cadd(xv[u], cm(alpha, pv[u]));
+                if (a.x_stream) { v2d_t t_; t_.x = xn_.x; t_.y = xn_.y; __builtin_nontemporal_store(t_, reinterpret_cast<v2d_t *>(a.x + off)); }
+                else a.x[off] = xn_;
+                if (!conv) a.p[off] = cadd(eo[u], cm(beta, pv[u]));
+            }
+        }
+        if (threadIdx.x == 0 && tile == 0) {
+            CgState &s = a.st[sys];
+            s.eps = eps;
+            s.iters += 1;
+            if (conv) s.done = 1;
+            else if (s.iters >= s.maxiter) s.done = 2;
+        }
+    } else {
+        if (act) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int l = l0 + u * LSTEP;
+                double2 x = eo[u];
+                if (a.post_tw) { const double2 w = a.post_tw[l]; x = cm(x, make_double2(w.x, -w.y)); }
+                a.dst[(size_t)l * sstride + base + sb] = x;
+            }
+        }
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // EFA leapfrog kernel.  Workgroup = (tile of SB phonon modes, walker), every τ of the tile in LDS, z = x + i p transformed with the
 // same Stockham passes as the state vectors (one complex transform carries both real fields: x̃_ω = (z̃_ω + conj z̃_{-ω})/2,
@@ -747,6 +977,14 @@ bool tfft_plan(int Lt, int N, TfftArgs &a)
     // register-blocked two-image form (tfft_kernel<…, EDGE>): Lτ = 64 or 128 with exactly four slices per lane; SMOQY_TFFT_EDGE=0 switches it off
     static const int edge_env = tuning_env(kTuneTfftEdge) == 0 ? 0 : 1;
     a.edge = (edge_env && (Lt == 64 || Lt == 128) && Lt * a.SB == 4 * kTfftThreads) ? Lt / 16 : 0;
+    // tfft_rb_kernel: Lτ = 80, 100, 200 at the tile width chosen above (320 lanes); SMOQY_TFFT_EDGE=1 keeps only the 256-lane form above
+    static const int rb_env = (tuning_env(kTuneTfftEdge) < 0 || tuning_env(kTuneTfftEdge) >= 2) ? 1 : 0;
+    a.rb = 0;
+    if (rb_env) {
+        if (Lt == 80 && a.SB == 16) a.rb = 16 * 4 + 5;
+        else if (Lt == 100 && a.SB == 16) a.rb = 16 * 5 + 4;
+        else if (Lt == 200 && a.SB == 8) a.rb = 16 * 5 + 8;
+    }
     return true;
 }
 
@@ -782,7 +1020,7 @@ hipError_t configure_tfft_kernels(const char **what)
     SMOQY_SET_LDS((tfft_kernel<2, true>), 160 * 1024 - 512);
     SMOQY_SET_LDS((tfft_kernel<3, true>), 160 * 1024 - 512);
     SMOQY_SET_LDS(efa_kernel, 160 * 1024 - 512);
-    return first;
+    return first;  // tfft_rb_kernel stays under the default 64 KB of dynamic LDS (29 KB at most)
 }
 
 void launch_tfft(hipStream_t st, int mode, const TfftArgs &a)
@@ -796,6 +1034,24 @@ void launch_tfft(hipStream_t st, int mode, const TfftArgs &a)
             case 2: hipLaunchKernelGGL((tfft_kernel<2, false, true>), grid, block, lds, st, a); break;
             default: hipLaunchKernelGGL((tfft_kernel<3, false, true>), grid, block, lds, st, a); break;
         }
+        return;
+    }
+    if (a.rb) {  // register-blocked form for Lτ = R·M·R (80, 100, 200): one image, one pass — likewise stands in for both requests
+        const size_t lds = ((size_t)a.Lt * a.SB + a.Lt) * sizeof(double2);
+#define SMOQY_RB_LAUNCH(R_, M_, SB_)                                                                                        \
+        {                                                                                                                   \
+            const dim3 blk((R_) * (M_) * (SB_));                                                                            \
+            switch (mode) {                                                                                                 \
+                case 0: hipLaunchKernelGGL((tfft_rb_kernel<0, R_, M_, SB_>), grid, blk, lds, st, a); break;                 \
+                case 1: hipLaunchKernelGGL((tfft_rb_kernel<1, R_, M_, SB_>), grid, blk, lds, st, a); break;                 \
+                case 2: hipLaunchKernelGGL((tfft_rb_kernel<2, R_, M_, SB_>), grid, blk, lds, st, a); break;                 \
+                default: hipLaunchKernelGGL((tfft_rb_kernel<3, R_, M_, SB_>), grid, blk, lds, st, a); break;                \
+            }                                                                                                               \
+        }
+        if (a.rb == 16 * 4 + 5) SMOQY_RB_LAUNCH(4, 5, 16)
+        else if (a.rb == 16 * 5 + 4) SMOQY_RB_LAUNCH(5, 4, 16)
+        else SMOQY_RB_LAUNCH(5, 8, 8)
+#undef SMOQY_RB_LAUNCH
         return;
     }
     if (a.slim && a.pos) {

@@ -330,6 +330,7 @@ struct TfftArgs {
     int x_stream;                         // inverse CG mode: nontemporal loads / stores for x
     int xcd_map;                          // blockIdx -> (tile, system) map that keeps a system's workgroups on one XCD
     int edge;                             // two-image form with its first and last radix-4 stage in registers: the radix M (4 or 8) of the one LDS pass, 0 = off
+    int rb;                               // tfft_rb_kernel (Lτ = R·M·R on R·M·SB lanes): 16·R + M, 0 = off
     int fac[16];
     unsigned long long fpack, sfpack;     // fac / sfac packed four bits per radix: what the kernels read
     // in-place form (one LDS image): radix 2 / 3 / 4 / 5 factors `sfac` applied as decimation-in-frequency passes (forward) or, in reverse
