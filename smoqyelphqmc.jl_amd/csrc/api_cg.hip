@@ -70,6 +70,20 @@ int smoqy_cg_split(smoqy_ctx *c, int parts)
     return set_part_streams(c, std::min(parts == 0 ? auto_parts(c) : parts, c->g.nsys));
 }
 
+// Where tfft_rb_kernel (Lτ = 80, 100, 200) runs, from the measurements in profiles/r04_rb_bench_ab.txt and r04_rb_rule_scan.txt:
+//  * a handle left at the library's default form (one stream): up to 64 systems per launch — one-stream sweeps at 16 / 32 / 64 walkers
+//    are 13-27 / 7-12 / 1-13 % shorter than with the two-image / in-place forms; larger launches were not measured and keep the in-place form;
+//  * a handle whose caller asked for the in-place form (smoqy_tfft_form(1): several handles share the GPU, bench.py's timed batches):
+//    below 32 systems per launch (chain, 8 x 16: +3.7 %); at 4 x 64 its 92-109 VGPRs (three or four 320-lane workgroups per CU against
+//    five or six of 256) lose 3-8 %, at 8 x 32 the optical-SSH lattice gains 6.5 % and the chain loses 2 %.
+// SMOQY_TFFT_EDGE=3 lifts every limit, =1 switches the kernel off (A/B aids).
+void tfft_rb_rule(smoqy_ctx *c, bool shared_gpu)
+{
+    const int nsys = c->g.nsys;
+    const bool on = tuning_env(kTuneTfftEdge) >= 3 || nsys < 32 || (!shared_gpu && nsys <= 64);
+    c->tf.rb = on ? c->tf_rb_plan : 0;
+}
+
 // form of the handle's own τ-FFT: 0 = two LDS images (fewer passes: fastest alone), 1 = in place (fewer registers and half the LDS: more
 // workgroups per CU, better when several handles share the GPU)
 int smoqy_tfft_form(smoqy_ctx *c, int in_place)
@@ -77,7 +91,9 @@ int smoqy_tfft_form(smoqy_ctx *c, int in_place)
     CHECK_CTX(c);
     if (in_place != 0 && in_place != 1) FAIL(c, 1, "in_place must be 0 or 1");
     const int want = (in_place && c->tf_ok && c->tf.slim_ok && c->tf.pos) ? 1 : 0;  // lengths with a factor 7 keep the two-image form
-    if (want != c->tf.slim) {
+    const int rb_before = c->tf.rb;
+    tfft_rb_rule(c, in_place != 0);
+    if (want != c->tf.slim || rb_before != c->tf.rb) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->tf.slim = want;
         drop_graphs(c);

@@ -487,11 +487,8 @@ static int create_impl(smoqy_ctx *c, const int64_t *nt, const int64_t *cr)
     {   // own tau-FFT (kernels_tfft.hip) when Lt factors into 2, 3, 5, 7
         c->tf_ok = tfft_plan(g.Lt, g.N, c->tf) ? 1 : 0;
         c->tf.nsys = g.nsys;
-        // tfft_rb_kernel (Lτ = 80, 100, 200) where it was measured to win: launches of fewer than 32 systems — alone at 16 systems the two
-        // transforms of an iteration take 10.4 / 11.3 / 21.2 µs against 17.0 / 19.8 / 30.0, and the chain's eight-stream bench (16 per
-        // launch) gains 3.7 %; at 64 systems per launch on four streams its 92-109 VGPRs (three or four workgroups per CU) lose 3-8 % to
-        // the in-place form's five or six (profiles/r04_rb_bench_ab.txt).  SMOQY_TFFT_EDGE=3 lifts the limit (A/B aid).
-        if (g.nsys >= 32 && tuning_env(kTuneTfftEdge) < 3) c->tf.rb = 0;
+        c->tf_rb_plan = c->tf.rb;
+        tfft_rb_rule(c, false);
         std::vector<double2> wt((size_t)g.Lt);
         for (int q = 0; q < g.Lt; ++q) wt[q] = make_double2(std::cos(2.0 * M_PI * q / g.Lt), -std::sin(2.0 * M_PI * q / g.Lt));
         HIPCHK(c, hipMalloc(&c->d_wtab, wt.size() * sizeof(double2)));

@@ -119,6 +119,7 @@ struct smoqy_ctx {
     int *d_tpos = nullptr;      // in-place tau-FFT: LDS row of each spectrum element
     TfftArgs tf{};            // plan of the own tau-FFT
     int tf_ok = 0, use_tfft = 1;
+    int tf_rb_plan = 0;       // tfft_plan's register-blocked R·M·R choice (tf.rb is that, or 0 where the rule of tfft_rb_rule switches it off)
     int pstride = 0;          // per-system stride of the partial-sum arrays
     // kpm
     double rbuf = 0.10, a1 = 1.0, a2 = 1.0;
@@ -271,6 +272,7 @@ int upload_into(smoqy_ctx *c, double2 *dev, const void *host, int sys0, int coun
 int download_from(smoqy_ctx *c, const double2 *dev, void *host, int sys0, int count);  // api_handle.hip
 int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, double2 *partial, const CgState *cg, int sys0, int count, bool twiddled = false, hipStream_t st = nullptr);  // api_operator.hip
 int pstat_wait(smoqy_ctx *c);  // api_precond.hip
+void tfft_rb_rule(smoqy_ctx *c, bool shared_gpu);  // api_cg.hip: where tfft_rb_kernel runs (shared_gpu: the caller asked for the in-place form, smoqy_tfft_form)
 int precond_update_range(smoqy_ctx *c, int w0, int nw, const double *randvecs, const double *d_randvecs = nullptr);  // api_precond.hip
 int precond_core(smoqy_ctx *c, const double2 *src, double2 *v, const CgState *cg, double2 *part_rz, bool half = false);  // api_precond.hip
 int cg_dev(smoqy_ctx *c, double2 *x, const double2 *b, bool x_is_b, double tol, int maxiter, int use_precond, int *iters, double *eps, const double2 *pff_phi = nullptr, double2 *pff_out = nullptr, int async_step = -1);  // api_cg.hip

@@ -492,6 +492,56 @@ def test_in_place_tau_fft_form(Lt, is_sym):
     assert abs(int(it1[0]) - ito) <= max(1, ito // 40) and relerr(x1[:, :, 0], xo) < 1e-8
 
 
+@pytest.mark.parametrize("Lt, N, nrhs", [(80, 37, 5), (100, 50, 5), (200, 21, 5), (200, 256, 2), (100, 24, 33)])
+def test_register_blocked_tau_fft_for_R_M_R_lengths(Lt, N, nrhs):
+    """tfft_rb_kernel (round 4): Lτ = R·M·R (80 = 4·5·4, 100 = 5·4·5, 200 = 5·8·5) with the first and the last radix-R stage in the
+    registers of R·M·SB = 320 lanes and ONE LDS pass — FourierTransformer.jl:39-64 and the fused BLAS-1 lines of cg_solve!
+    (ConjugateGradient.jl:219-245) as in the other forms.  smoqy_describe says which form the handle
+    runs; ragged last tiles (N = 37, 50, 21 are no multiples of the tile width), several systems, both plain transforms against
+    the oracle's dense-unitary-checked FourierTransformer, and the CG solves (iteration counts within one of the oracle's)."""
+    is_sym = True
+    h, o, nt, colors = make(lat.chain_neighbor_table(N), Lt, N, is_sym, seed=11, nrhs=nrhs, vscale=0.5)
+    # the rule (api_cg.hip, tfft_rb_rule): up to 64 systems per launch on a handle left at the library's default; below 32 once the caller
+    # has asked for the in-place form (several handles share the GPU)
+    assert h.describe()["tfft"].startswith("tfft_rb_kernel")
+    h.call("smoqy_tfft_form", 1)
+    assert h.describe()["tfft"].startswith("tfft_rb_kernel" if nrhs < 32 else "tfft_kernel (in-place"), h.describe()
+    h.call("smoqy_tfft_form", 0)
+    assert h.describe()["tfft"].startswith("tfft_rb_kernel")
+    v = rand(Lt, N, nrhs, 9)
+    ft = orc.OracleFT(Lt, N)
+    w = v.copy(order="F")
+    h.call("smoqy_fft_forward", L.ptr(w), 0, nrhs)
+    for s in range(nrhs):
+        assert relerr(w[:, :, s], ft.forward(v[:, :, s])) < 1e-13, s
+    h.call("smoqy_fft_inverse", L.ptr(w), 0, nrhs)
+    assert relerr(w, v) < 1e-13
+    # a sub-range of systems (sys_first > 0)
+    if nrhs >= 3:
+        w = v.copy(order="F")
+        h.call("smoqy_fft_forward", L.ptr(w[:, :, 1:]), 1, 2)
+        assert relerr(w[:, :, 1], ft.forward(v[:, :, 1])) < 1e-13 and relerr(w[:, :, 2], ft.forward(v[:, :, 2])) < 1e-13
+        assert np.array_equal(w[:, :, 0], v[:, :, 0])
+    rv = np.random.default_rng(5).standard_normal(N)
+    P = orc.OracleKPM(o[0])
+    P.update(rv)
+    h.call("smoqy_precond_update", 0, L.ptr(rv))
+    out = np.zeros_like(v)
+    h.call("smoqy_precond_apply", L.ptr(out), L.ptr(v), 0, nrhs)
+    assert relerr(out[:, :, nrhs - 1], P.apply(v[:, :, nrhs - 1])) < 1e-10
+    x, it, eps = solve(h, v, 1e-10, 5000, 1)
+    for s in (0, nrhs - 1):
+        xo, ito, _ = o[0].cg_solve(v[:, :, s], precond=P, tol=1e-10, maxiter=5000)
+        assert abs(int(it[s]) - ito) <= max(1, ito // 40) and relerr(x[:, :, s], xo) < 1e-8, (s, int(it[s]), ito)
+        r = v[:, :, s] - o[0].mul_MtM(x[:, :, s])
+        assert np.linalg.norm(r) / np.linalg.norm(v[:, :, s]) < 1.05e-10
+
+
+def test_register_blocked_tau_fft_is_not_taken_above_64_systems():
+    h, o, nt, colors = make(lat.chain_neighbor_table(24), 100, 24, True, seed=11, nrhs=65, vscale=0.5)
+    assert h.describe()["tfft"].startswith("tfft_kernel (in-place"), h.describe()  # 32 systems or more: the library's default is the in-place form
+
+
 def test_speculative_solve_restarts_when_the_preconditioner_grows():
     """Round 3: a solve that can be restarted (x === b) is launched on the host's CURRENT knowledge of the preconditioner (how many
     frequencies carry a chain, whether any walker is active) while the status record of the update in front of it is still on its way,
