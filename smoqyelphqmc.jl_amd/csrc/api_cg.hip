@@ -80,7 +80,7 @@ int smoqy_cg_split(smoqy_ctx *c, int parts)
 void tfft_rb_rule(smoqy_ctx *c, bool shared_gpu)
 {
     const int nsys = c->g.nsys;
-    const bool on = tuning_env(kTuneTfftEdge) >= 3 || nsys < 32 || (!shared_gpu && nsys <= 64);
+    const bool on = tuning_env(kTuneTfftEdge) == 3 || nsys < 32 || (!shared_gpu && nsys <= 64);
     c->tf.rb = on ? c->tf_rb_plan : 0;
 }
 

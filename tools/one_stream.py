@@ -11,4 +11,7 @@ b = WalkerBatch(wl, nwalkers=nw, is_sym=form != "asym", cg_split=int(os.environ.
 if os.environ.get('SMOQY_GRAPH'): b.h.call('smoqy_cg_use_graph', int(os.environ['SMOQY_GRAPH']))
 if os.environ.get('SMOQY_ASYNC'): b.h.call('smoqy_hmc_async', int(os.environ['SMOQY_ASYNC']), None, None)
 b.sweep(); b.sweep()
-t0 = time.perf_counter(); b.sweep(); b.h.call("smoqy_sync"); print("sweep ms", 1e3 * (time.perf_counter() - t0))
+ns = int(os.environ.get("SMOQY_SWEEPS", "1"))  # timed sweeps (mean)
+t0 = time.perf_counter()
+for _ in range(ns): b.sweep()
+b.h.call("smoqy_sync"); print("sweep ms", 1e3 * (time.perf_counter() - t0) / ns)
