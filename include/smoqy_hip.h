@@ -222,7 +222,9 @@ int smoqy_cg_split(smoqy_ctx *ctx, int parts);
  * in_place = 0 (default) keeps two images of a tile in LDS (three passes at Lτ = 128; fastest for one handle), 1 transforms in place
  * (half the LDS, two thirds of the registers, four passes: more workgroups per CU, +2.7 % sweeps/s with six handles on one GPU).
  * Same results to rounding (different pass order: a solve whose residual lands on the tolerance may take one more iteration); lengths
- * with a factor 7 keep the two-image form. */
+ * with a factor 7 keep the two-image form.  Time extents with a register-blocked kernel (one LDS pass: Lτ = 64, 128 always; Lτ = 80,
+ * 100, 200 up to 64 systems per launch, and below 32 once in_place = 1 has said that several handles share the GPU) run that kernel
+ * whatever is asked for here; smoqy_describe names the form in use. */
 int smoqy_tfft_form(smoqy_ctx *ctx, int in_place);
 /* host <-> device convergence polling period of the on-device CG loop (iterations per poll) */
 int smoqy_cg_config(smoqy_ctx *ctx, int check_every);
