@@ -56,8 +56,12 @@ static int wave_run_length(const smoqy_ctx *c, int count)
         // wavefronts to hide one wavefront's chain of 2R + 1 dependent propagates)
         if (c->fw.kind == 1) return 0;
         if (c->fw.kind == 3 && (count < 64 || c->fw.lanes < 64)) return 0;
+        // wavefronts a launch should keep: one per SIMD (1024) — which is all the honeycomb-block program's 264 registers admit, and what the
+        // other programs were tuned at; two per SIMD for the honeycomb twin of SMOQY_FDM_WAVE_OCC=2 (kernels_fdm_wave.hip, not yet timed)
+        static const int occ = tuning_env(kTuneFdmWaveOcc);
+        const long want = (c->fw.kind == 3 && occ == 2) ? 2048 : 1024;
         R = c->Tc;
-        while (2 * R <= 32 && (long)((g.Lt + 2 * R - 1) / (2 * R)) * count >= 1024) R *= 2;
+        while (2 * R <= 32 && (long)((g.Lt + 2 * R - 1) / (2 * R)) * count >= want) R *= 2;
     }
     R = std::min(R, g.Lt);
     R -= R % c->Tc;
@@ -102,7 +106,7 @@ int matvec_dev(smoqy_ctx *c, int op, double2 *out, const double2 *in, double2 *p
     aw.run_len = wave_R;
     if (wave_R > 0 && fdm_wave_supported(aw, c->ff, c->fw, c->g.is_sym != 0, csm)) {
         launch_fdm_wave(st, aw, c->ff, c->fw, csm);
-        name = c->fw.kind == 1 ? "fdm_wave_kernel<ring>" : (c->fw.kind == 2 ? "fdm_wave_kernel<plaquette>" : "fdm_wave_kernel<honeycomb block>");
+        name = c->fw.kind == 1 ? "fdm_wave_kernel<ring>" : (c->fw.kind == 2 ? "fdm_wave_kernel<plaquette>" : (tuning_env(kTuneFdmWaveOcc) == 2 ? "fdm_wave_kernel<honeycomb block, two wavefronts per SIMD>" : "fdm_wave_kernel<honeycomb block>"));
     } else if (a.run_len > 0 && fdm_own_stream_supported(a, c->ff, c->g.is_sym != 0, cs_const)) { launch_fdm_own_stream(st, a, c->ff); name = "fdm_own_stream_kernel"; }
     else if (a.run_len > 0 && fdm_stream_supported(a, c->ff, c->g.is_sym != 0)) { launch_fdm_stream(st, a, c->ff, cs_const); name = cs_const ? "fdm_stream_kernel<CSV=false>" : "fdm_stream_kernel<CSV=true>"; }
     else if (fdm_own_supported(a, c->ff, c->g.is_sym != 0)) { launch_fdm_own(st, op, a, c->ff); name = "fdm_own_kernel"; }

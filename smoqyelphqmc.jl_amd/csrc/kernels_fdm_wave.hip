@@ -62,8 +62,11 @@ struct SliceFields {
 
 // CSM: 0 — one (cosh, sinh) per COLOUR for the whole launch (the host has shown the hoppings τ-independent and uniform per colour:
 // the Holstein models), kept in scalar registers; 1 — one per bond slot, τ-independent; 2 — one per bond slot and slice (SSH models)
-template <class D, int CSM, bool ROT>
-__global__ void __launch_bounds__(64) fdm_wave_kernel(FdmArgs a, FdmFast ff, FdmWave fw)
+// MINW: wavefronts per SIMD the register allocation must leave room for (the second __launch_bounds__ argument).  1 everywhere but in the
+// honeycomb-block twin below: at MINW = 1 that program takes 256 VGPRs + 2 AGPRs = 264 allocated registers, i.e. ONE wavefront per SIMD
+// (tools/kernel_resources.py; 512 // 264), at MINW = 2 it fits 256 with one 8-byte value per slice in scratch.
+template <class D, int CSM, bool ROT, int MINW = 1>
+__global__ void __launch_bounds__(64, MINW) fdm_wave_kernel(FdmArgs a, FdmFast ff, FdmWave fw)
 {
     constexpr int S = D::S, NCOL = D::NCOL, NB = D::NB, NR = D::NR;
     __shared__ double2 xch[ROT ? 1 : S * 64];
@@ -250,7 +253,18 @@ void launch_fdm_wave(hipStream_t st, const FdmArgs &a, const FdmFast &ff, const 
             else launch_kind<RingD, false>(st, a, ff, fw, csm);
             break;
         case 2: launch_kind<PlaqD, false>(st, a, ff, fw, csm); break;
-        default: launch_kind<HoneyD, false>(st, a, ff, fw, 0); break;
+        default: {
+            // SMOQY_FDM_WAVE_OCC=2: the two-wavefronts-per-SIMD twin (same arithmetic, 256 registers).  Built at the end of round 4 from the
+            // static register counts, NOT yet timed on a GPU: off unless asked for (wave_run_length aims at 2048 wavefronts with it).
+            static const int occ = tuning_env(kTuneFdmWaveOcc);
+            if (occ == 2) {
+                const int nrun = (a.Lt + a.run_len - 1) / a.run_len;
+                hipLaunchKernelGGL((fdm_wave_kernel<HoneyD, 0, false, 2>), dim3((unsigned)(nrun * a.sys_count)), dim3(64), 0, st, a, ff, fw);
+            } else {
+                launch_kind<HoneyD, false>(st, a, ff, fw, 0);
+            }
+            break;
+        }
     }
 }
 

@@ -381,7 +381,7 @@ void launch_tfft(hipStream_t st, int mode, const TfftArgs &a);
 // none needed for normal use.  Read once per process; tuning_env("NAME") is the variable's integer value, or -1 when it is not set.
 enum TuningKnob {
     kTuneChebWl0, kTuneChebSplit, kTuneChebOwn, kTuneChebGroup, kTuneFdmStream, kTuneFdmOwn, kTuneFdmOwnMax, kTuneFdmOwnStream, kTuneNtFields,
-    kTuneXStream, kTuneXcdMap, kTuneTfftSlim, kTuneTfftSb, kTuneTfftEdge, kTuneChebWave, kTuneFdmWave, kTuneFdmWaveR, kTuneDmdxFast, kTuneCount
+    kTuneXStream, kTuneXcdMap, kTuneTfftSlim, kTuneTfftSb, kTuneTfftEdge, kTuneChebWave, kTuneFdmWave, kTuneFdmWaveR, kTuneDmdxFast, kTuneFdmWaveOcc, kTuneCount
 };
 inline int tuning_env(TuningKnob k)
 {
@@ -391,7 +391,7 @@ inline int tuning_env(TuningKnob k)
         {
             static const char *const names[kTuneCount] = {"SMOQY_CHEB_WL0", "SMOQY_CHEB_SPLIT", "SMOQY_CHEB_OWN", "SMOQY_CHEB_GROUP", "SMOQY_FDM_STREAM", "SMOQY_FDM_OWN",
                                                           "SMOQY_FDM_OWN_MAX", "SMOQY_FDM_OWNSTREAM", "SMOQY_NT_FIELDS", "SMOQY_X_STREAM", "SMOQY_XCD_MAP", "SMOQY_TFFT_SLIM",
-                                                          "SMOQY_TFFT_SB", "SMOQY_TFFT_EDGE", "SMOQY_CHEB_WAVE", "SMOQY_FDM_WAVE", "SMOQY_FDM_WAVE_R", "SMOQY_DMDX_FAST"};
+                                                          "SMOQY_TFFT_SB", "SMOQY_TFFT_EDGE", "SMOQY_CHEB_WAVE", "SMOQY_FDM_WAVE", "SMOQY_FDM_WAVE_R", "SMOQY_DMDX_FAST", "SMOQY_FDM_WAVE_OCC"};
             for (int q = 0; q < kTuneCount; ++q) {
                 const char *e = getenv(names[q]);
                 v[q] = e ? atoi(e) : -1;

@@ -140,3 +140,46 @@ def test_wave_mtm_at_the_benchmarked_shapes(name, nw):
         o = orc.OracleFDM(batch.nt, expV, ch, sh, True)
         assert relerr(got[:, :, w], o.mul_MtM(v[:, :, w])) < 1e-13
     h.close()
+
+
+_TWIN_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import test_gpu_wave_mtm as T
+L = T.L
+for Ls, Lt, nw in ((16, 8, 3), (4, 12, 3), (16, 6, 5)):
+    ms = T.models("honeycomb", Ls, Lt, nw, "uniform")
+    h, oracles = T.handle(ms)
+    N = ms[0].fpi.N
+    g = np.random.default_rng(7)
+    v = np.asfortranarray(g.standard_normal((Lt, N, nw)) + 1j * g.standard_normal((Lt, N, nw)))
+    a, b = h.vec_alloc(), h.vec_alloc()
+    h.vec_upload(a, v)
+    want = np.stack([oracles[w].mul_MtM(v[:, :, w]) for w in range(nw)], axis=2)
+    h.call("smoqy_set_tau_chunk", 2)
+    for R in (2, 4):
+        h.call("smoqy_matvec_wave", R)
+        h.call("smoqy_matvec_v", L.OP_MTM, b, a)
+        name = h.describe()["mtm"]
+        assert "two wavefronts per SIMD" in name, name
+        err = T.relerr(h.vec_download(b), want)
+        assert err < 1e-13, (Ls, Lt, R, err)
+    h.close()
+print("TWIN_OK")
+"""
+
+
+def test_two_wave_twin_of_the_block_program_in_a_child_process():
+    """SMOQY_FDM_WAVE_OCC=2 (read once per process, hence the child): the honeycomb-block program compiled for two wavefronts per SIMD
+    (256 registers, one 8-byte value per slice in scratch; tests/test_kernel_resources.py holds the static counts) computes the same
+    mul_MtM! (src/FermionDetMatrix.jl:329-340) — against the oracle at 1e-13 like every operator kernel.  Correctness only: the twin has not
+    been timed yet and is off by default."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, SMOQY_FDM_WAVE_OCC="2")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-c", _TWIN_CHILD, here], env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "TWIN_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
