@@ -48,6 +48,12 @@ __device__ __forceinline__ double2 hopcomb(double2 v, double2 u, bool wrap, bool
     return make_double2(v.x - (pr * u.x - pi * u.y), v.y - (pr * u.y + pi * u.x));
 }
 
+template <int K>
+__device__ __forceinline__ void opaque(double (&d)[K])
+{
+#pragma unroll
+    for (int i = 0; i < K; ++i) asm volatile("" : "+v"(d[i]));
+}
 __device__ __forceinline__ double2 shfl2(double2 x, int lane)
 {
     return make_double2(__shfl(x.x, lane, 64), __shfl(x.y, lane, 64));
@@ -58,13 +64,15 @@ template <class D, int CSM>
 struct SliceFields {
     double2 cs[CSM == 2 ? D::NB : 1];
     double e0[D::S], e1[D::S];
+    double d[D::S];   // LEAN form: exp(-ΔτV) itself, the two centre coefficients are formed where they are used
 };
 
 // CSM: 0 — one (cosh, sinh) per COLOUR for the whole launch (the host has shown the hoppings τ-independent and uniform per colour:
 // the Holstein models), kept in scalar registers; 1 — one per bond slot, τ-independent; 2 — one per bond slot and slice (SSH models)
 // MINW: wavefronts per SIMD the register allocation must leave room for (the second __launch_bounds__ argument).  1 everywhere but in the
 // honeycomb-block twin below: at MINW = 1 that program takes 256 VGPRs + 2 AGPRs = 264 allocated registers, i.e. ONE wavefront per SIMD
-// (tools/kernel_resources.py; 512 // 264), at MINW = 2 it fits 256 with one 8-byte value per slice in scratch.
+// (tools/kernel_resources.py; 512 // 264); at MINW = 2 the LEAN form below (exp(-ΔτV) kept instead of the two folded centre coefficients per
+// site, which are formed again inside each propagate: 16 more fp64 operations per slice) takes 252 registers, no scratch, no AGPR.
 template <class D, int CSM, bool ROT, int MINW = 1>
 __global__ void __launch_bounds__(64, MINW) fdm_wave_kernel(FdmArgs a, FdmFast ff, FdmWave fw)
 {
@@ -130,7 +138,12 @@ __global__ void __launch_bounds__(64, MINW) fdm_wave_kernel(FdmArgs a, FdmFast f
         else if constexpr (CSM == 1) return kcs[D::bs(decltype(C)::value, decltype(P)::value)];
         else return F.cs[D::bs(decltype(C)::value, decltype(P)::value)];
     };
+    constexpr bool LEAN = MINW >= 2 && !D::REMOTE0;
     auto set_fields = [&](const Raw &r) {
+        if constexpr (LEAN) {
+            static_for<0, S>([&](auto P) { F.d[P] = r.d[P]; });
+            return;
+        }
         static_for<0, S>([&](auto P) {
             // C₀ D C₀ on own site p with partner q: x' = (c² d_p + s² d_q) x_p + c s (d_p + d_q) x_q
             const double2 k = CS(std::integral_constant<int, 0>{}, P);
@@ -171,6 +184,18 @@ __global__ void __launch_bounds__(64, MINW) fdm_wave_kernel(FdmArgs a, FdmFast f
         {
             double2 m[S];
             partners(std::integral_constant<int, 0>{}, x, m);
+            if constexpr (LEAN) {
+                // the coefficients of C₀ D C₀ from exp(-ΔτV) on the spot (the same expressions as set_fields): 8 registers instead of 24-32 across
+                // both propagates of a slice; the empty asm keeps the compiler from carrying them from one propagate to the next
+                opaque(F.d);
+                static_for<0, S>([&](auto P) {
+                    const double2 k = CS(std::integral_constant<int, 0>{}, P);
+                    const double dp = F.d[P], dq = F.d[D::pp(0, decltype(P)::value)];
+                    const double e0 = k.x * k.x * dp + k.y * k.y * dq;
+                    const double e1 = k.x * k.y * (dp + dq);
+                    x[P] = lin(e0, x[P], e1, m[P]);
+                });
+            } else
             static_for<0, S>([&](auto P) { x[P] = lin(F.e0[P], x[P], F.e1[P], m[P]); });           // C_0 D C_0
         }
         static_for<1, NCOL>([&](auto I) { stage(I, x); });                                            // C_1 … C_{L-1}
@@ -254,7 +279,7 @@ void launch_fdm_wave(hipStream_t st, const FdmArgs &a, const FdmFast &ff, const 
             break;
         case 2: launch_kind<PlaqD, false>(st, a, ff, fw, csm); break;
         default: {
-            // SMOQY_FDM_WAVE_OCC=2: the two-wavefronts-per-SIMD twin (same arithmetic, 256 registers).  Built at the end of round 4 from the
+            // SMOQY_FDM_WAVE_OCC=2: the two-wavefronts-per-SIMD twin (same expressions, 252 registers).  Built at the end of round 4 from the
             // static register counts, NOT yet timed on a GPU: off unless asked for (wave_run_length aims at 2048 wavefronts with it).
             static const int occ = tuning_env(kTuneFdmWaveOcc);
             if (occ == 2) {

@@ -172,7 +172,8 @@ print("TWIN_OK")
 
 def test_two_wave_twin_of_the_block_program_in_a_child_process():
     """SMOQY_FDM_WAVE_OCC=2 (read once per process, hence the child): the honeycomb-block program compiled for two wavefronts per SIMD
-    (256 registers, one 8-byte value per slice in scratch; tests/test_kernel_resources.py holds the static counts) computes the same
+    (252 registers: exp(-ΔτV) held instead of the folded centre coefficients, which each propagate forms again; tests/test_kernel_resources.py
+    holds the static counts) computes the same
     mul_MtM! (src/FermionDetMatrix.jl:329-340) — against the oracle at 1e-13 like every operator kernel.  Correctness only: the twin has not
     been timed yet and is off by default."""
     import os
