@@ -282,12 +282,12 @@ void launch_fdm_wave(hipStream_t st, const FdmArgs &a, const FdmFast &ff, const 
             // SMOQY_FDM_WAVE_OCC=2: the two-wavefronts-per-SIMD twin (same expressions, 252 registers).  Built at the end of round 4 from the
             // static register counts, NOT yet timed on a GPU: off unless asked for (wave_run_length aims at 2048 wavefronts with it).
             static const int occ = tuning_env(kTuneFdmWaveOcc);
-            if (occ == 2) {
-                const int nrun = (a.Lt + a.run_len - 1) / a.run_len;
-                hipLaunchKernelGGL((fdm_wave_kernel<HoneyD, 0, false, 2>), dim3((unsigned)(nrun * a.sys_count)), dim3(64), 0, st, a, ff, fw);
-            } else {
-                launch_kind<HoneyD, false>(st, a, ff, fw, 0);
-            }
+            // (launched directly, not through launch_kind: the per-bond hopping modes of this program are refused by fdm_wave_supported and
+            // would only add two never-launched 314- and 380-register kernels to the library)
+            const int nrun = (a.Lt + a.run_len - 1) / a.run_len;
+            const dim3 grid((unsigned)(nrun * a.sys_count)), block(64);
+            if (occ == 2) hipLaunchKernelGGL((fdm_wave_kernel<HoneyD, 0, false, 2>), grid, block, 0, st, a, ff, fw);
+            else hipLaunchKernelGGL((fdm_wave_kernel<HoneyD, 0, false>), grid, block, 0, st, a, ff, fw);
             break;
         }
     }
